@@ -1,0 +1,62 @@
+"""Stock-PyTorch (CPU, fp32) functional port of the reference scorers.  TEST INFRASTRUCTURE ONLY.
+
+This is (1) a second, autograd-capable checker for the HIP path (forward AND gradients), and
+(2) the `cpu_baseline` ("kind": "port") that bench.py times on the GPU node's host cores: it issues the
+same ATen op sequence as the reference modules (Linear / bmm / softmax / layer_norm / nn.LSTM), one video
+per call, exactly like Trainer.test (summarizer/models/__init__.py:45-54).
+Pinned against the real reference by tests/golden/*.npz (see tests/test_oracle.py).
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+
+def vasnet_scores(x, p, ignore_self=False, aperture=None, scale=None, eps=1e-6, pos_table=None,
+                  pos_kind="simple", drop_masks=None):
+    """x: (T,B,D) -> (T,B,1).  Op order of vasnet.py:99-147.
+
+    drop_masks: optional (m_alpha (B,T,T), m_y (B,T,D), m_z (B,T,D)) of already-scaled keep masks
+    (0 or 1/(1-p)) so training-mode dropout can be checked deterministically.
+    """
+    T, B, D = x.shape
+    xb = x.permute(1, 0, 2)
+    if pos_table is not None:
+        bi = torch.arange(B).unsqueeze(1); ti = torch.arange(T).unsqueeze(0)
+        rows = ti.expand(B, T) if pos_kind == "simple" else (bi * T + ti) // B     # vasnet.py:108-111 (see vasnet_np.pos_rows)
+        xb = xb + pos_table[rows]
+    sc = scale if scale is not None else 1.0 / math.sqrt(D)
+    K = F.linear(xb, p["K.weight"]); Q = F.linear(xb, p["Q.weight"]); V = F.linear(xb, p["V.weight"])
+    e = torch.bmm(Q, K.transpose(1, 2)) * sc
+    if ignore_self:
+        e = e.masked_fill(torch.eye(T, dtype=torch.bool, device=e.device).unsqueeze(0), float("-inf"))
+    if aperture is not None:
+        scope = torch.tril(e, diagonal=aperture) * torch.triu(e, diagonal=-aperture)
+        e = e.masked_fill(scope == 0, float("-inf"))
+    alpha = torch.softmax(e, dim=2)
+    if drop_masks is not None:
+        alpha = alpha * drop_masks[0]
+    c = F.linear(torch.bmm(alpha, V), p["attention_head_projection.weight"])
+    y = c + xb
+    if drop_masks is not None:
+        y = y * drop_masks[1]
+    y = F.layer_norm(y, (D,), p["layer_norm.weight"], p["layer_norm.bias"], eps)
+    z = torch.relu(F.linear(y, p["k1.weight"], p["k1.bias"]))
+    if drop_masks is not None:
+        z = z * drop_masks[2]
+    z = F.layer_norm(z, (D,), p["layer_norm.weight"], p["layer_norm.bias"], eps)
+    s = torch.sigmoid(F.linear(z, p["k2.weight"], p["k2.bias"]))
+    return s.permute(1, 0, 2)
+
+
+def make_lstm(p, prefix, input_size, hidden_size, num_layers):
+    """Builds a stock nn.LSTM carrying the given weights (dsn.py:23-27 / sumgan.py:27-32)."""
+    m = torch.nn.LSTM(input_size, hidden_size, num_layers=num_layers, bidirectional=True)
+    sd = {k[len(prefix):]: torch.as_tensor(v) for k, v in p.items() if k.startswith(prefix)}
+    m.load_state_dict(sd)
+    return m
+
+
+def bilstm_scores(x, p, prefix, head_w, head_b, input_size, hidden_size, num_layers, lstm=None):
+    lstm = lstm if lstm is not None else make_lstm(p, prefix, input_size, hidden_size, num_layers)
+    h, _ = lstm(x)
+    return torch.sigmoid(F.linear(h, p[head_w], p[head_b]))

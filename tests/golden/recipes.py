@@ -1,0 +1,80 @@
+"""Seeded input/weight recipes shared by the golden generator (make_golden.py, run once in the build
+container against the real reference) and by the tests (which regenerate the same inputs anywhere).
+numpy's PCG64 `default_rng` stream is platform independent, so full-size (D=1024) cases need only their
+expected OUTPUTS committed, not 21 MB of weights."""
+import hashlib
+import numpy as np
+
+VASNET_KEYS = ["K.weight", "Q.weight", "V.weight", "attention_head_projection.weight",
+               "k1.weight", "k1.bias", "k2.weight", "k2.bias", "layer_norm.weight", "layer_norm.bias"]
+
+
+def vasnet_weights(D, seed, max_length=None):
+    """Xavier-like uniform matrices, non-trivial biases and LN affine (so the shared-LN quirk is exercised)."""
+    rng = np.random.default_rng(seed)
+    a = np.sqrt(2.0) * np.sqrt(6.0 / (2 * D))
+    p = {}
+    for k in ["K.weight", "Q.weight", "V.weight", "attention_head_projection.weight", "k1.weight"]:
+        p[k] = rng.uniform(-a, a, (D, D)).astype(np.float32)
+    p["k1.bias"] = rng.uniform(-0.2, 0.2, (D,)).astype(np.float32)
+    p["k2.weight"] = rng.uniform(-a * 4, a * 4, (1, D)).astype(np.float32)
+    p["k2.bias"] = rng.uniform(-0.2, 0.2, (1,)).astype(np.float32)
+    p["layer_norm.weight"] = rng.uniform(0.5, 1.5, (D,)).astype(np.float32)
+    p["layer_norm.bias"] = rng.uniform(-0.1, 0.1, (D,)).astype(np.float32)
+    if max_length:
+        p["pos_embed.weight"] = rng.normal(0, 1, (max_length, D)).astype(np.float32)
+    return p
+
+
+def lstm_weights(prefix, D, H, num_layers, seed, head_prefix):
+    rng = np.random.default_rng(seed)
+    k = 1.0 / np.sqrt(H)
+    p = {}
+    for l in range(num_layers):
+        In = D if l == 0 else 2 * H
+        for suf in ("", "_reverse"):
+            p[f"{prefix}weight_ih_l{l}{suf}"] = rng.uniform(-k, k, (4 * H, In)).astype(np.float32)
+            p[f"{prefix}weight_hh_l{l}{suf}"] = rng.uniform(-k, k, (4 * H, H)).astype(np.float32)
+            p[f"{prefix}bias_ih_l{l}{suf}"] = rng.uniform(-k, k, (4 * H,)).astype(np.float32)
+            p[f"{prefix}bias_hh_l{l}{suf}"] = rng.uniform(-k, k, (4 * H,)).astype(np.float32)
+    kh = 1.0 / np.sqrt(2 * H)
+    p[f"{head_prefix}weight"] = rng.uniform(-kh * 3, kh * 3, (1, 2 * H)).astype(np.float32)
+    p[f"{head_prefix}bias"] = rng.uniform(-kh, kh, (1,)).astype(np.float32)
+    return p
+
+
+def features(T, B, D, seed):
+    """pool5-like non-negative features: 0.5*|N(0,1)|."""
+    rng = np.random.default_rng(seed)
+    return (0.5 * np.abs(rng.standard_normal((T, B, D)))).astype(np.float32)
+
+
+def digest(arrs):
+    h = hashlib.sha256()
+    for k in sorted(arrs):
+        h.update(k.encode()); h.update(np.ascontiguousarray(arrs[k]).tobytes())
+    return h.hexdigest()
+
+
+def synthetic_video(T, seed, n_users=15, D=None):
+    """SumMe/TVSum-shaped evaluation metadata: picks every 15th frame, random change points."""
+    rng = np.random.default_rng(seed)
+    n_frames = int(15 * T - rng.integers(0, 15))
+    picks = (15 * np.arange(T)).astype(np.int32)
+    n_seg = max(1, T // 15)
+    cuts = np.sort(rng.choice(np.arange(15, n_frames - 15), size=n_seg - 1, replace=False)) if n_seg > 1 else np.array([], int)
+    starts = np.concatenate([[0], cuts]).astype(np.int64)
+    ends = np.concatenate([cuts - 1, [n_frames - 1]]).astype(np.int64)
+    cps = np.stack([starts, ends], axis=1).astype(np.int32)
+    nfps = (ends - starts + 1).astype(np.int32)
+    user_summary = (rng.random((n_users, n_frames)) < 0.15).astype(np.float32)
+    gt = rng.random((T + 1) // 2).repeat(2)[:T].astype(np.float32)
+    user_scores = np.clip(gt[None, :] + 0.3 * rng.standard_normal((n_users, T)), 0, 1).astype(np.float32)
+    user_scores_frames = np.repeat(user_scores, 15, axis=1)[:, :n_frames]
+    if user_scores_frames.shape[1] < n_frames:
+        user_scores_frames = np.pad(user_scores_frames, ((0, 0), (0, n_frames - user_scores_frames.shape[1])))
+    d = dict(n_frames=n_frames, picks=picks, change_points=cps, n_frame_per_seg=nfps,
+             user_summary=user_summary, gtscore=gt, user_scores=user_scores_frames.astype(np.float32))
+    if D:
+        d["features"] = features(T, 1, D, seed + 7)[:, 0, :]
+    return d
