@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- frames scored / second for the VASNet scoring path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the scorer over one packed batch of synthetic TVSum-shaped videos (S-TVSum):
+50 videos, T_i = ceil(U(150,320)) from numpy default_rng(0), D = 1024 fp32 features already resident in HBM.
+N > 1: one process per GPU (torchrun), each rank scores its OWN 50 videos (sharded by video, no data-path
+collective) -> "scaling": "weak"; value = frames all ranks scored / max-over-ranks time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def tvsum_lens(n_videos=50):
+    return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
+
+
+def cpu_baseline(lens, D, budget_s=12.0):
+    """Reference-equivalent stock-PyTorch CPU path (oracle/torch_port.py), one video per call as in
+    Trainer.test (summarizer/models/__init__.py:45-54), all host cores.  Bounded sample."""
+    import recipes as R
+    from oracle import torch_port
+    torch.manual_seed(1234)
+    from summarizer_amd.models.vasnet import VASNet
+    m = VASNet(input_size=D)
+    p = {k: v.detach() for k, v in m.named_parameters()}
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    xs = [torch.from_numpy(R.features(T, 1, D, 1000 + i)) for i, T in enumerate(lens)]
+    with torch.no_grad():
+        for x in xs[:3]:
+            torch_port.vasnet_scores(x, p)
+        frames, t0, n = 0, time.perf_counter(), 0
+        while True:
+            x = xs[n % len(xs)]
+            torch_port.vasnet_scores(x, p)
+            frames += x.shape[0]; n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s and n >= len(xs):
+                break
+            if el > 3 * budget_s:
+                break
+    return dict(value=frames / el, unit="frames/s", cores=ncores, kind="port",
+                sample=f"{n} single-video VASNet forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops, "
+                       f"{torch.get_num_threads()} threads) in {el:.1f}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--videos", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import recipes as R
+    from summarizer_amd import _lib
+    from summarizer_amd.models.vasnet import VASNet
+    lib = _lib.load()
+
+    D = 1024
+    lens = tvsum_lens(args.videos)
+    frames = int(sum(lens))
+    torch.manual_seed(1234)
+    model = VASNet(input_size=D).eval().to(dev)
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 1000 * rank + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            s = model.score_packed(x, lens)
+        barrier()
+        lib.sumk_prof_read(_lib.PROF_GEMM_QKV, None, None, 1)
+        lib.sumk_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s = model.score_packed(x, lens)
+        barrier()
+        t1 = time.perf_counter()
+        lib.sumk_prof_enable(0)
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(s).all())
+
+    ms = C.c_double(0); n = C.c_int64(0)
+    lib.sumk_prof_read(_lib.PROF_GEMM_QKV, C.byref(ms), C.byref(n), 1)
+    qkv_flops = 2.0 * frames * (3 * D) * D
+    roof = None
+    if n.value > 0:
+        avg_s = ms.value / n.value / 1e3
+        ach = qkv_flops / avg_s / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get("gemm_qkv_hbm_bytes_per_launch")
+        roof = dict(bound="mfma", kernel="gemm_f32_kernel<128,NT> (QKV projection)", achieved=round(ach, 2),
+                    peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    traffic=traffic, avg_launch_us=round(avg_s * 1e6, 2), launches=int(n.value),
+                    flops_per_launch=qkv_flops)
+
+    if rank == 0:
+        flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
+        out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
+                   unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"VASNet eval scoring, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch",
+                               frames_per_step_per_gpu=frames, parallelism=f"video-sharded x{world}"),
+                   whole_path_tflops=round(frames * world * args.steps / elapsed * flops_frame / 1e12, 2),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(lens, D)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/* sumk.h -- C ABI of libsumk.so: MI355X (gfx950) frame-importance scoring kernels.
+ *
+ * Drop-in boundary for the sequence-scorer hot path of sylvainma/Summarizer.  The reference has NO native
+ * layer: its hot path is the implicit ATen dispatch under the nn.Module.forward calls
+ * cited per entry point below, so each entry replaces "what torch would run" for one reference call site.
+ * Python binds this header with ctypes (summarizer_amd/_lib.py); a maintainer's stub is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error; sumk_last_error() gives the message (thread local).
+ *  - all matrices are dense row-major fp32 in DEVICE memory, BORROWED for the duration of the call.
+ *  - a batch of videos is PACKED: frames of video s are rows [seq_off[s], seq_off[s+1]) of every per-frame
+ *    matrix.  seq_off is given twice: a host copy (grid sizing, workspace carving) and a device copy
+ *    (read by the kernels).  n_rows == seq_off[n_seq].
+ *  - no hidden allocation: the caller owns the workspace; query its size first.
+ *  - `stream` is a hipStream_t (passed as void*); calls only enqueue work and are graph-capturable.
+ *  - D (feature size) and H (LSTM hidden size) must be multiples of 4.
+ */
+#ifndef SUMK_H
+#define SUMK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUMK_OK 0
+#define SUMK_ERR_ARG (-1)       /* bad shape / null pointer / unsupported size */
+#define SUMK_ERR_WORKSPACE (-2) /* workspace too small */
+#define SUMK_ERR_HIP (-3)       /* HIP runtime error (message has hipGetErrorString) */
+
+const char* sumk_last_error(void);
+int sumk_version(void);
+/* number of HIP devices visible; <0 if the runtime cannot be initialised (the library never falls back to CPU) */
+int sumk_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------ VASNet
+ * Weights of summarizer/models/vasnet.py:56-66, each as stored by nn.Linear ([out][in]).
+ * The SAME layer_norm (ln_w, ln_b) is applied twice (vasnet.py:137 and :143). */
+typedef struct sumk_vasnet_weights {
+  const float* Wk; const float* Wq; const float* Wv; /* (D,D)  K/Q/V.weight            vasnet.py:57-59 */
+  const float* Wo;                                   /* (D,D)  attention_head_projection vasnet.py:60  */
+  const float* W1; const float* b1;                  /* (D,D),(D)  k1                   vasnet.py:64   */
+  const float* w2; const float* b2;                  /* (D),(1)    k2                   vasnet.py:65   */
+  const float* ln_w; const float* ln_b;              /* (D)        layer_norm           vasnet.py:54   */
+} sumk_vasnet_weights;
+
+typedef struct sumk_vasnet_opts {
+  float scale;          /* logits multiplier, 1/sqrt(D) by default      vasnet.py:34,119 */
+  float eps;            /* LayerNorm epsilon                            vasnet.py:18,54  */
+  int32_t ignore_self;  /* diag -> -inf                                 vasnet.py:121-122 */
+  int32_t aperture;     /* -1 = global; w>=0: |i-j|>w -> -inf, and in-band logits with e*e==0 -> -inf
+                           (tril*triu==0 quirk)                         vasnet.py:124-127 */
+  /* training-mode dropout (vasnet.py:53,130,136,142): p=0 disables (eval).  Keep-masks are a pure function
+     of (seed, site, element index) -- see DESIGN.md "Dropout" -- so backward regenerates them. */
+  float dropout_p;
+  uint64_t seed;
+} sumk_vasnet_opts;
+
+/* Bytes of workspace sumk_vasnet_forward / _backward need for this batch (seq_off_host has n_seq+1 entries). */
+size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
+
+/* Replaces VASNet.forward (vasnet.py:92-148) for a packed batch: x (n_rows,D) -> scores (n_rows,), sigmoid
+ * outputs in (0,1).  If pos_rows != NULL, x[r,:] += pos_table[pos_rows[r],:] is applied IN PLACE first
+ * (vasnet.py:106-112 mutates the caller's tensor the same way).  When training != 0 the workspace keeps the
+ * intermediates sumk_vasnet_backward consumes. */
+int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                        const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
+                        const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
+                        float* scores, void* workspace, size_t workspace_bytes, int32_t training,
+                        void* stream);
+
+#if 0 /* SUMK_PENDING: declared when implemented */
+/* Gradients of sum_r dscores[r]*scores[r] w.r.t. every weight (same struct, non-const targets) and,
+ * optionally (dx != NULL), the input.  Must follow a training-mode forward on the same workspace.
+ * Gradients are ACCUMULATED into grads (caller zeroes them), matching autograd's .grad semantics. */
+typedef struct sumk_vasnet_grads {
+  float* Wk; float* Wq; float* Wv; float* Wo; float* W1; float* b1; float* w2; float* b2; float* ln_w; float* ln_b;
+} sumk_vasnet_grads;
+int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                         const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
+                         const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
+                         float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ BiLSTM
+ * One bidirectional LSTM layer (torch.nn.LSTM semantics: gates i,f,g,o; h0=c0=0), as used by DSN
+ * (summarizer/models/dsn.py:23-27,45) and sLSTM (summarizer/models/sumgan.py:27-32,43).
+ * dir 0 = forward, dir 1 = reverse.  Output h (n_rows, 2H) = [h_fwd || h_rev] per frame. */
+typedef struct sumk_lstm_layer_weights {
+  const float* w_ih[2]; /* (4H, In)  weight_ih_l{k}[_reverse] */
+  const float* w_hh[2]; /* (4H, H)   weight_hh_l{k}[_reverse] */
+  const float* b_ih[2]; /* (4H)      bias_ih_l{k}[_reverse]   */
+  const float* b_hh[2]; /* (4H)      bias_hh_l{k}[_reverse]   */
+} sumk_lstm_layer_weights;
+
+size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
+int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq,
+                              const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                              const sumk_lstm_layer_weights* w, float* h_out,
+                              void* workspace, size_t workspace_bytes, int32_t training, void* stream);
+
+typedef struct sumk_lstm_layer_grads {
+  float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
+} sumk_lstm_layer_grads;
+/* dh_out (n_rows,2H) -> accumulates weight grads; dx (n_rows,In) written if non-NULL.  Needs the workspace of
+ * a training-mode sumk_bilstm_layer_forward and that call's h_out. */
+int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* dh_out, int32_t In, int32_t H,
+                               int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                               const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* grads, float* dx,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-frame head shared by DSN (dsn.py:34-36,46: Linear(2H,1)+Sigmoid) and sLSTM (sumgan.py:33-34,44-45):
+ * scores[r] = sigmoid(dot(h[r,:F], w) + b[0]). */
+int sumk_frame_head_forward(const float* h, int32_t n_rows, int32_t F, const float* w, const float* b,
+                            float* scores, void* stream);
+/* dh[r,:] = ds[r]*s(1-s)*w ; dw += sum_r ds*s(1-s)*h[r,:] ; db += sum_r ds*s(1-s) */
+int sumk_frame_head_backward(const float* h, const float* scores, const float* dscores, int32_t n_rows,
+                             int32_t F, const float* w, float* dh, float* dw, float* db, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ DSN reward
+ * DSNTrainer.compute_reward (dsn.py:185-236) for E episodes of one or more packed videos:
+ * actions (E, n_rows) of 0/1 floats -> reward (E, n_seq).  Zero picks -> 0 (dsn.py:199-203); one pick ->
+ * r_div = 0 (dsn.py:211-214) and r_rep from that pick (the reference itself raises IndexError there). */
+size_t sumk_dsn_reward_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t n_episodes);
+int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                    const int32_t* seq_off_dev, const float* actions, int32_t n_episodes, int32_t far_sim,
+                    int32_t temp_dist_thre, float* reward, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ optimiser
+ * torch.optim.Adam(lr, betas, eps, weight_decay) exactly as the trainers construct it (vasnet.py:181,
+ * dsn.py:70-73): L2 weight decay folded into the gradient, bias-corrected moments.  One flat launch over
+ * n elements; `step` is the 1-based step count.  grad_scale multiplies the gradient first (used for
+ * clip_grad_norm_, dsn.py:145, and for the 1/world_size of a data-parallel average). */
+int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float grad_scale, void* stream);
+/* sum of squares of a flat buffer -> out[0] (for clip_grad_norm_); out must be zeroed by the caller. */
+int sumk_sumsq(const float* v, int64_t n, float* out, void* stream);
+
+#endif /* SUMK_PENDING */
+
+/* ------------------------------------------------------------------------------------------------ generic
+ * fp32 MFMA GEMM (the dominant kernel), exposed for tests and for bench.py's roofline probe:
+ * C(M,N) = A(M,K) * B^T  with B given as (N,K) row-major ("NT", both operands K-contiguous). */
+int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
+/* C(M,N) = A(M,K) * B(K,N) */
+int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
+/* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */
+int sumk_gemm_tn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
+
+/* Per-kernel timing for bench.py's roofline object: when enabled, launches of the tagged kernel are
+ * bracketed with hipEvents ON THE LAUNCH STREAM.  sumk_prof_read synchronises and returns the sums. */
+#define SUMK_PROF_GEMM_QKV 0
+#define SUMK_PROF_GEMM_ALL 1
+#define SUMK_PROF_LSTM_REC 2
+#define SUMK_PROF_NTAGS 8
+int sumk_prof_enable(int32_t on);
+int sumk_prof_read(int32_t tag, double* total_ms, int64_t* launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMK_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of libsumk.so (include/sumk.h).  The HIP library is the ONLY compute path: if it is missing
+or a call fails, this module raises -- there is no CPU or eager-PyTorch fallback anywhere in summarizer_amd."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsumk.so")
+
+c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+c_i32p = C.c_void_p
+HOST_I32P = C.POINTER(C.c_int32)
+
+
+class SumkError(RuntimeError):
+    pass
+
+
+class VasnetWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Wk", "Wq", "Wv", "Wo", "W1", "b1", "w2", "b2", "ln_w", "ln_b")]
+
+
+class VasnetGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Wk", "Wq", "Wv", "Wo", "W1", "b1", "w2", "b2", "ln_w", "ln_b")]
+
+
+class VasnetOpts(C.Structure):
+    _fields_ = [("scale", C.c_float), ("eps", C.c_float), ("ignore_self", C.c_int32), ("aperture", C.c_int32),
+                ("dropout_p", C.c_float), ("seed", C.c_uint64)]
+
+
+class LstmLayerWeights(C.Structure):
+    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2)]
+
+
+class LstmLayerGrads(C.Structure):
+    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2)]
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "sumk_last_error": (C.c_char_p, []),
+    "sumk_version": (C.c_int, []),
+    "sumk_device_count": (C.c_int, []),
+    "sumk_vasnet_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_vasnet_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
+                                      C.POINTER(VasnetOpts), c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
+                                      C.c_int32, C.c_void_p]),
+    "sumk_vasnet_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
+                                       C.POINTER(VasnetOpts), c_f32p, C.POINTER(VasnetGrads), c_f32p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+    "sumk_bilstm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_bilstm_layer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
+                                            C.POINTER(LstmLayerWeights), c_f32p, C.c_void_p, C.c_size_t, C.c_int32,
+                                            C.c_void_p]),
+    "sumk_bilstm_layer_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P,
+                                             c_i32p, C.POINTER(LstmLayerWeights), C.POINTER(LstmLayerGrads), c_f32p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sumk_frame_head_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sumk_frame_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
+                                           c_f32p, C.c_void_p]),
+    "sumk_dsn_reward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_dsn_reward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, c_f32p, C.c_int32, C.c_int32,
+                                  C.c_int32, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sumk_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "sumk_sumsq": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "sumk_gemm_nt": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_gemm_nn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_gemm_tn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_prof_enable": (C.c_int, [C.c_int32]),
+    "sumk_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+}
+
+PROF_GEMM_QKV, PROF_GEMM_ALL, PROF_LSTM_REC = 0, 1, 2
+
+PENDING = ['sumk_vasnet_backward', 'sumk_bilstm_workspace_bytes', 'sumk_bilstm_layer_forward', 'sumk_bilstm_layer_backward', 'sumk_frame_head_forward', 'sumk_frame_head_backward', 'sumk_dsn_reward_workspace_bytes', 'sumk_dsn_reward', 'sumk_adam_step', 'sumk_sumsq']   # fenced with `#if 0` in include/sumk.h until implemented
+for _n in PENDING:
+    _SIGS.pop(_n)
+
+_lib = None
+
+
+def load():
+    """Loads libsumk.so (once).  Raises SumkError -- loudly -- if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SumkError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C summarizer_amd/csrc`).  summarizer_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [n for n in _SIGS if not hasattr(lib, n)]
+    if missing:
+        raise SumkError(f"{LIB_PATH} does not export {missing}: stale build, rebuild with `make -C summarizer_amd/csrc`")
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sumk_last_error().decode(errors="replace")
+        raise SumkError(f"{what} failed (code {rc}): {msg}")
+
+
+def host_i32(arr):
+    """numpy int32 array -> ctypes pointer (array must stay alive for the call)."""
+    return arr.ctypes.data_as(HOST_I32P)

@@ -1,0 +1,344 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact f32 in / f32 accumulate, 64 FLOP/clk/SIMD).
+//
+// One kernel template serves every dense contraction on the scoring path:
+//   NT  C = A(M,K) . B(N,K)^T   QKV / out-proj / k1 projections (vasnet.py:114-116,132,140), Q.K^T (vasnet.py:118),
+//                               LSTM input projection (dsn.py:45), dgrad of the attention products
+//   NN  C = A(M,K) . B(K,N)     alpha.V (vasnet.py:131), dX = dY.W
+//   TN  C = A(K,M)^T . B(K,N)   weight gradients, dV = P^T dC, dK = dS^T Q
+// A launch is GROUPED: a device table of GemmProb sub-problems (one per video for the ragged per-sequence
+// products, a single entry for the packed row-wise projections); blockIdx.x -> (problem, m-tile, n-tile).
+//
+// Tiling: 256 threads = 4 waves (2x2); block tile BTxBT (128 or 64), BK = 32; each wave owns a (BT/2)^2 tile =
+// TMxTN MFMA tiles of 32x32 (16 accumulator VGPRs each).  Operands are staged global -> registers (16-B loads,
+// issued one k-tile ahead so HBM/L2 latency hides under the 64-cycle MFMAs) -> LDS.
+//   K-contiguous operand ("KC": A of NT/NN, B of NT): LDS image [row][BK+4]; the +4 pad makes the wave's
+//     ds_read_b128 (16 rows x 16 B per lane group) conflict free.  A lane reads 4 consecutive k at once.
+//   M/N-contiguous operand ("MC": B of NN, A and B of TN): LDS image [k][BT]; a lane reads [k][i] with
+//     ds_read_b32, consecutive lanes consecutive i.
+// K ORDER: the 32x32x2 MFMA takes k from the lane half h (A[i][k=h], B[k=h][j]).  Within an 8-wide k chunk we
+//   feed step j (0..3) with k = 4h + j for BOTH operands, so a KC lane's float4 supplies four MFMA steps.
+//   The sum over k is therefore re-associated relative to a sequential loop (fp32, ~1e-7 relative).
+#include "sumk_internal.h"
+
+namespace sumk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int KC_PITCH = BK + 4;
+
+struct GemmKArgs {
+  const float* A;
+  const float* B[4];
+  float* C;
+  const float* R;
+  const float* bias0[4];
+  const float* bias1[4];
+  const GemmProb* probs;
+  int32_t nprob;
+  int32_t n_group;
+  float alpha;
+};
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int BT, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
+  constexpr int WT = BT / 2;        // wave tile edge
+  constexpr int TM = WT / 32;       // MFMA tiles per wave along M (and N)
+  constexpr int NLD = BT / 32;      // float4 loads per thread per operand per k-tile
+  constexpr int A_ELEMS = A_KC ? BT * KC_PITCH : BK * BT;
+  constexpr int B_ELEMS = B_KC ? BT * KC_PITCH : BK * BT;
+  __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
+  float* sA = lds;
+  float* sB = lds + A_ELEMS;
+
+  // ---- which sub-problem / tile (wave-uniform scalar work)
+  const int tile = blockIdx.x;
+  int lo = 0, hi = ka.nprob - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (ka.probs[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+  }
+  const GemmProb P = ka.probs[lo];
+  const int local = tile - P.tile_start;
+  const int m0 = (local / P.tiles_n) * BT;
+  const int n0 = (local % P.tiles_n) * BT;
+  const int M = P.M, N = P.N, K = P.K;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // ---- per-thread global source descriptors (row pointers are fixed across the k loop)
+  const float* pa[NLD];
+  const float* pb[NLD];
+  if constexpr (A_KC) {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      int r = m0 + (tid >> 3) + 32 * p;
+      pa[p] = (r < M) ? ka.A + P.a_off + (int64_t)r * P.lda + (tid & 7) * 4 : nullptr;
+    }
+  } else {
+    // A stored (K,M): thread covers k rows kr + (256/(BT/4))*p, columns m0 + 4*(tid % (BT/4))
+    constexpr int TPR = BT / 4;  // threads per k-row
+    int c = m0 + (tid % TPR) * 4;
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) pa[p] = (c < M) ? ka.A + P.a_off + c : nullptr;
+  }
+  if constexpr (B_KC) {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      int n = n0 + (tid >> 3) + 32 * p;
+      const float* base = nullptr;
+      if (n < N) {
+        int g = 0, nl = n;
+        if (ka.n_group > 0) { g = n / ka.n_group; nl = n - g * ka.n_group; }
+        const float* bg = g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3];
+        base = bg + P.b_off + (int64_t)nl * P.ldb + (tid & 7) * 4;
+      }
+      pb[p] = base;
+    }
+  } else {
+    constexpr int TPR = BT / 4;
+    int c = n0 + (tid % TPR) * 4;
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) pb[p] = (c < N) ? ka.B[0] + P.b_off + c : nullptr;
+  }
+
+  float4 ra[NLD], rb[NLD];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      if constexpr (A_KC) {
+        int k = k0 + (tid & 7) * 4;
+        float4 v = z4;
+        if (pa[p] != nullptr && k < K) {
+          v = ldg4(pa[p] + k0);
+          if (k + 3 >= K) {  // ragged K tail: elements past K must contribute zero
+            if (k + 1 >= K) v.y = 0.f;
+            if (k + 2 >= K) v.z = 0.f;
+            v.w = 0.f;
+          }
+        }
+        ra[p] = v;
+      } else {
+        constexpr int TPR = BT / 4;
+        int k = k0 + tid / TPR + (256 / TPR) * p;
+        ra[p] = (pa[p] != nullptr && k < K) ? ldg4(pa[p] + (int64_t)k * P.lda) : z4;
+      }
+      if constexpr (B_KC) {
+        int k = k0 + (tid & 7) * 4;
+        float4 v = z4;
+        if (pb[p] != nullptr && k < K) {
+          v = ldg4(pb[p] + k0);
+          if (k + 3 >= K) {
+            if (k + 1 >= K) v.y = 0.f;
+            if (k + 2 >= K) v.z = 0.f;
+            v.w = 0.f;
+          }
+        }
+        rb[p] = v;
+      } else {
+        constexpr int TPR = BT / 4;
+        int k = k0 + tid / TPR + (256 / TPR) * p;
+        rb[p] = (pb[p] != nullptr && k < K) ? ldg4(pb[p] + (int64_t)k * P.ldb) : z4;
+      }
+    }
+  };
+  auto swrite = [&]() {
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
+      if constexpr (A_KC) {
+        *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * p) * KC_PITCH + (tid & 7) * 4]) = ra[p];
+      } else {
+        constexpr int TPR = BT / 4;
+        *reinterpret_cast<float4*>(&sA[(tid / TPR + (256 / TPR) * p) * BT + (tid % TPR) * 4]) = ra[p];
+      }
+      if constexpr (B_KC) {
+        *reinterpret_cast<float4*>(&sB[((tid >> 3) + 32 * p) * KC_PITCH + (tid & 7) * 4]) = rb[p];
+      } else {
+        constexpr int TPR = BT / 4;
+        *reinterpret_cast<float4*>(&sB[(tid / TPR + (256 / TPR) * p) * BT + (tid % TPR) * 4]) = rb[p];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+    swrite();
+    __syncthreads();
+    if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float av[TM][4], bv[TM][4];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        if constexpr (A_KC) {
+          float4 v = *reinterpret_cast<const float4*>(&sA[(wm * WT + t * 32 + li) * KC_PITCH + kk * 8 + 4 * lh]);
+          av[t][0] = v.x; av[t][1] = v.y; av[t][2] = v.z; av[t][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) av[t][j] = sA[(kk * 8 + 4 * lh + j) * BT + wm * WT + t * 32 + li];
+        }
+        if constexpr (B_KC) {
+          float4 v = *reinterpret_cast<const float4*>(&sB[(wn * WT + t * 32 + li) * KC_PITCH + kk * 8 + 4 * lh]);
+          bv[t][0] = v.x; bv[t][1] = v.y; bv[t][2] = v.z; bv[t][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[t][j] = sB[(kk * 8 + 4 * lh + j) * BT + wn * WT + t * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TM; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int tn = 0; tn < TM; ++tn) {
+    const int col = n0 + wn * WT + tn * 32 + li;
+    if (col >= N) continue;
+    float bsum = 0.f;
+    if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2) {
+      int g = 0, nl = col;
+      if (ka.n_group > 0) { g = col / ka.n_group; nl = col - g * ka.n_group; }
+      const float* b0 = g == 0 ? ka.bias0[0] : g == 1 ? ka.bias0[1] : g == 2 ? ka.bias0[2] : ka.bias0[3];
+      bsum = b0[nl];
+      if constexpr (EPI == EPI_BIAS2) {
+        const float* b1 = g == 0 ? ka.bias1[0] : g == 1 ? ka.bias1[1] : g == 2 ? ka.bias1[2] : ka.bias1[3];
+        bsum += b1[nl];
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WT + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= M) continue;
+        float v = acc[tm][tn][r];
+        float* cp = ka.C + P.c_off + (int64_t)row * P.ldc + col;
+        if constexpr (EPI == EPI_NONE) v *= ka.alpha;
+        if constexpr (EPI == EPI_RESIDUAL) v += ka.R[P.r_off + (int64_t)row * P.ldr + col];
+        if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bsum, 0.f);
+        if constexpr (EPI == EPI_BIAS2) v += bsum;
+        if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
+        *cp = v;
+      }
+    }
+  }
+}
+
+template <int BT, bool A_KC, bool B_KC>
+static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
+  dim3 grid(tiles), block(256);
+  switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
+    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
+    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
+    default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
+  }
+  return SUMK_OK;
+}
+
+int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream) {
+  SUMK_ARG(g.A && g.B[0] && g.C && g.probs, "gemm: null operand");
+  if (g.total_tiles <= 0) return SUMK_OK;
+  GemmKArgs ka;
+  ka.A = g.A;
+  for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
+  ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = g.nprob; ka.n_group = g.n_group; ka.alpha = g.alpha;
+  if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
+  prof_begin(SUMK_PROF_GEMM_ALL, stream);
+  int rc;
+  if (g.small_tile) {
+    if (layout == GEMM_NT) rc = launch_epi<64, true, true>(epi, ka, g.total_tiles, stream);
+    else if (layout == GEMM_NN) rc = launch_epi<64, true, false>(epi, ka, g.total_tiles, stream);
+    else rc = launch_epi<64, false, false>(epi, ka, g.total_tiles, stream);
+  } else {
+    if (layout == GEMM_NT) rc = launch_epi<128, true, true>(epi, ka, g.total_tiles, stream);
+    else if (layout == GEMM_NN) rc = launch_epi<128, true, false>(epi, ka, g.total_tiles, stream);
+    else rc = launch_epi<128, false, false>(epi, ka, g.total_tiles, stream);
+  }
+  prof_end(SUMK_PROF_GEMM_ALL, stream);
+  if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
+  if (rc != SUMK_OK) return rc;
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+__global__ void fill_single_prob_kernel(GemmProb* p, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int bt) {
+  GemmProb q;
+  q.a_off = q.b_off = q.c_off = q.r_off = 0;
+  q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldr = ldr;
+  q.tile_start = 0; q.tiles_n = (N + bt - 1) / bt;
+  for (int i = 0; i < 7; ++i) q.pad_[i] = 0;
+  *p = q;
+}
+
+int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int small_tile,
+                     hipStream_t stream) {
+  hipLaunchKernelGGL(fill_single_prob_kernel, dim3(1), dim3(1), 0, stream, dev_prob, M, N, K, lda, ldb, ldc, ldr,
+                     gemm_tile_dim(small_tile));
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+}  // namespace sumk
+
+// ------------------------------------------------------------------------------------------------ C ABI
+// The plain GEMM entry points keep their one-entry problem table in a small per-thread device scratch that is
+// allocated once (first call) -- the only allocation the library ever makes, and only on this test/bench path.
+namespace {
+sumk::GemmProb* scratch_prob() {
+  static thread_local sumk::GemmProb* p = nullptr;
+  if (!p) { if (hipMalloc(&p, sizeof(sumk::GemmProb)) != hipSuccess) p = nullptr; }
+  return p;
+}
+int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C, int M, int N, int K, int lda,
+               int ldb, void* stream) {
+  using namespace sumk;
+  SUMK_ARG(A && B && C, "gemm: null pointer");
+  SUMK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive size M=%d N=%d K=%d", M, N, K);
+  SUMK_ARG(lda % 4 == 0 && ldb % 4 == 0, "gemm: leading dimensions must be multiples of 4 (lda=%d ldb=%d)", lda, ldb);
+  GemmProb* p = scratch_prob();
+  SUMK_ARG(p != nullptr, "gemm: cannot allocate problem scratch");
+  hipStream_t s = (hipStream_t)stream;
+  int small = (M <= 64 || N <= 64) ? 1 : 0;
+  SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, small, s));
+  GemmLaunch g;
+  g.A = A; g.B[0] = B; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = small;
+  g.total_tiles = gemm_tiles(M, N, small);
+  return launch_gemm(layout, EPI_NONE, g, s);
+}
+}  // namespace
+
+extern "C" int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+  return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream);
+}
+extern "C" int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+  return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream);
+}
+extern "C" int sumk_gemm_tn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
+  return plain_gemm(sumk::GEMM_TN, A, B, C, M, N, K, M, N, stream);
+}

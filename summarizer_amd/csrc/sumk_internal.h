@@ -1,0 +1,79 @@
+// Internal declarations shared by the .hip translation units of libsumk.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/sumk.h"
+
+namespace sumk {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define SUMK_HIP(call)                                             \
+  do {                                                             \
+    hipError_t _e = (call);                                        \
+    if (_e != hipSuccess) return ::sumk::hip_fail(_e, #call);      \
+  } while (0)
+#define SUMK_ARG(cond, ...)                                        \
+  do {                                                             \
+    if (!(cond)) { ::sumk::set_error(__VA_ARGS__); return SUMK_ERR_ARG; } \
+  } while (0)
+#define SUMK_TRY(call)                                             \
+  do { int _r = (call); if (_r != SUMK_OK) return _r; } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------- GEMM
+// One sub-problem of a grouped launch.  Offsets are in elements from the launch's base pointers.
+struct GemmProb {
+  int64_t a_off, b_off, c_off, r_off;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldr;
+  int32_t tile_start;  // first tile id of this problem in the launch
+  int32_t tiles_n;     // tiles along N
+  int32_t pad_[7];
+};
+static_assert(sizeof(GemmProb) == 96, "GemmProb layout");
+
+enum GemmLayout { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+enum GemmEpi {
+  EPI_NONE = 0,       // C = alpha*acc
+  EPI_RESIDUAL = 1,   // C = acc + R
+  EPI_BIAS_RELU = 2,  // C = relu(acc + bias0[col])
+  EPI_BIAS2 = 3,      // C = acc + bias0[col] + bias1[col]
+  EPI_ACCUM = 4,      // C += alpha*acc   (gradient accumulation)
+};
+
+struct GemmLaunch {
+  const float* A = nullptr;
+  const float* B[4] = {nullptr, nullptr, nullptr, nullptr};  // B is split in groups of n_group columns of C
+  float* C = nullptr;
+  const float* R = nullptr;
+  const float* bias0[4] = {nullptr, nullptr, nullptr, nullptr};
+  const float* bias1[4] = {nullptr, nullptr, nullptr, nullptr};
+  const GemmProb* probs = nullptr;  // device table, nprob entries
+  int32_t nprob = 1;
+  int32_t n_group = 0;  // columns of C per B pointer (0 -> single group)
+  int32_t total_tiles = 0;
+  float alpha = 1.f;
+  int32_t small_tile = 0;  // 1 -> 64x64 block tiles (ragged per-sequence problems), 0 -> 128x128
+  int32_t prof_tag = -1;
+};
+
+// number of tiles an (M,N) problem takes with the chosen tile size
+inline int gemm_tile_dim(int small_tile) { return small_tile ? 64 : 128; }
+inline int gemm_tiles(int M, int N, int small_tile) {
+  int t = gemm_tile_dim(small_tile);
+  return ((M + t - 1) / t) * ((N + t - 1) / t);
+}
+int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream);
+// Fills ONE GemmProb (device) for a plain single problem; returns SUMK_OK.
+int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int small_tile,
+                     hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------- profiling
+void prof_begin(int tag, hipStream_t s);
+void prof_end(int tag, hipStream_t s);
+
+}  // namespace sumk

@@ -1,0 +1,113 @@
+"""Thin Python layer over the C ABI: packed-batch bookkeeping (sequence offsets, workspaces) and
+torch.autograd.Function wrappers.  Every arithmetic result comes from libsumk.so; nothing here computes on
+the CPU or through torch ops (torch only allocates the buffers and carries the stream)."""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SumkError
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise SumkError(f"{what}: expected a GPU tensor, got device={t.device}. summarizer_amd runs only on the "
+                        "HIP path (no CPU fallback); move the model and inputs to cuda.")
+    if t.dtype != torch.float32:
+        raise SumkError(f"{what}: expected float32, got {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SeqBatch:
+    """Packed batch geometry: frames of video s are rows [off[s], off[s+1])."""
+    _cache = {}
+
+    def __init__(self, lens, device):
+        lens = [int(v) for v in lens]
+        if len(lens) == 0 or min(lens) <= 0:
+            raise SumkError(f"empty video in batch: lens={lens}")
+        self.lens = lens
+        self.off_host = np.zeros(len(lens) + 1, dtype=np.int32)
+        np.cumsum(lens, out=self.off_host[1:])
+        self.n_seq = len(lens)
+        self.n_rows = int(self.off_host[-1])
+        self.device = device
+        self.off_dev = torch.from_numpy(self.off_host).to(device)
+
+    @classmethod
+    def get(cls, lens, device):
+        key = (tuple(int(v) for v in lens), str(device))
+        sb = cls._cache.get(key)
+        if sb is None:
+            if len(cls._cache) > 256:
+                cls._cache.clear()
+            sb = cls._cache[key] = SeqBatch(lens, device)
+        return sb
+
+    @property
+    def off_host_p(self):
+        return _lib.host_i32(self.off_host)
+
+    @property
+    def off_dev_p(self):
+        return C.c_void_p(self.off_dev.data_ptr())
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, persistent=False):
+    """Caller-owned scratch for one call.  Inference reuses one grow-only buffer per device; a training
+    forward gets its own buffer (it must survive until backward)."""
+    if persistent:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    buf = _ws_cache.get(str(device))
+    if buf is None or buf.numel() < nbytes:
+        buf = _ws_cache[str(device)] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+    return buf
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ------------------------------------------------------------------------------------------------ VASNet
+VASNET_FIELDS = [("Wk", "K.weight"), ("Wq", "Q.weight"), ("Wv", "V.weight"), ("Wo", "attention_head_projection.weight"),
+                 ("W1", "k1.weight"), ("b1", "k1.bias"), ("w2", "k2.weight"), ("b2", "k2.bias"),
+                 ("ln_w", "layer_norm.weight"), ("ln_b", "layer_norm.bias")]
+
+
+def _vasnet_structs(params, opts):
+    w = _lib.VasnetWeights()
+    for f, k in VASNET_FIELDS:
+        t = params[k]
+        _require_gpu(t, f"VASNet weight {k}")
+        if not t.is_contiguous():
+            raise SumkError(f"VASNet weight {k} must be contiguous")
+        setattr(w, f, t.data_ptr())
+    o = _lib.VasnetOpts(float(opts["scale"]), float(opts["eps"]), int(bool(opts.get("ignore_self", False))),
+                        -1 if opts.get("aperture") is None else int(opts["aperture"]),
+                        float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)))
+    return w, o
+
+
+def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, training=False):
+    """x: (n_rows, D) packed, contiguous, on GPU.  Returns (scores (n_rows,), workspace or None)."""
+    lib = _lib.load()
+    _require_gpu(x, "vasnet input")
+    if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
+        raise SumkError(f"vasnet input must be contiguous (n_rows={sb.n_rows}, D), got {tuple(x.shape)}")
+    D = x.shape[1]
+    w, o = _vasnet_structs(params, opts)
+    nbytes = lib.sumk_vasnet_workspace_bytes(D, sb.n_seq, sb.off_host_p, int(training))
+    if nbytes == 0:
+        _lib.check(-1, "sumk_vasnet_workspace_bytes")
+    ws = workspace(nbytes, x.device, persistent=training)
+    scores = torch.empty(sb.n_rows, dtype=torch.float32, device=x.device)
+    rc = lib.sumk_vasnet_forward(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o),
+                                 _p(pos_table), _p(pos_rows), _p(scores), _p(ws), ws.numel(), int(training), _stream())
+    _lib.check(rc, "sumk_vasnet_forward")
+    return scores, (ws if training else None)

@@ -1,0 +1,138 @@
+"""VASNet scorer on MI355X -- drop-in for `summarizer/models/vasnet.py` (reference) at the model-class level.
+
+Same constructor signature, same parameter names / state_dict keys, same forward contract
+`x (seq_len, batch, input_size) -> (seq_len, batch, 1)` (vasnet.py:18, 92-98), but the arithmetic runs in
+libsumk.so (HIP, gfx950) through `summarizer_amd.kernels`.  Reference quirks are reproduced, not fixed:
+the single LayerNorm applied twice (vasnet.py:137,143), scale = 1/sqrt(D) (vasnet.py:34), the tril*triu
+aperture mask (vasnet.py:126-127), the in-place positional-embedding add that mutates the caller's tensor
+(vasnet.py:109,111) including its batch>1 re-view for the sinusoid table.
+Extension (not in the reference): `score_packed` scores MANY videos of different lengths in one launch --
+that is the path `Trainer.test` / bench.py use to fill the GPU.
+"""
+import math
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from .. import kernels
+from .._lib import SumkError
+
+
+class VASNet(nn.Module):
+    def __init__(self, input_size=1024, max_length=None, pos_embed="simple", ignore_self=False,
+                 attention_aperture=None, scale=None, epsilon=1e-6, weight_init="xavier"):
+        super().__init__()
+        self.input_size = input_size
+        self.aperture = attention_aperture
+        self.ignore_self = ignore_self
+        self.scale = scale if scale is not None else 1 / np.sqrt(self.input_size)
+        self.epsilon = epsilon
+
+        # module creation order follows vasnet.py:42-66 so that a given torch seed yields the same weights
+        self.max_length = max_length
+        if self.max_length:
+            self.pos_embed_type = pos_embed
+            if pos_embed == "simple":
+                self.pos_embed = nn.Embedding(self.max_length, self.input_size)
+            elif pos_embed == "attention":
+                self.pos_embed = _sinusoid_table(self.max_length, self.input_size)   # plain tensor, like the reference
+            else:
+                self.max_length = None
+        self.dropout = nn.Dropout(0.5)
+        self.layer_norm = nn.LayerNorm(self.input_size, epsilon)
+        self.K = nn.Linear(self.input_size, self.input_size, bias=False)
+        self.Q = nn.Linear(self.input_size, self.input_size, bias=False)
+        self.V = nn.Linear(self.input_size, self.input_size, bias=False)
+        self.attention_head_projection = nn.Linear(self.input_size, self.input_size, bias=False)
+        self.k1 = nn.Linear(self.input_size, self.input_size)
+        self.k2 = nn.Linear(self.input_size, 1)
+
+        mats = [self.K, self.Q, self.V, self.attention_head_projection, self.k1, self.k2]   # vasnet.py:70-86
+        for m in mats:
+            if weight_init.lower() in ["he", "kaiming"]:
+                init.kaiming_uniform_(m.weight)
+            else:
+                init.xavier_uniform_(m.weight, gain=np.sqrt(2.0))
+        init.constant_(self.k1.bias, 0.1)
+        init.constant_(self.k2.bias, 0.1)
+        self._pos_rows_cache = {}
+        self._seed_counter = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _params(self):
+        return {k: v for k, v in self.named_parameters()}
+
+    def _opts(self, training):
+        o = dict(scale=float(self.scale), eps=float(self.epsilon), ignore_self=bool(self.ignore_self),
+                 aperture=self.aperture)
+        if self.aperture is not None:
+            assert isinstance(self.aperture, int)      # vasnet.py:125
+        if training:
+            self._seed_counter += 1
+            o.update(dropout_p=float(self.dropout.p), seed=(torch.initial_seed() * 1000003 + self._seed_counter) & (2**63 - 1))
+        return o
+
+    def _pos(self, T, B, device):
+        """(table, rows) for the in-place positional add over batch-major packed rows r = b*T + t."""
+        if self.max_length is None:
+            return None, None
+        assert self.max_length >= T, "input sequence has higher length than max_length"     # vasnet.py:107
+        key = (T, B, str(device))
+        rows = self._pos_rows_cache.get(key)
+        if rows is None:
+            r = np.arange(B * T)
+            idx = (r % T) if self.pos_embed_type == "simple" else (r // B)     # vasnet.py:108 vs :111 (re-view quirk)
+            rows = self._pos_rows_cache[key] = torch.from_numpy(idx.astype(np.int32)).to(device)
+        if self.pos_embed_type == "simple":
+            table = self.pos_embed.weight
+        else:
+            if self.pos_embed.device != device:
+                self.pos_embed = self.pos_embed.to(device)
+            table = self.pos_embed
+        return table, rows
+
+    # ------------------------------------------------------------------ reference interface
+    def forward(self, x):
+        """x: (seq_len, batch_size, input_size) -> (seq_len, batch_size, 1)"""
+        seq_len, batch_size, input_size = x.shape
+        assert self.input_size == input_size                                   # vasnet.py:104
+        kernels._require_gpu(x, "VASNet.forward")
+        if batch_size == 1 and x.is_contiguous():
+            xp = x.view(seq_len, input_size)                                   # zero-copy; pos add lands in caller's x
+        else:
+            xp = x.permute(1, 0, 2).contiguous().view(batch_size * seq_len, input_size)
+        table, rows = self._pos(seq_len, batch_size, x.device)
+        sb = kernels.SeqBatch.get([seq_len] * batch_size, x.device)
+        s = self._score(xp, sb, table, rows)
+        if table is not None and xp.data_ptr() != x.data_ptr():
+            with torch.no_grad():                                              # mirror the caller-visible mutation
+                x.copy_(xp.view(batch_size, seq_len, input_size).permute(1, 0, 2))
+        return s.view(batch_size, seq_len, 1).permute(1, 0, 2)
+
+    # ------------------------------------------------------------------ batched extension
+    def score_packed(self, x_packed, lens):
+        """x_packed: (sum(lens), D) frames of several videos back to back -> (sum(lens),) scores."""
+        assert self.max_length is None, "score_packed does not take positional embeddings (use forward)"
+        sb = kernels.SeqBatch.get(lens, x_packed.device)
+        return self._score(x_packed, sb, None, None)
+
+    def _score(self, xp, sb, table, rows):
+        training = self.training and torch.is_grad_enabled()
+        if training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            from ..autograd import VasnetFunction
+            names = [k for _, k in kernels.VASNET_FIELDS]
+            p = self._params()
+            return VasnetFunction.apply(xp, sb, self._opts(self.training), table, rows, names, *[p[n] for n in names])
+        scores, _ = kernels.vasnet_forward_packed(xp, sb, self._params(), self._opts(False), table, rows, training=False)
+        return scores
+
+
+def _sinusoid_table(max_length, d):
+    """vasnet.py:44-48 (vectorised; same float64 -> float32 rounding as the reference's element-wise loop)."""
+    pos = np.arange(max_length, dtype=np.float64)[:, None]
+    i = np.arange(0, d, 2, dtype=np.float64)[None, :]
+    tab = np.zeros((max_length, d), dtype=np.float32)
+    tab[:, 0::2] = np.sin(pos / (10000 ** ((2 * i) / d)))
+    tab[:, 1::2] = np.cos(pos / (10000 ** ((2 * (i + 1)) / d)))
+    return torch.from_numpy(tab)

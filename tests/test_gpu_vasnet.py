@@ -1,0 +1,148 @@
+"""GPU parity: the HIP VASNet path (through the C ABI) vs the oracle and the committed golden vectors.
+Bar (BASELINE.json north_star): per-frame scores within 1e-4 (fp32) of the reference's CPU path."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+import recipes as R
+from conftest import load_golden, js
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(dev, D, w, **kw):
+    from summarizer_amd.models.vasnet import VASNet
+    m = VASNet(input_size=D, **kw).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    return m.to(dev)
+
+
+def _gemm(lib_fn, A, B, M, N, K, dev):
+    from summarizer_amd import _lib
+    a = torch.from_numpy(A).to(dev); b = torch.from_numpy(B).to(dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    _lib.check(lib_fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    torch.cuda.synchronize()
+    return c.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (37, 64, 64), (130, 192, 100), (129, 128, 1024), (300, 3072, 1024), (64, 1000, 36), (257, 260, 8)])
+def test_gemm_layouts_vs_float64(dev, M, N, K):
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bt = rng.standard_normal((N, K)).astype(np.float32)      # asymmetric, non-square: catches transposed C writes
+    ref = A.astype(np.float64) @ Bt.astype(np.float64).T
+    tol = 2e-6 * np.abs(A).astype(np.float64) @ np.abs(Bt).astype(np.float64).T + 1e-6
+    got = _gemm(lib.sumk_gemm_nt, A, Bt, M, N, K, dev)
+    assert (np.abs(got - ref) <= tol).all(), f"NT max err {np.abs(got-ref).max()}"
+    if N % 4 == 0:
+        got = _gemm(lib.sumk_gemm_nn, A, np.ascontiguousarray(Bt.T), M, N, K, dev)
+        assert (np.abs(got - ref) <= tol).all(), f"NN max err {np.abs(got-ref).max()}"
+        if M % 4 == 0:
+            got = _gemm(lib.sumk_gemm_tn, np.ascontiguousarray(A.T), np.ascontiguousarray(Bt.T), M, N, K, dev)
+            assert (np.abs(got - ref) <= tol).all(), f"TN max err {np.abs(got-ref).max()}"
+
+
+def test_gemm_exact_integer_data_asymmetric(dev):
+    # exact small-integer operands: any mis-mapped fragment / k pairing shows up as an exact mismatch
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    M, N, K = 96, 160, 72
+    A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)
+    Bt = (np.arange(N * K).reshape(N, K) % 5 - 2).astype(np.float32) + (np.arange(N)[:, None] % 3)
+    ref = A.astype(np.int64) @ Bt.astype(np.int64).T
+    np.testing.assert_array_equal(_gemm(lib.sumk_gemm_nt, A, Bt, M, N, K, dev), ref)
+    np.testing.assert_array_equal(_gemm(lib.sumk_gemm_nn, A, np.ascontiguousarray(Bt.T), M, N, K, dev), ref)
+    np.testing.assert_array_equal(_gemm(lib.sumk_gemm_tn, np.ascontiguousarray(A.T), np.ascontiguousarray(Bt.T), M, N, K, dev), ref)
+
+
+def test_vasnet_small_goldens_all_variants(dev):
+    g = load_golden("vasnet_small")
+    meta = js(g["meta"])
+    worst = 0.0
+    for vname, m in meta.items():
+        w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{vname}/w/")}
+        model = _model(dev, 64, w, **m)
+        for c in sorted(k.split("/")[-1] for k in g.files if k.startswith(f"{vname}/x/")):
+            x = torch.from_numpy(g[f"{vname}/x/{c}"].copy()).to(dev)
+            with torch.no_grad():
+                y = model(x).cpu().numpy()
+            ref = g[f"{vname}/y/{c}"]
+            assert y.shape == ref.shape
+            np.testing.assert_allclose(y, ref, atol=TOL, rtol=0, equal_nan=True, err_msg=f"{vname} {c}")
+            worst = max(worst, float(np.nanmax(np.abs(y - ref))) if np.isfinite(ref).any() else 0.0)
+    print("worst |d| over small goldens:", worst)
+
+
+def test_vasnet_pos_embed_mutates_callers_tensor_like_reference(dev):
+    g = load_golden("vasnet_small")
+    w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith("pos_simple/w/")}
+    model = _model(dev, 64, w, max_length=64, pos_embed="simple")
+    x0 = g["pos_simple/x/T37B1"]
+    x = torch.from_numpy(x0.copy()).to(dev)
+    with torch.no_grad():
+        model(x)
+    np.testing.assert_allclose(x.cpu().numpy()[:, 0, :], x0[:, 0, :] + w["pos_embed.weight"][:37], atol=1e-6)
+
+
+def test_vasnet_full_size_goldens(dev):
+    g = load_golden("vasnet_full")
+    n = len([k for k in g.files if k.endswith("/cfg")])
+    for ci in range(n):
+        cfg = js(g[f"c{ci}/cfg"])
+        w = R.vasnet_weights(cfg["D"], cfg["wseed"]); x = R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"])
+        assert R.digest(w) == cfg["wdigest"] and R.digest({"x": x}) == cfg["xdigest"]
+        model = _model(dev, cfg["D"], w, **cfg["kw"])
+        with torch.no_grad():
+            y = model(torch.from_numpy(x).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(y, g[f"c{ci}/y"], atol=TOL, rtol=0, err_msg=str(cfg))
+
+
+def test_vasnet_packed_ragged_batch_vs_oracle(dev):
+    from oracle import vasnet_np
+    D = 256
+    w = R.vasnet_weights(D, 31)
+    lens = [1, 2, 63, 64, 65, 129, 200, 7]
+    xs = [R.features(T, 1, D, 40 + i) - 0.1 for i, T in enumerate(lens)]
+    for kw, okw in [(dict(), dict()), (dict(attention_aperture=9, ignore_self=True), dict(aperture=9, ignore_self=True))]:
+        model = _model(dev, D, w, **kw)
+        xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev)
+        with torch.no_grad():
+            s = model.score_packed(xp, lens).cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for i, x in enumerate(xs):
+            ref = vasnet_np.vasnet_forward(x, w, **okw)[:, 0, 0]
+            np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, equal_nan=True, err_msg=f"video {i} T={lens[i]} {kw}")
+
+
+def test_vasnet_batch_properties_full_size(dev):
+    """BASELINE-size properties that need no oracle: scoring is per-video independent (permuting / re-batching the
+    videos permutes the scores bit-for-bit) and repeatable."""
+    D = 1024
+    model = _model(dev, D, R.vasnet_weights(D, 5))
+    rng = np.random.default_rng(0)
+    lens = [int(np.ceil(v)) for v in rng.uniform(150, 320, 12)]
+    xs = [torch.from_numpy(R.features(T, 1, D, 90 + i)[:, 0, :]).to(dev) for i, T in enumerate(lens)]
+    with torch.no_grad():
+        a = model.score_packed(torch.cat(xs), lens)
+        b = model.score_packed(torch.cat(xs), lens)
+        perm = [5, 0, 11, 3, 7, 1, 9, 2, 10, 4, 8, 6]
+        c = model.score_packed(torch.cat([xs[i] for i in perm]), [lens[i] for i in perm])
+        singles = [model(x.unsqueeze(1))[:, 0, 0] for x in xs]
+    assert torch.equal(a, b)
+    off = np.concatenate([[0], np.cumsum(lens)]); offp = np.concatenate([[0], np.cumsum([lens[i] for i in perm])])
+    for j, i in enumerate(perm):
+        assert torch.equal(c[offp[j]:offp[j + 1]], a[off[i]:off[i + 1]])
+    for i, s in enumerate(singles):
+        assert torch.equal(s, a[off[i]:off[i + 1]])
+    assert bool(((a > 0) & (a < 1)).all())
