@@ -29,9 +29,11 @@ def tvsum_lens(n_videos=50):
     return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
 
 
-def cpu_baseline(lens, D, budget_s=12.0):
+def cpu_baseline(lens, D, budget_s=20.0):
     """Reference-equivalent stock-PyTorch CPU path (oracle/torch_port.py), one video per call as in
-    Trainer.test (summarizer/models/__init__.py:45-54), all host cores.  Bounded sample."""
+    Trainer.test (summarizer/models/__init__.py:45-54).  torch's intra-op pool is swept over a few thread
+    counts (a 256-thread pool is far slower than 16-32 threads on (T<=320, 1024) matrices); the BEST setting is
+    reported as `value`, with `cores` = the threads that setting used.  Bounded sample (~budget_s seconds)."""
     import recipes as R
     from oracle import torch_port
     torch.manual_seed(1234)
@@ -39,24 +41,28 @@ def cpu_baseline(lens, D, budget_s=12.0):
     m = VASNet(input_size=D)
     p = {k: v.detach() for k, v in m.named_parameters()}
     ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     xs = [torch.from_numpy(R.features(T, 1, D, 1000 + i)) for i, T in enumerate(lens)]
+    cands = sorted({t for t in (1, 8, 16, 32, 64, ncores) if t <= ncores})
+    per = budget_s / len(cands)
+    res = {}
     with torch.no_grad():
-        for x in xs[:3]:
-            torch_port.vasnet_scores(x, p)
-        frames, t0, n = 0, time.perf_counter(), 0
-        while True:
-            x = xs[n % len(xs)]
-            torch_port.vasnet_scores(x, p)
-            frames += x.shape[0]; n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s and n >= len(xs):
-                break
-            if el > 3 * budget_s:
-                break
-    return dict(value=frames / el, unit="frames/s", cores=ncores, kind="port",
-                sample=f"{n} single-video VASNet forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops, "
-                       f"{torch.get_num_threads()} threads) in {el:.1f}s")
+        for nt in cands:
+            torch.set_num_threads(nt)
+            torch_port.vasnet_scores(xs[0], p)
+            frames, t0, n = 0, time.perf_counter(), 0
+            while True:
+                x = xs[n % len(xs)]
+                torch_port.vasnet_scores(x, p)
+                frames += x.shape[0]; n += 1
+                el = time.perf_counter() - t0
+                if el > per:
+                    break
+            res[nt] = (frames / el, n, el)
+    best = max(res, key=lambda k: res[k][0])
+    return dict(value=round(res[best][0], 1), unit="frames/s", cores=best, kind="port",
+                sample=f"single-video VASNet forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops) on a "
+                       f"{ncores}-cpu host; frames/s by intra-op threads: " +
+                       ", ".join(f"{k}t={v[0]:.0f} ({v[1]} videos/{v[2]:.1f}s)" for k, v in res.items()))
 
 
 def main():

@@ -72,99 +72,87 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  // ---- per-thread global source descriptors (row pointers are fixed across the k loop)
+  // ---- per-thread global source descriptors (fixed across the k loop).  Loads are UNCONDITIONAL: addresses
+  // are clamped into the operand so the compiler can issue all of a k-tile's 16-B loads back to back and wait
+  // for them only where they are written to LDS.  Rows/columns past M or N are clamped, not zeroed -- they only
+  // feed output rows/columns the epilogue never stores.  Only the K tail must contribute zeros: masked in swrite.
   const float* pa[NLD];
   const float* pb[NLD];
+  constexpr int TPR = BT / 4;          // MC image: threads per k-row
+  constexpr int KROWS = 256 / TPR;     // MC image: k-rows covered per pass
+  const int kq4 = (tid & 7) * 4;       // KC image: this thread's k offset inside a k-tile
+  const int klast = K > 4 ? ((K + 3) & ~3) - 4 : 0;   // last legal float4 start along a K-contiguous row
   if constexpr (A_KC) {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
-      int r = m0 + (tid >> 3) + 32 * p;
-      pa[p] = (r < M) ? ka.A + P.a_off + (int64_t)r * P.lda + (tid & 7) * 4 : nullptr;
+      int r = min(m0 + (tid >> 3) + 32 * p, M - 1);
+      pa[p] = ka.A + P.a_off + (int64_t)r * P.lda;
     }
   } else {
-    // A stored (K,M): thread covers k rows kr + (256/(BT/4))*p, columns m0 + 4*(tid % (BT/4))
-    constexpr int TPR = BT / 4;  // threads per k-row
     int c = m0 + (tid % TPR) * 4;
+    c = c < M ? c : 0;
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) pa[p] = (c < M) ? ka.A + P.a_off + c : nullptr;
+    for (int p = 0; p < NLD; ++p) pa[p] = ka.A + P.a_off + c;
   }
   if constexpr (B_KC) {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
-      int n = n0 + (tid >> 3) + 32 * p;
-      const float* base = nullptr;
-      if (n < N) {
-        int g = 0, nl = n;
-        if (ka.n_group > 0) { g = n / ka.n_group; nl = n - g * ka.n_group; }
-        const float* bg = g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3];
-        base = bg + P.b_off + (int64_t)nl * P.ldb + (tid & 7) * 4;
-      }
-      pb[p] = base;
+      int n = min(n0 + (tid >> 3) + 32 * p, N - 1);
+      int g = 0, nl = n;
+      if (ka.n_group > 0) { g = n / ka.n_group; nl = n - g * ka.n_group; }
+      const float* bg = g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3];
+      pb[p] = bg + P.b_off + (int64_t)nl * P.ldb;
     }
   } else {
-    constexpr int TPR = BT / 4;
     int c = n0 + (tid % TPR) * 4;
+    c = c < N ? c : 0;
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) pb[p] = (c < N) ? ka.B[0] + P.b_off + c : nullptr;
+    for (int p = 0; p < NLD; ++p) pb[p] = ka.B[0] + P.b_off + c;
   }
 
   float4 ra[NLD], rb[NLD];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
+      if constexpr (A_KC) ra[p] = ldg4(pa[p] + min(k0 + kq4, klast));
+      else ra[p] = ldg4(pa[p] + (int64_t)min(k0 + tid / TPR + KROWS * p, K - 1) * P.lda);
+      if constexpr (B_KC) rb[p] = ldg4(pb[p] + min(k0 + kq4, klast));
+      else rb[p] = ldg4(pb[p] + (int64_t)min(k0 + tid / TPR + KROWS * p, K - 1) * P.ldb);
+    }
+  };
+  // zero what lies past K (wave-uniform branch: only the last k-tile of a ragged K pays for it)
+  auto ktail = [&](int k0) {
+    if (k0 + BK <= K) return;
+#pragma unroll
+    for (int p = 0; p < NLD; ++p) {
       if constexpr (A_KC) {
-        int k = k0 + (tid & 7) * 4;
-        float4 v = z4;
-        if (pa[p] != nullptr && k < K) {
-          v = ldg4(pa[p] + k0);
-          if (k + 3 >= K) {  // ragged K tail: elements past K must contribute zero
-            if (k + 1 >= K) v.y = 0.f;
-            if (k + 2 >= K) v.z = 0.f;
-            v.w = 0.f;
-          }
-        }
-        ra[p] = v;
+        int k = k0 + kq4;
+        if (k >= K) ra[p].x = 0.f;
+        if (k + 1 >= K) ra[p].y = 0.f;
+        if (k + 2 >= K) ra[p].z = 0.f;
+        if (k + 3 >= K) ra[p].w = 0.f;
       } else {
-        constexpr int TPR = BT / 4;
-        int k = k0 + tid / TPR + (256 / TPR) * p;
-        ra[p] = (pa[p] != nullptr && k < K) ? ldg4(pa[p] + (int64_t)k * P.lda) : z4;
+        if (k0 + tid / TPR + KROWS * p >= K) ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       if constexpr (B_KC) {
-        int k = k0 + (tid & 7) * 4;
-        float4 v = z4;
-        if (pb[p] != nullptr && k < K) {
-          v = ldg4(pb[p] + k0);
-          if (k + 3 >= K) {
-            if (k + 1 >= K) v.y = 0.f;
-            if (k + 2 >= K) v.z = 0.f;
-            v.w = 0.f;
-          }
-        }
-        rb[p] = v;
+        int k = k0 + kq4;
+        if (k >= K) rb[p].x = 0.f;
+        if (k + 1 >= K) rb[p].y = 0.f;
+        if (k + 2 >= K) rb[p].z = 0.f;
+        if (k + 3 >= K) rb[p].w = 0.f;
       } else {
-        constexpr int TPR = BT / 4;
-        int k = k0 + tid / TPR + (256 / TPR) * p;
-        rb[p] = (pb[p] != nullptr && k < K) ? ldg4(pb[p] + (int64_t)k * P.ldb) : z4;
+        if (k0 + tid / TPR + KROWS * p >= K) rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
   auto swrite = [&]() {
 #pragma unroll
     for (int p = 0; p < NLD; ++p) {
-      if constexpr (A_KC) {
-        *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * p) * KC_PITCH + (tid & 7) * 4]) = ra[p];
-      } else {
-        constexpr int TPR = BT / 4;
-        *reinterpret_cast<float4*>(&sA[(tid / TPR + (256 / TPR) * p) * BT + (tid % TPR) * 4]) = ra[p];
-      }
-      if constexpr (B_KC) {
-        *reinterpret_cast<float4*>(&sB[((tid >> 3) + 32 * p) * KC_PITCH + (tid & 7) * 4]) = rb[p];
-      } else {
-        constexpr int TPR = BT / 4;
-        *reinterpret_cast<float4*>(&sB[(tid / TPR + (256 / TPR) * p) * BT + (tid % TPR) * 4]) = rb[p];
-      }
+      if constexpr (A_KC) *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * p) * KC_PITCH + kq4]) = ra[p];
+      else *reinterpret_cast<float4*>(&sA[(tid / TPR + KROWS * p) * BT + (tid % TPR) * 4]) = ra[p];
+      if constexpr (B_KC) *reinterpret_cast<float4*>(&sB[((tid >> 3) + 32 * p) * KC_PITCH + kq4]) = rb[p];
+      else *reinterpret_cast<float4*>(&sB[(tid / TPR + KROWS * p) * BT + (tid % TPR) * 4]) = rb[p];
     }
   };
 
@@ -179,6 +167,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
   gload(0);
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();
+    ktail(k0);
     swrite();
     __syncthreads();
     if (k0 + BK < K) gload(k0 + BK);
@@ -238,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
         float* cp = ka.C + P.c_off + (int64_t)row * P.ldc + col;
         if constexpr (EPI == EPI_NONE) v *= ka.alpha;
         if constexpr (EPI == EPI_RESIDUAL) v += ka.R[P.r_off + (int64_t)row * P.ldr + col];
-        if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bsum, 0.f);
+        if constexpr (EPI == EPI_BIAS_RELU) { v += bsum; v = (v < 0.f) ? 0.f : v; }  // NaN-propagating, like torch.relu
         if constexpr (EPI == EPI_BIAS2) v += bsum;
         if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
         *cp = v;

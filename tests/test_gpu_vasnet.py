@@ -59,7 +59,7 @@ def test_gemm_exact_integer_data_asymmetric(dev):
     lib = _lib.load()
     M, N, K = 96, 160, 72
     A = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)
-    Bt = (np.arange(N * K).reshape(N, K) % 5 - 2).astype(np.float32) + (np.arange(N)[:, None] % 3)
+    Bt = ((np.arange(N * K).reshape(N, K) % 5 - 2) + (np.arange(N)[:, None] % 3)).astype(np.float32)
     ref = A.astype(np.int64) @ Bt.astype(np.int64).T
     np.testing.assert_array_equal(_gemm(lib.sumk_gemm_nt, A, Bt, M, N, K, dev), ref)
     np.testing.assert_array_equal(_gemm(lib.sumk_gemm_nn, A, np.ascontiguousarray(Bt.T), M, N, K, dev), ref)
