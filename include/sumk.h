@@ -70,18 +70,6 @@ int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int32_t* seq_o
                         float* scores, void* workspace, size_t workspace_bytes, int32_t training,
                         void* stream);
 
-#if 0 /* SUMK_PENDING: declared when implemented */
-/* Gradients of sum_r dscores[r]*scores[r] w.r.t. every weight (same struct, non-const targets) and,
- * optionally (dx != NULL), the input.  Must follow a training-mode forward on the same workspace.
- * Gradients are ACCUMULATED into grads (caller zeroes them), matching autograd's .grad semantics. */
-typedef struct sumk_vasnet_grads {
-  float* Wk; float* Wq; float* Wv; float* Wo; float* W1; float* b1; float* w2; float* b2; float* ln_w; float* ln_b;
-} sumk_vasnet_grads;
-int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
-                         const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
-                         const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
-                         float* dx, void* workspace, size_t workspace_bytes, void* stream);
-
 /* ------------------------------------------------------------------------------------------------ BiLSTM
  * One bidirectional LSTM layer (torch.nn.LSTM semantics: gates i,f,g,o; h0=c0=0), as used by DSN
  * (summarizer/models/dsn.py:23-27,45) and sLSTM (summarizer/models/sumgan.py:27-32,43).
@@ -99,6 +87,23 @@ int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_s
                               const sumk_lstm_layer_weights* w, float* h_out,
                               void* workspace, size_t workspace_bytes, int32_t training, void* stream);
 
+/* Per-frame head shared by DSN (dsn.py:34-36,46: Linear(2H,1)+Sigmoid) and sLSTM (sumgan.py:33-34,44-45):
+ * scores[r] = sigmoid(dot(h[r,:F], w) + b[0]). */
+int sumk_frame_head_forward(const float* h, int32_t n_rows, int32_t F, const float* w, const float* b,
+                            float* scores, void* stream);
+
+#if 0 /* SUMK_PENDING: declared when implemented */
+/* Gradients of sum_r dscores[r]*scores[r] w.r.t. every weight (same struct, non-const targets) and,
+ * optionally (dx != NULL), the input.  Must follow a training-mode forward on the same workspace.
+ * Gradients are ACCUMULATED into grads (caller zeroes them), matching autograd's .grad semantics. */
+typedef struct sumk_vasnet_grads {
+  float* Wk; float* Wq; float* Wv; float* Wo; float* W1; float* b1; float* w2; float* b2; float* ln_w; float* ln_b;
+} sumk_vasnet_grads;
+int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                         const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
+                         const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
+                         float* dx, void* workspace, size_t workspace_bytes, void* stream);
+
 typedef struct sumk_lstm_layer_grads {
   float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
 } sumk_lstm_layer_grads;
@@ -109,10 +114,6 @@ int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* 
                                const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* grads, float* dx,
                                void* workspace, size_t workspace_bytes, void* stream);
 
-/* Per-frame head shared by DSN (dsn.py:34-36,46: Linear(2H,1)+Sigmoid) and sLSTM (sumgan.py:33-34,44-45):
- * scores[r] = sigmoid(dot(h[r,:F], w) + b[0]). */
-int sumk_frame_head_forward(const float* h, int32_t n_rows, int32_t F, const float* w, const float* b,
-                            float* scores, void* stream);
 /* dh[r,:] = ds[r]*s(1-s)*w ; dw += sum_r ds*s(1-s)*h[r,:] ; db += sum_r ds*s(1-s) */
 int sumk_frame_head_backward(const float* h, const float* scores, const float* dscores, int32_t n_rows,
                              int32_t F, const float* w, float* dh, float* dw, float* db, void* stream);

@@ -111,3 +111,45 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
                                  _p(pos_table), _p(pos_rows), _p(scores), _p(ws), ws.numel(), int(training), _stream())
     _lib.check(rc, "sumk_vasnet_forward")
     return scores, (ws if training else None)
+
+
+# ------------------------------------------------------------------------------------------------ BiLSTM scorers
+def _lstm_layer_struct(params, prefix, layer):
+    w = _lib.LstmLayerWeights()
+    for d, suf in enumerate(("", "_reverse")):
+        for f, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
+            t = params[f"{prefix}{n}_l{layer}{suf}"]
+            _require_gpu(t, f"LSTM weight {prefix}{n}_l{layer}{suf}")
+            if not t.is_contiguous():
+                raise SumkError(f"LSTM weight {prefix}{n}_l{layer}{suf} must be contiguous")
+            getattr(w, f)[d] = t.data_ptr()
+    return w
+
+
+def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False):
+    """x: (n_rows, In) packed -> h (n_rows, 2H) = [h_fwd || h_rev].  Returns (h, workspace or None)."""
+    lib = _lib.load()
+    _require_gpu(x, "bilstm input")
+    if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
+        raise SumkError(f"bilstm input must be contiguous (n_rows={sb.n_rows}, In), got {tuple(x.shape)}")
+    In = x.shape[1]
+    w = _lstm_layer_struct(params, prefix, layer)
+    nbytes = lib.sumk_bilstm_workspace_bytes(In, H, sb.n_seq, sb.off_host_p, int(training))
+    if nbytes == 0:
+        _lib.check(-1, "sumk_bilstm_workspace_bytes")
+    ws = workspace(nbytes, x.device, persistent=training)
+    h = torch.empty(sb.n_rows, 2 * H, dtype=torch.float32, device=x.device)
+    rc = lib.sumk_bilstm_layer_forward(_p(x), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), _p(h), _p(ws),
+                                       ws.numel(), int(training), _stream())
+    _lib.check(rc, "sumk_bilstm_layer_forward")
+    return h, (ws if training else None)
+
+
+def frame_head_forward(h, w, b):
+    """scores = sigmoid(h @ w.T + b) for h (n_rows, F), w (1, F) or (F,), b (1,)."""
+    lib = _lib.load()
+    _require_gpu(h, "frame head input")
+    scores = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+    rc = lib.sumk_frame_head_forward(_p(h), h.shape[0], h.shape[1], _p(w), _p(b), _p(scores), _stream())
+    _lib.check(rc, "sumk_frame_head_forward")
+    return scores

@@ -1,0 +1,98 @@
+"""GPU parity: BiLSTM scorers (DSN, sLSTM) through the C ABI vs golden vectors from the real reference and
+vs the numpy oracle.  Bar: 1e-4 on per-frame probabilities."""
+import numpy as np
+import pytest
+import torch
+
+import recipes as R
+from conftest import load_golden, js
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _load(m, w, dev):
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    return m.eval().to(dev)
+
+
+def test_lstm_small_goldens(dev):
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.sumgan import sLSTM
+    g = load_golden("lstm_small")
+    for name, mk in [("dsn_small", lambda: DSN(64, 16, 1)), ("dsn_small_2l", lambda: DSN(64, 16, 2)), ("slstm_small", lambda: sLSTM(64, 32, 2))]:
+        w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{name}/w/")}
+        m = _load(mk(), w, dev)
+        for c in sorted(k.split("/")[-1] for k in g.files if k.startswith(f"{name}/x/")):
+            with torch.no_grad():
+                y = m(torch.from_numpy(g[f"{name}/x/{c}"].copy()).to(dev)).cpu().numpy()
+            np.testing.assert_allclose(y, g[f"{name}/y/{c}"], atol=TOL, rtol=0, err_msg=f"{name} {c}")
+
+
+def test_lstm_hidden_states_vs_golden(dev):
+    from summarizer_amd import kernels
+    from summarizer_amd.models.dsn import DSN
+    g = load_golden("lstm_small")
+    w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith("dsn_small/w/")}
+    m = _load(DSN(64, 16, 1), w, dev)
+    x = torch.from_numpy(g["dsn_small/x/T37B1"][:, 0, :].copy()).to(dev)
+    sb = kernels.SeqBatch.get([37], dev)
+    h, _ = kernels.bilstm_layer_forward(x, sb, dict(m.named_parameters()), "rnn.", 0, 16)
+    np.testing.assert_allclose(h.detach().cpu().numpy(), g["dsn_small/h/T37B1"][:, 0, :], atol=2e-5)
+
+
+def test_lstm_full_size_goldens(dev):
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.sumgan import sLSTM
+    g = load_golden("lstm_full")
+    for ci in range(3):
+        cfg = js(g[f"c{ci}/cfg"])
+        if cfg["kind"] == "dsn":
+            w = R.lstm_weights("rnn.", cfg["D"], cfg["H"], cfg["L"], cfg["wseed"], "out.0."); m = DSN(cfg["D"], cfg["H"], cfg["L"])
+        else:
+            w = R.lstm_weights("lstm.", cfg["D"], cfg["H"], cfg["L"], cfg["wseed"], "out."); m = sLSTM(cfg["D"], cfg["H"], cfg["L"])
+        assert R.digest(w) == cfg["wdigest"]
+        m = _load(m, w, dev)
+        with torch.no_grad():
+            y = m(torch.from_numpy(R.features(cfg["T"], 1, cfg["D"], cfg["xseed"])).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(y, g[f"c{ci}/y"], atol=TOL, rtol=0, err_msg=str(cfg))
+
+
+def test_dsn_packed_ragged_batch_vs_oracle(dev):
+    from oracle import lstm_np
+    from summarizer_amd.models.dsn import DSN
+    D, H = 128, 40          # H not a multiple of 8/32: exercises the k-chunk and unit-block tails
+    w = R.lstm_weights("rnn.", D, H, 1, 77, "out.0.")
+    m = _load(DSN(D, H, 1), w, dev)
+    lens = [1, 2, 33, 64, 5, 100] + [3] * 30          # > 32 videos: two M tiles in the step kernel
+    xs = [R.features(T, 1, D, 500 + i) - 0.2 for i, T in enumerate(lens)]
+    with torch.no_grad():
+        s = m.score_packed(torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev), lens).cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, x in enumerate(xs):
+        ref = lstm_np.dsn_forward(x, w)[:, 0, 0]
+        np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i} T={lens[i]}")
+
+
+def test_dsn_batch_properties_full_size(dev):
+    from summarizer_amd.models.dsn import DSN
+    torch.manual_seed(3)
+    m = DSN().eval().to(dev)
+    lens = [int(np.ceil(v)) for v in np.random.default_rng(1).uniform(150, 320, 10)]
+    xs = [torch.from_numpy(R.features(T, 1, 1024, 700 + i)[:, 0, :]).to(dev) for i, T in enumerate(lens)]
+    with torch.no_grad():
+        a = m.score_packed(torch.cat(xs), lens)
+        b = m.score_packed(torch.cat(xs[::-1]), lens[::-1])
+        singles = [m(x.unsqueeze(1))[:, 0, 0] for x in xs]
+    off = np.concatenate([[0], np.cumsum(lens)]); offr = np.concatenate([[0], np.cumsum(lens[::-1])])
+    for i in range(len(lens)):
+        j = len(lens) - 1 - i
+        assert torch.equal(b[offr[j]:offr[j + 1]], a[off[i]:off[i + 1]])
+        assert torch.equal(singles[i], a[off[i]:off[i + 1]])
+    assert bool(((a > 0) & (a < 1)).all())
