@@ -149,6 +149,13 @@ int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N,
 /* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */
 int sumk_gemm_tn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ shot selection
+ * HOST function (no GPU work).  Replaces knapsack_ortools (summarizer/utils/knapsack.py:5-23): maximise
+ * sum(values[i]) subject to sum(weights[i]) <= capacity; selected[i] = 1 for chosen items.  values/weights are the
+ * integers the reference builds (knapsack.py:11-15: int(score*1000), int(n_frames_of_segment)). */
+int sumk_knapsack_dp(const int64_t* values, const int64_t* weights, int32_t n_items, int64_t capacity,
+                     uint8_t* selected);
+
 /* Per-kernel timing for bench.py's roofline object: when enabled, launches of the tagged kernel are
  * bracketed with hipEvents ON THE LAUNCH STREAM.  sumk_prof_read synchronises and returns the sums. */
 #define SUMK_PROF_GEMM_QKV 0

@@ -1,0 +1,75 @@
+"""CPU: host-side evaluation tail (summarizer_amd/utils/eval.py + native knapsack) vs golden vectors from the real
+reference and vs the literal oracle.  Bit-exact for the integer / index work (upsample, summaries, picks)."""
+import numpy as np
+import pytest
+
+import recipes as R
+from conftest import load_golden
+from oracle import eval_np, knapsack_np
+from summarizer_amd.utils import eval as E
+from summarizer_amd.utils.knapsack import knapsack_ortools
+
+
+def test_metrics_vs_reference_goldens():
+    g = load_golden("metrics")
+    for ci in range(3):
+        T, U, seed = g[f"c{ci}/T_U_seed"]
+        v = R.synthetic_video(int(T), int(seed), n_users=int(U))
+        sc = g[f"c{ci}/scores"]
+        fs = E.upsample(sc, v["n_frames"], v["picks"])
+        np.testing.assert_array_equal(fs, g[f"c{ci}/frame_scores"])
+        assert fs.dtype == np.float32
+        summ = E.generate_summary(sc, v["change_points"], v["n_frames"], v["n_frame_per_seg"].tolist(), v["picks"], 0.15, "rank")
+        np.testing.assert_array_equal(summ, g[f"c{ci}/summary_rank"])
+        assert summ.dtype == np.float32
+        np.testing.assert_array_equal(np.array(E.evaluate_summary(summ, v["user_summary"])), g[f"c{ci}/fscore"])
+        np.testing.assert_array_equal(np.array(E.evaluate_summary(summ[:-7], v["user_summary"])), g[f"c{ci}/fscore_short"])
+        long = np.concatenate([summ, np.ones(5, np.float32)])
+        np.testing.assert_array_equal(np.array(E.evaluate_summary(long, v["user_summary"])), g[f"c{ci}/fscore_long"])
+        assert E.evaluate_scores(fs, v["user_scores"]) == g[f"c{ci}/spearman"]
+        if np.isfinite(g[f"c{ci}/kendall"]):
+            assert E.evaluate_scores(fs, v["user_scores"], metric="kendalltau") == g[f"c{ci}/kendall"]
+    with pytest.raises(KeyError):
+        E.evaluate_scores(fs, v["user_scores"], metric="pearson")
+    with pytest.raises(KeyError):
+        E.generate_summary(sc, v["change_points"], v["n_frames"], v["n_frame_per_seg"].tolist(), v["picks"], 0.15, "greedy")
+
+
+def test_upsample_edge_cases_vs_literal_oracle():
+    rng = np.random.default_rng(0)
+    for T, n_frames, picks in [
+        (5, 75, 15 * np.arange(5)),                     # sentinel appended
+        (5, 60, np.array([0, 15, 30, 45, 60])),         # last pick == n_frames: no sentinel, 4 intervals
+        (3, 50, np.array([5, 20, 35])),                 # first pick > 0 -> leading zeros
+        (1, 10, np.array([0])),
+        (4, 61, np.array([0, 15, 30, 45], dtype=np.float32)),   # non-int dtype is cast (eval.py:25-26)
+    ]:
+        sc = rng.random(T).astype(np.float32)
+        np.testing.assert_array_equal(E.upsample(sc, n_frames, picks), eval_np.upsample(sc, n_frames, picks))
+
+
+def test_knapsack_native_matches_oracle_and_bruteforce_value():
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        n = int(rng.integers(1, 14))
+        vals = rng.random(n).tolist()
+        wts = rng.integers(1, 60, n).tolist()
+        cap = int(rng.integers(0, 200))
+        picks = knapsack_ortools(vals, wts, n, cap)
+        assert picks == knapsack_np.knapsack_dp(vals, wts, n, cap)          # bit-exact vs the CPU restatement
+        v, w = knapsack_np.knapsack_value(vals, wts, picks)
+        assert w <= cap
+        if trial < 60:
+            assert v == knapsack_np.knapsack_bruteforce_value(vals, wts, cap)
+
+
+def test_knapsack_summary_budget_and_equality_with_oracle():
+    for ci, T in enumerate([300, 120, 640]):
+        v = R.synthetic_video(T, 40 + ci, n_users=5)
+        sc = np.random.default_rng(ci).random(T).astype(np.float32)
+        args = (sc, v["change_points"], v["n_frames"], v["n_frame_per_seg"].tolist(), v["picks"], 0.15, "knapsack")
+        a = E.generate_summary(*args)
+        b = eval_np.generate_summary(*args)
+        np.testing.assert_array_equal(a, b)
+        assert a.sum() <= int(np.floor(v["n_frames"] * 0.15))
+        assert a.shape == (v["n_frames"],)
