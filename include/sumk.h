@@ -92,7 +92,6 @@ int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_s
 int sumk_frame_head_forward(const float* h, int32_t n_rows, int32_t F, const float* w, const float* b,
                             float* scores, void* stream);
 
-#if 0 /* SUMK_PENDING: declared when implemented */
 /* Gradients of sum_r dscores[r]*scores[r] w.r.t. every weight (same struct, non-const targets) and,
  * optionally (dx != NULL), the input.  Must follow a training-mode forward on the same workspace.
  * Gradients are ACCUMULATED into grads (caller zeroes them), matching autograd's .grad semantics. */
@@ -104,6 +103,7 @@ int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t
                          const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+#if 0 /* SUMK_PENDING: declared when implemented */
 typedef struct sumk_lstm_layer_grads {
   float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
 } sumk_lstm_layer_grads;
@@ -127,6 +127,8 @@ int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq
                     const int32_t* seq_off_dev, const float* actions, int32_t n_episodes, int32_t far_sim,
                     int32_t temp_dist_thre, float* reward, void* workspace, size_t workspace_bytes, void* stream);
 
+#endif /* SUMK_PENDING */
+
 /* ------------------------------------------------------------------------------------------------ optimiser
  * torch.optim.Adam(lr, betas, eps, weight_decay) exactly as the trainers construct it (vasnet.py:181,
  * dsn.py:70-73): L2 weight decay folded into the gradient, bias-corrected moments.  One flat launch over
@@ -135,10 +137,10 @@ int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq
 int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
-/* sum of squares of a flat buffer -> out[0] (for clip_grad_norm_); out must be zeroed by the caller. */
-int sumk_sumsq(const float* v, int64_t n, float* out, void* stream);
-
-#endif /* SUMK_PENDING */
+/* out[0] += sum of squares of a flat buffer (for clip_grad_norm_), deterministic two-stage reduction.
+ * workspace: sumk_sumsq_workspace_bytes() bytes of device scratch. */
+size_t sumk_sumsq_workspace_bytes(void);
+int sumk_sumsq(const float* v, int64_t n, float* out, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ generic
  * fp32 MFMA GEMM (the dominant kernel), exposed for tests and for bench.py's roofline probe:

@@ -63,7 +63,8 @@ _SIGS = {
                                   C.c_int32, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
-    "sumk_sumsq": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "sumk_sumsq_workspace_bytes": (C.c_size_t, []),
+    "sumk_sumsq": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_void_p]),
     "sumk_gemm_nt": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_nn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_tn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -75,7 +76,7 @@ _SIGS = {
 
 PROF_GEMM_QKV, PROF_GEMM_ALL, PROF_LSTM_REC = 0, 1, 2
 
-PENDING = ['sumk_vasnet_backward', 'sumk_bilstm_layer_backward', 'sumk_frame_head_backward', 'sumk_dsn_reward_workspace_bytes', 'sumk_dsn_reward', 'sumk_adam_step', 'sumk_sumsq']   # fenced with `#if 0` in include/sumk.h until implemented
+PENDING = ['sumk_bilstm_layer_backward', 'sumk_frame_head_backward', 'sumk_dsn_reward_workspace_bytes', 'sumk_dsn_reward']   # fenced with `#if 0` in include/sumk.h until implemented
 for _n in PENDING:
     _SIGS.pop(_n)
 

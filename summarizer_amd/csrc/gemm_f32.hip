@@ -19,6 +19,7 @@
 //   feed step j (0..3) with k = 4h + j for BOTH operands, so a KC lane's float4 supplies four MFMA steps.
 //   The sum over k is therefore re-associated relative to a sequential loop (fp32, ~1e-7 relative).
 #include "sumk_internal.h"
+#include <algorithm>
 
 namespace sumk {
 
@@ -289,6 +290,97 @@ int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, 
                      hipStream_t stream) {
   hipLaunchKernelGGL(fill_single_prob_kernel, dim3(1), dim3(1), 0, stream, dev_prob, M, N, K, lda, ldb, ldc, ldr,
                      gemm_tile_dim(small_tile));
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+// ------------------------------------------------------------------------------------------- split-K (TN)
+// Weight gradients contract over ALL frames (K = n_rows ~ 1e4) into a small (M,N): one tile grid would leave most
+// CUs idle, so K is cut into S slices, each slice writes its own fp32 slab, and a second kernel sums the slabs in a
+// fixed order (deterministic; no float atomics) and ACCUMULATES alpha*sum into up to four row-group outputs.
+__global__ void splitk_setup_kernel(GemmProb* p, int S, int M, int N, int K, int kchunk, int lda, int ldb, int bt) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  GemmProb q;
+  int k0 = s * kchunk;
+  q.a_off = (int64_t)k0 * lda; q.b_off = (int64_t)k0 * ldb; q.c_off = (int64_t)s * M * N; q.r_off = 0;
+  q.M = M; q.N = N; q.K = min(kchunk, K - k0); q.lda = lda; q.ldb = ldb; q.ldc = N; q.ldr = 0;
+  int tn = (N + bt - 1) / bt, tm = (M + bt - 1) / bt;
+  q.tile_start = s * tm * tn; q.tiles_n = tn;
+  for (int i = 0; i < 7; ++i) q.pad_[i] = 0;
+  p[s] = q;
+}
+
+struct SlabReduceArgs { const float* slab; float* out[4]; int32_t S, M, N, rows_per_out, ldo; float alpha; };
+__global__ void slab_reduce_kernel(SlabReduceArgs a) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t mn = (int64_t)a.M * a.N;
+  if (idx >= mn) return;
+  float v = 0.f;
+  for (int s = 0; s < a.S; ++s) v += a.slab[(int64_t)s * mn + idx];
+  int row = (int)(idx / a.N), col = (int)(idx % a.N);
+  int g = row / a.rows_per_out, rl = row - g * a.rows_per_out;
+  float* o = g == 0 ? a.out[0] : g == 1 ? a.out[1] : g == 2 ? a.out[2] : a.out[3];
+  o[(int64_t)rl * a.ldo + col] += a.alpha * v;
+}
+
+int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
+                         size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
+                         int ldo, float alpha, hipStream_t stream) {
+  SUMK_ARG(M > 0 && N > 0 && K > 0, "splitk: bad shape");
+  SUMK_ARG(slab_elems >= (size_t)M * N, "splitk: slab too small");
+  const int small = gemm_tiles(M, N, 0) >= 64 ? 0 : 1;
+  const int tiles = gemm_tiles(M, N, small);
+  int S = (1024 + tiles - 1) / tiles;
+  S = std::min(S, (K + 63) / 64);
+  S = std::min(S, (int)std::min<size_t>(slab_elems / ((size_t)M * N), (size_t)probs_cap));
+  S = std::max(S, 1);
+  int kchunk = ((K + S - 1) / S + 31) / 32 * 32;
+  S = (K + kchunk - 1) / kchunk;
+  hipLaunchKernelGGL(splitk_setup_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, probs_dev, S, M, N, K, kchunk, lda, ldb,
+                     gemm_tile_dim(small));
+  GemmLaunch g;
+  g.A = A; g.B[0] = B; g.C = slab; g.probs = probs_dev; g.nprob = S; g.small_tile = small; g.total_tiles = S * tiles;
+  SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
+  SlabReduceArgs r;
+  r.slab = slab; for (int i = 0; i < 4; ++i) r.out[i] = out[i];
+  r.S = S; r.M = M; r.N = N; r.rows_per_out = rows_per_out; r.ldo = ldo; r.alpha = alpha;
+  int64_t mn = (int64_t)M * N;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, r);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+// ------------------------------------------------------------------------------------------- column sums
+// out[c] += sum_r X[r, c]  in two deterministic stages: (chunk, column) partials, then a fixed-order sum.
+__global__ void colsum_partial_kernel(const float* __restrict__ X, int ld, int R, int N, int rows_per_chunk,
+                                      float* __restrict__ partial) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += X[(int64_t)r * ld + c];
+  partial[(int64_t)blockIdx.y * N + c] = s;
+}
+__global__ void partial_reduce_kernel(const float* __restrict__ partial, int n_part, int stride, int N,
+                                      float* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < n_part; ++p) s += partial[(int64_t)p * stride + c];
+  out[c] += s;
+}
+int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream) {
+  int chunks = std::max(1, std::min(max_chunks, (R + 63) / 64));
+  int rpc = (R + chunks - 1) / chunks;
+  chunks = (R + rpc - 1) / rpc;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, stream, X, ld, R, N, rpc, partial);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial, chunks, N, N, out);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+int partial_reduce_accum(const float* partial, int n_part, int stride, int N, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial, n_part, stride, N, out);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

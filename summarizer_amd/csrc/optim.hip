@@ -1,0 +1,89 @@
+// Flat-buffer optimiser kernels: Adam exactly as torch.optim.Adam(lr, weight_decay) computes it
+// (the trainers' optimiser: summarizer/models/vasnet.py:181, dsn.py:70-73) and the sum of squares behind
+// clip_grad_norm_ (dsn.py:145).  HBM-bound streaming kernels: 16 B per lane, grid-stride.
+#include "sumk_internal.h"
+#include <math.h>
+#include <algorithm>
+
+namespace sumk {
+
+// torch (non-amsgrad, maximize=False):  g = grad*grad_scale + wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float step_size, float inv_sqrt_bc2, float grad_scale) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(c)                                                        \
+    {                                                                   \
+      float gr = gg.c * grad_scale + wd * pp.c;                         \
+      mm.c = b1 * mm.c + (1.f - b1) * gr;                               \
+      vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                          \
+      pp.c -= step_size * (mm.c / (sqrtf(vv.c) * inv_sqrt_bc2 + eps));  \
+    }
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gr = g[i] * grad_scale + wd * p[i];
+    float mi = b1 * m[i] + (1.f - b1) * gr, vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { float v = x[i]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  // one wave, fixed order -> deterministic
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) out[0] += s;
+}
+
+}  // namespace sumk
+
+using namespace sumk;
+
+extern "C" int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                              void* stream) {
+  SUMK_ARG(param && grad && exp_avg && exp_avg_sq, "adam: null pointer");
+  SUMK_ARG(n > 0 && step >= 1, "adam: n=%lld step=%d", (long long)n, step);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+extern "C" size_t sumk_sumsq_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+extern "C" int sumk_sumsq(const float* v, int64_t n, float* out, void* workspace, void* stream) {
+  SUMK_ARG(v && out && workspace, "sumsq: null pointer");
+  SUMK_ARG(n > 0, "sumsq: n=%lld", (long long)n);
+  int blocks = (int)std::min<int64_t>((n + 1023) / 1024, 1024);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, n, (float*)workspace);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, blocks, out);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}

@@ -72,6 +72,30 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
 int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int small_tile,
                      hipStream_t stream);
 
+// C(M,N) = A(K,M)^T B(K,N) contracted over a long K with deterministic split-K; out[g][rl*ldo+col] += alpha*C[row][col]
+// for row = g*rows_per_out + rl.  probs_dev must hold probs_cap entries; slab holds slab_elems floats.
+int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
+                         size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
+                         int ldo, float alpha, hipStream_t stream);
+// out[c] += sum_r X[r*ld + c]; partial must hold max_chunks*N floats.
+int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream);
+// out[c] += sum_p partial[p*stride + c]
+int partial_reduce_accum(const float* partial, int n_part, int stride, int N, float* out, hipStream_t stream);
+
+// Dropout keep-mask: a pure function of (seed, site, element index) so backward regenerates it and the numpy oracle
+// can reproduce it bit for bit (tests/golden/recipes.py: dropout_keep).  splitmix64 finaliser.
+__host__ __device__ inline bool dropout_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr) {
+  uint64_t z = (seed ^ ((uint64_t)(site + 1) * 0x9E3779B97F4A7C15ull)) + idx * 0xD1342543DE82EF95ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32) >= thr;
+}
+inline uint32_t dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
 // ------------------------------------------------------------------------------------------- profiling
 void prof_begin(int tag, hipStream_t s);
 void prof_end(int tag, hipStream_t s);

@@ -14,6 +14,7 @@
 // traffic, far above the fp32 ridge (~20 FLOP/B), so a flash-style kernel would buy nothing.
 #include "sumk_internal.h"
 #include <math.h>
+#include <algorithm>
 
 namespace sumk {
 
@@ -22,11 +23,19 @@ struct SeqInfo {
   int32_t row0, T, ldE, pad_;
 };
 
+// per-video problem tables built on device by vasnet_setup_kernel (index = table id)
+enum { TB_S = 0, TB_PV = 1, TB_DV = 2, TB_DP = 3, TB_DQ = 4, TB_DK = 5, TB_COUNT = 6 };
+constexpr int ROW_PROBS = 8;
+constexpr int SPLITK_PROBS = 64;
+constexpr int LNB_MAX_WAVES = 1024;  // partial-sum slots of the LayerNorm backward kernels
+constexpr int COLSUM_CHUNKS = 128;
+
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
-  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_s, prob_pv, stats, total;
+  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, total;
   // training-only buffers
-  size_t dz, dy1, dy0, dctx, dqkv, de, rowtmp;
+  size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
+  size_t slab_elems;
   int64_t e_elems;
   int32_t n_rows;
 };
@@ -41,6 +50,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   for (int s = 0; s < n_seq; ++s) {
     int T = off[s + 1] - off[s];
     SUMK_ARG(T > 0, "vasnet: video %d has %d frames", s, T);
+    SUMK_ARG(T < (1 << 20), "vasnet: video %d has %d frames (limit 2^20)", s, T);
     e += (int64_t)T * round4(T);
   }
   const size_t R = (size_t)off[n_seq];
@@ -54,51 +64,89 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->y1 = take(R * D * 4);
   w->z = take(R * D * 4);
   w->seq = take((size_t)n_seq * sizeof(SeqInfo));
-  w->prob_row = take(8 * sizeof(GemmProb));
-  w->prob_s = take((size_t)n_seq * sizeof(GemmProb));
-  w->prob_pv = take((size_t)n_seq * sizeof(GemmProb));
+  w->prob_row = take(ROW_PROBS * sizeof(GemmProb));
+  w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
   w->stats = take(R * 4 * 4);  // mean/rstd of both LayerNorm applications (training)
-  w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->de = w->rowtmp = 0;
+  w->scores = take(R * 4);
+  w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
+  w->slab_elems = 0;
   if (training) {
+    w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
     w->dz = take(R * D * 4);
     w->dy1 = take(R * D * 4);
     w->dy0 = take(R * D * 4);
     w->dctx = take(R * D * 4);
     w->dqkv = take(R * 3 * D * 4);
-    w->de = take((size_t)e * 4);
-    w->rowtmp = take(R * 4 * 4);
+    w->lnpart = take((size_t)LNB_MAX_WAVES * (3 * (size_t)D + 4) * 4);
+    w->colpart = take((size_t)COLSUM_CHUNKS * D * 4);
+    w->slab_elems = (size_t)32 * D * D;
+    w->slab = take(w->slab_elems * 4);
+    w->prob_sk = take(SPLITK_PROBS * sizeof(GemmProb));
   }
   w->total = p;
   return SUMK_OK;
 }
 
 // ------------------------------------------------------------------------------------------- setup tables
-__global__ void vasnet_setup_kernel(const int32_t* off, int n_seq, int D, SeqInfo* seq, GemmProb* ps, GemmProb* ppv,
-                                    int bt) {
-  // serial prefix sums: n_seq is a few tens to a few thousands, this runs once per call in ~microseconds
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One launch builds every table of the call: per-video SeqInfo + the six per-video GEMM tables (threads 0..n_seq-1,
+// each computing its own prefix sums -- O(n_seq^2) reads of the tiny offset array, but fully parallel), and the
+// row-wise single-problem entries (threads of block 1).
+struct RowProbSpec { int32_t M, N, K, lda, ldb, ldc, ldr, small; };
+struct SetupArgs {
+  const int32_t* off; int32_t n_seq, D;
+  SeqInfo* seq; GemmProb* tabs;   // tabs[TB_COUNT][n_seq]
+  GemmProb* prow; RowProbSpec rows[ROW_PROBS]; int32_t n_rowprobs;
+};
+
+__device__ inline void put_prob(GemmProb* p, int64_t a_off, int64_t b_off, int64_t c_off, int M, int N, int K, int lda,
+                                int ldb, int ldc, int tile_start, int tiles_n) {
+  GemmProb q;
+  q.a_off = a_off; q.b_off = b_off; q.c_off = c_off; q.r_off = 0;
+  q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldr = 0;
+  q.tile_start = tile_start; q.tiles_n = tiles_n;
+  for (int i = 0; i < 7; ++i) q.pad_[i] = 0;
+  *p = q;
+}
+
+__global__ void vasnet_setup_kernel(SetupArgs a) {
+  const int bt = 64;
+  if (blockIdx.y == 1) {
+    int i = threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n_rowprobs) {
+      const RowProbSpec r = a.rows[i];
+      int t = r.small ? 64 : 128;
+      GemmProb q;
+      q.a_off = q.b_off = q.c_off = q.r_off = 0;
+      q.M = r.M; q.N = r.N; q.K = r.K; q.lda = r.lda; q.ldb = r.ldb; q.ldc = r.ldc; q.ldr = r.ldr;
+      q.tile_start = 0; q.tiles_n = (r.N + t - 1) / t;
+      for (int k = 0; k < 7; ++k) q.pad_[k] = 0;
+      a.prow[i] = q;
+    }
+    return;
+  }
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_seq) return;
+  const int D = a.D, tn = (D + bt - 1) / bt;
   int64_t eoff = 0;
   int ts = 0, tpv = 0;
-  for (int s = 0; s < n_seq; ++s) {
-    int row0 = off[s], T = off[s + 1] - off[s], ldE = (T + 3) & ~3;
-    SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0;
-    seq[s] = si;
-    int tm = (T + bt - 1) / bt;
-    GemmProb a;  // E_s = Q_s K_s^T
-    a.a_off = (int64_t)row0 * 3 * D; a.b_off = (int64_t)row0 * 3 * D + D; a.c_off = eoff; a.r_off = 0;
-    a.M = T; a.N = T; a.K = D; a.lda = 3 * D; a.ldb = 3 * D; a.ldc = ldE; a.ldr = 0;
-    a.tile_start = ts; a.tiles_n = tm;
-    for (int i = 0; i < 7; ++i) a.pad_[i] = 0;
-    ps[s] = a; ts += tm * tm;
-    GemmProb b;  // C_s = alpha_s V_s
-    int tn = (D + bt - 1) / bt;
-    b.a_off = eoff; b.b_off = (int64_t)row0 * 3 * D + 2 * D; b.c_off = (int64_t)row0 * D; b.r_off = 0;
-    b.M = T; b.N = D; b.K = T; b.lda = ldE; b.ldb = 3 * D; b.ldc = D; b.ldr = 0;
-    b.tile_start = tpv; b.tiles_n = tn;
-    for (int i = 0; i < 7; ++i) b.pad_[i] = 0;
-    ppv[s] = b; tpv += tm * tn;
-    eoff += (int64_t)T * ldE;
+  for (int q = 0; q < s; ++q) {
+    int T = a.off[q + 1] - a.off[q], tm = (T + bt - 1) / bt;
+    eoff += (int64_t)T * ((T + 3) & ~3);
+    ts += tm * tm; tpv += tm * tn;
   }
+  const int row0 = a.off[s], T = a.off[s + 1] - a.off[s], ldE = (T + 3) & ~3, tm = (T + bt - 1) / bt;
+  SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0;
+  a.seq[s] = si;
+  const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
+  const int n = a.n_seq;
+  // forward
+  put_prob(a.tabs + TB_S * n + s, q0, q0 + D, eoff, T, T, D, 3 * D, 3 * D, ldE, ts, tm);            // E = Q K^T        (NT)
+  put_prob(a.tabs + TB_PV * n + s, eoff, q0 + 2 * D, c0, T, D, T, ldE, 3 * D, D, tpv, tn);           // C = alpha V      (NN)
+  // backward
+  put_prob(a.tabs + TB_DV * n + s, eoff, c0, q0 + 2 * D, T, D, T, ldE, D, 3 * D, tpv, tn);           // dV = alpha^T dC  (TN)
+  put_prob(a.tabs + TB_DP * n + s, c0, q0 + 2 * D, eoff, T, T, D, D, 3 * D, ldE, ts, tm);            // dAlpha = dC V^T  (NT)
+  put_prob(a.tabs + TB_DQ * n + s, eoff, q0 + D, q0, T, D, T, ldE, 3 * D, 3 * D, tpv, tn);           // dQ = dS K        (NN)
+  put_prob(a.tabs + TB_DK * n + s, eoff, q0, q0 + D, T, D, T, ldE, 3 * D, 3 * D, tpv, tn);           // dK = dS^T Q      (TN)
 }
 
 // ------------------------------------------------------------------------------------------- wave helpers
@@ -135,12 +183,19 @@ __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int
   return e;
 }
 
+struct Drop {  // dropout site descriptor; thr == 0 means "no dropout"
+  uint64_t seed; uint32_t thr; float scale;
+};
+__device__ __forceinline__ float drop_apply(const Drop& d, uint32_t site, uint64_t idx, float v) {
+  return dropout_keep(d.seed, site, idx, d.thr) ? v * d.scale : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------- softmax rows
-// One wave per query row.  Reads raw Q.K^T, writes alpha in place and zeroes the [T, ldE) pad so the
-// alpha.V product can stream K in float4 units.
-__global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, const SeqInfo* seq, const int32_t* off,
+// One wave per query row.  Reads raw Q.K^T, writes alpha in place and zeroes the [T, ldE) pad so the alpha.V product
+// can stream K in float4 units.  Training with dropout (vasnet.py:130) also writes dropout(alpha) to E2.
+__global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2, const SeqInfo* seq, const int32_t* off,
                                                              int n_seq, int n_rows, float scale, int ignore_self,
-                                                             int aperture) {
+                                                             int aperture, Drop drop) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -154,79 +209,202 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, const Seq
   float sum = 0.f;
   for (int j = lane; j < T; j += 64) sum += expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m);
   sum = wave_sum(sum);
+  float* e2 = E2 ? E2 + si.eoff + (int64_t)i * si.ldE : nullptr;
   for (int j = lane; j < si.ldE; j += 64) {
     float v = 0.f;
     if (j < T) v = expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m) / sum;
     e[j] = v;
+    if (e2) e2[j] = drop.thr ? drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, v) : v;
+  }
+}
+
+// dLogits(raw) = scale * alpha * (dAlpha - sum_j dAlpha_j alpha_j), dAlpha = dropout'(dAlphaDropped).  In place on E2.
+__global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E, float* E2, const SeqInfo* seq,
+                                                                 const int32_t* off, int n_seq, int n_rows, float scale,
+                                                                 Drop drop) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int s = find_seq(off, n_seq, row);
+  const SeqInfo si = seq[s];
+  const int i = row - si.row0, T = si.T;
+  const float* p = E + si.eoff + (int64_t)i * si.ldE;
+  float* g = E2 + si.eoff + (int64_t)i * si.ldE;
+  float dot = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    float d = g[j];
+    if (drop.thr) d = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d);
+    dot += d * p[j];
+  }
+  dot = wave_sum(dot);
+  for (int j = lane; j < si.ldE; j += 64) {
+    float v = 0.f;
+    if (j < T) {
+      float d = g[j];
+      if (drop.thr) d = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d);
+      v = p[j] * (d - dot) * scale;
+    }
+    g[j] = v;
   }
 }
 
 // ------------------------------------------------------------------------------------------- LayerNorm rows
 // y = (x - mean) * rstd * g + b over D, biased variance, one wave per row (torch.nn.LayerNorm, vasnet.py:54).
+// `site` dropout (vasnet.py:136 / :142) is applied to x on load.  HEAD: no y is written; instead
+// scores[r] = sigmoid(y . w2 + b2)  (vasnet.py:144-145).
+template <bool HEAD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, float* __restrict__ Y,
                                                         const float* __restrict__ g, const float* __restrict__ b,
-                                                        int n_rows, int D, float eps, float* __restrict__ stats) {
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ scores, int n_rows, int D, float eps,
+                                                        float* __restrict__ stats, Drop drop, uint32_t site) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
   const float4* x4 = reinterpret_cast<const float4*>(X + (int64_t)row * D);
   const int D4 = D >> 2;
+  auto ld = [&](int c) {
+    float4 v = x4[c];
+    if (drop.thr) {
+      uint64_t base = (uint64_t)row * D + 4 * c;
+      v.x = drop_apply(drop, site, base, v.x); v.y = drop_apply(drop, site, base + 1, v.y);
+      v.z = drop_apply(drop, site, base + 2, v.z); v.w = drop_apply(drop, site, base + 3, v.w);
+    }
+    return v;
+  };
   float s = 0.f;
-  for (int c = lane; c < D4; c += 64) { float4 v = x4[c]; s += (v.x + v.y) + (v.z + v.w); }
+  for (int c = lane; c < D4; c += 64) { float4 v = ld(c); s += (v.x + v.y) + (v.z + v.w); }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
   for (int c = lane; c < D4; c += 64) {
-    float4 v = x4[c];
+    float4 v = ld(c);
     float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, d = v.w - mean;
     q += (a * a + bb * bb) + (cc * cc + d * d);
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  float4* y4 = reinterpret_cast<float4*>(Y + (int64_t)row * D);
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* b4 = reinterpret_cast<const float4*>(b);
-  for (int c = lane; c < D4; c += 64) {
-    float4 v = x4[c], gg = g4[c], bv = b4[c], o;
-    o.x = (v.x - mean) * rstd * gg.x + bv.x; o.y = (v.y - mean) * rstd * gg.y + bv.y;
-    o.z = (v.z - mean) * rstd * gg.z + bv.z; o.w = (v.w - mean) * rstd * gg.w + bv.w;
-    y4[c] = o;
+  if constexpr (!HEAD) {
+    float4* y4 = reinterpret_cast<float4*>(Y + (int64_t)row * D);
+    for (int c = lane; c < D4; c += 64) {
+      float4 v = ld(c), gg = g4[c], bv = b4[c], o;
+      o.x = (v.x - mean) * rstd * gg.x + bv.x; o.y = (v.y - mean) * rstd * gg.y + bv.y;
+      o.z = (v.z - mean) * rstd * gg.z + bv.z; o.w = (v.w - mean) * rstd * gg.w + bv.w;
+      y4[c] = o;
+    }
+  } else {
+    const float4* w4 = reinterpret_cast<const float4*>(w2);
+    float dot = 0.f;
+    for (int c = lane; c < D4; c += 64) {
+      float4 v = ld(c), gg = g4[c], bv = b4[c], ww = w4[c];
+      dot += ((v.x - mean) * rstd * gg.x + bv.x) * ww.x + ((v.y - mean) * rstd * gg.y + bv.y) * ww.y +
+             ((v.z - mean) * rstd * gg.z + bv.z) * ww.z + ((v.w - mean) * rstd * gg.w + bv.w) * ww.w;
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) scores[row] = 1.0f / (1.0f + expf(-(dot + b2[0])));
   }
   if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
-// scores[r] = sigmoid( LayerNorm(Z[r]) . w2 + b2 )        vasnet.py:143-145
-__global__ __launch_bounds__(256) void ln_head_kernel(const float* __restrict__ Z, const float* __restrict__ g,
-                                                      const float* __restrict__ b, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, float* __restrict__ scores,
-                                                      int n_rows, int D, float eps, float* __restrict__ stats) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n_rows) return;
+// Backward of  y = LN(drop(x)) * g + b  for a strided set of rows per wave.
+//   HEAD : upstream is the scalar du = dscore * s(1-s) through y . w2 + b2; x = Z (post-ReLU): dX also takes the ReLU mask.
+//   !HEAD: upstream is the matrix dY.
+// Each wave keeps per-column partial sums (dgamma, dbeta [, dw2]) in registers over its rows and writes them to its own
+// slot of `part` ([n_waves][3*D + 4]); a fixed-order reduction kernel adds the slots into the gradients (deterministic).
+template <int NQ, bool HEAD>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ X, const float* __restrict__ stats,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            const float* __restrict__ dY, const float* __restrict__ w2,
+                                                            const float* __restrict__ scores,
+                                                            const float* __restrict__ dscores, float* __restrict__ dX,
+                                                            float* __restrict__ part, int n_rows, int D, Drop drop,
+                                                            uint32_t site) {
   const int lane = threadIdx.x & 63;
-  const float4* x4 = reinterpret_cast<const float4*>(Z + (int64_t)row * D);
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
   const int D4 = D >> 2;
-  float s = 0.f;
-  for (int c = lane; c < D4; c += 64) { float4 v = x4[c]; s += (v.x + v.y) + (v.z + v.w); }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-  for (int c = lane; c < D4; c += 64) {
-    float4 v = x4[c];
-    float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, d = v.w - mean;
-    q += (a * a + bb * bb) + (cc * cc + d * d);
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float4 ag[NQ], ab[NQ], aw[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) ag[q] = ab[q] = aw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float ab2 = 0.f;
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* b4 = reinterpret_cast<const float4*>(b);
   const float4* w4 = reinterpret_cast<const float4*>(w2);
-  float dot = 0.f;
-  for (int c = lane; c < D4; c += 64) {
-    float4 v = x4[c], gg = g4[c], bv = b4[c], ww = w4[c];
-    dot += ((v.x - mean) * rstd * gg.x + bv.x) * ww.x + ((v.y - mean) * rstd * gg.y + bv.y) * ww.y +
-           ((v.z - mean) * rstd * gg.z + bv.z) * ww.z + ((v.w - mean) * rstd * gg.w + bv.w) * ww.w;
+  for (int row = wave_id; row < n_rows; row += n_waves) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float4* x4 = reinterpret_cast<const float4*>(X + (int64_t)row * D);
+    float du = 0.f;
+    if constexpr (HEAD) { float sc = scores[row]; du = dscores[row] * sc * (1.f - sc); ab2 += du; }
+    float4 xh[NQ], dxh[NQ], keep[NQ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int c = lane + 64 * q;
+      xh[q] = dxh[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      keep[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (c < D4) {
+        float4 v = x4[c];
+        if constexpr (HEAD) {  // ReLU mask on the stored post-ReLU value (vasnet.py:141)
+          keep[q].x = v.x > 0.f ? 1.f : 0.f; keep[q].y = v.y > 0.f ? 1.f : 0.f;
+          keep[q].z = v.z > 0.f ? 1.f : 0.f; keep[q].w = v.w > 0.f ? 1.f : 0.f;
+        }
+        if (drop.thr) {
+          uint64_t base = (uint64_t)row * D + 4 * c;
+          float k0 = dropout_keep(drop.seed, site, base, drop.thr) ? drop.scale : 0.f;
+          float k1 = dropout_keep(drop.seed, site, base + 1, drop.thr) ? drop.scale : 0.f;
+          float k2 = dropout_keep(drop.seed, site, base + 2, drop.thr) ? drop.scale : 0.f;
+          float k3 = dropout_keep(drop.seed, site, base + 3, drop.thr) ? drop.scale : 0.f;
+          v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
+          keep[q].x *= k0; keep[q].y *= k1; keep[q].z *= k2; keep[q].w *= k3;
+        }
+        float4 h;
+        h.x = (v.x - mean) * rstd; h.y = (v.y - mean) * rstd; h.z = (v.z - mean) * rstd; h.w = (v.w - mean) * rstd;
+        xh[q] = h;
+        const float4 gg = g4[c];
+        float4 dy;
+        if constexpr (HEAD) {
+          const float4 ww = w4[c], bv = b4[c];
+          dy.x = du * ww.x; dy.y = du * ww.y; dy.z = du * ww.z; dy.w = du * ww.w;
+          aw[q].x += du * (h.x * gg.x + bv.x); aw[q].y += du * (h.y * gg.y + bv.y);
+          aw[q].z += du * (h.z * gg.z + bv.z); aw[q].w += du * (h.w * gg.w + bv.w);
+        } else {
+          dy = reinterpret_cast<const float4*>(dY + (int64_t)row * D)[c];
+        }
+        ag[q].x += dy.x * h.x; ag[q].y += dy.y * h.y; ag[q].z += dy.z * h.z; ag[q].w += dy.w * h.w;
+        ab[q].x += dy.x; ab[q].y += dy.y; ab[q].z += dy.z; ab[q].w += dy.w;
+        float4 dh;
+        dh.x = dy.x * gg.x; dh.y = dy.y * gg.y; dh.z = dy.z * gg.z; dh.w = dy.w * gg.w;
+        dxh[q] = dh;
+        s1 += (dh.x + dh.y) + (dh.z + dh.w);
+        s2 += (dh.x * h.x + dh.y * h.y) + (dh.z * h.z + dh.w * h.w);
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int c = lane + 64 * q;
+      if (c < D4) {
+        float4 o;
+        o.x = rstd * (dxh[q].x - s1 - xh[q].x * s2) * keep[q].x;
+        o.y = rstd * (dxh[q].y - s1 - xh[q].y * s2) * keep[q].y;
+        o.z = rstd * (dxh[q].z - s1 - xh[q].z * s2) * keep[q].z;
+        o.w = rstd * (dxh[q].w - s1 - xh[q].w * s2) * keep[q].w;
+        reinterpret_cast<float4*>(dX + (int64_t)row * D)[c] = o;
+      }
+    }
   }
-  dot = wave_sum(dot);
-  if (lane == 0) {
-    scores[row] = 1.0f / (1.0f + expf(-(dot + b2[0])));
-    if (stats != nullptr) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  float* slot = part + (int64_t)wave_id * (3 * D + 4);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q;
+    if (c < D4) {
+      reinterpret_cast<float4*>(slot)[c] = ag[q];
+      reinterpret_cast<float4*>(slot + D)[c] = ab[q];
+      reinterpret_cast<float4*>(slot + 2 * D)[c] = aw[q];
+    }
   }
+  if (lane == 0) slot[3 * D] = ab2;
 }
 
 // x[r,:] += table[pos_rows[r],:]   (in place, like vasnet.py:109/111)
@@ -242,6 +420,45 @@ __global__ void add_pos_kernel(float* x, const float* table, const int32_t* pos_
 }
 
 static int rowwise_small_tile(int M, int N) { return gemm_tiles(M, N, 0) >= 512 ? 0 : 1; }
+
+struct Geometry {  // what both forward and backward derive from the batch
+  VasnetWs L;
+  int R, st_qkv, st_d, tiles_s, tiles_pv;
+};
+
+static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry* G) {
+  SUMK_TRY(carve(D, n_seq, off, training, &G->L));
+  G->R = G->L.n_rows;
+  G->st_qkv = rowwise_small_tile(G->R, 3 * D);
+  G->st_d = rowwise_small_tile(G->R, D);
+  G->tiles_s = G->tiles_pv = 0;
+  for (int s = 0; s < n_seq; ++s) {
+    int T = off[s + 1] - off[s], tm = (T + 63) / 64;
+    G->tiles_s += tm * tm; G->tiles_pv += tm * ((D + 63) / 64);
+  }
+  return SUMK_OK;
+}
+
+// row-wise problem slots (index into prob_row)
+enum { RP_QKV = 0, RP_DD = 1, RP_DX = 2 };
+
+static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off_dev, char* ws, hipStream_t stream) {
+  SetupArgs a;
+  a.off = off_dev; a.n_seq = n_seq; a.D = D;
+  a.seq = (SeqInfo*)(ws + G.L.seq); a.tabs = (GemmProb*)(ws + G.L.prob_seq); a.prow = (GemmProb*)(ws + G.L.prob_row);
+  const int R = G.R;
+  a.rows[RP_QKV] = RowProbSpec{R, 3 * D, D, D, D, 3 * D, 0, G.st_qkv};   // [Q|K|V] = X W^T
+  a.rows[RP_DD] = RowProbSpec{R, D, D, D, D, D, D, G.st_d};              // (R,D) = (R,D) x (D,D), any layout
+  a.rows[RP_DX] = RowProbSpec{R, D, D, 3 * D, D, D, D, G.st_d};          // dX += dQKV[:, part] W  (A has lda 3D)
+  a.n_rowprobs = 3;
+  hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2), dim3(64), 0, stream, a);
+}
+
+static Drop make_drop(const sumk_vasnet_opts* o) {
+  Drop d; d.seed = o->seed; d.thr = 0; d.scale = 1.f;
+  if (o->dropout_p > 0.f) { d.thr = dropout_threshold(o->dropout_p); d.scale = 1.0f / (1.0f - o->dropout_p); }
+  return d;
+}
 
 }  // namespace sumk
 
@@ -263,83 +480,211 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   SUMK_ARG(w->Wk && w->Wq && w->Wv && w->Wo && w->W1 && w->b1 && w->w2 && w->b2 && w->ln_w && w->ln_b,
            "vasnet_forward: null weight");
   SUMK_ARG((pos_table == nullptr) == (pos_rows == nullptr), "vasnet_forward: pos_table and pos_rows go together");
+  SUMK_ARG(opts->dropout_p >= 0.f && opts->dropout_p < 1.f, "vasnet_forward: dropout_p=%f out of [0,1)", opts->dropout_p);
   SUMK_ARG(opts->dropout_p == 0.f || training, "vasnet_forward: dropout needs training mode");
-  VasnetWs L;
-  SUMK_TRY(carve(D, n_seq, seq_off_host, training, &L));
+  Geometry G;
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, training, &G));
+  const VasnetWs& L = G.L;
   if (workspace_bytes < L.total) {
     set_error("vasnet_forward: workspace %zu < required %zu", workspace_bytes, L.total);
     return SUMK_ERR_WORKSPACE;
   }
   char* ws = (char*)workspace;
-  const int R = L.n_rows;
+  const int R = G.R;
   float* QKV = (float*)(ws + L.qkv);
   float* E = (float*)(ws + L.e);
+  float* E2 = training ? (float*)(ws + L.e2) : nullptr;
   float* CTX = (float*)(ws + L.ctx);
   float* Y0 = (float*)(ws + L.y0);
   float* Y1 = (float*)(ws + L.y1);
   float* Z = (float*)(ws + L.z);
   SeqInfo* seq = (SeqInfo*)(ws + L.seq);
   GemmProb* prow = (GemmProb*)(ws + L.prob_row);
-  GemmProb* ps = (GemmProb*)(ws + L.prob_s);
-  GemmProb* ppv = (GemmProb*)(ws + L.prob_pv);
+  GemmProb* tabs = (GemmProb*)(ws + L.prob_seq);
   float* stats = training ? (float*)(ws + L.stats) : nullptr;
+  const Drop drop = make_drop(opts);
+  const bool use_e2 = training && drop.thr != 0;
 
   if (pos_table) {
     int64_t n4 = (int64_t)R * (D >> 2);
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
-  hipLaunchKernelGGL(vasnet_setup_kernel, dim3(1), dim3(64), 0, stream, seq_off_dev, n_seq, D, seq, ps, ppv, 64);
-  int tiles_s = 0, tiles_pv = 0;
-  for (int s = 0; s < n_seq; ++s) {
-    int T = seq_off_host[s + 1] - seq_off_host[s], tm = (T + 63) / 64;
-    tiles_s += tm * tm; tiles_pv += tm * ((D + 63) / 64);
-  }
+  launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
 
-  // 1: QKV projection
-  const int st_qkv = rowwise_small_tile(R, 3 * D), st_d = rowwise_small_tile(R, D);
-  SUMK_TRY(fill_single_prob(prow + 0, R, 3 * D, D, D, D, 3 * D, 0, st_qkv, stream));
-  SUMK_TRY(fill_single_prob(prow + 1, R, D, D, D, D, D, D, st_d, stream));
-  {
+  {  // 1: QKV projection
     GemmLaunch g;
-    g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + 0;
-    g.small_tile = st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
+    g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
+    g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
-  // 2: logits per video
-  {
+  {  // 2: logits per video
     GemmLaunch g;
-    g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = ps; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = tiles_s;
+    g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = 1;
+    g.total_tiles = G.tiles_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
-  // 3: softmax
-  hipLaunchKernelGGL(vasnet_softmax_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, seq, seq_off_dev, n_seq, R,
-                     opts->scale, opts->ignore_self, opts->aperture);
-  // 4: context
-  {
+  // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
+  hipLaunchKernelGGL(vasnet_softmax_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, use_e2 ? E2 : nullptr, seq,
+                     seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop);
+  {  // 4: context
     GemmLaunch g;
-    g.A = E; g.B[0] = QKV; g.C = CTX; g.probs = ppv; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = tiles_pv;
+    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = 1;
+    g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
-  // 5: output projection + residual
-  {
+  {  // 5: output projection + residual
     GemmLaunch g;
-    g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + 1; g.small_tile = st_d;
-    g.total_tiles = gemm_tiles(R, D, st_d);
+    g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
+    g.total_tiles = gemm_tiles(R, D, G.st_d);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
   }
-  // 6: LayerNorm
-  hipLaunchKernelGGL(layernorm_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Y0, Y1, w->ln_w, w->ln_b, R, D,
-                     opts->eps, stats);
-  // 7: k1 + bias + ReLU
-  {
+  // 6: dropout + LayerNorm
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, stream, Y0, Y1, w->ln_w, w->ln_b, nullptr,
+                     nullptr, nullptr, R, D, opts->eps, stats, drop, 1u);
+  {  // 7: k1 + bias + ReLU
     GemmLaunch g;
-    g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + 1; g.small_tile = st_d;
-    g.total_tiles = gemm_tiles(R, D, st_d);
+    g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
+    g.total_tiles = gemm_tiles(R, D, G.st_d);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
-  // 8: LayerNorm (same weights) + k2 + sigmoid
-  hipLaunchKernelGGL(ln_head_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, Z, w->ln_w, w->ln_b, w->w2, w->b2,
-                     scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr);
+  // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((R + 3) / 4), dim3(256), 0, stream, Z, nullptr, w->ln_w, w->ln_b, w->w2,
+                     w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u);
+  SUMK_HIP(hipGetLastError());
+  if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+  return SUMK_OK;
+}
+
+template <bool HEAD>
+static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const float* g, const float* b,
+                         const float* dY, const float* w2, const float* scores, const float* dscores, float* dX,
+                         float* part, Drop drop, uint32_t site, int* n_waves_out, hipStream_t stream) {
+  const int D4 = D >> 2;
+  const int nq = (D4 + 63) / 64;
+  int blocks = std::min((R + 3) / 4, LNB_MAX_WAVES / 4);
+  blocks = std::max(blocks, 1);
+  *n_waves_out = blocks * 4;
+  dim3 grid(blocks), block(256);
+#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site)
+  if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
+  else { set_error("vasnet_backward: D=%d > 2048 is not supported by the LayerNorm backward kernel", D); return SUMK_ERR_ARG; }
+#undef LNB
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                                    const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
+                                    const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* gr,
+                                    float* dx, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(x && seq_off_dev && w && opts && dscores && gr && workspace, "vasnet_backward: null pointer");
+  SUMK_ARG(gr->Wk && gr->Wq && gr->Wv && gr->Wo && gr->W1 && gr->b1 && gr->w2 && gr->b2 && gr->ln_w && gr->ln_b,
+           "vasnet_backward: null gradient target");
+  Geometry G;
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, 1, &G));
+  const VasnetWs& L = G.L;
+  if (workspace_bytes < L.total) {
+    set_error("vasnet_backward: workspace %zu < required %zu (needs the training-mode forward's workspace)", workspace_bytes, L.total);
+    return SUMK_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  const int R = G.R;
+  float* QKV = (float*)(ws + L.qkv);
+  float* E = (float*)(ws + L.e);
+  float* E2 = (float*)(ws + L.e2);
+  float* CTX = (float*)(ws + L.ctx);
+  float* Y0 = (float*)(ws + L.y0);
+  float* Y1 = (float*)(ws + L.y1);
+  float* Z = (float*)(ws + L.z);
+  float* dZ = (float*)(ws + L.dz);
+  float* dY1 = (float*)(ws + L.dy1);
+  float* dY0 = (float*)(ws + L.dy0);
+  float* dCTX = (float*)(ws + L.dctx);
+  float* dQKV = (float*)(ws + L.dqkv);
+  float* lnpart = (float*)(ws + L.lnpart);
+  float* colpart = (float*)(ws + L.colpart);
+  float* slab = (float*)(ws + L.slab);
+  float* stats = (float*)(ws + L.stats);
+  const float* scores = (const float*)(ws + L.scores);
+  SeqInfo* seq = (SeqInfo*)(ws + L.seq);
+  GemmProb* prow = (GemmProb*)(ws + L.prob_row);
+  GemmProb* tabs = (GemmProb*)(ws + L.prob_seq);
+  GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
+  const Drop drop = make_drop(opts);
+  const bool use_e2 = drop.thr != 0;
+  const int pstride = 3 * D + 4;
+  int nw = 0;
+
+  // 8': head + second LayerNorm + dropout + ReLU  ->  dZ (w.r.t. the k1 pre-activation), dw2, db2, dgamma, dbeta
+  SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, dZ, lnpart,
+                               drop, 2u, &nw, stream));
+  SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, gr->ln_w, stream));
+  SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, gr->ln_b, stream));
+  SUMK_TRY(partial_reduce_accum(lnpart + 2 * D, nw, pstride, D, gr->w2, stream));
+  SUMK_TRY(partial_reduce_accum(lnpart + 3 * D, nw, pstride, 1, gr->b2, stream));
+  // 7': k1
+  SUMK_TRY(colsum_accum(dZ, D, R, D, colpart, COLSUM_CHUNKS, gr->b1, stream));
+  {
+    float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
+    GemmLaunch g;  // dY1 = dZ . W1
+    g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d);
+    SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+  }
+  // 6': first LayerNorm + dropout -> dY0 (gradient of the residual sum)
+  SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, dY1, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream));
+  SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, gr->ln_w, stream));
+  SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, gr->ln_b, stream));
+  // 5': output projection (+ residual branch into dx)
+  {
+    float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum(dY0, D, CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
+    GemmLaunch g;  // dCTX = dY0 . Wo
+    g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d);
+    SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+  }
+  // 4': dV = alphaD^T dC ; dAlphaD = dC V^T
+  const float* Pd = use_e2 ? E2 : E;
+  {
+    GemmLaunch g;
+    g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_pv;
+    SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
+  }
+  {
+    GemmLaunch g;
+    g.A = dCTX; g.B[0] = QKV; g.C = E2; g.probs = tabs + TB_DP * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_s;
+    SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
+  }
+  // 3': softmax (+dropout, +scale) backward, in place on E2
+  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, seq_off_dev, n_seq, R,
+                     opts->scale, drop);
+  // 2': dQ = dS K ; dK = dS^T Q
+  {
+    GemmLaunch g;
+    g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_pv;
+    SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+  }
+  {
+    GemmLaunch g;
+    g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_pv;
+    SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
+  }
+  // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X
+  {
+    float* out[4] = {gr->Wq, gr->Wk, gr->Wv, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum(dQKV, 3 * D, x, D, 3 * D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
+  }
+  if (dx) {  // dX = dY0 (residual) + dQ Wq + dK Wk + dV Wv
+    SUMK_HIP(hipMemcpyAsync(dx, dY0, (size_t)R * D * 4, hipMemcpyDeviceToDevice, stream));
+    const float* Ws[3] = {w->Wq, w->Wk, w->Wv};
+    for (int part = 0; part < 3; ++part) {
+      GemmLaunch g;
+      g.A = dQKV + (size_t)part * D; g.B[0] = Ws[part]; g.C = dx; g.probs = prow + RP_DX; g.small_tile = G.st_d;
+      g.total_tiles = gemm_tiles(R, D, G.st_d);
+      SUMK_TRY(launch_gemm(GEMM_NN, EPI_ACCUM, g, stream));
+    }
+  }
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

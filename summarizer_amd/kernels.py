@@ -153,3 +153,51 @@ def frame_head_forward(h, w, b):
     rc = lib.sumk_frame_head_forward(_p(h), h.shape[0], h.shape[1], _p(w), _p(b), _p(scores), _stream())
     _lib.check(rc, "sumk_frame_head_forward")
     return scores
+
+
+# ------------------------------------------------------------------------------------------------ training
+def vasnet_backward_packed(x, sb, params, opts, dscores, ws, grads, want_dx=False):
+    """Accumulates d(sum dscores*scores)/d(weights) into `grads` (dict state_dict-key -> preallocated tensor)."""
+    lib = _lib.load()
+    D = x.shape[1]
+    w, o = _vasnet_structs(params, opts)
+    g = _lib.VasnetGrads()
+    for f, k in VASNET_FIELDS:
+        t = grads[k]
+        _require_gpu(t, f"VASNet grad {k}")
+        setattr(g, f, t.data_ptr())
+    dx = torch.empty_like(x) if want_dx else None
+    if not dscores.is_contiguous():
+        dscores = dscores.contiguous()
+    rc = lib.sumk_vasnet_backward(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o), _p(dscores),
+                                  C.byref(g), _p(dx), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "sumk_vasnet_backward")
+    return dx
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """In-place torch.optim.Adam-equivalent update of one flat fp32 buffer (HIP kernel)."""
+    lib = _lib.load()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _require_gpu(t, "adam_step")
+        if not t.is_contiguous():
+            raise SumkError("adam_step: buffers must be contiguous")
+    rc = lib.sumk_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
+                            weight_decay, int(step), float(grad_scale), _stream())
+    _lib.check(rc, "sumk_adam_step")
+
+
+_sumsq_ws = {}
+
+
+def sumsq(v, out=None):
+    """out[0] += sum(v*v) (HIP, deterministic).  Returns the 1-element device tensor."""
+    lib = _lib.load()
+    _require_gpu(v, "sumsq")
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=v.device)
+    ws = _sumsq_ws.get(str(v.device))
+    if ws is None:
+        ws = _sumsq_ws[str(v.device)] = torch.empty(lib.sumk_sumsq_workspace_bytes(), dtype=torch.uint8, device=v.device)
+    _lib.check(lib.sumk_sumsq(_p(v), v.numel(), _p(out), _p(ws), _stream()), "sumk_sumsq")
+    return out

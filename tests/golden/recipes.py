@@ -78,3 +78,31 @@ def synthetic_video(T, seed, n_users=15, D=None):
     if D:
         d["features"] = features(T, 1, D, seed + 7)[:, 0, :]
     return d
+
+
+def dropout_keep(seed, site, idx, p):
+    """numpy twin of sumk::dropout_keep (csrc/sumk_internal.h): keep-mask of training-mode dropout as a pure
+    function of (seed, site, element index).  idx: uint64 array.  Returns a bool array (True = kept)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) ^ (np.uint64(site + 1) * np.uint64(0x9E3779B97F4A7C15))) + idx * np.uint64(0xD1342543DE82EF95)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    thr = min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF)
+    return (z >> np.uint64(32)).astype(np.uint64) >= np.uint64(thr)
+
+
+def vasnet_drop_masks(seed, p, lens, D):
+    """Scaled keep-masks (0 or 1/(1-p)) of the three dropout sites for a packed batch, per video:
+    returns list of (m_alpha (T,T), m_y (T,D), m_z (T,D)) float32, indexed exactly like the HIP kernels."""
+    sc = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    out, row0 = [], 0
+    for T in lens:
+        rows = (np.arange(T, dtype=np.uint64) + np.uint64(row0))
+        ia = (rows[:, None] << np.uint64(20)) | np.arange(T, dtype=np.uint64)[None, :]
+        iy = rows[:, None] * np.uint64(D) + np.arange(D, dtype=np.uint64)[None, :]
+        out.append(tuple((dropout_keep(seed, site, ix, p).astype(np.float32) * sc) for site, ix in ((0, ia), (1, iy), (2, iy))))
+        row0 += T
+    return out

@@ -1,0 +1,108 @@
+"""GPU parity of the TRAINING path: HIP backward kernels + Adam vs (a) golden gradients / parameters produced by the
+real reference (tests/golden/train_small.npz: MSE, Adam lr 5e-5 wd 1e-5, vasnet.py:176-212 with dropout off) and
+(b) autograd through the stock-PyTorch port of the oracle, including training-mode dropout with the deterministic
+keep-masks (recipes.dropout_keep mirrors the kernel's hash bit for bit)."""
+import numpy as np
+import pytest
+import torch
+
+import recipes as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("tag,kw", [("vasnet", dict()), ("vasnet_loc", dict(attention_aperture=4, ignore_self=True))])
+def test_vasnet_train_step_goldens(dev, tag, kw):
+    from summarizer_amd.models.vasnet import VASNet
+    g = load_golden("train_small")
+    w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{tag}/w/")}
+    m = VASNet(input_size=64, **kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m = m.to(dev).eval()            # eval(): dropout off, exactly how the golden was generated
+    x = torch.from_numpy(g["vasnet/x"]).to(dev); tgt = torch.from_numpy(g["vasnet/target"]).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-5, weight_decay=1e-5)
+    for s in range(3):
+        scores = m(x)
+        loss = torch.nn.functional.mse_loss(scores, tgt)
+        opt.zero_grad(); loss.backward()
+        if s == 0:
+            np.testing.assert_allclose(loss.item(), g[f"{tag}/loss0"], rtol=2e-5)
+            for k, p in m.named_parameters():
+                ref = g[f"{tag}/grad0/{k}"]
+                assert _rel(p.grad.cpu().numpy(), ref) < 2e-4, (k, _rel(p.grad.cpu().numpy(), ref))
+        opt.step()
+        if s in (0, 2):
+            for k, p in m.named_parameters():
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"{tag}/param{s+1}/{k}"], atol=2e-6, err_msg=f"{k} step {s+1}")
+
+
+def test_vasnet_grads_vs_torch_port_ragged_batch_with_dropout(dev):
+    from oracle import torch_port
+    from summarizer_amd import kernels
+    from summarizer_amd.models.vasnet import VASNet
+    D, lens, p, seed = 128, [70, 1, 33, 129], 0.5, 1234567
+    w = R.vasnet_weights(D, 9)
+    m = VASNet(input_size=D); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    xs = [R.features(T, 1, D, 60 + i) - 0.15 for i, T in enumerate(lens)]
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev).requires_grad_(True)
+    sb = kernels.SeqBatch.get(lens, dev)
+    opts = dict(scale=float(m.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=p, seed=seed)
+    from summarizer_amd.autograd import VasnetFunction
+    names = [k for _, k in kernels.VASNET_FIELDS]
+    params = dict(m.named_parameters())
+    s = VasnetFunction.apply(xp, sb, opts, None, None, names, *[params[n] for n in names])
+    cw = torch.from_numpy(np.random.default_rng(2).standard_normal(sum(lens)).astype(np.float32)).to(dev)
+    (s * cw).sum().backward()
+    # reference: per video through the torch port with the SAME masks
+    masks = R.vasnet_drop_masks(seed, p, lens, D)
+    pt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    off = np.concatenate([[0], np.cumsum(lens)])
+    total = 0
+    xrefs = []
+    for i, x in enumerate(xs):
+        xt = torch.from_numpy(x).clone().requires_grad_(True); xrefs.append(xt)
+        dm = tuple(torch.from_numpy(mm).unsqueeze(0) for mm in masks[i])
+        y = torch_port.vasnet_scores(xt, pt, drop_masks=dm)[:, 0, 0]
+        np.testing.assert_allclose(s.detach().cpu().numpy()[off[i]:off[i + 1]], y.detach().numpy(), atol=1e-4)
+        total = total + (y * cw.cpu()[off[i]:off[i + 1]]).sum()
+    total.backward()
+    for k in names:
+        got, ref = params[k].grad.cpu().numpy(), pt[k].grad.numpy()
+        assert _rel(got, ref) < 3e-4, (k, _rel(got, ref))
+    gx = xp.grad.cpu().numpy()
+    for i, xt in enumerate(xrefs):
+        assert _rel(gx[off[i]:off[i + 1]], xt.grad.numpy()[:, 0, :]) < 3e-4
+
+
+def test_dropout_mask_statistics_and_determinism(dev):
+    keep = R.dropout_keep(42, 1, np.arange(1 << 20, dtype=np.uint64), 0.5)
+    assert abs(keep.mean() - 0.5) < 2e-3
+    assert not np.array_equal(keep, R.dropout_keep(43, 1, np.arange(1 << 20, dtype=np.uint64), 0.5))
+    assert abs(R.dropout_keep(42, 2, np.arange(1 << 18, dtype=np.uint64), 0.1).mean() - 0.9) < 3e-3
+
+
+def test_adam_and_sumsq_vs_torch(dev):
+    from summarizer_amd import kernels
+    rng = np.random.default_rng(0)
+    n = 100003
+    p0 = rng.standard_normal(n).astype(np.float32); g = [rng.standard_normal(n).astype(np.float32) for _ in range(3)]
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([pt], lr=5e-5, weight_decay=1e-5)
+    p = torch.from_numpy(p0.copy()).to(dev); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step, gi in enumerate(g, 1):
+        pt.grad = torch.from_numpy(gi.copy()); opt.step()
+        kernels.adam_step(p, torch.from_numpy(gi).to(dev), m, v, step, 5e-5, weight_decay=1e-5)
+    np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), atol=1e-6, rtol=1e-6)
+    ss = kernels.sumsq(torch.from_numpy(g[0]).to(dev))
+    np.testing.assert_allclose(ss.item(), float((g[0].astype(np.float64) ** 2).sum()), rtol=1e-5)
