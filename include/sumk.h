@@ -103,7 +103,6 @@ int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t
                          const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
-#if 0 /* SUMK_PENDING: declared when implemented */
 typedef struct sumk_lstm_layer_grads {
   float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
 } sumk_lstm_layer_grads;
@@ -115,9 +114,12 @@ int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* 
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* dh[r,:] = ds[r]*s(1-s)*w ; dw += sum_r ds*s(1-s)*h[r,:] ; db += sum_r ds*s(1-s) */
+size_t sumk_frame_head_workspace_bytes(int32_t F);
 int sumk_frame_head_backward(const float* h, const float* scores, const float* dscores, int32_t n_rows,
-                             int32_t F, const float* w, float* dh, float* dw, float* db, void* stream);
+                             int32_t F, const float* w, float* dh, float* dw, float* db, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
+#if 0 /* SUMK_PENDING: declared when implemented */
 /* ------------------------------------------------------------------------------------------------ DSN reward
  * DSNTrainer.compute_reward (dsn.py:185-236) for E episodes of one or more packed videos:
  * actions (E, n_rows) of 0/1 floats -> reward (E, n_seq).  Zero picks -> 0 (dsn.py:199-203); one pick ->

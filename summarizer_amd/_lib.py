@@ -56,8 +56,9 @@ _SIGS = {
                                              c_i32p, C.POINTER(LstmLayerWeights), C.POINTER(LstmLayerGrads), c_f32p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_frame_head_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sumk_frame_head_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "sumk_frame_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
-                                           c_f32p, C.c_void_p]),
+                                           c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_dsn_reward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_dsn_reward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, c_f32p, C.c_int32, C.c_int32,
                                   C.c_int32, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -76,7 +77,7 @@ _SIGS = {
 
 PROF_GEMM_QKV, PROF_GEMM_ALL, PROF_LSTM_REC = 0, 1, 2
 
-PENDING = ['sumk_bilstm_layer_backward', 'sumk_frame_head_backward', 'sumk_dsn_reward_workspace_bytes', 'sumk_dsn_reward']   # fenced with `#if 0` in include/sumk.h until implemented
+PENDING = ['sumk_dsn_reward_workspace_bytes', 'sumk_dsn_reward']   # fenced with `#if 0` in include/sumk.h until implemented
 for _n in PENDING:
     _SIGS.pop(_n)
 

@@ -35,3 +35,36 @@ class VasnetFunction(torch.autograd.Function):
             ctx.table.grad = tg if ctx.table.grad is None else ctx.table.grad + tg
         gx = dx if ctx.needs_input_grad[0] else None
         return (gx, None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class BiLstmScorerFunction(torch.autograd.Function):
+    """scores = sigmoid(Linear(BiLSTM_stack(x))) for a packed batch (DSN: dsn.py:45-46, sLSTM: sumgan.py:43-45)."""
+
+    @staticmethod
+    def forward(ctx, xp, sb, prefix, num_layers, H, head_w, head_b, names, *params):
+        p = dict(zip(names, params))
+        acts, wss = [xp], []
+        for layer in range(num_layers):
+            h, ws = kernels.bilstm_layer_forward(acts[-1], sb, p, prefix, layer, H, training=True)
+            acts.append(h); wss.append(ws)
+        scores = kernels.frame_head_forward(acts[-1], p[head_w], p[head_b])
+        ctx.meta = (sb, prefix, num_layers, H, head_w, head_b, names)
+        ctx.wss = wss
+        ctx.save_for_backward(scores, *acts, *params)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        sb, prefix, num_layers, H, head_w, head_b, names = ctx.meta
+        saved = ctx.saved_tensors
+        scores, acts, params = saved[0], saved[1:2 + num_layers], saved[2 + num_layers:]
+        p = dict(zip(names, params))
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        dh = kernels.frame_head_backward(acts[-1], scores, dscores, p[head_w], grads[head_w], grads[head_b])
+        for layer in range(num_layers - 1, -1, -1):
+            want_dx = layer > 0 or ctx.needs_input_grad[0]
+            dh = kernels.bilstm_layer_backward(acts[layer], acts[layer + 1], dh, sb, p, grads, prefix, layer, H,
+                                               ctx.wss[layer], want_dx)
+        ctx.wss = None
+        gx = dh if ctx.needs_input_grad[0] else None
+        return (gx, None, None, None, None, None, None, None) + tuple(grads[n] for n in names)

@@ -201,3 +201,35 @@ def sumsq(v, out=None):
         ws = _sumsq_ws[str(v.device)] = torch.empty(lib.sumk_sumsq_workspace_bytes(), dtype=torch.uint8, device=v.device)
     _lib.check(lib.sumk_sumsq(_p(v), v.numel(), _p(out), _p(ws), _stream()), "sumk_sumsq")
     return out
+
+
+def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, want_dx):
+    """BPTT of one bidirectional layer; accumulates into grads[<prefix>{weight,bias}_{ih,hh}_l{layer}[_reverse]]."""
+    lib = _lib.load()
+    In = x.shape[1]
+    w = _lstm_layer_struct(params, prefix, layer)
+    g = _lib.LstmLayerGrads()
+    for d, suf in enumerate(("", "_reverse")):
+        for f, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
+            getattr(g, f)[d] = grads[f"{prefix}{n}_l{layer}{suf}"].data_ptr()
+    dx = torch.empty_like(x) if want_dx else None
+    if not dh.is_contiguous():
+        dh = dh.contiguous()
+    rc = lib.sumk_bilstm_layer_backward(_p(x), _p(h), _p(dh), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w),
+                                        C.byref(g), _p(dx), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "sumk_bilstm_layer_backward")
+    return dx
+
+
+def frame_head_backward(h, scores, dscores, w, dw, db):
+    lib = _lib.load()
+    F = h.shape[1]
+    nb = lib.sumk_frame_head_workspace_bytes(F)
+    ws = torch.empty(nb, dtype=torch.uint8, device=h.device)
+    dh = torch.empty_like(h)
+    if not dscores.is_contiguous():
+        dscores = dscores.contiguous()
+    rc = lib.sumk_frame_head_backward(_p(h), _p(scores), _p(dscores), h.shape[0], F, _p(w), _p(dh), _p(dw), _p(db), _p(ws),
+                                      nb, _stream())
+    _lib.check(rc, "sumk_frame_head_backward")
+    return dh

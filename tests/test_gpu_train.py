@@ -106,3 +106,70 @@ def test_adam_and_sumsq_vs_torch(dev):
     np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), atol=1e-6, rtol=1e-6)
     ss = kernels.sumsq(torch.from_numpy(g[0]).to(dev))
     np.testing.assert_allclose(ss.item(), float((g[0].astype(np.float64) ** 2).sum()), rtol=1e-5)
+
+
+def test_dsn_train_step_goldens(dev):
+    """DSN (BiLSTM 64->2x16) MSE + Adam for 3 steps vs the real reference (loss, all gradients, parameters)."""
+    from summarizer_amd.models.dsn import DSN
+    g = load_golden("train_small")
+    w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith("dsn/w/")}
+    m = DSN(64, 16, 1); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    x = torch.from_numpy(g["vasnet/x"]).to(dev); tgt = torch.from_numpy(g["vasnet/target"]).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-5, weight_decay=1e-5)
+    for s in range(3):
+        loss = torch.nn.functional.mse_loss(m(x), tgt)
+        opt.zero_grad(); loss.backward()
+        if s == 0:
+            np.testing.assert_allclose(loss.item(), g["dsn/loss0"], rtol=2e-5)
+            for k, p in m.named_parameters():
+                assert _rel(p.grad.cpu().numpy(), g[f"dsn/grad0/{k}"]) < 2e-4, k
+        opt.step()
+        if s in (0, 2):
+            for k, p in m.named_parameters():
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"dsn/param{s+1}/{k}"], atol=2e-6, err_msg=f"{k} step {s+1}")
+
+
+def test_dsn_bce_grads_golden(dev):
+    from summarizer_amd.models.dsn import DSN
+    g = load_golden("train_small")
+    w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith("dsn/w/")}
+    m = DSN(64, 16, 1); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    x = torch.from_numpy(g["vasnet/x"]).to(dev); tgt = torch.from_numpy(g["vasnet/target"]).to(dev)
+    loss = torch.nn.functional.binary_cross_entropy(m(x), tgt)          # dsn.py:76,117-119 (sup extension)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["dsn_bce/loss0"], rtol=2e-5)
+    for k, p in m.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), g[f"dsn_bce/grad0/{k}"]) < 2e-4, k
+
+
+@pytest.mark.parametrize("kind,D,H,L,lens", [("dsn", 128, 40, 1, [50, 1, 33, 7] + [4] * 30), ("slstm", 64, 32, 2, [37, 90, 2])])
+def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens):
+    from oracle import torch_port
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.sumgan import sLSTM
+    pre, hw, hb = ("rnn.", "out.0.weight", "out.0.bias") if kind == "dsn" else ("lstm.", "out.weight", "out.bias")
+    w = R.lstm_weights(pre, D, H, L, 21, hw[:-6])
+    m = DSN(D, H, L) if kind == "dsn" else sLSTM(D, H, L)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    xs = [R.features(T, 1, D, 80 + i) - 0.2 for i, T in enumerate(lens)]
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev).requires_grad_(True)
+    s = m.score_packed(xp, lens)
+    cw = torch.from_numpy(np.random.default_rng(4).standard_normal(sum(lens)).astype(np.float32)).to(dev)
+    (s * cw).sum().backward()
+    pt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    lstm = torch_port.make_lstm({k: v.detach() for k, v in pt.items()}, pre, D, H, L)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    total, xrefs = 0, []
+    for i, x in enumerate(xs):
+        xt = torch.from_numpy(x).clone().requires_grad_(True); xrefs.append(xt)
+        y = torch_port.bilstm_scores(xt, pt, pre, hw, hb, D, H, L, lstm=lstm)[:, 0, 0]
+        np.testing.assert_allclose(s.detach().cpu().numpy()[off[i]:off[i + 1]], y.detach().numpy(), atol=1e-4)
+        total = total + (y * cw.cpu()[off[i]:off[i + 1]]).sum()
+    total.backward()
+    ref_grads = {f"{pre}{k}": v.grad.numpy() for k, v in lstm.named_parameters()}
+    ref_grads[hw] = pt[hw].grad.numpy(); ref_grads[hb] = pt[hb].grad.numpy()
+    for k, p in m.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), ref_grads[k]) < 3e-4, (k, _rel(p.grad.cpu().numpy(), ref_grads[k]))
+    gx = xp.grad.cpu().numpy()
+    for i, xt in enumerate(xrefs):
+        assert _rel(gx[off[i]:off[i + 1]], xt.grad.numpy()[:, 0, :]) < 3e-4
