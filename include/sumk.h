@@ -119,7 +119,6 @@ int sumk_frame_head_backward(const float* h, const float* scores, const float* d
                              int32_t F, const float* w, float* dh, float* dw, float* db, void* workspace,
                              size_t workspace_bytes, void* stream);
 
-#if 0 /* SUMK_PENDING: declared when implemented */
 /* ------------------------------------------------------------------------------------------------ DSN reward
  * DSNTrainer.compute_reward (dsn.py:185-236) for E episodes of one or more packed videos:
  * actions (E, n_rows) of 0/1 floats -> reward (E, n_seq).  Zero picks -> 0 (dsn.py:199-203); one pick ->
@@ -128,8 +127,6 @@ size_t sumk_dsn_reward_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* 
 int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
                     const int32_t* seq_off_dev, const float* actions, int32_t n_episodes, int32_t far_sim,
                     int32_t temp_dist_thre, float* reward, void* workspace, size_t workspace_bytes, void* stream);
-
-#endif /* SUMK_PENDING */
 
 /* ------------------------------------------------------------------------------------------------ optimiser
  * torch.optim.Adam(lr, betas, eps, weight_decay) exactly as the trainers construct it (vasnet.py:181,

@@ -77,10 +77,6 @@ _SIGS = {
 
 PROF_GEMM_QKV, PROF_GEMM_ALL, PROF_LSTM_REC = 0, 1, 2
 
-PENDING = ['sumk_dsn_reward_workspace_bytes', 'sumk_dsn_reward']   # fenced with `#if 0` in include/sumk.h until implemented
-for _n in PENDING:
-    _SIGS.pop(_n)
-
 _lib = None
 
 

@@ -1,0 +1,154 @@
+// DSN diversity-representativeness reward (reference: DSNTrainer.compute_reward, summarizer/models/dsn.py:185-236)
+// for E episodes of a packed batch of videos.
+//
+// The reference rebuilds two (T,D)x(D,T) products per episode (cosine Gram, dsn.py:217-218; squared distances,
+// dsn.py:228-230).  Both are functions of the features only, so here ONE Gram matrix G = X X^T per video is built
+// with the MFMA GEMM and every episode is a cheap masked reduction over it:
+//   cos(a,b)   = G[a][b] / (|x_a| |x_b|),  |x_a|^2 = G[a][a]
+//   d2(t,p)    = G[t][t] + G[p][p] - 2 G[t][p]
+//   R_div      = sum_{a,b in picks} (|a-b| > thre && !far_sim ? 1 : 1 - cos(a,b)) / (n (n-1))      dsn.py:219-225
+//   R_rep      = exp(- mean_t min_{p in picks} d2(t,p))                                           dsn.py:231-233
+//   reward     = (R_div + R_rep) / 2 ; 0 when nothing is picked (dsn.py:199-203); R_div = 0 for one pick (dsn.py:211-214;
+//                the reference then crashes on a 0-dim index, dsn.py:229-230 -- here R_rep is simply evaluated).
+#include "sumk_internal.h"
+#include <math.h>
+
+namespace sumk {
+
+struct RSeq { int64_t goff; int32_t row0, T, ldG, pad_; };
+
+struct RewardWs { size_t gram, seq, prob, rowres, total; int64_t g_elems; int32_t n_rows; };
+
+static int reward_carve(int D, int n_seq, const int32_t* off, int n_ep, RewardWs* w) {
+  SUMK_ARG(D > 0 && D % 4 == 0, "dsn_reward: D=%d must be a positive multiple of 4", D);
+  SUMK_ARG(n_seq > 0 && off && off[0] == 0 && n_ep > 0, "dsn_reward: empty batch");
+  int64_t e = 0;
+  for (int s = 0; s < n_seq; ++s) {
+    int T = off[s + 1] - off[s];
+    SUMK_ARG(T > 0, "dsn_reward: video %d has %d frames", s, T);
+    e += (int64_t)T * ((T + 3) & ~3);
+  }
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  w->n_rows = off[n_seq]; w->g_elems = e;
+  w->gram = take((size_t)e * 4);
+  w->seq = take((size_t)n_seq * sizeof(RSeq));
+  w->prob = take((size_t)n_seq * sizeof(GemmProb));
+  w->rowres = take((size_t)n_ep * w->n_rows * 2 * 4);
+  w->total = p;
+  return SUMK_OK;
+}
+
+__global__ void reward_setup_kernel(const int32_t* off, int n_seq, int D, RSeq* seq, GemmProb* prob) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seq) return;
+  int64_t goff = 0; int ts = 0;
+  for (int q = 0; q < s; ++q) {
+    int T = off[q + 1] - off[q], tm = (T + 63) / 64;
+    goff += (int64_t)T * ((T + 3) & ~3); ts += tm * tm;
+  }
+  const int row0 = off[s], T = off[s + 1] - row0, ld = (T + 3) & ~3, tm = (T + 63) / 64;
+  RSeq si; si.goff = goff; si.row0 = row0; si.T = T; si.ldG = ld; si.pad_ = 0;
+  seq[s] = si;
+  GemmProb q;
+  q.a_off = (int64_t)row0 * D; q.b_off = (int64_t)row0 * D; q.c_off = goff; q.r_off = 0;
+  q.M = T; q.N = T; q.K = D; q.lda = D; q.ldb = D; q.ldc = ld; q.ldr = 0; q.tile_start = ts; q.tiles_n = tm;
+  for (int i = 0; i < 7; ++i) q.pad_[i] = 0;
+  prob[s] = q;
+}
+
+// one wave per (episode, frame): min over picks of d2, and (if the frame is picked) its row of the diversity sum
+__global__ __launch_bounds__(256) void reward_rows_kernel(const float* __restrict__ G, const RSeq* __restrict__ seq,
+                                                          const int32_t* __restrict__ off, int n_seq, int n_rows,
+                                                          const float* __restrict__ actions, int n_ep, int far_sim,
+                                                          int thre, float* __restrict__ rowres) {
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (int64_t)n_ep * n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int ep = (int)(wid / n_rows), row = (int)(wid % n_rows);
+  int lo = 0, hi = n_seq - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (off[mid] <= row) lo = mid; else hi = mid - 1; }
+  const RSeq si = seq[lo];
+  const int t = row - si.row0, T = si.T;
+  const float* g = G + si.goff;
+  const float* act = actions + (int64_t)ep * n_rows + si.row0;
+  const float gtt = g[(int64_t)t * si.ldG + t];
+  const bool picked = act[t] != 0.f;
+  const float inv_nt = 1.0f / sqrtf(gtt);
+  float mn = INFINITY, div = 0.f;
+  for (int p = lane; p < T; p += 64) {
+    if (act[p] == 0.f) continue;
+    const float gtp = g[(int64_t)t * si.ldG + p], gpp = g[(int64_t)p * si.ldG + p];
+    mn = fminf(mn, (gtt + gpp) - 2.f * gtp);
+    if (picked) {
+      int dist = t > p ? t - p : p - t;
+      div += (!far_sim && dist > thre) ? 1.f : 1.f - gtp * inv_nt * (1.0f / sqrtf(gpp));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); div += __shfl_xor(div, o); }
+  if (lane == 0) { rowres[2 * wid] = mn; rowres[2 * wid + 1] = div; }
+}
+
+// one wave per (episode, video): fixed-order sums over the video's frames
+__global__ __launch_bounds__(64) void reward_final_kernel(const float* __restrict__ rowres, const RSeq* __restrict__ seq,
+                                                          const float* __restrict__ actions, int n_seq, int n_rows,
+                                                          float* __restrict__ reward) {
+  const int ep = blockIdx.x / n_seq, s = blockIdx.x % n_seq, lane = threadIdx.x;
+  const RSeq si = seq[s];
+  float smin = 0.f, sdiv = 0.f, cnt = 0.f;
+  for (int t = lane; t < si.T; t += 64) {
+    const int64_t wid = (int64_t)ep * n_rows + si.row0 + t;
+    smin += rowres[2 * wid]; sdiv += rowres[2 * wid + 1];
+    cnt += actions[(int64_t)ep * n_rows + si.row0 + t] != 0.f ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { smin += __shfl_xor(smin, o); sdiv += __shfl_xor(sdiv, o); cnt += __shfl_xor(cnt, o); }
+  if (lane == 0) {
+    float r = 0.f;
+    if (cnt > 0.f) {
+      float rdiv = cnt > 1.f ? sdiv / (cnt * (cnt - 1.f)) : 0.f;
+      float rrep = expf(-(smin / (float)si.T));
+      r = (rdiv + rrep) * 0.5f;
+    }
+    reward[(int64_t)ep * n_seq + s] = r;
+  }
+}
+
+}  // namespace sumk
+
+using namespace sumk;
+
+extern "C" size_t sumk_dsn_reward_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t n_episodes) {
+  RewardWs w;
+  if (reward_carve(D, n_seq, seq_off_host, n_episodes, &w) != SUMK_OK) return 0;
+  return w.total;
+}
+
+extern "C" int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                               const int32_t* seq_off_dev, const float* actions, int32_t n_episodes, int32_t far_sim,
+                               int32_t temp_dist_thre, float* reward, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(x && seq_off_dev && actions && reward && workspace, "dsn_reward: null pointer");
+  RewardWs L;
+  SUMK_TRY(reward_carve(D, n_seq, seq_off_host, n_episodes, &L));
+  if (workspace_bytes < L.total) { set_error("dsn_reward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
+  char* ws = (char*)workspace;
+  float* G = (float*)(ws + L.gram);
+  RSeq* seq = (RSeq*)(ws + L.seq);
+  GemmProb* prob = (GemmProb*)(ws + L.prob);
+  float* rowres = (float*)(ws + L.rowres);
+  hipLaunchKernelGGL(reward_setup_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, seq_off_dev, n_seq, D, seq, prob);
+  int tiles = 0;
+  for (int s = 0; s < n_seq; ++s) { int tm = (seq_off_host[s + 1] - seq_off_host[s] + 63) / 64; tiles += tm * tm; }
+  GemmLaunch g;
+  g.A = x; g.B[0] = x; g.C = G; g.probs = prob; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = tiles;
+  SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
+  const int64_t nw = (int64_t)n_episodes * L.n_rows;
+  hipLaunchKernelGGL(reward_rows_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, stream, G, seq, seq_off_dev, n_seq,
+                     L.n_rows, actions, n_episodes, far_sim, temp_dist_thre, rowres);
+  hipLaunchKernelGGL(reward_final_kernel, dim3(n_episodes * n_seq), dim3(64), 0, stream, rowres, seq, actions, n_seq, L.n_rows,
+                     reward);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}

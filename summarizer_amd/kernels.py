@@ -233,3 +233,23 @@ def frame_head_backward(h, scores, dscores, w, dw, db):
                                       nb, _stream())
     _lib.check(rc, "sumk_frame_head_backward")
     return dh
+
+
+# ------------------------------------------------------------------------------------------------ DSN reward
+def dsn_reward(x, sb, actions, far_sim=False, temp_dist_thre=20):
+    """actions: (E, n_rows) 0/1 floats -> rewards (E, n_seq) (dsn.py:185-236) for a packed batch."""
+    lib = _lib.load()
+    _require_gpu(x, "dsn_reward features"); _require_gpu(actions, "dsn_reward actions")
+    E = actions.shape[0]
+    if actions.dim() != 2 or actions.shape[1] != sb.n_rows or not actions.is_contiguous():
+        raise SumkError(f"dsn_reward: actions must be contiguous (E, {sb.n_rows}), got {tuple(actions.shape)}")
+    D = x.shape[1]
+    nb = lib.sumk_dsn_reward_workspace_bytes(D, sb.n_seq, sb.off_host_p, E)
+    if nb == 0:
+        _lib.check(-1, "sumk_dsn_reward_workspace_bytes")
+    ws = workspace(nb, x.device)
+    out = torch.empty(E, sb.n_seq, dtype=torch.float32, device=x.device)
+    rc = lib.sumk_dsn_reward(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, _p(actions), E, int(bool(far_sim)),
+                             int(temp_dist_thre), _p(out), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "sumk_dsn_reward")
+    return out
