@@ -3,12 +3,18 @@
 Same constructor (dsn.py:19), same state_dict keys (`rnn.weight_ih_l0[_reverse]`, ..., `out.0.weight`,
 `out.0.bias`), same forward contract x (seq_len, batch, input_size) -> (seq_len, batch, 1) (dsn.py:38-47).
 """
+import math
+import random
+import numpy as np
 import torch
 import torch.nn as nn
+from torch.distributions import Bernoulli
 
 from .. import kernels
 from .._lib import SumkError
+from . import Trainer
 from ._bilstm import pack_time_major, bilstm_scores
+from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
 
 
 class DSN(nn.Module):
@@ -35,3 +41,125 @@ class DSN(nn.Module):
         """Batched extension: frames of several videos back to back (sum(lens), D) -> (sum(lens),) probabilities."""
         sb = kernels.SeqBatch.get(lens, x_packed.device)
         return bilstm_scores(self, x_packed, sb, "rnn.", self.num_layers, self.hidden_size, "out.0.weight", "out.0.bias")
+
+
+class DSNTrainer(Trainer):
+    """Mirror of the reference trainer (dsn.py:50-236): REINFORCE with `num_episodes` Bernoulli episodes per video,
+    diversity-representativeness reward, per-video moving-average baseline, grad-norm clip 5.0, Adam; optional
+    supervised BCE term (`sup`).  `extra_params` parsing keeps the reference's quirks: beta = int(...) so the default
+    0.01 becomes 0 (dsn.py:52), bool("False") is True.
+
+    Differences underneath: the reward of all episodes comes from ONE HIP call (one Gram GEMM + masked reductions,
+    csrc/reward.hip) instead of 2 matmuls per episode; the optimiser is the flat-bucket HIP Adam with the clip folded in.
+    Extensions: extra_params["batch_videos"], and sharding of the training videos over torch.distributed ranks with one
+    gradient all-reduce per step; per-video baselines stay on the rank that owns the video (static assignment)."""
+
+    def _init_model(self):
+        ep = self.hps.extra_params
+        self.beta = int(ep.get("beta", 0.01))
+        self.num_episodes = int(ep.get("num_episodes", 5))
+        self.eps = float(ep.get("eps", 0.5))
+        self.far_sim = bool(ep.get("far_sim", False))
+        self.temp_dist_thre = int(ep.get("temp_dist_thre", 20))
+        self.sup = bool(ep.get("sup", False))
+        model = DSN(**({"input_size": int(ep["input_size"])} if "input_size" in ep else {}),
+                    **({"hidden_size": int(ep["hidden_size"])} if "hidden_size" in ep else {}))
+        return model
+
+    def compute_reward(self, seq, actions, far_sim=False, temp_dist_thre=20):
+        """Reference signature (dsn.py:185): seq (seq_len,1,input_size), actions (seq_len,1,1) -> 0-d reward tensor."""
+        T = seq.shape[0]
+        sb = kernels.SeqBatch.get([T], seq.device)
+        r = kernels.dsn_reward(seq.detach().reshape(T, -1).contiguous(), sb, actions.detach().reshape(1, T).contiguous(),
+                               far_sim=far_sim, temp_dist_thre=temp_dist_thre)
+        return r.reshape(())
+
+    def _load_video(self, key, dev):
+        d = self.dataset[key]
+        seq = torch.from_numpy(d["features"][...])
+        target = torch.from_numpy(d["gtscore"][...]).view(-1)
+        target = target - target.min()                                   # dsn.py:104-105
+        target = target / (target.max() - target.min())
+        return seq.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+
+    def train(self, fold):
+        self.model.train()
+        train_keys, _ = self._get_train_test_keys(fold)
+        self.draw_gtscores(fold, train_keys)
+        self.log.debug("Parameters: {}".format(sum([_.numel() for _ in self.model.parameters()])))
+        dev = self._device()
+        rank, world = dist_info()
+        broadcast_parameters(self.model)
+        bv = int(self.hps.extra_params.get("batch_videos", 1))
+        self.optimizer = FlatAdam(self.model.parameters(), lr=self.hps.lr, weight_decay=self.hps.weight_decay)
+        if world > 1:
+            lens = [self.dataset[k]["features"].shape[0] for k in train_keys]
+            my_keys = shard_keys(train_keys, lens, rank, world)
+            steps_per_epoch = max(1, math.ceil(max(len(shard_keys(train_keys, lens, r, world)) for r in range(world)) / bv))
+        else:
+            my_keys = train_keys
+            steps_per_epoch = math.ceil(len(my_keys) / bv)
+
+        baselines = {key: 0. for key in my_keys}                         # dsn.py:81
+        reward_writers = {key: [] for key in my_keys}                    # dsn.py:84
+        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        E = self.num_episodes
+
+        for epoch in range(self.hps.epochs):
+            losses, dist_scores = [], {}
+            random.shuffle(my_keys)
+            for step in range(steps_per_epoch):
+                keys = my_keys[step * bv:(step + 1) * bv]
+                self.optimizer.zero_grad()
+                if keys:
+                    vids = [self._load_video(k, dev) for k in keys]
+                    lens_b = [v[0].shape[0] for v in vids]
+                    x = torch.cat([v[0] for v in vids]) if len(vids) > 1 else vids[0][0]
+                    sb = kernels.SeqBatch.get(lens_b, dev)
+                    probs = self.model.score_packed(x, lens_b)            # (sum T,)
+                    dist = Bernoulli(probs)
+                    actions = dist.sample((E,))                           # (E, sum T)   dsn.py:125
+                    log_probs = dist.log_prob(actions)                    # dsn.py:126
+                    rewards = kernels.dsn_reward(x, sb, actions.contiguous(), far_sim=self.far_sim,
+                                                 temp_dist_thre=self.temp_dist_thre)       # (E, n_videos)  dsn.py:129-131
+                    off = np.concatenate([[0], np.cumsum(lens_b)])
+                    base = torch.tensor([baselines[k] for k in keys], dtype=torch.float32, device=dev)
+                    loss = 0
+                    for i, k in enumerate(keys):
+                        p_i = probs[off[i]:off[i + 1]]
+                        l_i = self.beta * (p_i.mean() - self.eps) ** 2                      # dsn.py:115
+                        if self.sup:
+                            l_i = l_i + torch.nn.functional.binary_cross_entropy(p_i, vids[i][1])   # dsn.py:117-119
+                        lp = log_probs[:, off[i]:off[i + 1]].mean(dim=1)                    # (E,)
+                        l_i = l_i - (lp * (rewards[:, i] - base[i])).sum()                  # dsn.py:134
+                        loss = loss + l_i / float(E) / len(keys)                            # dsn.py:140
+                        dist_scores[k] = p_i.detach().view(-1, 1, 1)
+                    loss.backward()
+                    losses.append(loss.detach())
+                    mean_r = rewards.mean(dim=0).tolist()                 # one D2H per step (the reference does E per video)
+                    for i, k in enumerate(keys):
+                        baselines[k] = 0.9 * baselines[k] + 0.1 * mean_r[i]                 # dsn.py:149
+                        reward_writers[k].append(mean_r[i])
+                scale = self.optimizer.all_reduce_grads()
+                self.optimizer.step(grad_scale=scale, max_norm=5.0)       # clip_grad_norm_(…, 5.0) dsn.py:145, post all-reduce
+
+            epoch_avg_reward = float(np.mean([reward_writers[k][-1] for k in my_keys if reward_writers[k]])) if my_keys else float("nan")
+            epoch_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")
+            self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Reward: {epoch_avg_reward:.05f}  Loss: {epoch_avg_loss:.05f}")
+            self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Reward", epoch_avg_reward, epoch)
+            self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", epoch_avg_loss, epoch)
+
+            if epoch % self.hps.test_every_epochs == 0:
+                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
+                self.model.train()
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/Correlation", avg_corr, epoch)
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_avg", avg_f_score, epoch)
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_max", max_f_score, epoch)
+                best_avg_f_score = max(best_avg_f_score, avg_f_score)
+                best_max_f_score = max(best_max_f_score, max_f_score)
+                if avg_corr > best_corr:
+                    best_corr = avg_corr
+                    self.best_weights = self.model.state_dict()
+
+        self.draw_scores(fold, dist_scores)
+        return best_corr, best_avg_f_score, best_max_f_score

@@ -10,6 +10,7 @@ Extension (not in the reference): `score_packed` scores MANY videos of different
 that is the path `Trainer.test` / bench.py use to fill the GPU.
 """
 import math
+import random
 import numpy as np
 import torch
 import torch.nn as nn
@@ -17,6 +18,8 @@ import torch.nn.init as init
 
 from .. import kernels
 from .._lib import SumkError
+from . import Trainer
+from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
 
 
 class VASNet(nn.Module):
@@ -136,3 +139,104 @@ def _sinusoid_table(max_length, d):
     tab[:, 0::2] = np.sin(pos / (10000 ** ((2 * i) / d)))
     tab[:, 1::2] = np.cos(pos / (10000 ** ((2 * (i + 1)) / d)))
     return torch.from_numpy(tab)
+
+
+class VASNetTrainer(Trainer):
+    """Mirror of the reference trainer (vasnet.py:151-238): per-video MSE regression to the min-max normalised gtscore,
+    Adam(lr, weight_decay), periodic test, best-correlation weights.  Same `extra_params` parsing, quirks included
+    (bool("False") is True, vasnet.py:156).
+
+    Extensions (all default to the reference schedule): extra_params["batch_videos"] = videos per optimiser step on each
+    rank (default 1); under torch.distributed the training videos are sharded over ranks (balanced by frames) and the
+    flat gradient bucket is all-reduced once per step (RCCL)."""
+
+    def _init_model(self):
+        ep = self.hps.extra_params
+        model = VASNet(
+            max_length=int(ep["max_pos"]) if "max_pos" in ep else None,
+            pos_embed=ep.get("pos_embed", "simple"),
+            ignore_self=bool(ep.get("ignore_self", False)),
+            attention_aperture=int(ep["local"]) if "local" in ep else None,
+            scale=float(ep["scale"]) if "scale" in ep else None,
+            epsilon=float(ep.get("epsilon", 1e-6)),
+            weight_init=ep.get("weight_init", "xavier"),
+            **({"input_size": int(ep["input_size"])} if "input_size" in ep else {}))
+        if self.hps.use_cuda:
+            self.log.info(f"Setting CUDA device: {self.hps.cuda_device}")
+            torch.cuda.set_device(self.hps.cuda_device)
+            model.cuda()
+        return model
+
+    def _load_video(self, key, dev):
+        d = self.dataset[key]
+        seq = torch.from_numpy(d["features"][...])                       # (seq_len, input_size)
+        target = torch.from_numpy(d["gtscore"][...]).view(-1)
+        target = target - target.min()                                   # vasnet.py:201-202
+        target = target / (target.max() - target.min())
+        return seq.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+
+    def train(self, fold):
+        self.model.train()
+        train_keys, _ = self._get_train_test_keys(fold)
+        self.draw_gtscores(fold, train_keys)
+        dev = self._device()
+        rank, world = dist_info()
+        broadcast_parameters(self.model)
+        bv = int(self.hps.extra_params.get("batch_videos", 1))
+        self.optimizer = FlatAdam(filter(lambda p: p.requires_grad, self.model.parameters()), lr=self.hps.lr,
+                                  weight_decay=self.hps.weight_decay)
+        if world > 1:
+            lens = [self.dataset[k]["features"].shape[0] for k in train_keys]
+            my_keys = shard_keys(train_keys, lens, rank, world)
+            steps_per_epoch = max(1, math.ceil(max(len(shard_keys(train_keys, lens, r, world)) for r in range(world)) / bv))
+        else:
+            my_keys = train_keys
+            steps_per_epoch = math.ceil(len(my_keys) / bv)
+
+        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        use_packed = self.model.max_length is None
+        for epoch in range(self.hps.epochs):
+            losses, dist_scores = [], {}
+            random.shuffle(my_keys)
+            for step in range(steps_per_epoch):
+                keys = my_keys[step * bv:(step + 1) * bv]
+                self.optimizer.zero_grad()
+                if keys:
+                    vids = [self._load_video(k, dev) for k in keys]
+                    if use_packed:
+                        lens_b = [v[0].shape[0] for v in vids]
+                        scores = self.model.score_packed(torch.cat([v[0] for v in vids]) if len(vids) > 1 else vids[0][0], lens_b)
+                        off = np.concatenate([[0], np.cumsum(lens_b)])
+                        # mean over videos of the per-video MSE (== nn.MSELoss per video, vasnet.py:209, when bv == 1)
+                        loss = sum(torch.mean((scores[off[i]:off[i + 1]] - vids[i][1]) ** 2) for i in range(len(vids))) / len(vids)
+                        for i, k in enumerate(keys):
+                            dist_scores[k] = scores[off[i]:off[i + 1]].detach().view(-1, 1, 1)
+                    else:
+                        loss = 0
+                        for k, (seq, target) in zip(keys, vids):
+                            sc = self.model(seq.unsqueeze(1))
+                            loss = loss + torch.mean((sc.view(-1) - target) ** 2) / len(vids)
+                            dist_scores[k] = sc.detach()
+                    loss.backward()
+                    losses.append(loss.detach())
+                scale = self.optimizer.all_reduce_grads()
+                self.optimizer.step(grad_scale=scale)
+
+            train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")   # one D2H sync per epoch
+            self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Loss: {train_avg_loss:.05f}")
+            self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", train_avg_loss, epoch)
+
+            if epoch % self.hps.test_every_epochs == 0:
+                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
+                self.model.train()
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/Correlation", avg_corr, epoch)
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_avg", avg_f_score, epoch)
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_max", max_f_score, epoch)
+                best_avg_f_score = max(best_avg_f_score, avg_f_score)
+                best_max_f_score = max(best_max_f_score, max_f_score)
+                if avg_corr > best_corr:
+                    best_corr = avg_corr
+                    self.best_weights = self.model.state_dict()     # live references, like vasnet.py:233
+
+        self.draw_scores(fold, dist_scores)
+        return best_corr, best_avg_f_score, best_max_f_score

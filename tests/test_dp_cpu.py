@@ -1,0 +1,55 @@
+"""CPU (gloo, world_size 2): the data-parallel plumbing -- video->rank sharding and the single flat-bucket gradient
+all-reduce -- without any compute call (the HIP path needs a GPU)."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from summarizer_amd.training import shard_keys, all_reduce_flat, dist_info
+
+
+def test_shard_keys_partition_and_balance():
+    rng = np.random.default_rng(0)
+    lens = [int(v) for v in rng.integers(100, 700, 40)]
+    keys = [f"video_{i+1}" for i in range(40)]
+    for world in (1, 2, 4, 8):
+        parts = [shard_keys(keys, lens, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == sorted(keys)                       # disjoint cover
+        loads = [sum(lens[keys.index(k)] for k in p) for p in parts]
+        assert max(loads) - min(loads) <= max(lens)                          # greedy longest-first bound
+        assert parts == [shard_keys(keys, lens, r, world) for r in range(world)]   # deterministic
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert dist_info() == (rank, world)
+        bucket = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        scale = all_reduce_flat(bucket)
+        avg = bucket * scale
+        expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        ok = bool(torch.allclose(avg, expect))
+        keys = [f"video_{i}" for i in range(11)]
+        lens = [50 + 7 * i for i in range(11)]
+        mine = shard_keys(keys, lens, rank, world)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ok = ok and sorted(sum(gathered, [])) == sorted(keys)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_gloo_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
