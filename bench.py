@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["vasnet", "dsn"], default="vasnet", help="headline = vasnet")
+    ap.add_argument("--mode", choices=["score", "train"], default="score", help="headline = score (frames scored/sec)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,26 +96,46 @@ def main():
     lens = tvsum_lens(args.videos)
     frames = int(sum(lens))
     torch.manual_seed(1234)
-    model = VASNet(input_size=D).eval().to(dev)
+    if args.model == "vasnet":
+        model = VASNet(input_size=D).to(dev)
+    else:
+        from summarizer_amd.models.dsn import DSN
+        model = DSN(input_size=D).to(dev)
+    model.train(args.mode == "train")
     x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 1000 * rank + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    if args.mode == "train":
+        # one optimiser step per packed batch: forward + MSE to a random target + backward + flat-bucket Adam
+        # (+ one gradient all-reduce under torch.distributed)
+        from summarizer_amd.training import FlatAdam
+        opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
+        target = torch.rand(frames, device=dev)
+        def run_step():
+            opt.zero_grad()
+            loss = torch.mean((model.score_packed(x, lens) - target) ** 2)
+            loss.backward()
+            opt.step(grad_scale=opt.all_reduce_grads())
+            return loss.detach()
+    else:
+        def run_step():
+            with torch.no_grad():
+                return model.score_packed(x, lens)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            s = model.score_packed(x, lens)
-        barrier()
-        lib.sumk_prof_read(_lib.PROF_GEMM_QKV, None, None, 1)
-        lib.sumk_prof_enable(1)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            s = model.score_packed(x, lens)
-        barrier()
-        t1 = time.perf_counter()
-        lib.sumk_prof_enable(0)
+    for _ in range(args.warmup):
+        s = run_step()
+    barrier()
+    lib.sumk_prof_read(_lib.PROF_GEMM_QKV, None, None, 1)
+    lib.sumk_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = run_step()
+    barrier()
+    t1 = time.perf_counter()
+    lib.sumk_prof_enable(0)
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -143,11 +165,13 @@ def main():
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"VASNet eval scoring, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch",
+                   config=dict(workload=f"{args.model} {args.mode}, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch",
                                frames_per_step_per_gpu=frames, parallelism=f"video-sharded x{world}"),
                    whole_path_tflops=round(frames * world * args.steps / elapsed * flops_frame / 1e12, 2),
                    roofline=roof)
-        if world == 1 and not args.no_cpu_baseline:
+        if args.model != "vasnet" or args.mode != "score":
+            out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
+        if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score":
             out["cpu_baseline"] = cpu_baseline(lens, D)
         print(json.dumps(out), flush=True)
     if dist is not None:
