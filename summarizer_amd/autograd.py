@@ -6,6 +6,20 @@ import torch
 from . import kernels
 
 
+def _grad_targets(names, params):
+    """Gradient buffers for the HIP backward (which ACCUMULATES).  A parameter that already owns a contiguous .grad
+    (FlatAdam's bucket views) is accumulated into directly -- no zeros_like + add kernels, no extra 21 MB of traffic --
+    and autograd is handed None for it; otherwise a fresh zero buffer is returned to autograd as usual."""
+    grads, ret = {}, []
+    for n, p in zip(names, params):
+        g = getattr(p, "grad", None)
+        if g is not None and g.is_contiguous() and g.dtype == p.dtype and g.shape == p.shape:
+            grads[n] = g; ret.append(None)
+        else:
+            grads[n] = torch.zeros_like(p); ret.append(grads[n])
+    return grads, ret
+
+
 class VasnetFunction(torch.autograd.Function):
     """scores = VASNet(x) for a packed batch.  inputs: x, SeqBatch, opts, pos table/rows, param names, *params."""
 
@@ -16,15 +30,16 @@ class VasnetFunction(torch.autograd.Function):
         ctx.sb, ctx.opts, ctx.names, ctx.ws, ctx.rows = sb, opts, names, ws, rows
         ctx.table_is_param = isinstance(table, torch.nn.Parameter) and table.requires_grad
         ctx.table = table
-        ctx.save_for_backward(xp, *params)
-        ctx.mark_non_differentiable()
+        ctx.params = params          # the Parameter objects themselves (their .grad may be a bucket view)
+        ctx.save_for_backward(xp)
         return scores
 
     @staticmethod
     def backward(ctx, dscores):
-        xp, *params = ctx.saved_tensors
+        (xp,) = ctx.saved_tensors
+        params = ctx.params
         p = dict(zip(ctx.names, params))
-        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        grads, ret = _grad_targets(ctx.names, params)
         want_dx = ctx.needs_input_grad[0] or ctx.table_is_param
         dx = kernels.vasnet_backward_packed(xp, ctx.sb, p, ctx.opts, dscores, ctx.ws, grads, want_dx=want_dx)
         ctx.ws = None
@@ -34,7 +49,8 @@ class VasnetFunction(torch.autograd.Function):
             tg = torch.zeros_like(ctx.table).index_add_(0, ctx.rows.long(), dx)
             ctx.table.grad = tg if ctx.table.grad is None else ctx.table.grad + tg
         gx = dx if ctx.needs_input_grad[0] else None
-        return (gx, None, None, None, None, None) + tuple(grads[n] for n in ctx.names)
+        ctx.params = None
+        return (gx, None, None, None, None, None) + tuple(ret)
 
 
 class BiLstmScorerFunction(torch.autograd.Function):
@@ -50,16 +66,17 @@ class BiLstmScorerFunction(torch.autograd.Function):
         scores = kernels.frame_head_forward(acts[-1], p[head_w], p[head_b])
         ctx.meta = (sb, prefix, num_layers, H, head_w, head_b, names)
         ctx.wss = wss
-        ctx.save_for_backward(scores, *acts, *params)
+        ctx.params = params
+        ctx.save_for_backward(scores, *acts)
         return scores
 
     @staticmethod
     def backward(ctx, dscores):
         sb, prefix, num_layers, H, head_w, head_b, names = ctx.meta
         saved = ctx.saved_tensors
-        scores, acts, params = saved[0], saved[1:2 + num_layers], saved[2 + num_layers:]
+        scores, acts, params = saved[0], saved[1:2 + num_layers], ctx.params
         p = dict(zip(names, params))
-        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        grads, ret = _grad_targets(names, params)
         dh = kernels.frame_head_backward(acts[-1], scores, dscores, p[head_w], grads[head_w], grads[head_b])
         for layer in range(num_layers - 1, -1, -1):
             want_dx = layer > 0 or ctx.needs_input_grad[0]
@@ -67,4 +84,5 @@ class BiLstmScorerFunction(torch.autograd.Function):
                                                ctx.wss[layer], want_dx)
         ctx.wss = None
         gx = dh if ctx.needs_input_grad[0] else None
-        return (gx, None, None, None, None, None, None, None) + tuple(grads[n] for n in names)
+        ctx.params = None
+        return (gx, None, None, None, None, None, None, None) + tuple(ret)

@@ -362,25 +362,37 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, int ld, int R
   for (int r = r0; r < r1; ++r) s += X[(int64_t)r * ld + c];
   partial[(int64_t)blockIdx.y * N + c] = s;
 }
-__global__ void partial_reduce_kernel(const float* __restrict__ partial, int n_part, int stride, int N,
-                                      float* __restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+// block = 16 columns x 16 partial-groups; each thread strides over the partials of its group, then a fixed-order LDS
+// combine (deterministic).  n_part can be ~1000 (per-wave partials of the LayerNorm backward), so the partial axis must
+// be spread over threads: a one-thread-per-column loop took 190 us per call.
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int n_part, int stride, int N,
+                                                             float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += partial[(int64_t)p * stride + c];
-  out[c] += s;
+  if (c < N)
+    for (int p = pg; p < n_part; p += 16) s += partial[(int64_t)p * stride + c];
+  red[pg][cl] = s;
+  __syncthreads();
+  if (pg == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cl];
+    out[c] += t;
+  }
 }
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream) {
   int chunks = std::max(1, std::min(max_chunks, (R + 63) / 64));
   int rpc = (R + chunks - 1) / chunks;
   chunks = (R + rpc - 1) / rpc;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, stream, X, ld, R, N, rpc, partial);
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial, chunks, N, N, out);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, partial, chunks, N, N, out);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 int partial_reduce_accum(const float* partial, int n_part, int stride, int N, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial, n_part, stride, N, out);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, partial, n_part, stride, N, out);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

@@ -89,8 +89,32 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
   const int j0 = ublk * 8;
   const int t = a.t;
 
+  // ---- epilogue operands first: their loads (G row slice, previous cell state) do not depend on the mat-vec, so they
+  // are issued before it and their latency hides under the fragment loads / MFMAs.
+  const int ei = tid >> 3, eu = tid & 7;
+  const int esv = mtile * 32 + ei, j = j0 + eu;
+  bool eact = false;
+  int64_t row = 0, prow = 0;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float cprev = 0.f;
+  if (esv < a.n_seq && j < H) {
+    const int r0 = a.off[esv], T = a.off[esv + 1] - r0;
+    if (t < T) {
+      eact = true;
+      row = d == 0 ? r0 + t : r0 + T - 1 - t;
+      prow = d == 0 ? row - 1 : row + 1;
+      const float* g = a.G + row * (8 * H) + d * 4 * H;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[q] = g[q * H + j];
+      if (t > 0) cprev = a.c_all ? a.c_all[prow * (2 * H) + d * H + j] : a.cstate[((int64_t)esv * 2 + d) * H + j];
+    }
+  }
+
   if (t > 0) {
-    // A operand: h_prev of video (mtile*32 + li); B operand: W_hh row of gate-column li = g*8 + u
+    // A operand: h_prev of video (mtile*32 + li); B operand: W_hh row of gate-column li = g*8 + u.
+    // Fragments come straight from memory (L2 does not survive the kernel boundary: Infinity Cache / HBM).  Measured
+    // alternatives: staging the 32x128 panels through LDS in 128-B-coalesced segments was SLOWER (12.3 vs 10.5 us per
+    // step at 50 videos, H=256: two extra barriers on a latency-bound kernel); see DESIGN.md "LSTM step latency".
     const int sv = mtile * 32 + li;
     bool act = false;
     const float* hp = a.Hout;  // clamped to a legal row when inactive
@@ -105,42 +129,41 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int nchunk = (H + 7) >> 3;
-    for (int kk = wave; kk < nchunk; kk += 4) {
-      const int k = kk * 8 + 4 * lh, kc = min(k, H - 4);
-      // unconditional 16-B loads (legal clamped addresses), zeroed afterwards: keeps the loads back to back
-      float4 bv = *reinterpret_cast<const float4*>(wp + kc);
-      float4 av = *reinterpret_cast<const float4*>(hp + kc);
-      if (!act || k >= H) av = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k >= H) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    // chunks kk = wave, wave+4, ...; handled 8 at a time with ALL 16 fragment loads in flight before the first MFMA
+    for (int kb = wave; kb < nchunk; kb += 32) {
+      float4 av[8], bv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = (kb + 4 * q) * 8 + 4 * lh, kc = min(k, H - 4);
+        bv[q] = *reinterpret_cast<const float4*>(wp + kc);
+        av[q] = *reinterpret_cast<const float4*>(hp + kc);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = (kb + 4 * q) * 8 + 4 * lh;
+        if (!act || k >= H) av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k >= H) bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
     __syncthreads();
   }
 
-  // ---- cell update: thread = (video i, unit u)
-  const int i = tid >> 3, u = tid & 7;
-  const int sv = mtile * 32 + i, j = j0 + u;
-  if (sv >= a.n_seq || j >= H) return;
-  const int r0 = a.off[sv], T = a.off[sv + 1] - r0;
-  if (t >= T) return;
-  const int64_t row = d == 0 ? r0 + t : r0 + T - 1 - t;
-  const float* g = a.G + row * (8 * H) + d * 4 * H;
-  float pre[4];
+  // ---- cell update: thread = (video ei, unit eu)
+  if (!eact) return;
+  const int i = ei, u = eu;
+  if (t > 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float v = g[q * H + j];
-    if (t > 0) v += (part[0][i][q * 8 + u] + part[1][i][q * 8 + u]) + (part[2][i][q * 8 + u] + part[3][i][q * 8 + u]);
-    pre[q] = v;
+    for (int q = 0; q < 4; ++q)
+      pre[q] += (part[0][i][q * 8 + u] + part[1][i][q * 8 + u]) + (part[2][i][q * 8 + u] + part[3][i][q * 8 + u]);
   }
   const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-  float cprev = 0.f;
-  const int64_t prow = d == 0 ? row - 1 : row + 1;
-  if (t > 0) cprev = a.c_all ? a.c_all[prow * (2 * H) + d * H + j] : a.cstate[((int64_t)sv * 2 + d) * H + j];
+  const int sv = esv;
   const float c = fg * cprev + ig * gg;
   const float h = og * tanhf(c);
   a.Hout[row * (2 * H) + d * H + j] = h;
@@ -212,15 +235,26 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(BwdStepArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int nchunk = H4 >> 3;   // 4H is a multiple of 16
-    for (int kk = wave; kk < nchunk; kk += 8) {
-      const int k = kk * 8 + 4 * lh;
-      float4 av = *reinterpret_cast<const float4*>(gp + k);
-      float b0 = wp[(int64_t)(k + 0) * H], b1 = wp[(int64_t)(k + 1) * H], b2 = wp[(int64_t)(k + 2) * H], b3 = wp[(int64_t)(k + 3) * H];
-      if (!act) av = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+    // chunks kk = wave, wave+8, ...; 8 at a time with all 40 loads in flight before the first MFMA (see lstm_step_kernel)
+    for (int kb = wave; kb < nchunk; kb += 64) {
+      float4 av[8];
+      float bq[8][4];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = min((kb + 8 * q) * 8 + 4 * lh, H4 - 4);
+        av[q] = *reinterpret_cast<const float4*>(gp + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[q][e] = wp[(int64_t)(k + e) * H];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool live = act && (kb + 8 * q) < nchunk;
+        if (!live) av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bq[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bq[q][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bq[q][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bq[q][3], acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
