@@ -20,6 +20,7 @@
 //   The sum over k is therefore re-associated relative to a sequential loop (fp32, ~1e-7 relative).
 #include "sumk_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace sumk {
 
@@ -38,95 +39,128 @@ struct GemmKArgs {
   const GemmProb* probs;
   int32_t nprob;
   int32_t n_group;
+  int32_t total_tiles;   // loop bound of the persistent tile walk (virtual tiles when xcd_tiles_m > 0)
+  int32_t xcd_tiles_m;   // > 0: single-problem launch with the XCD-aware tile map below; value = tiles along M
   float alpha;
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int BT, bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
-  constexpr int WT = BT / 2;        // wave tile edge
-  constexpr int TM = WT / 32;       // MFMA tiles per wave along M (and N)
-  constexpr int NLD = BT / 32;      // float4 loads per thread per operand per k-tile
-  constexpr int A_ELEMS = A_KC ? BT * KC_PITCH : BK * BT;
-  constexpr int B_ELEMS = B_KC ? BT * KC_PITCH : BK * BT;
+// Per-tile scalars (wave-uniform, live in SGPRs).
+struct TileCtx {
+  int64_t c_off, r_off;
+  int32_t M, N, K, lda, ldb, ldc, ldr, m0, n0, klast;
+};
+
+// __launch_bounds__(256, 3): three blocks per CU (152 VGPRs, 36 KB LDS for the 128x128 tile).
+// PERSISTENT tile loop: the grid is at most (resident slots) blocks and block b walks tiles b, b+grid, ...  While the
+// LAST k-tile of a tile is being multiplied, the block already decodes its next tile and issues that tile's first global
+// loads, so the epilogue stores of tile i and the prologue latency of tile i+1 overlap instead of leaving the MFMA pipe
+// idle (measured before: ~19k idle cycles per tile per SIMD at K=1024, because co-resident blocks run in lockstep).
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32; // MFMA tiles per wave along M / N
+  constexpr int NLDA = BM / 32, NLDB = BN / 32;  // float4 loads per thread per operand per k-tile
+  constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : BK * BM;
+  constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : BK * BN;
   __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
   float* sA = lds;
   float* sB = lds + A_ELEMS;
-
-  // ---- which sub-problem / tile (wave-uniform scalar work)
-  const int tile = blockIdx.x;
-  int lo = 0, hi = ka.nprob - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (ka.probs[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
-  }
-  const GemmProb P = ka.probs[lo];
-  const int local = tile - P.tile_start;
-  const int m0 = (local / P.tiles_n) * BT;
-  const int n0 = (local % P.tiles_n) * BT;
-  const int M = P.M, N = P.N, K = P.K;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-
-  // ---- per-thread global source descriptors (fixed across the k loop).  Loads are UNCONDITIONAL: addresses
-  // are clamped into the operand so the compiler can issue all of a k-tile's 16-B loads back to back and wait
-  // for them only where they are written to LDS.  Rows/columns past M or N are clamped, not zeroed -- they only
-  // feed output rows/columns the epilogue never stores.  Only the K tail must contribute zeros: masked in swrite.
-  const float* pa[NLD];
-  const float* pb[NLD];
-  constexpr int TPR = BT / 4;          // MC image: threads per k-row
-  constexpr int KROWS = 256 / TPR;     // MC image: k-rows covered per pass
+  constexpr int TPRA = BM / 4, TPRB = BN / 4;              // MC image: threads per k-row
+  constexpr int KROWSA = 256 / TPRA, KROWSB = 256 / TPRB;  // MC image: k-rows covered per pass
   const int kq4 = (tid & 7) * 4;       // KC image: this thread's k offset inside a k-tile
-  const int klast = K > 4 ? ((K + 3) & ~3) - 4 : 0;   // last legal float4 start along a K-contiguous row
-  if constexpr (A_KC) {
-#pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      int r = min(m0 + (tid >> 3) + 32 * p, M - 1);
-      pa[p] = ka.A + P.a_off + (int64_t)r * P.lda;
-    }
-  } else {
-    int c = m0 + (tid % TPR) * 4;
-    c = c < M ? c : 0;
-#pragma unroll
-    for (int p = 0; p < NLD; ++p) pa[p] = ka.A + P.a_off + c;
-  }
-  if constexpr (B_KC) {
-#pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      int n = min(n0 + (tid >> 3) + 32 * p, N - 1);
-      int g = 0, nl = n;
-      if (ka.n_group > 0) { g = n / ka.n_group; nl = n - g * ka.n_group; }
-      const float* bg = g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3];
-      pb[p] = bg + P.b_off + (int64_t)nl * P.ldb;
-    }
-  } else {
-    int c = n0 + (tid % TPR) * 4;
-    c = c < N ? c : 0;
-#pragma unroll
-    for (int p = 0; p < NLD; ++p) pb[p] = ka.B[0] + P.b_off + c;
-  }
 
-  float4 ra[NLD], rb[NLD];
+  // Per-thread global source descriptors of the tile whose operands are being LOADED.  Loads are UNCONDITIONAL:
+  // addresses are clamped into the operand so the compiler can issue all of a k-tile's 16-B loads back to back and wait
+  // for them only where they are written to LDS.  Rows/columns past M or N are clamped, not zeroed -- they only feed
+  // output rows/columns the epilogue never stores.  Only the K tail must contribute zeros: masked before the LDS write.
+  const float* pa[NLDA];
+  const float* pb[NLDB];
 
-  auto gload = [&](int k0) {
+  // ---- tile decode: which sub-problem / tile (wave-uniform scalar work) + this thread's row pointers
+  auto setup = [&](int tile, TileCtx& c) -> bool {
+    int lo = 0, hi = ka.nprob - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (ka.probs[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+    }
+    const GemmProb P = ka.probs[lo];
+    int mt, nt;
+    if (ka.xcd_tiles_m > 0) {
+      // XCD-aware map (speed only; correctness never depends on placement).  Blocks b and b+8 share an XCD and its 4 MB
+      // L2 (round-robin dispatch), and the persistent stride is a multiple of 8, so tile%8 labels the XCD for the whole
+      // walk.  The tile grid is cut into 2 (M) x 4 (N) rectangles, one per XCD: a weight quarter (3 MB at D=1024) stays
+      // L2-resident and each A panel is fetched by 4 XCDs instead of 8 -- HBM/Infinity-Cache reads drop ~2.4x vs the
+      // plain round-robin order (PMC FETCH_SIZE, profiles/).
+      const int x = tile & 7, j = tile >> 3;
+      const int sm = (ka.xcd_tiles_m + 1) >> 1, sn = P.tiles_n >> 2;
+      mt = (x >> 2) * sm + j / sn;
+      nt = (x & 3) * sn + j % sn;
+      if (mt >= ka.xcd_tiles_m) return false;
+    } else {
+      const int local = tile - P.tile_start;
+      mt = local / P.tiles_n; nt = local % P.tiles_n;
+    }
+    c.m0 = mt * BM; c.n0 = nt * BN;
+    c.M = P.M; c.N = P.N; c.K = P.K; c.lda = P.lda; c.ldb = P.ldb; c.ldc = P.ldc; c.ldr = P.ldr;
+    c.c_off = P.c_off; c.r_off = P.r_off;
+    c.klast = P.K > 4 ? ((P.K + 3) & ~3) - 4 : 0;   // last legal float4 start along a K-contiguous row
+    if constexpr (A_KC) {
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) {
-      if constexpr (A_KC) ra[p] = ldg4(pa[p] + min(k0 + kq4, klast));
-      else ra[p] = ldg4(pa[p] + (int64_t)min(k0 + tid / TPR + KROWS * p, K - 1) * P.lda);
-      if constexpr (B_KC) rb[p] = ldg4(pb[p] + min(k0 + kq4, klast));
-      else rb[p] = ldg4(pb[p] + (int64_t)min(k0 + tid / TPR + KROWS * p, K - 1) * P.ldb);
+      for (int p = 0; p < NLDA; ++p) {
+        int r = min(c.m0 + (tid >> 3) + 32 * p, P.M - 1);
+        pa[p] = ka.A + P.a_off + (int64_t)r * P.lda;
+      }
+    } else {
+      int col = c.m0 + (tid % TPRA) * 4;
+      col = col < P.M ? col : 0;
+#pragma unroll
+      for (int p = 0; p < NLDA; ++p) pa[p] = ka.A + P.a_off + col;
+    }
+    if constexpr (B_KC) {
+#pragma unroll
+      for (int p = 0; p < NLDB; ++p) {
+        int n = min(c.n0 + (tid >> 3) + 32 * p, P.N - 1);
+        int g = 0, nl = n;
+        if (ka.n_group > 0) { g = n / ka.n_group; nl = n - g * ka.n_group; }
+        const float* bg = g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3];
+        pb[p] = bg + P.b_off + (int64_t)nl * P.ldb;
+      }
+    } else {
+      int col = c.n0 + (tid % TPRB) * 4;
+      col = col < P.N ? col : 0;
+#pragma unroll
+      for (int p = 0; p < NLDB; ++p) pb[p] = ka.B[0] + P.b_off + col;
+    }
+    return true;
+  };
+
+  float4 ra[NLDA], rb[NLDB];
+
+  auto gload = [&](const TileCtx& c, int k0) {
+#pragma unroll
+    for (int p = 0; p < NLDA; ++p) {
+      if constexpr (A_KC) ra[p] = ldg4(pa[p] + min(k0 + kq4, c.klast));
+      else ra[p] = ldg4(pa[p] + (int64_t)min(k0 + tid / TPRA + KROWSA * p, c.K - 1) * c.lda);
+    }
+#pragma unroll
+    for (int p = 0; p < NLDB; ++p) {
+      if constexpr (B_KC) rb[p] = ldg4(pb[p] + min(k0 + kq4, c.klast));
+      else rb[p] = ldg4(pb[p] + (int64_t)min(k0 + tid / TPRB + KROWSB * p, c.K - 1) * c.ldb);
     }
   };
   // zero what lies past K (wave-uniform branch: only the last k-tile of a ragged K pays for it)
-  auto ktail = [&](int k0) {
+  auto ktail = [&](int K, int k0) {
     if (k0 + BK <= K) return;
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) {
+    for (int p = 0; p < NLDA; ++p) {
       if constexpr (A_KC) {
         int k = k0 + kq4;
         if (k >= K) ra[p].x = 0.f;
@@ -134,8 +168,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
         if (k + 2 >= K) ra[p].z = 0.f;
         if (k + 3 >= K) ra[p].w = 0.f;
       } else {
-        if (k0 + tid / TPR + KROWS * p >= K) ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + tid / TPRA + KROWSA * p >= K) ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
+#pragma unroll
+    for (int p = 0; p < NLDB; ++p) {
       if constexpr (B_KC) {
         int k = k0 + kq4;
         if (k >= K) rb[p].x = 0.f;
@@ -143,112 +180,147 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmKArgs ka) {
         if (k + 2 >= K) rb[p].z = 0.f;
         if (k + 3 >= K) rb[p].w = 0.f;
       } else {
-        if (k0 + tid / TPR + KROWS * p >= K) rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + tid / TPRB + KROWSB * p >= K) rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
   auto swrite = [&]() {
 #pragma unroll
-    for (int p = 0; p < NLD; ++p) {
+    for (int p = 0; p < NLDA; ++p) {
       if constexpr (A_KC) *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * p) * KC_PITCH + kq4]) = ra[p];
-      else *reinterpret_cast<float4*>(&sA[(tid / TPR + KROWS * p) * BT + (tid % TPR) * 4]) = ra[p];
+      else *reinterpret_cast<float4*>(&sA[(tid / TPRA + KROWSA * p) * BM + (tid % TPRA) * 4]) = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NLDB; ++p) {
       if constexpr (B_KC) *reinterpret_cast<float4*>(&sB[((tid >> 3) + 32 * p) * KC_PITCH + kq4]) = rb[p];
-      else *reinterpret_cast<float4*>(&sB[(tid / TPR + KROWS * p) * BT + (tid % TPR) * 4]) = rb[p];
+      else *reinterpret_cast<float4*>(&sB[(tid / TPRB + KROWSB * p) * BN + (tid % TPRB) * 4]) = rb[p];
     }
   };
 
-  f32x16 acc[TM][TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int tile = blockIdx.x;
+  if (tile >= ka.total_tiles) return;
+  TileCtx cur, nxt;
+  if (!setup(tile, cur)) return;   // (remapped walk: a rectangle's tiles are exhausted in increasing order)
+  gload(cur, 0);
 
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
-    ktail(k0);
-    swrite();
-    __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);
+  while (true) {
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float av[TM][4], bv[TM][4];
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        if constexpr (A_KC) {
-          float4 v = *reinterpret_cast<const float4*>(&sA[(wm * WT + t * 32 + li) * KC_PITCH + kk * 8 + 4 * lh]);
-          av[t][0] = v.x; av[t][1] = v.y; av[t][2] = v.z; av[t][3] = v.w;
-        } else {
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) av[t][j] = sA[(kk * 8 + 4 * lh + j) * BT + wm * WT + t * 32 + li];
-        }
-        if constexpr (B_KC) {
-          float4 v = *reinterpret_cast<const float4*>(&sB[(wn * WT + t * 32 + li) * KC_PITCH + kk * 8 + 4 * lh]);
-          bv[t][0] = v.x; bv[t][1] = v.y; bv[t][2] = v.z; bv[t][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[t][j] = sB[(kk * 8 + 4 * lh + j) * BT + wn * WT + t * 32 + li];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TM; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
-    }
-  }
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const int next_tile = tile + gridDim.x;
+    bool has_next = next_tile < ka.total_tiles;
+    const int K = cur.K;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+      __syncthreads();
+      ktail(K, k0);
+      swrite();
+      __syncthreads();
+      if (k0 + BK < K) {
+        gload(cur, k0 + BK);
+      } else if (has_next) {   // last k-tile: fetch the NEXT tile's first operands under this tile's last 64 MFMAs
+        has_next = setup(next_tile, nxt);
+        if (has_next) gload(nxt, 0);
+      }
 #pragma unroll
-  for (int tn = 0; tn < TM; ++tn) {
-    const int col = n0 + wn * WT + tn * 32 + li;
-    if (col >= N) continue;
-    float bsum = 0.f;
-    if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2) {
-      int g = 0, nl = col;
-      if (ka.n_group > 0) { g = col / ka.n_group; nl = col - g * ka.n_group; }
-      const float* b0 = g == 0 ? ka.bias0[0] : g == 1 ? ka.bias0[1] : g == 2 ? ka.bias0[2] : ka.bias0[3];
-      bsum = b0[nl];
-      if constexpr (EPI == EPI_BIAS2) {
-        const float* b1 = g == 0 ? ka.bias1[0] : g == 1 ? ka.bias1[1] : g == 2 ? ka.bias1[2] : ka.bias1[3];
-        bsum += b1[nl];
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        float av[TM][4], bv[TN][4];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          if constexpr (A_KC) {
+            float4 v = *reinterpret_cast<const float4*>(&sA[(wm * WTM + t * 32 + li) * KC_PITCH + kk * 8 + 4 * lh]);
+            av[t][0] = v.x; av[t][1] = v.y; av[t][2] = v.z; av[t][3] = v.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[t][j] = sA[(kk * 8 + 4 * lh + j) * BM + wm * WTM + t * 32 + li];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          if constexpr (B_KC) {
+            float4 v = *reinterpret_cast<const float4*>(&sB[(wn * WTN + t * 32 + li) * KC_PITCH + kk * 8 + 4 * lh]);
+            bv[t][0] = v.x; bv[t][1] = v.y; bv[t][2] = v.z; bv[t][3] = v.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[t][j] = sB[(kk * 8 + 4 * lh + j) * BN + wn * WTN + t * 32 + li];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
       }
     }
+
+    // ---- epilogue of `cur`.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = cur.n0 + wn * WTN + tn * 32 + li;
+      if (col >= cur.N) continue;
+      float bsum = 0.f;
+      if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2) {
+        int g = 0, nl = col;
+        if (ka.n_group > 0) { g = col / ka.n_group; nl = col - g * ka.n_group; }
+        const float* b0 = g == 0 ? ka.bias0[0] : g == 1 ? ka.bias0[1] : g == 2 ? ka.bias0[2] : ka.bias0[3];
+        bsum = b0[nl];
+        if constexpr (EPI == EPI_BIAS2) {
+          const float* b1 = g == 0 ? ka.bias1[0] : g == 1 ? ka.bias1[1] : g == 2 ? ka.bias1[2] : ka.bias1[3];
+          bsum += b1[nl];
+        }
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WT + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
-        float v = acc[tm][tn][r];
-        float* cp = ka.C + P.c_off + (int64_t)row * P.ldc + col;
-        if constexpr (EPI == EPI_NONE) v *= ka.alpha;
-        if constexpr (EPI == EPI_RESIDUAL) v += ka.R[P.r_off + (int64_t)row * P.ldr + col];
-        if constexpr (EPI == EPI_BIAS_RELU) { v += bsum; v = (v < 0.f) ? 0.f : v; }  // NaN-propagating, like torch.relu
-        if constexpr (EPI == EPI_BIAS2) v += bsum;
-        if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
-        *cp = v;
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = cur.m0 + wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row >= cur.M) continue;
+          float v = acc[tm][tn][r];
+          float* cp = ka.C + cur.c_off + (int64_t)row * cur.ldc + col;
+          if constexpr (EPI == EPI_NONE) v *= ka.alpha;
+          if constexpr (EPI == EPI_RESIDUAL) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+          if constexpr (EPI == EPI_BIAS_RELU) { v += bsum; v = (v < 0.f) ? 0.f : v; }  // NaN-propagating, like torch.relu
+          if constexpr (EPI == EPI_BIAS2) v += bsum;
+          if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
+          *cp = v;
+        }
       }
     }
+    if (!has_next) break;
+    tile = next_tile;
+    cur = nxt;
   }
 }
 
-template <int BT, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC>
 static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
-  dim3 grid(tiles), block(256);
+  // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
+  // every block then loops over tiles  b, b+grid, ...
+  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : 8);
+  static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
+  dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
   switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
-    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
-    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
-    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
-    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BT, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
+    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
+    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
+    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;
+}
+
+template <int BM, int BN>
+static int launch_layout(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
+  if (layout == GEMM_NT) return launch_epi<BM, BN, true, true>(epi, ka, tiles, s);
+  if (layout == GEMM_NN) return launch_epi<BM, BN, true, false>(epi, ka, tiles, s);
+  return launch_epi<BM, BN, false, false>(epi, ka, tiles, s);
 }
 
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream) {
@@ -258,18 +330,19 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   ka.A = g.A;
   for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = g.nprob; ka.n_group = g.n_group; ka.alpha = g.alpha;
+  ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0;
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
-  int rc;
-  if (g.small_tile) {
-    if (layout == GEMM_NT) rc = launch_epi<64, true, true>(epi, ka, g.total_tiles, stream);
-    else if (layout == GEMM_NN) rc = launch_epi<64, true, false>(epi, ka, g.total_tiles, stream);
-    else rc = launch_epi<64, false, false>(epi, ka, g.total_tiles, stream);
-  } else {
-    if (layout == GEMM_NT) rc = launch_epi<128, true, true>(epi, ka, g.total_tiles, stream);
-    else if (layout == GEMM_NN) rc = launch_epi<128, true, false>(epi, ka, g.total_tiles, stream);
-    else rc = launch_epi<128, false, false>(epi, ka, g.total_tiles, stream);
+  static const bool xcd_map = !(getenv("SUMK_XCD_MAP") && getenv("SUMK_XCD_MAP")[0] == '0');
+  if (xcd_map && g.nprob == 1 && g.xcd_M > 0) {
+    const int tm = (g.xcd_M + gemm_tile_m(g.small_tile) - 1) / gemm_tile_m(g.small_tile);
+    const int tn = (g.xcd_N + gemm_tile_n(g.small_tile) - 1) / gemm_tile_n(g.small_tile);
+    if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
+  int rc;
+  if (g.small_tile == 1) rc = launch_layout<64, 64>(layout, epi, ka, ka.total_tiles, stream);
+  else if (g.small_tile == 2) rc = launch_layout<128, 64>(layout, epi, ka, ka.total_tiles, stream);
+  else rc = launch_layout<128, 128>(layout, epi, ka, ka.total_tiles, stream);
   prof_end(SUMK_PROF_GEMM_ALL, stream);
   if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
   if (rc != SUMK_OK) return rc;
@@ -418,10 +491,11 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
   SUMK_ARG(p != nullptr, "gemm: cannot allocate problem scratch");
   hipStream_t s = (hipStream_t)stream;
   int small = (M <= 64 || N <= 64) ? 1 : 0;
+  if (const char* env = getenv("SUMK_ROW_CFG")) if (env[0] >= '0' && env[0] <= '2') small = env[0] - '0';
   SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, small, s));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = small;
-  g.total_tiles = gemm_tiles(M, N, small);
+  g.total_tiles = gemm_tiles(M, N, small); g.xcd_M = M; g.xcd_N = N;
   return launch_gemm(layout, EPI_NONE, g, s);
 }
 }  // namespace

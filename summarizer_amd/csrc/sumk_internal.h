@@ -57,15 +57,18 @@ struct GemmLaunch {
   int32_t n_group = 0;  // columns of C per B pointer (0 -> single group)
   int32_t total_tiles = 0;
   float alpha = 1.f;
-  int32_t small_tile = 0;  // 1 -> 64x64 block tiles (ragged per-sequence problems), 0 -> 128x128
+  int32_t small_tile = 0;  // tile config: 0 -> 128x128, 1 -> 64x64 (ragged per-video problems), 2 -> 128x64
   int32_t prof_tag = -1;
+  int32_t xcd_M = 0, xcd_N = 0;  // single-problem launches: (M,N) so the kernel may use the XCD-aware tile map
 };
 
 // number of tiles an (M,N) problem takes with the chosen tile size
-inline int gemm_tile_dim(int small_tile) { return small_tile ? 64 : 128; }
-inline int gemm_tiles(int M, int N, int small_tile) {
-  int t = gemm_tile_dim(small_tile);
-  return ((M + t - 1) / t) * ((N + t - 1) / t);
+inline int gemm_tile_m(int cfg) { return cfg == 1 ? 64 : 128; }
+inline int gemm_tile_n(int cfg) { return cfg == 0 ? 128 : 64; }
+inline int gemm_tile_dim(int cfg) { return gemm_tile_n(cfg); }   // tiles_n divisor of a config
+inline int gemm_tiles(int M, int N, int cfg) {
+  int tm = gemm_tile_m(cfg), tn = gemm_tile_n(cfg);
+  return ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
 }
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream);
 // Fills ONE GemmProb (device) for a plain single problem; returns SUMK_OK.

@@ -15,6 +15,7 @@
 #include "sumk_internal.h"
 #include <math.h>
 #include <algorithm>
+#include <cstdlib>
 
 namespace sumk {
 
@@ -419,7 +420,11 @@ __global__ void add_pos_kernel(float* x, const float* table, const int32_t* pos_
   reinterpret_cast<float4*>(x)[idx] = a;
 }
 
-static int rowwise_small_tile(int M, int N) { return gemm_tiles(M, N, 0) >= 512 ? 0 : 1; }
+static int rowwise_small_tile(int M, int N) {
+  static const char* env = getenv("SUMK_ROW_CFG");   // tuning override: 0 = 128x128, 1 = 64x64, 2 = 128x64
+  if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+  return gemm_tiles(M, N, 0) >= 512 ? 0 : 1;
+}
 
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
@@ -515,6 +520,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
     GemmLaunch g;
     g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
+    g.xcd_M = R; g.xcd_N = 3 * D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
@@ -535,7 +541,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   {  // 5: output projection + residual
     GemmLaunch g;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
-    g.total_tiles = gemm_tiles(R, D, G.st_d);
+    g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
   }
   // 6: dropout + LayerNorm
@@ -544,7 +550,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   {  // 7: k1 + bias + ReLU
     GemmLaunch g;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
-    g.total_tiles = gemm_tiles(R, D, G.st_d);
+    g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
@@ -629,7 +635,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
     GemmLaunch g;  // dY1 = dZ . W1
-    g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d);
+    g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // 6': first LayerNorm + dropout -> dY0 (gradient of the residual sum)
@@ -641,7 +647,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dY0, D, CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
     GemmLaunch g;  // dCTX = dY0 . Wo
-    g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d);
+    g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // 4': dV = alphaD^T dC ; dAlphaD = dC V^T
@@ -681,7 +687,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     for (int part = 0; part < 3; ++part) {
       GemmLaunch g;
       g.A = dQKV + (size_t)part * D; g.B[0] = Ws[part]; g.C = dx; g.probs = prow + RP_DX; g.small_tile = G.st_d;
-      g.total_tiles = gemm_tiles(R, D, G.st_d);
+      g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_ACCUM, g, stream));
     }
   }
