@@ -16,13 +16,17 @@
 #include "sumk_internal.h"
 #include <math.h>
 #include <algorithm>
+#include <cstdlib>
 
 namespace sumk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one step counter per work item
 
 struct LstmWs {
-  size_t g, cstate, prob, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, total;
+  size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, total;
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
@@ -44,6 +48,7 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
   w->g = take(R * 8 * H * 4);                       // pre-activations from the input projection
   w->cstate = take((size_t)n_seq * 2 * H * 4);      // running cell state (inference)
   w->prob = take(8 * sizeof(GemmProb));
+  w->pstate = take(PSTATE_WORDS * 4);               // persistent-kernel error flag + per-item step counters
   w->gates = w->call = w->hprev = w->dg = w->slab = w->dhrec = w->dcstate = w->prob_sk = w->colpart = 0;
   w->slab_elems = 0;
   if (training) {
@@ -194,6 +199,192 @@ __global__ __launch_bounds__(256) void frame_head_kernel(const float* __restrict
   if (lane == 0) scores[row] = sigmoidf_(dot + b[0]);
 }
 
+
+// ------------------------------------------------------------------------------------------- persistent recurrence
+// One launch runs ALL time steps (H <= 256).  256 blocks (one per CU, cooperative launch so all are resident) form 8 teams
+// of 32; team = blockIdx % 8, which under the observed round-robin dispatch puts a team on one XCD -- used for SPEED only:
+// every cross-block hand-off follows the placement-independent protocol of cdna_hip_programming.md Guideline 16 (R1):
+//   producer: payload stored write-through (sc1: agent-scope relaxed atomic stores), every storing wave drains vmcnt(0),
+//             workgroup barrier, ONE lane adds to the item's step counter (agent-scope relaxed atomic);
+//   consumer: ONE lane polls the counter (relaxed, agent scope, s_sleep), workgroup barrier, then EVERY load of handed-off
+//             bytes is an sc1 load (agent-scope relaxed atomic load) -- no plain load ever touches them.
+// A work item = (video group <= 32 videos, direction); items are dealt to teams round-robin.  Team member m owns hidden
+// units [m*upm, (m+1)*upm) of every video of the item: its 4*upm rows of W_hh stay in LDS for the whole item, its cell
+// state stays in registers, and per step it needs only h_{t-1} of the group (<= 32 KB, published by the 32 members).
+// Versus the launch-per-step chain this removes the kernel boundary, the per-step re-read of W_hh (L2 does not survive a
+// boundary) and three dependent global-load hops: measured step time in DESIGN.md.
+struct PersistArgs {
+  const float* G; const float* whh[2]; float* Hout;
+  float* gates; float* c_all; float* hprev;   // training-mode saves (nullptr in inference)
+  const int32_t* off; unsigned* state;
+  int32_t n_seq, H, gsize, n_groups, upm, n_active, hout_bytes;
+};
+
+constexpr int PK_THREADS = 512;
+constexpr int PK_TEAMS = 8;
+constexpr unsigned PK_SPIN_LIMIT = 1u << 20;   // ~1 s of polling; after one timeout the block stops waiting altogether
+
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, P = H + 4;
+  float* sW = smem;                       // [32][P]   W_hh rows of this member: row = gate*8 + unit
+  float* sH = sW + 32 * P;                // [32][P]   h_{t-1} of the group's videos
+  float* part = sH + 32 * P;              // [8][32][33] split-K partial tiles
+  int* sR0 = reinterpret_cast<int*>(part + 8 * 32 * 33);   // [32] first row of each video
+  int* sT = sR0 + 32;                     // [32] length of each video
+  int* sTg = sT + 32;                     // [1]  longest video of the group
+
+  const int team = blockIdx.x % PK_TEAMS, slot = blockIdx.x / PK_TEAMS;
+  if (slot >= a.n_active) return;
+  // buffer descriptor over the output/exchange matrix (wave-uniform: built from kernel arguments only)
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(a.Hout, (short)0, a.hout_bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
+  const int n_items = 2 * a.n_groups;
+  int loaded_dir = -1;
+  bool dead = false;   // (thread 0 only) a wait timed out: results are invalid, state[0] says so
+
+  for (int item = team; item < n_items; item += PK_TEAMS) {
+    const int g = item >> 1, d = item & 1;
+    const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
+    unsigned* bar = a.state + 16 + item;
+    __syncthreads();   // previous item fully done with LDS
+    if (loaded_dir != d) {   // this member's W_hh rows -> LDS (plain loads: weights are never written in this launch)
+      for (int idx = tid; idx < 32 * (H >> 2); idx += PK_THREADS) {
+        const int r = idx / (H >> 2), k4 = (idx % (H >> 2)) * 4;
+        const int unit = min(u0 + (r & 7), H - 1);
+        *reinterpret_cast<float4*>(&sW[r * P + k4]) =
+            *reinterpret_cast<const float4*>(a.whh[d] + (int64_t)((r >> 3) * H + unit) * H + k4);
+      }
+      loaded_dir = d;
+    }
+    if (tid == 0) *sTg = 0;
+    __syncthreads();
+    if (tid < 32) {
+      int r0 = 0, T = 0;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; atomicMax(sTg, T); }
+      sR0[tid] = r0; sT[tid] = T;
+    }
+    __syncthreads();
+    const int Tg = *sTg;
+
+    // epilogue role: thread (video i, unit u) for tid < 256; cell state lives in a register for the whole item
+    const int ei = tid >> 3, eu = tid & 7;
+    const bool erole = tid < 256 && ei < nv && eu < nu;
+    const int er0 = erole ? sR0[ei] : 0, eT = erole ? sT[ei] : 0;
+    const int j = u0 + eu;
+    float c = 0.f;
+    float gcur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (erole && eT > 0) {
+      const int64_t row = d == 0 ? er0 : er0 + eT - 1;
+      const float* gp = a.G + row * (8 * H) + d * 4 * H;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+    }
+
+    for (int t = 0; t < Tg; ++t) {
+      if (t > 0) {
+        if (tid == 0 && !dead) {   // wait until every member published step t-1
+          const unsigned want = (unsigned)t * (unsigned)a.n_active;
+          unsigned spins = 0;
+          while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
+                 __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicOr(a.state, 1u); dead = true; break;   // never hang the GPU: flag the failure and stop waiting
+            }
+          }
+        }
+        __syncthreads();
+        // h_{t-1} of every video of the group -> LDS.  sc1 (write-through / L1-bypassing) 16-B buffer loads ONLY, four in
+        // flight per thread before the first LDS write.
+        {
+          const int H4 = H >> 2, n4 = nv * H4;
+          for (int base = 0; base < n4; base += 4 * PK_THREADS) {
+            u32x4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const int idx = base + tid + p * PK_THREADS;
+              dst[p] = -1; v[p] = u32x4{0u, 0u, 0u, 0u};
+              if (idx < n4) {
+                const int i = idx / H4, k = (idx - i * H4) * 4;
+                const int r0 = sR0[i], T = sT[i];
+                dst[p] = i * P + k;
+                if (t < T) {
+                  const unsigned boff = (unsigned)(((int64_t)(d == 0 ? r0 + t - 1 : r0 + T - t) * (2 * H) + d * H + k) * 4);
+                  v[p] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, boff, 0, 16 /* sc1 */);
+                }
+              }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              if (dst[p] >= 0) *reinterpret_cast<u32x4*>(&sH[dst[p]]) = v[p];
+          }
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int nchunk = (H + 7) >> 3;
+        for (int kk = wave; kk < nchunk; kk += 8) {
+          const int k = kk * 8 + 4 * lh;
+          float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
+          if (k < H) {
+            bv = *reinterpret_cast<const float4*>(&sW[li * P + k]);
+            if (li < nv) av = *reinterpret_cast<const float4*>(&sH[li * P + k]);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+        __syncthreads();
+      }
+      if (erole && t < eT) {
+        const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = gcur[q];
+          if (t > 0) {
+            float ps = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) ps += part[(w8 * 32 + ei) * 33 + q * 8 + eu];
+            v += ps;
+          }
+          pre[q] = v;
+        }
+        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+        c = fg * c + ig * gg;
+        const float h = og * tanhf(c);
+        st_sc1(a.Hout + row * (2 * H) + d * H + j, h);
+        if (a.gates) {
+          float* gs = a.gates + row * (8 * H) + d * 4 * H;
+          gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
+          a.c_all[row * (2 * H) + d * H + j] = c;
+          a.hprev[row * (2 * H) + d * H + j] = t > 0 ? sH[ei * P + j] : 0.f;
+        }
+        if (t + 1 < eT) {   // next step's input-projection slice, one step ahead
+          const int64_t nrow = d == 0 ? row + 1 : row - 1;
+          const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+        }
+      }
+      // publish step t: every storing wave drains its stores, then one lane signals
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------- BPTT step kernel
 // Step t (run for t = t_max-1 .. 0).  Block = (32 videos) x (32 hidden units) x direction, 512 threads = 8 waves that
@@ -356,6 +547,34 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
   // 2: recurrence
+  static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
+  if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
+    PersistArgs pa;
+    pa.G = G; pa.whh[0] = w->w_hh[0]; pa.whh[1] = w->w_hh[1]; pa.Hout = h_out;
+    pa.gates = training ? (float*)(ws + L.gates) : nullptr;
+    pa.c_all = training ? (float*)(ws + L.call) : nullptr;
+    pa.hprev = training ? (float*)(ws + L.hprev) : nullptr;
+    pa.off = seq_off_dev; pa.state = (unsigned*)(ws + L.pstate);
+    pa.n_seq = n_seq; pa.H = H; pa.hout_bytes = (int32_t)std::min<size_t>((size_t)R * 2 * H * 4, 0x7fffffff);
+    pa.upm = std::min(8, (H + 31) / 32); pa.n_active = (H + pa.upm - 1) / pa.upm;
+    int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));
+    pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize;
+    if (2 * pa.n_groups <= PSTATE_WORDS - 16) {
+      const size_t shmem = ((size_t)2 * 32 * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
+      void* kargs[] = {&pa};
+      prof_begin(SUMK_PROF_LSTM_REC, stream);
+      SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_persist_kernel, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs,
+                                          (unsigned)shmem, stream));
+      prof_end(SUMK_PROF_LSTM_REC, stream);
+      return SUMK_OK;
+    }
+  }
   StepArgs a;
   a.G = G; a.whh[0] = w->w_hh[0]; a.whh[1] = w->w_hh[1]; a.Hout = h_out;
   a.cstate = training ? nullptr : (float*)(ws + L.cstate);
