@@ -26,7 +26,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one step counter per work item
 
 struct LstmWs {
-  size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, total;
+  size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, pstate_b, xchg, total;
+  size_t xchg_bytes;
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
@@ -50,6 +51,7 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
   w->prob = take(8 * sizeof(GemmProb));
   w->pstate = take(PSTATE_WORDS * 4);               // persistent-kernel error flag + per-item step counters
   w->gates = w->call = w->hprev = w->dg = w->slab = w->dhrec = w->dcstate = w->prob_sk = w->colpart = 0;
+  w->pstate_b = w->xchg = 0; w->xchg_bytes = 0;
   w->slab_elems = 0;
   if (training) {
     w->gates = take(R * 8 * H * 4);                 // post-nonlinearity i,f,g,o per row and direction
@@ -62,6 +64,13 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
     w->slab = take(w->slab_elems * 4);
     w->prob_sk = take(64 * sizeof(GemmProb));
     w->colpart = take((size_t)128 * 8 * H * 4);
+    w->pstate_b = take(PSTATE_WORDS * 4);
+    {  // persistent BPTT exchange: [parity 2][item][member 32][video 32][H] partial sums of dh (H <= 256 only)
+      int gsize = std::min(32, std::max(1, (2 * n_seq + 7) / 8));
+      int items = 2 * ((n_seq + gsize - 1) / gsize);
+      w->xchg_bytes = H <= 256 ? (size_t)2 * items * 32 * 32 * H * 4 : 0;
+      w->xchg = take(w->xchg_bytes);
+    }
   }
   w->total = p;
   return SUMK_OK;
@@ -481,6 +490,156 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(BwdStepArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- persistent BPTT
+// Same teams / work items / hand-off protocol as lstm_persist_kernel.  Member m owns hidden units U_m = [m*upm, ...):
+//   step t:  dh[i][j in U_m] = dHout[row][j] + sum over the 32 members m' of  partial_{m'}(t+1)[i][j]      (sc1 loads)
+//            cell backward -> dG_t[i][4 gates x U_m]  (kept in LDS as the MFMA A operand, and stored for the weight-gradient GEMMs)
+//            partial_m(t)[i][all j] = dG_t[i][cols of U_m] . W_hh[rows of U_m][all j]   (MFMA, K = 32, one N-tile per wave)
+//            published (sc1 stores) to the exchange buffer of parity t&1, then the step counter is bumped.
+// So a member publishes H floats per video per step and reads 32 x |U_m| -- the same bytes as the forward pass, with the
+// sum over members taken in a FIXED order (deterministic).  dc lives in a register; W_hh rows of U_m stay in LDS.
+struct PersistBwdArgs {
+  const float* whh[2]; const float* dHout; const float* gates; const float* c_all;
+  float* dG; float* xchg; const int32_t* off; unsigned* state;
+  int32_t n_seq, H, gsize, n_groups, upm, n_active, n_items;
+};
+
+__global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, P = H + 4;
+  float* sW = smem;                       // [32][P]  W_hh rows (gate*8+unit) of this member, all H columns
+  float* sA = sW + 32 * P;                // [32][36] dG_t of the group's videos, this member's 32 gate columns
+  int* sR0 = reinterpret_cast<int*>(sA + 32 * 36);
+  int* sT = sR0 + 32;
+  int* sTg = sT + 32;
+
+  const int team = blockIdx.x % PK_TEAMS, slot = blockIdx.x / PK_TEAMS;
+  if (slot >= a.n_active) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
+  const int H4 = 4 * H;
+  int loaded_dir = -1;
+  bool dead = false;
+
+  for (int item = team; item < a.n_items; item += PK_TEAMS) {
+    const int g = item >> 1, d = item & 1;
+    const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
+    unsigned* bar = a.state + 16 + item;
+    __syncthreads();
+    if (loaded_dir != d) {
+      for (int idx = tid; idx < 32 * (H >> 2); idx += PK_THREADS) {
+        const int r = idx / (H >> 2), k4 = (idx % (H >> 2)) * 4;
+        const int unit = min(u0 + (r & 7), H - 1);
+        *reinterpret_cast<float4*>(&sW[r * P + k4]) =
+            *reinterpret_cast<const float4*>(a.whh[d] + (int64_t)((r >> 3) * H + unit) * H + k4);
+      }
+      loaded_dir = d;
+    }
+    if (tid == 0) *sTg = 0;
+    __syncthreads();
+    if (tid < 32) {
+      int r0 = 0, T = 0;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; atomicMax(sTg, T); }
+      sR0[tid] = r0; sT[tid] = T;
+    }
+    __syncthreads();
+    const int Tg = *sTg;
+
+    const int ei = tid >> 3, eu = tid & 7;
+    const bool erole = tid < 256 && ei < nv && eu < nu;
+    const int er0 = erole ? sR0[ei] : 0, eT = erole ? sT[ei] : 0;
+    const int j = u0 + eu;
+    float dcarry = 0.f;
+    // saved activations of the step about to be processed (prefetched one step ahead)
+    float sv_i = 0.f, sv_f = 0.f, sv_g = 0.f, sv_o = 0.f, sv_c = 0.f, sv_cp = 0.f, sv_dh = 0.f;
+    auto fetch = [&](int t) {
+      const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+      const float* gs = a.gates + row * (8 * H) + d * H4;
+      sv_i = gs[j]; sv_f = gs[H + j]; sv_g = gs[2 * H + j]; sv_o = gs[3 * H + j];
+      sv_c = a.c_all[row * (2 * H) + d * H + j];
+      sv_cp = t > 0 ? a.c_all[(d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j] : 0.f;
+      sv_dh = a.dHout[row * (2 * H) + d * H + j];
+    };
+    if (erole && eT > 0 && eT - 1 == Tg - 1) fetch(Tg - 1);
+
+    for (int t = Tg - 1; t >= 0; --t) {
+      // zero this step's A tile (rows of inactive videos and columns of absent units must contribute nothing)
+      for (int idx = tid; idx < 32 * 36; idx += PK_THREADS) sA[idx] = 0.f;
+      if (t < Tg - 1) {
+        if (tid == 0 && !dead) {   // wait until every member published step t+1
+          const unsigned want = (unsigned)(Tg - 1 - t) * (unsigned)a.n_active;
+          unsigned spins = 0;
+          while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
+                 __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicOr(a.state, 1u); dead = true; break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (erole && t < eT) {
+        float dh = sv_dh;
+        if (t + 1 < eT) {   // recurrent part: fixed-order sum of the 32 members' partials of step t+1 (sc1 loads)
+          const float* xp = a.xchg + ((((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * 32 + ei) * H + j;
+          float pv[32];
+#pragma unroll
+          for (int m = 0; m < 32; ++m) pv[m] = m < a.n_active ? ld_sc1(xp + (int64_t)m * 32 * H) : 0.f;
+          float rec = 0.f;
+#pragma unroll
+          for (int m = 0; m < 32; ++m) rec += pv[m];
+          dh += rec;
+        }
+        const float tc = tanhf(sv_c);
+        const float dc = dcarry + dh * sv_o * (1.f - tc * tc);
+        const float d_i = dc * sv_g * sv_i * (1.f - sv_i);
+        const float d_f = dc * sv_cp * sv_f * (1.f - sv_f);
+        const float d_g = dc * sv_i * (1.f - sv_g * sv_g);
+        const float d_o = dh * tc * sv_o * (1.f - sv_o);
+        dcarry = dc * sv_f;
+        const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+        float* dg = a.dG + row * (8 * H) + d * H4;
+        dg[j] = d_i; dg[H + j] = d_f; dg[2 * H + j] = d_g; dg[3 * H + j] = d_o;
+        sA[ei * 36 + eu] = d_i; sA[ei * 36 + 8 + eu] = d_f; sA[ei * 36 + 16 + eu] = d_g; sA[ei * 36 + 24 + eu] = d_o;
+      }
+      if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, one step ahead
+      __syncthreads();
+      if (t > 0) {   // partial_m(t) is only ever read by step t-1
+        float* xo = a.xchg + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * 32) * H;
+        const int ntile = (H + 31) >> 5;
+        for (int nt = wave; nt < ntile; nt += 8) {
+          const int n = nt * 32 + li, nc = min(n, H - 1);
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const float4 av = *reinterpret_cast<const float4*>(&sA[li * 36 + kk * 8 + 4 * lh]);
+            const float b0 = sW[(kk * 8 + 4 * lh + 0) * P + nc], b1 = sW[(kk * 8 + 4 * lh + 1) * P + nc];
+            const float b2 = sW[(kk * 8 + 4 * lh + 2) * P + nc], b3 = sW[(kk * 8 + 4 * lh + 3) * P + nc];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+          }
+          if (n < H) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (i < nv && t < sT[i]) st_sc1(xo + (int64_t)i * H + n, acc[r]);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Frame head backward: du = ds*s*(1-s); dh[r,:] = du*w; per-wave partial sums of du*h[r,:] and du (deterministic reduce).
 __global__ __launch_bounds__(256) void frame_head_bwd_kernel(const float* __restrict__ h, const float* __restrict__ scores,
                                                              const float* __restrict__ dscores, const float* __restrict__ w,
@@ -560,7 +719,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize;
     if (2 * pa.n_groups <= PSTATE_WORDS - 16) {
-      const size_t shmem = ((size_t)2 * 32 * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float);
+      const size_t shmem = std::max<size_t>(((size_t)2 * 32 * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
       static bool attr_set = false;
       if (!attr_set) {
         SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -628,17 +787,44 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   GemmProb* prob = (GemmProb*)(ws + L.prob);
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
 
-  BwdStepArgs a;
-  a.whh[0] = w->w_hh[0]; a.whh[1] = w->w_hh[1]; a.dHout = dh_out; a.gates = (const float*)(ws + L.gates);
-  a.c_all = (const float*)(ws + L.call); a.dG = dG; a.dcstate = (float*)(ws + L.dcstate);
-  a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_jblk = (H + 31) / 32;
-  const int n_mtiles = (n_seq + 31) / 32;
-  const dim3 grid((unsigned)(n_mtiles * a.n_jblk * 2)), block(512);
-  for (int t = L.t_max - 1; t >= 0; --t) {
-    a.t = t;
-    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, 0, stream, a);
+  static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
+  bool done = false;
+  if (persist_ok && H <= 256 && L.xchg_bytes > 0) {
+    PersistBwdArgs pa;
+    pa.whh[0] = w->w_hh[0]; pa.whh[1] = w->w_hh[1]; pa.dHout = dh_out; pa.gates = (const float*)(ws + L.gates);
+    pa.c_all = (const float*)(ws + L.call); pa.dG = dG; pa.xchg = (float*)(ws + L.xchg);
+    pa.off = seq_off_dev; pa.state = (unsigned*)(ws + L.pstate_b);
+    pa.n_seq = n_seq; pa.H = H;
+    pa.upm = std::min(8, (H + 31) / 32); pa.n_active = (H + pa.upm - 1) / pa.upm;
+    int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));
+    pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize; pa.n_items = 2 * pa.n_groups;
+    if (pa.n_items <= PSTATE_WORDS - 16) {
+      const size_t shmem = std::max<size_t>(((size_t)32 * (H + 4) + 32 * 36 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
+      static bool attr_set = false;
+      if (!attr_set) {
+        SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      SUMK_HIP(hipMemsetAsync(ws + L.pstate_b, 0, (size_t)PSTATE_WORDS * 4, stream));
+      void* kargs[] = {&pa};
+      SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_persist_bwd_kernel, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs,
+                                          (unsigned)shmem, stream));
+      done = true;
+    }
   }
-  SUMK_HIP(hipGetLastError());
+  if (!done) {
+    BwdStepArgs a;
+    a.whh[0] = w->w_hh[0]; a.whh[1] = w->w_hh[1]; a.dHout = dh_out; a.gates = (const float*)(ws + L.gates);
+    a.c_all = (const float*)(ws + L.call); a.dG = dG; a.dcstate = (float*)(ws + L.dcstate);
+    a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_jblk = (H + 31) / 32;
+    const int n_mtiles = (n_seq + 31) / 32;
+    const dim3 grid((unsigned)(n_mtiles * a.n_jblk * 2)), block(512);
+    for (int t = L.t_max - 1; t >= 0; --t) {
+      a.t = t;
+      hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, 0, stream, a);
+    }
+    SUMK_HIP(hipGetLastError());
+  }
   // weight gradients: dW_ih[d] += dG_d^T X (both directions in one split-K launch), dW_hh[d] += dG_d^T h_prev_d
   {
     float* out[4] = {gr->w_ih[0], gr->w_ih[1], nullptr, nullptr};

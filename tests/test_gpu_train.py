@@ -173,3 +173,15 @@ def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens):
     gx = xp.grad.cpu().numpy()
     for i, xt in enumerate(xrefs):
         assert _rel(gx[off[i]:off[i + 1]], xt.grad.numpy()[:, 0, :]) < 3e-4
+
+
+def test_lstm_launch_chain_path_still_matches(dev):
+    """H > 256 (sLSTM) takes the launch-per-step kernels; force that path for the small golden cases too
+    (SUMK_LSTM_PERSIST=0 is read once per process, hence the subprocess)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, SUMK_LSTM_PERSIST="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        os.path.join(ROOT, "tests", "test_gpu_train.py"), "-k", "dsn_train_step or bilstm_grads",
+                        os.path.join(ROOT, "tests", "test_gpu_lstm.py")], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
