@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["vasnet", "dsn"], default="vasnet", help="headline = vasnet")
     ap.add_argument("--mode", choices=["score", "train"], default="score", help="headline = score (frames scored/sec)")
+    ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
+                    help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,6 +96,8 @@ def main():
 
     D = 1024
     lens = tvsum_lens(args.videos)
+    if args.workload == "stress":
+        D, lens = 2048, [10000] * 8
     frames = int(sum(lens))
     torch.manual_seed(1234)
     if args.model == "vasnet":
@@ -102,7 +106,11 @@ def main():
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)
     model.train(args.mode == "train")
-    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 1000 * rank + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    if args.workload == "stress":
+        g = torch.Generator(device=dev); g.manual_seed(rank)
+        x = torch.randn(frames, D, device=dev, generator=g) * 0.05
+    else:
+        x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 1000 * rank + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
     if args.mode == "train":
         # one optimiser step per packed batch: forward + MSE to a random target + backward + flat-bucket Adam
         # (+ one gradient all-reduce under torch.distributed)
@@ -152,8 +160,8 @@ def main():
         ach = qkv_flops / avg_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("gemm_qkv_hbm_bytes_per_launch")
+        if os.path.exists(tp) and args.workload == "tvsum" and args.model == "vasnet" and args.videos == 50:
+            traffic = json.load(open(tp)).get("gemm_qkv_hbm_bytes_per_launch")   # PMC pass of this exact launch shape
         roof = dict(bound="mfma", kernel="gemm_f32_kernel<128,NT> (QKV projection)", achieved=round(ach, 2),
                     peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     traffic=traffic, avg_launch_us=round(avg_s * 1e6, 2), launches=int(n.value),
@@ -165,13 +173,15 @@ def main():
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"{args.model} {args.mode}, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch",
+                   config=dict(workload=(f"{args.model} {args.mode}, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch"
+                                         if args.workload == "tvsum" else
+                                         f"{args.model} {args.mode}, S-stress (BASELINE config 5): 8 sequences/GPU, T=10000, D=2048, packed batch"),
                                frames_per_step_per_gpu=frames, parallelism=f"video-sharded x{world}"),
                    whole_path_tflops=round(frames * world * args.steps / elapsed * flops_frame / 1e12, 2),
                    roofline=roof)
-        if args.model != "vasnet" or args.mode != "score":
+        if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
-        if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score":
+        if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum":
             out["cpu_baseline"] = cpu_baseline(lens, D)
         print(json.dumps(out), flush=True)
     if dist is not None:

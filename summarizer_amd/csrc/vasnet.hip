@@ -96,6 +96,7 @@ struct RowProbSpec { int32_t M, N, K, lda, ldb, ldc, ldr, small; };
 struct SetupArgs {
   const int32_t* off; int32_t n_seq, D;
   SeqInfo* seq; GemmProb* tabs;   // tabs[TB_COUNT][n_seq]
+  int32_t s_tm, s_tn, pv_tm, pv_tn;  // block-tile dims of the (T x T) and (T x D) per-video products
   GemmProb* prow; RowProbSpec rows[ROW_PROBS]; int32_t n_rowprobs;
 };
 
@@ -110,7 +111,6 @@ __device__ inline void put_prob(GemmProb* p, int64_t a_off, int64_t b_off, int64
 }
 
 __global__ void vasnet_setup_kernel(SetupArgs a) {
-  const int bt = 64;
   if (blockIdx.y == 1) {
     int i = threadIdx.x;
     if (blockIdx.x == 0 && i < a.n_rowprobs) {
@@ -127,15 +127,17 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.n_seq) return;
-  const int D = a.D, tn = (D + bt - 1) / bt;
+  const int D = a.D, tn = (D + a.pv_tn - 1) / a.pv_tn;
   int64_t eoff = 0;
   int ts = 0, tpv = 0;
   for (int q = 0; q < s; ++q) {
-    int T = a.off[q + 1] - a.off[q], tm = (T + bt - 1) / bt;
+    int T = a.off[q + 1] - a.off[q];
     eoff += (int64_t)T * ((T + 3) & ~3);
-    ts += tm * tm; tpv += tm * tn;
+    ts += ((T + a.s_tm - 1) / a.s_tm) * ((T + a.s_tn - 1) / a.s_tn);
+    tpv += ((T + a.pv_tm - 1) / a.pv_tm) * tn;
   }
-  const int row0 = a.off[s], T = a.off[s + 1] - a.off[s], ldE = (T + 3) & ~3, tm = (T + bt - 1) / bt;
+  const int row0 = a.off[s], T = a.off[s + 1] - a.off[s], ldE = (T + 3) & ~3;
+  const int tm = (T + a.s_tn - 1) / a.s_tn;   // tiles along N of the (T x T) products
   SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0;
   a.seq[s] = si;
   const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
@@ -428,7 +430,7 @@ static int rowwise_small_tile(int M, int N) {
 
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
-  int R, st_qkv, st_d, tiles_s, tiles_pv;
+  int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv;
 };
 
 static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry* G) {
@@ -436,10 +438,18 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
   G->R = G->L.n_rows;
   G->st_qkv = rowwise_small_tile(G->R, 3 * D);
   G->st_d = rowwise_small_tile(G->R, D);
+  // Tile shape of the ragged per-video products.  64x64 is the measured best on S-TVSum (T~235: 8.66 M frames/s vs 8.57
+  // with 128x128 for the (T x D) products and 8.28 with 128x128 for both -- bigger tiles waste more on ragged T and
+  // under-fill the resident slots); long videos (mean T >= 1024, e.g. BASELINE config 5) take the 128x128 tile, whose
+  // 2x2 register blocking halves the LDS traffic per MFMA.
+  static const char* env = getenv("SUMK_ATTN_CFG");   // tuning override "<cfg_s><cfg_pv>", e.g. "20"
+  const int cfg_auto = (G->R / n_seq >= 1024) ? 0 : 1;
+  G->cfg_s = cfg_auto; G->cfg_pv = cfg_auto;
+  if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
-    int T = off[s + 1] - off[s], tm = (T + 63) / 64;
-    G->tiles_s += tm * tm; G->tiles_pv += tm * ((D + 63) / 64);
+    int T = off[s + 1] - off[s];
+    G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
   return SUMK_OK;
 }
@@ -456,6 +466,7 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   a.rows[RP_DD] = RowProbSpec{R, D, D, D, D, D, D, G.st_d};              // (R,D) = (R,D) x (D,D), any layout
   a.rows[RP_DX] = RowProbSpec{R, D, D, 3 * D, D, D, D, G.st_d};          // dX += dQKV[:, part] W  (A has lda 3D)
   a.n_rowprobs = 3;
+  a.s_tm = gemm_tile_m(G.cfg_s); a.s_tn = gemm_tile_n(G.cfg_s); a.pv_tm = gemm_tile_m(G.cfg_pv); a.pv_tn = gemm_tile_n(G.cfg_pv);
   hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2), dim3(64), 0, stream, a);
 }
 
@@ -525,7 +536,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   }
   {  // 2: logits per video
     GemmLaunch g;
-    g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = 1;
+    g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
     g.total_tiles = G.tiles_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
@@ -534,7 +545,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
                      seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop);
   {  // 4: context
     GemmLaunch g;
-    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = 1;
+    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
@@ -654,12 +665,12 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   const float* Pd = use_e2 ? E2 : E;
   {
     GemmLaunch g;
-    g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_pv;
+    g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   {
     GemmLaunch g;
-    g.A = dCTX; g.B[0] = QKV; g.C = E2; g.probs = tabs + TB_DP * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_s;
+    g.A = dCTX; g.B[0] = QKV; g.C = E2; g.probs = tabs + TB_DP * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s; g.total_tiles = G.tiles_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3': softmax (+dropout, +scale) backward, in place on E2
@@ -668,12 +679,12 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   // 2': dQ = dS K ; dK = dS^T Q
   {
     GemmLaunch g;
-    g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_pv;
+    g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {
     GemmLaunch g;
-    g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = 1; g.total_tiles = G.tiles_pv;
+    g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X

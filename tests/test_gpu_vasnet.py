@@ -146,3 +146,18 @@ def test_vasnet_batch_properties_full_size(dev):
     for i, s in enumerate(singles):
         assert torch.equal(s, a[off[i]:off[i + 1]])
     assert bool(((a > 0) & (a < 1)).all())
+
+
+def test_vasnet_long_sequence_D2048_vs_oracle(dev):
+    """BASELINE config 5 shape class (long video, D=2048) at an oracle-checkable length: T=1500, plus a local-attention
+    variant; the full T=10000 x 8 batch is exercised by `bench.py --workload stress` (properties only)."""
+    from oracle import vasnet_np
+    D, T = 2048, 1500
+    w = R.vasnet_weights(D, 71)
+    x = (R.features(T, 1, D, 72) * 0.1).astype(np.float32)       # N(0,1)*0.05-like magnitude (SURVEY 8d, S-stress)
+    for kw, okw in [(dict(), dict()), (dict(attention_aperture=64), dict(aperture=64))]:
+        model = _model(dev, D, w, **kw)
+        with torch.no_grad():
+            y = model(torch.from_numpy(x).to(dev)).cpu().numpy()
+        ref = vasnet_np.vasnet_forward(x, w, **okw)
+        np.testing.assert_allclose(y, ref, atol=TOL, rtol=0, err_msg=str(kw))
