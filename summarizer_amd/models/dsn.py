@@ -75,12 +75,7 @@ class DSNTrainer(Trainer):
         return r.reshape(())
 
     def _load_video(self, key, dev):
-        d = self.dataset[key]
-        seq = torch.from_numpy(d["features"][...])
-        target = torch.from_numpy(d["gtscore"][...]).view(-1)
-        target = target - target.min()                                   # dsn.py:104-105
-        target = target / (target.max() - target.min())
-        return seq.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+        return self._video_on_device(key, dev, want_target=True)
 
     def train(self, fold):
         self.model.train()

@@ -168,12 +168,7 @@ class VASNetTrainer(Trainer):
         return model
 
     def _load_video(self, key, dev):
-        d = self.dataset[key]
-        seq = torch.from_numpy(d["features"][...])                       # (seq_len, input_size)
-        target = torch.from_numpy(d["gtscore"][...]).view(-1)
-        target = target - target.min()                                   # vasnet.py:201-202
-        target = target / (target.max() - target.min())
-        return seq.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+        return self._video_on_device(key, dev, want_target=True)
 
     def train(self, fold):
         self.model.train()

@@ -44,18 +44,34 @@ def generate_scores(probs, n_frames, positions):
     return upsample(probs, n_frames, positions)
 
 
-def evaluate_scores(machine_scores, user_scores, metric="spearmanr"):
-    """Compare machine scores with user scores, mean rank correlation over annotators (eval.py:49-72)."""
+def evaluate_scores(machine_scores, user_scores, metric="spearmanr", user_ranks=None):
+    """Compare machine scores with user scores, mean rank correlation over annotators (eval.py:49-72).
+
+    The reference calls `stats.spearmanr(rankdata(-x), rankdata(-y))` per annotator, i.e. it ranks the (constant)
+    annotator scores again for every video of every evaluation and lets spearmanr re-rank both inputs.  Here the machine
+    ranks are computed once per video, annotator ranks can be passed in precomputed (`user_ranks`, see `rank_users`), and
+    Spearman's rho is the Pearson correlation of the two rank vectors (float64, like scipy) -- the same value up to
+    floating-point summation order (~1e-15)."""
     n_users, _ = user_scores.shape
     if metric == "kendalltau":
-        f = lambda x, y: stats.kendalltau(x, y)[0]
-    elif metric == "spearmanr":
-        f = lambda x, y: stats.spearmanr(x, y)[0]
-    else:
+        rm = stats.rankdata(-machine_scores)
+        corrs = [stats.kendalltau(rm, stats.rankdata(-user_scores[i]))[0] for i in range(n_users)]
+        return np.mean(corrs)
+    if metric != "spearmanr":
         raise KeyError(f"Unknown metric {metric}")
-    rm = stats.rankdata(-machine_scores)                         # ranked once, not once per annotator
-    corrs = [f(rm, stats.rankdata(-user_scores[i])) for i in range(n_users)]
+    rm = stats.rankdata(-machine_scores)
+    ru = rank_users(user_scores) if user_ranks is None else user_ranks
+    rm = rm - rm.mean()
+    ru = ru - ru.mean(axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        corrs = (ru @ rm) / np.sqrt((ru * ru).sum(axis=1) * (rm @ rm))   # NaN for a constant vector, like scipy
     return np.mean(corrs)
+
+
+def rank_users(user_scores):
+    """rankdata(-user_scores[i]) for every annotator, stacked (n_users, n_frames) float64: constant per video, so
+    callers (Trainer._eval_scores) compute it once and reuse it at every evaluation."""
+    return np.stack([stats.rankdata(-user_scores[i]) for i in range(user_scores.shape[0])])
 
 
 def generate_summary(scores, cps, n_frames, nfps, positions, proportion=0.15, method="knapsack"):
@@ -96,16 +112,14 @@ def evaluate_summary(machine_summary, user_summary):
     elif len(machine_summary) < n_frames:
         zero_padding = np.zeros((n_frames - len(machine_summary)))            # float64 on purpose (eval.py:142)
         machine_summary = np.concatenate([machine_summary, zero_padding])
-    f_scores = []
+    # all annotators at once; every operation below is the reference's, elementwise, in the same dtype
+    # (float32, or float64 after the float64 zero padding above), and the sums are sums of 0/1 values -- exact in any
+    # order -- so the result is bit-identical to the per-annotator loop of eval.py:149-160.
     m_sum = machine_summary.sum()
-    for user_idx in range(n_users):
-        gt_summary = user_summary[user_idx, :]
-        overlap_duration = (machine_summary * gt_summary).sum()
-        precision = overlap_duration / (m_sum + 1e-8)
-        recall = overlap_duration / (gt_summary.sum() + 1e-8)
-        if precision == 0 and recall == 0:
-            f_score = 0.
-        else:
-            f_score = (2 * precision * recall) / (precision + recall)
-        f_scores.append(f_score)
+    overlap = (user_summary * machine_summary[None, :]).sum(axis=1)
+    precision = overlap / (m_sum + 1e-8)
+    recall = overlap / (user_summary.sum(axis=1) + 1e-8)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f_scores = (2 * precision * recall) / (precision + recall)
+    f_scores = np.where((precision == 0) & (recall == 0), 0., f_scores)
     return np.mean(f_scores), np.max(f_scores)

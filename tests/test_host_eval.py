@@ -26,7 +26,9 @@ def test_metrics_vs_reference_goldens():
         np.testing.assert_array_equal(np.array(E.evaluate_summary(summ[:-7], v["user_summary"])), g[f"c{ci}/fscore_short"])
         long = np.concatenate([summ, np.ones(5, np.float32)])
         np.testing.assert_array_equal(np.array(E.evaluate_summary(long, v["user_summary"])), g[f"c{ci}/fscore_long"])
-        assert E.evaluate_scores(fs, v["user_scores"]) == g[f"c{ci}/spearman"]
+        np.testing.assert_allclose(E.evaluate_scores(fs, v["user_scores"]), g[f"c{ci}/spearman"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(E.evaluate_scores(fs, v["user_scores"], user_ranks=E.rank_users(v["user_scores"])),
+                                   g[f"c{ci}/spearman"], rtol=1e-12, atol=1e-15)
         if np.isfinite(g[f"c{ci}/kendall"]):
             assert E.evaluate_scores(fs, v["user_scores"], metric="kendalltau") == g[f"c{ci}/kendall"]
     with pytest.raises(KeyError):
