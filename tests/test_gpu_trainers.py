@@ -132,3 +132,43 @@ def test_dsn_trainer_reinforce_runs(data):
         act = (torch.rand(seq.shape[0], 1, 1, device="cuda") < 0.5).float()
         r = tr.compute_reward(seq, act)
         assert r.dim() == 0 and 0 < float(r) < 1
+
+
+def test_vasnet_trainer_reproduces_the_reference_trainer_end_to_end():
+    """G7: the REAL reference VASNetTrainer (CPU, dropout off, local attention w=12, rank selection) was run in the build
+    container (tests/golden/make_golden_e2e.py).  With the same torch / python seeds the HIP trainer must start from the
+    SAME weights (identical module creation order), follow the same loss trajectory, end at the same weights, score the
+    test videos within 1e-4 and report the same correlation / F-scores."""
+    import logging
+    from conftest import load_golden
+    from summarizer_amd.models.vasnet import VASNetTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    g = load_golden("e2e_vasnet")
+    D, SEED, n, dseed, t0, t1, nu = [int(v) for v in g["meta"]]
+    ds = synthetic_dataset(n, seed=dseed, D=D, t_range=(t0, t1), n_users=nu)
+    keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
+    hps = make_hps(ds, [{"train_keys": keys[3:], "test_keys": keys[:3]}], epochs=3, test_every_epochs=1, lr=1e-3,
+                   selection_algorithm="rank", extra_params={"local": "12", "input_size": str(D)})
+    torch.manual_seed(SEED); random.seed(SEED)
+    tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+    tr.model.dropout.p = 0.0
+    for k, v in tr.model.state_dict().items():
+        np.testing.assert_array_equal(v.detach().cpu().numpy(), g[f"w0/{k}"], err_msg=f"initial {k}")
+    best = tr.train(0)
+    losses = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Train/Loss"]]
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    for k, v in tr.model.state_dict().items():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"w1/{k}"], atol=3e-4, err_msg=f"final {k}")
+    tr.model.eval()
+    with torch.no_grad():
+        for k in keys[:3]:
+            s = tr.model(torch.from_numpy(ds[k]["features"][...]).unsqueeze(1).cuda()).squeeze().cpu().numpy()
+            np.testing.assert_allclose(s, g[f"scores/{k}"], atol=1e-3)     # after 24 optimiser steps of fp32 drift
+    corr = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/Correlation"]]
+    np.testing.assert_allclose(corr, g["corr"], atol=5e-3)
+    f_avg = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/F-score_avg"]]
+    f_max = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/F-score_max"]]
+    assert np.abs(np.array(f_avg) - g["f_avg"]).max() < 0.1 and np.abs(np.array(f_max) - g["f_max"]).max() < 0.1   # north_star bar
+    np.testing.assert_allclose(f_avg, g["f_avg"], atol=2e-2); np.testing.assert_allclose(f_max, g["f_max"], atol=2e-2)
+    np.testing.assert_allclose(best[0], g["best"][0], atol=5e-3)
