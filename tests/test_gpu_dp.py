@@ -1,0 +1,58 @@
+"""GPU, 2 processes on ONE device (gloo carries the collective; RCCL needs one GPU per rank, which the 1-GPU test box does
+not have): the data-parallel training path end to end -- video sharding, parameter broadcast, ONE flat-bucket gradient
+all-reduce per step folded into the fused Adam -- must give every rank the same weights, equal to a single process
+stepping on the same two videos as one batch (mean of per-video losses == average of per-rank gradients)."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(rank, world, port, q, bv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import random
+    import torch.distributed as dist
+    from summarizer_amd.models.vasnet import VASNetTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = synthetic_dataset(3, seed=9, D=128, t_range=(40, 90), n_users=4)
+        keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
+        hps = make_hps(ds, [{"train_keys": keys[:2], "test_keys": keys[2:]}], epochs=2, test_every_epochs=5, lr=1e-3,
+                       selection_algorithm="rank", extra_params={"input_size": "128", "batch_videos": str(bv)})
+        torch.manual_seed(100 + rank)          # DIFFERENT init per rank: broadcast_parameters must make them agree
+        random.seed(5)
+        tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+        tr.model.dropout.p = 0.0
+        if world == 1:
+            torch.manual_seed(100); tr = VASNetTrainer(hps, hps.splits_files[0]).reset(); tr.model.dropout.p = 0.0
+        tr.train(0)
+        q.put((rank, {k: v.detach().cpu().numpy() for k, v in tr.model.state_dict().items()}))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _spawn(world, bv):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, bv)) for r in range(world)]
+    for p in procs: p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs: p.join(timeout=120)
+    return res
+
+
+def test_dp_two_ranks_equal_single_process_batch_of_two():
+    dp = _spawn(2, 1)
+    single = _spawn(1, 2)[0]
+    for k in dp[0]:
+        np.testing.assert_array_equal(dp[0][k], dp[1][k], err_msg=f"ranks disagree on {k}")
+        np.testing.assert_allclose(dp[0][k], single[k], atol=2e-6, err_msg=f"DP != single-process batch for {k}")
