@@ -119,6 +119,31 @@ int sumk_frame_head_backward(const float* h, const float* scores, const float* d
                              int32_t F, const float* w, float* dh, float* dw, float* db, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ Transformer scorer
+ * Inference of the reference's Transformer-encoder scorer (summarizer/models/transformer.py:74-103): n_layers stock
+ * nn.TransformerEncoderLayer (post-norm, ReLU, dim_feedforward F), final norm = the SHARED layer_norm (also applied after
+ * k1), optional extra residual (more_residuals), k1 + ReLU + LN + k2 + sigmoid.  Weights as torch stores them. */
+typedef struct sumk_tf_layer_weights {
+  const float* in_proj_w;  const float* in_proj_b;    /* (3D,D),(3D)  self_attn.in_proj_{weight,bias} */
+  const float* out_proj_w; const float* out_proj_b;   /* (D,D),(D)    self_attn.out_proj              */
+  const float* lin1_w; const float* lin1_b;           /* (F,D),(F)    linear1                          */
+  const float* lin2_w; const float* lin2_b;           /* (D,F),(D)    linear2                          */
+  const float* norm1_w; const float* norm1_b; const float* norm2_w; const float* norm2_b;   /* (D) */
+} sumk_tf_layer_weights;
+typedef struct sumk_tf_head_weights {
+  const float* ln_w; const float* ln_b;               /* (D) layer_norm (== transformer_encoder.norm)  transformer.py:47,50,100 */
+  const float* k1_w; const float* k1_b;               /* (D,D),(D)                                     transformer.py:52 */
+  const float* k2_w; const float* k2_b;               /* (D),(1)                                       transformer.py:53 */
+} sumk_tf_head_weights;
+size_t sumk_transformer_workspace_bytes(int32_t D, int32_t F, int32_t n_heads, int32_t n_seq, const int32_t* seq_off_host);
+/* x (n_rows,D) packed -> scores (n_rows,).  pos_table/pos_rows as in sumk_vasnet_forward (in-place add, transformer.py:83-89).
+ * layer_eps: LayerNorm eps inside the encoder layers (torch default 1e-5); final_eps: eps of the shared layer_norm. */
+int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
+                             const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                             const sumk_tf_layer_weights* layers, const sumk_tf_head_weights* head,
+                             float layer_eps, float final_eps, int32_t more_residuals, const float* pos_table,
+                             const int32_t* pos_rows, float* scores, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ DSN reward
  * DSNTrainer.compute_reward (dsn.py:185-236) for E episodes of one or more packed videos:
  * actions (E, n_rows) of 0/1 floats -> reward (E, n_seq).  Zero picks -> 0 (dsn.py:199-203); one pick ->

@@ -265,14 +265,14 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       const int col = cur.n0 + wn * WTN + tn * 32 + li;
       if (col >= cur.N) continue;
       float bsum = 0.f;
-      if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2) {
+      if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2 || EPI == EPI_BIAS_RESIDUAL) {
         int g = 0, nl = col;
         if (ka.n_group > 0) { g = col / ka.n_group; nl = col - g * ka.n_group; }
         const float* b0 = g == 0 ? ka.bias0[0] : g == 1 ? ka.bias0[1] : g == 2 ? ka.bias0[2] : ka.bias0[3];
         bsum = b0[nl];
         if constexpr (EPI == EPI_BIAS2) {
           const float* b1 = g == 0 ? ka.bias1[0] : g == 1 ? ka.bias1[1] : g == 2 ? ka.bias1[2] : ka.bias1[3];
-          bsum += b1[nl];
+          if (b1 != nullptr) bsum += b1[nl];   // single-bias projections pass bias1 = nullptr
         }
       }
 #pragma unroll
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
           if constexpr (EPI == EPI_RESIDUAL) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
           if constexpr (EPI == EPI_BIAS_RELU) { v += bsum; v = (v < 0.f) ? 0.f : v; }  // NaN-propagating, like torch.relu
           if constexpr (EPI == EPI_BIAS2) v += bsum;
+          if constexpr (EPI == EPI_BIAS_RESIDUAL) v += bsum + ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
           if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
           *cp = v;
         }
@@ -311,6 +312,7 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
     case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
     case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
     case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS_RESIDUAL>), grid, block, 0, s, ka); break;
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;

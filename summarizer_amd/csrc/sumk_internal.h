@@ -43,6 +43,7 @@ enum GemmEpi {
   EPI_BIAS_RELU = 2,  // C = relu(acc + bias0[col])
   EPI_BIAS2 = 3,      // C = acc + bias0[col] + bias1[col]
   EPI_ACCUM = 4,      // C += alpha*acc   (gradient accumulation)
+  EPI_BIAS_RESIDUAL = 5,  // C = acc + bias0[col] + R
 };
 
 struct GemmLaunch {
@@ -98,6 +99,16 @@ inline uint32_t dropout_threshold(float p) {
   double t = (double)p * 4294967296.0;
   return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
+
+// ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
+// Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.
+int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
+                     hipStream_t stream);
+// scores[r] = sigmoid(LayerNorm(Z[r]) . w2 + b2)
+int launch_ln_head(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
+                   int n_rows, int D, float eps, hipStream_t stream);
+// x[r,:] += table[pos_rows[r],:]  in place
+int launch_add_pos(float* x, const float* table, const int32_t* pos_rows, int n_rows, int D, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------- profiling
 void prof_begin(int tag, hipStream_t s);

@@ -476,6 +476,29 @@ static Drop make_drop(const sumk_vasnet_opts* o) {
   return d;
 }
 
+int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
+                     hipStream_t stream) {
+  Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, X, Y, g, b, nullptr, nullptr,
+                     nullptr, n_rows, D, eps, stats, none, 0u);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+int launch_ln_head(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
+                   int n_rows, int D, float eps, hipStream_t stream) {
+  Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, Z, nullptr, g, b, w2, b2, scores,
+                     n_rows, D, eps, nullptr, none, 0u);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+int launch_add_pos(float* x, const float* table, const int32_t* pos_rows, int n_rows, int D, hipStream_t stream) {
+  int64_t n4 = (int64_t)n_rows * (D >> 2);
+  hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, table, pos_rows, n_rows, D);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
 }  // namespace sumk
 
 using namespace sumk;

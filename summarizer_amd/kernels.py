@@ -253,3 +253,42 @@ def dsn_reward(x, sb, actions, far_sim=False, temp_dist_thre=20):
                              int(temp_dist_thre), _p(out), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "sumk_dsn_reward")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ Transformer scorer
+def transformer_forward_packed(x, sb, params, n_layers, n_heads, dff, layer_eps, final_eps, more_residuals=False,
+                               pos_table=None, pos_rows=None):
+    """x: (n_rows, D) packed -> scores (n_rows,).  params: state_dict-keyed tensors of the reference Transformer."""
+    lib = _lib.load()
+    _require_gpu(x, "transformer input")
+    if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
+        raise SumkError(f"transformer input must be contiguous (n_rows={sb.n_rows}, D), got {tuple(x.shape)}")
+    D = x.shape[1]
+    def ptr(k):
+        t = params[k]
+        _require_gpu(t, f"Transformer weight {k}")
+        if not t.is_contiguous():
+            raise SumkError(f"Transformer weight {k} must be contiguous")
+        return t.data_ptr()
+    layers = (_lib.TfLayerWeights * n_layers)()
+    for l in range(n_layers):
+        pre = f"transformer_encoder.layers.{l}."
+        for f, k in (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_attn.in_proj_bias"),
+                     ("out_proj_w", "self_attn.out_proj.weight"), ("out_proj_b", "self_attn.out_proj.bias"),
+                     ("lin1_w", "linear1.weight"), ("lin1_b", "linear1.bias"), ("lin2_w", "linear2.weight"),
+                     ("lin2_b", "linear2.bias"), ("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
+                     ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias")):
+            setattr(layers[l], f, ptr(pre + k))
+    head = _lib.TfHeadWeights(ptr("layer_norm.weight"), ptr("layer_norm.bias"), ptr("k1.weight"), ptr("k1.bias"),
+                              ptr("k2.weight"), ptr("k2.bias"))
+    nbytes = lib.sumk_transformer_workspace_bytes(D, dff, n_heads, sb.n_seq, sb.off_host_p)
+    if nbytes == 0:
+        _lib.check(-1, "sumk_transformer_workspace_bytes")
+    ws = workspace(nbytes, x.device)
+    scores = torch.empty(sb.n_rows, dtype=torch.float32, device=x.device)
+    rc = lib.sumk_transformer_forward(_p(x), D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, sb.off_dev_p,
+                                      C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p), float(layer_eps),
+                                      float(final_eps), int(bool(more_residuals)), _p(pos_table), _p(pos_rows), _p(scores),
+                                      _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "sumk_transformer_forward")
+    return scores

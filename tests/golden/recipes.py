@@ -43,6 +43,34 @@ def lstm_weights(prefix, D, H, num_layers, seed, head_prefix):
     return p
 
 
+def transformer_weights(D, n_layers, seed, max_length=None):
+    """Weights of the reference Transformer scorer (state_dict keys of summarizer/models/transformer.py), seeded."""
+    rng = np.random.default_rng(seed)
+    a = np.sqrt(6.0 / (2 * D))
+    u = lambda *shape, s=1.0: rng.uniform(-a * s, a * s, shape).astype(np.float32)
+    p = {}
+    for l in range(n_layers):
+        pre = f"transformer_encoder.layers.{l}."
+        p[pre + "self_attn.in_proj_weight"] = u(3 * D, D, s=1.5)
+        p[pre + "self_attn.in_proj_bias"] = rng.uniform(-0.1, 0.1, (3 * D,)).astype(np.float32)
+        p[pre + "self_attn.out_proj.weight"] = u(D, D)
+        p[pre + "self_attn.out_proj.bias"] = rng.uniform(-0.1, 0.1, (D,)).astype(np.float32)
+        p[pre + "linear1.weight"] = u(D, D, s=1.4); p[pre + "linear1.bias"] = rng.uniform(-0.1, 0.1, (D,)).astype(np.float32)
+        p[pre + "linear2.weight"] = u(D, D, s=1.4); p[pre + "linear2.bias"] = rng.uniform(-0.1, 0.1, (D,)).astype(np.float32)
+        for n in ("norm1", "norm2"):
+            p[pre + n + ".weight"] = rng.uniform(0.7, 1.3, (D,)).astype(np.float32)
+            p[pre + n + ".bias"] = rng.uniform(-0.1, 0.1, (D,)).astype(np.float32)
+    p["layer_norm.weight"] = rng.uniform(0.7, 1.3, (D,)).astype(np.float32)
+    p["layer_norm.bias"] = rng.uniform(-0.1, 0.1, (D,)).astype(np.float32)
+    p["transformer_encoder.norm.weight"] = p["layer_norm.weight"]          # the same module registered twice
+    p["transformer_encoder.norm.bias"] = p["layer_norm.bias"]
+    p["k1.weight"] = u(D, D, s=1.4); p["k1.bias"] = rng.uniform(-0.2, 0.2, (D,)).astype(np.float32)
+    p["k2.weight"] = u(1, D, s=4.0); p["k2.bias"] = rng.uniform(-0.2, 0.2, (1,)).astype(np.float32)
+    if max_length:
+        p["pos_embed.weight"] = rng.normal(0, 1, (max_length, D)).astype(np.float32)
+    return p
+
+
 def features(T, B, D, seed):
     """pool5-like non-negative features: 0.5*|N(0,1)|."""
     rng = np.random.default_rng(seed)

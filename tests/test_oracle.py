@@ -136,3 +136,23 @@ def test_knapsack_value_optimal_vs_bruteforce():
         v, w = knapsack_np.knapsack_value(vals, wts, picks)
         assert w <= cap
         assert v == knapsack_np.knapsack_bruteforce_value(vals, wts, cap), (vals, wts, cap, picks)
+
+
+def test_transformer_oracle_vs_reference_goldens():
+    from oracle import transformer_np
+    g = load_golden("transformer_small")
+    meta = js(g["meta"])
+    for name, kw in meta.items():
+        w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{name}/w/")}
+        pos = w.get("pos_embed.weight") if kw.get("max_length") else None
+        for c in _cases(g, name):
+            y = transformer_np.transformer_forward(g[f"{name}/x/{c}"], w, kw["encoder_layers"], kw["attention_heads"],
+                                                   eps=kw.get("epsilon", 1e-5), more_residuals=kw.get("more_residuals", False),
+                                                   pos_table=pos)
+            np.testing.assert_allclose(y, g[f"{name}/y/{c}"], atol=TOL, rtol=0, err_msg=f"{name} {c}")
+    g = load_golden("transformer_full")
+    cfg = js(g["c1/cfg"])
+    w = R.transformer_weights(cfg["D"], cfg["layers"], cfg["wseed"])
+    assert R.digest(w) == cfg["wdigest"]
+    y = transformer_np.transformer_forward(R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"]), w, cfg["layers"], cfg["heads"])
+    np.testing.assert_allclose(y, g["c1/y"], atol=TOL, rtol=0)
