@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["vasnet", "dsn"], default="vasnet", help="headline = vasnet")
+    ap.add_argument("--model", choices=["vasnet", "dsn", "transformer"], default="vasnet", help="headline = vasnet")
     ap.add_argument("--mode", choices=["score", "train"], default="score", help="headline = score (frames scored/sec)")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
@@ -102,6 +102,10 @@ def main():
     torch.manual_seed(1234)
     if args.model == "vasnet":
         model = VASNet(input_size=D).to(dev)
+    elif args.model == "transformer":
+        from summarizer_amd.models.transformer import Transformer
+        model = Transformer(input_size=D).to(dev)
+        assert args.mode == "score", "the Transformer scorer is inference-only"
     else:
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)

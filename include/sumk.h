@@ -103,6 +103,11 @@ int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t
                          const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Synchronises `stream` and returns an error if a persistent recurrence kernel that used this workspace reported a
+ * timed-out hand-off (outputs invalid).  Cheap; the trainers call it once per evaluation, tests after every call. */
+int sumk_bilstm_check(const void* workspace, int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host,
+                      int32_t training, int32_t after_backward, void* stream);
+
 typedef struct sumk_lstm_layer_grads {
   float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
 } sumk_lstm_layer_grads;

@@ -705,7 +705,8 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 8 * H, small);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
-  // 2: recurrence
+  // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
+  SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
   static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
     PersistArgs pa;
@@ -725,7 +726,6 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
         SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
       }
-      SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
       void* kargs[] = {&pa};
       prof_begin(SUMK_PROF_LSTM_REC, stream);
       SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_persist_kernel, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs,
@@ -788,6 +788,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
 
   static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
+  SUMK_HIP(hipMemsetAsync(ws + L.pstate_b, 0, (size_t)PSTATE_WORDS * 4, stream));
   bool done = false;
   if (persist_ok && H <= 256 && L.xchg_bytes > 0) {
     PersistBwdArgs pa;
@@ -805,7 +806,6 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
         SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
       }
-      SUMK_HIP(hipMemsetAsync(ws + L.pstate_b, 0, (size_t)PSTATE_WORDS * 4, stream));
       void* kargs[] = {&pa};
       SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_persist_bwd_kernel, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs,
                                           (unsigned)shmem, stream));
@@ -864,5 +864,26 @@ extern "C" int sumk_frame_head_backward(const float* h, const float* scores, con
   hipLaunchKernelGGL(frame_head_bwd_kernel, dim3(blocks), dim3(256), 0, stream, h, scores, dscores, w, dh, part, n_rows, F);
   SUMK_TRY(partial_reduce_accum(part, blocks * 4, F + 4, F, dw, stream));
   SUMK_TRY(partial_reduce_accum(part + F, blocks * 4, F + 4, 1, db, stream));
+  return SUMK_OK;
+}
+
+// Synchronous health check of the persistent recurrence kernels that last ran on this workspace: their bounded waits set
+// an error word instead of hanging; a set word means some hand-off timed out (e.g. the 256 co-resident blocks the
+// cooperative launch asked for were not all running) and the layer's outputs are INVALID.
+extern "C" int sumk_bilstm_check(const void* workspace, int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host,
+                                 int32_t training, int32_t after_backward, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(workspace, "bilstm_check: null workspace");
+  LstmWs L;
+  SUMK_TRY(lstm_carve(In, H, n_seq, seq_off_host, training, &L));
+  unsigned flags[2] = {0u, 0u};
+  SUMK_HIP(hipMemcpyAsync(&flags[0], (const char*)workspace + L.pstate, 4, hipMemcpyDeviceToHost, stream));
+  if (training && after_backward) SUMK_HIP(hipMemcpyAsync(&flags[1], (const char*)workspace + L.pstate_b, 4, hipMemcpyDeviceToHost, stream));
+  SUMK_HIP(hipStreamSynchronize(stream));
+  if (flags[0] != 0u || flags[1] != 0u) {
+    set_error("bilstm: persistent recurrence kernel timed out waiting for a team member (forward flag %u, backward flag %u); "
+              "outputs are invalid -- rerun with SUMK_LSTM_PERSIST=0 to use the launch-per-step kernels", flags[0], flags[1]);
+    return SUMK_ERR_HIP;
+  }
   return SUMK_OK;
 }

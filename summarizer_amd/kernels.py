@@ -114,6 +114,12 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
 
 
 # ------------------------------------------------------------------------------------------------ BiLSTM scorers
+# SUMK_CHECK=1 (set by the test-suite): synchronise after every recurrent layer and verify that the persistent kernel's
+# bounded waits did not time out.  Off by default (it costs a host sync per layer).
+import os as _os
+CHECK_LSTM = _os.environ.get("SUMK_CHECK", "0") == "1"
+
+
 def _lstm_layer_struct(params, prefix, layer):
     w = _lib.LstmLayerWeights()
     for d, suf in enumerate(("", "_reverse")):
@@ -142,6 +148,8 @@ def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False):
     rc = lib.sumk_bilstm_layer_forward(_p(x), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), _p(h), _p(ws),
                                        ws.numel(), int(training), _stream())
     _lib.check(rc, "sumk_bilstm_layer_forward")
+    if CHECK_LSTM:
+        _lib.check(lib.sumk_bilstm_check(_p(ws), In, H, sb.n_seq, sb.off_host_p, int(training), 0, _stream()), "sumk_bilstm_check")
     return h, (ws if training else None)
 
 
@@ -218,6 +226,8 @@ def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, wan
     rc = lib.sumk_bilstm_layer_backward(_p(x), _p(h), _p(dh), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w),
                                         C.byref(g), _p(dx), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "sumk_bilstm_layer_backward")
+    if CHECK_LSTM:
+        _lib.check(lib.sumk_bilstm_check(_p(ws), In, H, sb.n_seq, sb.off_host_p, 1, 1, _stream()), "sumk_bilstm_check")
     return dx
 
 

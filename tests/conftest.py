@@ -1,4 +1,5 @@
 import os, sys, json
+os.environ.setdefault("SUMK_CHECK", "1")   # verify persistent-kernel health words after every recurrent layer
 import numpy as np
 import pytest
 
