@@ -1,0 +1,71 @@
+"""GPU: error behaviour of the C ABI -- bad shapes, short workspaces and null pointers come back as negative status codes
+with a message (never a crash, never a silent fallback), and edge-case inputs (single-frame videos) are handled."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+import recipes as R
+
+pytestmark = pytest.mark.gpu
+
+
+def test_status_codes_and_messages():
+    from summarizer_amd import _lib, kernels
+    from summarizer_amd._lib import SumkError
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.zeros(8, 8, device=dev)
+    assert lib.sumk_gemm_nt(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 6, st) == -1        # K not a multiple of 4
+    assert b"multiples of 4" in lib.sumk_last_error()
+    assert lib.sumk_gemm_nt(None, a.data_ptr(), a.data_ptr(), 8, 8, 8, st) == -1
+    off = np.array([0, 5, 5], dtype=np.int32)                                                    # empty video
+    assert lib.sumk_vasnet_workspace_bytes(64, 2, _lib.host_i32(off), 0) == 0
+    assert b"has 0 frames" in lib.sumk_last_error()
+    assert lib.sumk_vasnet_workspace_bytes(62, 1, _lib.host_i32(np.array([0, 5], dtype=np.int32)), 0) == 0   # D % 4 != 0
+    # workspace too small -> SUMK_ERR_WORKSPACE (-2)
+    from summarizer_amd.models.vasnet import VASNet
+    m = VASNet(input_size=64).eval().to(dev)
+    sb = kernels.SeqBatch.get([9], dev)
+    w, o = kernels._vasnet_structs(dict(m.named_parameters()), dict(scale=0.125, eps=1e-6))
+    x = torch.zeros(9, 64, device=dev); out = torch.zeros(9, device=dev); ws = torch.zeros(64, dtype=torch.uint8, device=dev)
+    rc = lib.sumk_vasnet_forward(x.data_ptr(), 64, 1, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o), None, None,
+                                 out.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
+    assert rc == -2 and b"workspace" in lib.sumk_last_error()
+    # dropout outside training mode is refused
+    o.dropout_p = 0.5
+    big = torch.zeros(lib.sumk_vasnet_workspace_bytes(64, 1, sb.off_host_p, 0), dtype=torch.uint8, device=dev)
+    rc = lib.sumk_vasnet_forward(x.data_ptr(), 64, 1, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o), None, None,
+                                 out.data_ptr(), big.data_ptr(), big.numel(), 0, st)
+    assert rc == -1 and b"dropout" in lib.sumk_last_error()
+    # python layer: wrong dtype / shape / device raise SumkError
+    with pytest.raises(SumkError):
+        kernels.vasnet_forward_packed(torch.zeros(9, 64, device=dev, dtype=torch.float64), sb, dict(m.named_parameters()), dict(scale=1, eps=1e-6))
+    with pytest.raises(SumkError):
+        kernels.vasnet_forward_packed(torch.zeros(8, 64, device=dev), sb, dict(m.named_parameters()), dict(scale=1, eps=1e-6))
+    with pytest.raises(SumkError):
+        kernels.SeqBatch([3, 0], dev)
+    from summarizer_amd.models.dsn import DSN
+    with pytest.raises(SumkError):
+        DSN(cell="gru")
+    with pytest.raises(AssertionError):
+        DSN(cell="rnn")                     # dsn.py:21
+
+
+def test_single_frame_videos_everywhere():
+    from oracle import vasnet_np, lstm_np
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.models.dsn import DSN
+    dev = torch.device("cuda:0")
+    D = 64
+    wv = R.vasnet_weights(D, 1); wl = R.lstm_weights("rnn.", D, 16, 1, 2, "out.0.")
+    mv = VASNet(input_size=D).eval(); mv.load_state_dict({k: torch.from_numpy(v) for k, v in wv.items()}); mv = mv.to(dev)
+    ml = DSN(D, 16, 1).eval(); ml.load_state_dict({k: torch.from_numpy(v) for k, v in wl.items()}); ml = ml.to(dev)
+    xs = [R.features(1, 1, D, 10 + i) for i in range(40)]                # 40 one-frame videos in one packed batch
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev)
+    with torch.no_grad():
+        sv = mv.score_packed(xp, [1] * 40).cpu().numpy(); sl = ml.score_packed(xp, [1] * 40).cpu().numpy()
+    for i, x in enumerate(xs):
+        np.testing.assert_allclose(sv[i], vasnet_np.vasnet_forward(x, wv)[0, 0, 0], atol=1e-4)
+        np.testing.assert_allclose(sl[i], lstm_np.dsn_forward(x, wl)[0, 0, 0], atol=1e-4)
