@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["vasnet", "dsn", "transformer"], default="vasnet", help="headline = vasnet")
-    ap.add_argument("--mode", choices=["score", "train"], default="score", help="headline = score (frames scored/sec)")
+    ap.add_argument("--mode", choices=["score", "train", "reinforce"], default="score",
+                    help="headline = score (frames scored/sec); train = MSE step; reinforce = DSN REINFORCE step (BASELINE config 4)")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     else:
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)
-    model.train(args.mode == "train")
+    model.train(args.mode != "score")
     if args.workload == "stress":
         g = torch.Generator(device=dev); g.manual_seed(rank)
         x = torch.randn(frames, D, device=dev, generator=g) * 0.05
@@ -126,6 +127,28 @@ def main():
             loss = torch.mean((model.score_packed(x, lens) - target) ** 2)
             loss.backward()
             opt.step(grad_scale=opt.all_reduce_grads())
+            return loss.detach()
+    elif args.mode == "reinforce":
+        # one DSNTrainer step on the packed batch (dsn.py:96-156): probabilities, 5 Bernoulli episodes, reward kernel,
+        # policy-gradient loss, backward, grad-norm clip folded into the flat Adam (+ gradient all-reduce under DP)
+        assert args.model == "dsn", "--mode reinforce is the DSN trainer step"
+        from torch.distributions import Bernoulli
+        from summarizer_amd import kernels
+        from summarizer_amd.training import FlatAdam
+        opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
+        sb = kernels.SeqBatch.get(lens, dev)
+        base = torch.zeros(len(lens), device=dev)
+        def run_step():
+            nonlocal base
+            opt.zero_grad()
+            probs = model.score_packed(x, lens)
+            dist_ = Bernoulli(probs)
+            actions = dist_.sample((5,))
+            rewards = kernels.dsn_reward(x, sb, actions.contiguous())
+            loss = (-(sb.segment_mean(dist_.log_prob(actions)) * (rewards - base)).sum(dim=0) / 5.0).mean()
+            loss.backward()
+            opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
+            base = 0.9 * base + 0.1 * rewards.mean(dim=0)
             return loss.detach()
     else:
         def run_step():

@@ -47,6 +47,16 @@ class SeqBatch:
             sb = cls._cache[key] = SeqBatch(lens, device)
         return sb
 
+    def segment_mean(self, v):
+        """Per-video mean of a per-frame quantity: v (..., n_rows) -> (..., n_seq).  Two tiny torch ops (index_add + div)
+        whatever the number of videos -- the trainers' loss glue, not a compute kernel."""
+        if getattr(self, "_seg", None) is None:
+            self._seg = torch.repeat_interleave(torch.arange(self.n_seq, device=self.device),
+                                                torch.tensor(self.lens, device=self.device))
+            self._len_f = torch.tensor(self.lens, dtype=torch.float32, device=self.device)
+        out = torch.zeros(v.shape[:-1] + (self.n_seq,), dtype=v.dtype, device=v.device)
+        return out.index_add_(v.dim() - 1, self._seg, v) / self._len_f
+
     @property
     def off_host_p(self):
         return _lib.host_i32(self.off_host)

@@ -119,16 +119,17 @@ class DSNTrainer(Trainer):
                                                  temp_dist_thre=self.temp_dist_thre)       # (E, n_videos)  dsn.py:129-131
                     off = np.concatenate([[0], np.cumsum(lens_b)])
                     base = torch.tensor([baselines[k] for k in keys], dtype=torch.float32, device=dev)
-                    loss = 0
+                    # all videos of the step at once (per-video means via SeqBatch.segment_mean); for one video this is
+                    # exactly dsn.py:115-140
+                    l_v = self.beta * (sb.segment_mean(probs) - self.eps) ** 2                      # dsn.py:115   (n_videos,)
+                    if self.sup:
+                        target = torch.cat([v[1] for v in vids]) if len(vids) > 1 else vids[0][1]
+                        l_v = l_v + sb.segment_mean(torch.nn.functional.binary_cross_entropy(probs, target, reduction="none"))  # dsn.py:117-119
+                    lp = sb.segment_mean(log_probs)                                                  # (E, n_videos)
+                    l_v = l_v - (lp * (rewards - base)).sum(dim=0)                                   # dsn.py:134
+                    loss = (l_v / float(E)).mean()                                                   # dsn.py:140
                     for i, k in enumerate(keys):
-                        p_i = probs[off[i]:off[i + 1]]
-                        l_i = self.beta * (p_i.mean() - self.eps) ** 2                      # dsn.py:115
-                        if self.sup:
-                            l_i = l_i + torch.nn.functional.binary_cross_entropy(p_i, vids[i][1])   # dsn.py:117-119
-                        lp = log_probs[:, off[i]:off[i + 1]].mean(dim=1)                    # (E,)
-                        l_i = l_i - (lp * (rewards[:, i] - base[i])).sum()                  # dsn.py:134
-                        loss = loss + l_i / float(E) / len(keys)                            # dsn.py:140
-                        dist_scores[k] = p_i.detach().view(-1, 1, 1)
+                        dist_scores[k] = probs[off[i]:off[i + 1]].detach().view(-1, 1, 1)
                     loss.backward()
                     losses.append(loss.detach())
                     mean_r = rewards.mean(dim=0).tolist()                 # one D2H per step (the reference does E per video)

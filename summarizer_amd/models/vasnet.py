@@ -203,7 +203,9 @@ class VASNetTrainer(Trainer):
                         scores = self.model.score_packed(torch.cat([v[0] for v in vids]) if len(vids) > 1 else vids[0][0], lens_b)
                         off = np.concatenate([[0], np.cumsum(lens_b)])
                         # mean over videos of the per-video MSE (== nn.MSELoss per video, vasnet.py:209, when bv == 1)
-                        loss = sum(torch.mean((scores[off[i]:off[i + 1]] - vids[i][1]) ** 2) for i in range(len(vids))) / len(vids)
+                        target = torch.cat([v[1] for v in vids]) if len(vids) > 1 else vids[0][1]
+                        sbb = kernels.SeqBatch.get(lens_b, dev)
+                        loss = sbb.segment_mean((scores - target) ** 2).mean()
                         for i, k in enumerate(keys):
                             dist_scores[k] = scores[off[i]:off[i + 1]].detach().view(-1, 1, 1)
                     else:
