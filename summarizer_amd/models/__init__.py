@@ -1,33 +1,40 @@
-"""Trainer base class -- mirror of `summarizer/models/__init__.py` (reference): same constructor, same methods, same
-return values, same exceptions, so `main.train` (summarizer/main.py:25-35,65-66) drives it unchanged.
+"""`Trainer` -- the base class `main.train` drives (reference protocol: summarizer/models/__init__.py:9-187; callers:
+summarizer/main.py:25-35,65-66).  Public surface kept: `Trainer(hps, splits_file)`, `.reset()`, `.train(fold)`,
+`.test(fold) -> (avg_corr, (avg_f, max_f))`, `.predict_dataset(path)`, `.save_best_weights(path)`, `.load_weights(path)`,
+attributes `.model`, `.best_weights`, `.dataset`, `.dataset_name`, and the helper names subclasses/users call
+(`_get_train_test_keys`, `_init_model`, `_eval_scores`, `_eval_summary`, `draw_gtscores`, `draw_scores`).
 
-What differs underneath: `test()` / `predict_dataset()` score ALL requested videos in ONE packed launch on the GPU
-(`model.score_packed`) instead of one forward per video, and the dataset may be any object with the h5py mapping
-protocol (utils/datasets.py).  Evaluation (rank correlation, knapsack key-shots, F-score) stays on the host like
-the reference (utils/eval.py)."""
+Built differently underneath (MI355X-first):
+  * scoring is BATCHED: all requested videos go through ONE packed launch (`model.score_packed`), not one forward each;
+  * every video's features / normalised target are uploaded once (pinned staging, async copy) and stay in HBM;
+  * per-video evaluation metadata (annotator ranks, change points, ...) is read from the dataset once and cached;
+  * the dataset is anything with the h5py mapping protocol (utils/datasets.py), HDF5 when h5py is installed.
+"""
 import os
+from types import SimpleNamespace
+
 import numpy as np
 import torch
 
-from ..utils.eval import generate_summary, evaluate_summary, generate_scores, evaluate_scores, rank_users
+from ..utils import eval as ev
 from ..utils.datasets import open_dataset
+
+_HBM_CACHE_LIMIT = 16 << 30      # bytes of features kept resident per trainer (a whole dataset is ~0.1 GB)
 
 
 class Trainer:
     """Abstract class handling the training process"""
+
+    # ------------------------------------------------------------------ construction / protocol
     def __init__(self, hps, splits_file):
-        self.hps = hps
-        self.log = hps.logger
-        self.splits_file = splits_file
+        self.hps, self.log, self.splits_file = hps, hps.logger, splits_file
         self.dataset = open_dataset(hps.dataset_of_file[splits_file], "r")
         self.dataset_name = hps.dataset_name_of_file[splits_file]
         self.best_weights = None
-        self._dev_cache = {}      # key -> (features, normalised gtscore) resident in HBM (datasets are ~100 MB)
-        self._dev_cache_bytes = 0
-        self._rank_cache = {}     # key -> annotator ranks (constant per video)
+        self._hbm, self._hbm_bytes, self._meta = {}, 0, {}
 
     def reset(self):
-        """Reset between two folds of the cross-validation"""
+        """Fresh model for the next cross-validation fold; returns self (main.py chains `.reset().train(fold)`)."""
         self.model = self._init_model()
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
@@ -36,182 +43,167 @@ class Trainer:
         return self
 
     def _get_train_test_keys(self, fold):
-        """Train/Test keys from current split file and fold"""
         self.fold = fold
         self.split = self.hps.splits_of_file[self.splits_file][fold]
-        return self.split["train_keys"][:], self.split["test_keys"][:]
+        return list(self.split["train_keys"]), list(self.split["test_keys"])
 
     def _init_model(self):
-        """Initialize here your model"""
         raise Exception("_init_model has not been implemented")
 
     def train(self, fold):
-        """Train model on train_keys"""
         raise Exception("train has not been implemented")
 
-    # ------------------------------------------------------------------ feature ingest
     def _device(self):
         return next(self.model.parameters()).device
 
+    # ------------------------------------------------------------------ feature ingest
     def _video_on_device(self, key, dev, want_target=False):
-        """(features (T,D), min-max normalised gtscore (T,) or None) as device tensors.  The reference re-reads the HDF5
-        file and re-uploads every video at every step (vasnet.py:194-205); a whole dataset is ~100 MB, so each video is
-        uploaded ONCE (pinned staging buffer, async copy) and stays in HBM (cache capped at 16 GiB)."""
-        hit = self._dev_cache.get((key, str(dev)))
-        if hit is None:
-            d = self.dataset[key]
-            f = torch.from_numpy(np.ascontiguousarray(d["features"][...], dtype=np.float32))
-            if torch.cuda.is_available() and str(dev).startswith("cuda"):
-                f = f.pin_memory()
-            feats = f.to(dev, non_blocking=True)
-            target = None
-            if "gtscore" in d:
-                t = torch.from_numpy(np.asarray(d["gtscore"][...], dtype=np.float32)).view(-1)
-                t = t - t.min()                              # vasnet.py:201-202 / dsn.py:104-105
-                t = t / (t.max() - t.min())
-                target = t.to(dev, non_blocking=True)
-            hit = (feats, target)
-            nbytes = feats.numel() * 4
-            if self._dev_cache_bytes + nbytes <= (16 << 30):
-                self._dev_cache[(key, str(dev))] = hit
-                self._dev_cache_bytes += nbytes
+        """(features (T,D), min-max normalised gtscore (T,) or None) as device tensors, uploaded once.  The reference
+        re-reads the HDF5 file and re-uploads every video at every step (vasnet.py:194-205)."""
+        slot = (key, str(dev))
+        hit = self._hbm.get(slot)
+        if hit is not None:
+            return hit
+        rec = self.dataset[key]
+        host = torch.from_numpy(np.ascontiguousarray(rec["features"][...], dtype=np.float32))
+        if str(dev).startswith("cuda"):
+            host = host.pin_memory()
+        feats = host.to(dev, non_blocking=True)
+        target = None
+        if "gtscore" in rec:
+            g = torch.from_numpy(np.asarray(rec["gtscore"][...], dtype=np.float32)).reshape(-1)
+            g = g - g.min()                                   # same normalisation as vasnet.py:201-202 / dsn.py:104-105
+            target = (g / (g.max() - g.min())).to(dev, non_blocking=True)
+        hit = (feats, target)
+        if self._hbm_bytes + feats.numel() * 4 <= _HBM_CACHE_LIMIT:
+            self._hbm[slot] = hit
+            self._hbm_bytes += feats.numel() * 4
         return hit
 
-    # ------------------------------------------------------------------ batched scoring (the hot path)
+    def _video_meta(self, key, need):
+        """Evaluation-side fields of one video, read from the dataset once.  `need` = "scores" | "summary" selects which
+        presence check applies (same exception text as the reference)."""
+        m = self._meta.get(key)
+        if m is None:
+            m = self._meta[key] = SimpleNamespace(rec=self.dataset[key], loaded=set())
+        if need not in m.loaded:
+            rec = m.rec
+            if "n_frames" not in m.__dict__:
+                m.n_frames = rec["n_frames"][()]
+                m.picks = rec["picks"][...]
+            if need == "scores":
+                if "user_scores" not in rec:
+                    raise Exception(f"No /user_scores in video {key} for score evaluation, "
+                                    "make sure you have up-to-date .h5 dataset files.")
+                m.user_scores = rec["user_scores"][...]
+                m.user_ranks = ev.rank_users(m.user_scores)       # constant per video: ranked once, not per evaluation
+            else:
+                if "change_points" not in rec:
+                    raise Exception(f"No /change_points in video {key} for summary evaluation, "
+                                    "make sure you have up-to-date .h5 dataset files.")
+                m.cps = rec["change_points"][...]
+                m.nfps = rec["n_frame_per_seg"][...].tolist()
+                m.user_summary = rec["user_summary"][...]
+            m.loaded.add(need)
+        return m
 
+    # ------------------------------------------------------------------ batched scoring (the hot path)
     def _score_keys(self, keys, max_frames_per_launch=1 << 17):
-        """{key: (seq_len,) float32 numpy} for `keys`, scoring many videos per launch.  Models with positional
-        embeddings (VASNet max_pos) go through the per-video reference interface."""
-        dev = self._device()
-        out = {}
+        """{key: (seq_len,) float32 numpy}.  Videos are packed back to back and scored in as few launches as the frame
+        budget allows; models with positional embeddings go through the per-video interface (they index by position)."""
+        dev, out = self._device(), {}
         if getattr(self.model, "max_length", None):
             for key in keys:
-                seq = torch.from_numpy(self.dataset[key]["features"][...]).unsqueeze(1).to(dev)
-                out[key] = self.model(seq).squeeze().detach().cpu().numpy()
+                feats = self._video_on_device(key, dev)[0]
+                out[key] = self.model(feats.unsqueeze(1).clone()).squeeze().detach().cpu().numpy()
             return out
-        batch, frames = [], 0
-        def flush():
-            nonlocal batch, frames
-            if not batch:
-                return
-            feats = [self._video_on_device(k, dev)[0] for k in batch]
-            lens = [f.shape[0] for f in feats]
-            x = torch.cat(feats) if len(feats) > 1 else feats[0]
-            s = self.model.score_packed(x, lens).detach().cpu().numpy()
-            off = np.concatenate([[0], np.cumsum(lens)])
-            for i, k in enumerate(batch):
-                out[k] = s[off[i]:off[i + 1]].copy() if lens[i] > 1 else s[off[i]:off[i + 1]].reshape(())   # .squeeze() quirk: T==1 -> 0-d
-            batch, frames = [], 0
+        groups, cur, frames = [], [], 0
         for key in keys:
-            T = self.dataset[key]["features"].shape[0]
-            if frames + T > max_frames_per_launch:
-                flush()
-            batch.append(key); frames += T
-        flush()
+            T = self._video_on_device(key, dev)[0].shape[0]
+            if cur and frames + T > max_frames_per_launch:
+                groups.append(cur); cur, frames = [], 0
+            cur.append(key); frames += T
+        if cur:
+            groups.append(cur)
+        for grp in groups:
+            feats = [self._video_on_device(k, dev)[0] for k in grp]
+            lens = [f.shape[0] for f in feats]
+            packed = feats[0] if len(feats) == 1 else torch.cat(feats)
+            flat = self.model.score_packed(packed, lens).detach().cpu().numpy()
+            for k, piece in zip(grp, np.split(flat, np.cumsum(lens)[:-1])):
+                out[k] = piece.copy() if piece.shape[0] > 1 else piece.reshape(())    # `.squeeze()` of the reference: T == 1 -> 0-d
         return out
 
     def test(self, fold):
-        """Test model on test_keys"""
+        """Score the fold's test videos, then rank correlation and key-shot F-scores: (avg_corr, (avg_f, max_f))."""
         self.model.eval()
-        _, test_keys = self._get_train_test_keys(fold)
+        test_keys = self._get_train_test_keys(fold)[1]
         with torch.no_grad():
-            summary = self._score_keys(test_keys)
-        avg_corr = self._eval_scores(summary, test_keys)
-        avg_f_score, max_f_score = self._eval_summary(summary, test_keys)
-        return avg_corr, (avg_f_score, max_f_score)
+            activations = self._score_keys(test_keys)
+        return self._eval_scores(activations, test_keys), self._eval_summary(activations, test_keys)
 
     def _eval_scores(self, machine_summary_activations, test_keys):
-        """Average (over test keys) of the mean Spearman correlation with each annotator."""
-        avg_corrs = []
+        """Mean over videos of the mean Spearman correlation with each annotator's scores."""
+        per_video = []
         for key in test_keys:
-            d = self.dataset[key]
-            probs = machine_summary_activations[key]
-            if "user_scores" not in d:
-                raise Exception(f"No /user_scores in video {key} for score evaluation, "
-                                "make sure you have up-to-date .h5 dataset files.")
-            user_scores = d["user_scores"][...]
-            n_frames = d["n_frames"][()]
-            positions = d["picks"][...]
-            machine_scores = generate_scores(probs, n_frames, positions)
-            ranks = self._rank_cache.get(key)
-            if ranks is None:
-                ranks = self._rank_cache[key] = rank_users(user_scores)
-            avg_corrs.append(evaluate_scores(machine_scores, user_scores, metric="spearmanr", user_ranks=ranks))
-        return np.mean(avg_corrs)
+            m = self._video_meta(key, "scores")
+            frame_scores = ev.generate_scores(machine_summary_activations[key], m.n_frames, m.picks)
+            per_video.append(ev.evaluate_scores(frame_scores, m.user_scores, metric="spearmanr", user_ranks=m.user_ranks))
+        return np.mean(per_video)
+
+    def _machine_summary(self, key, activations):
+        m = self._video_meta(key, "summary")
+        return m, ev.generate_summary(activations, m.cps, m.n_frames, m.nfps, m.picks, self.hps.summary_proportion,
+                                      self.hps.selection_algorithm)
 
     def _eval_summary(self, machine_summary_activations, test_keys):
-        """Average over test keys of the (avg, max) F-score of the generated key-shot summary."""
-        avg_f_scores, max_f_scores = [], []
-        for key in test_keys:
-            d = self.dataset[key]
-            probs = machine_summary_activations[key]
-            if "change_points" not in d:
-                raise Exception(f"No /change_points in video {key} for summary evaluation, "
-                                "make sure you have up-to-date .h5 dataset files.")
-            cps = d["change_points"][...]
-            num_frames = d["n_frames"][()]
-            nfps = d["n_frame_per_seg"][...].tolist()
-            positions = d["picks"][...]
-            user_summary = d["user_summary"][...]
-            machine_summary = generate_summary(probs, cps, num_frames, nfps, positions, self.hps.summary_proportion,
-                                               self.hps.selection_algorithm)
-            avg_f_score, max_f_score = evaluate_summary(machine_summary, user_summary)
-            avg_f_scores.append(avg_f_score)
-            max_f_scores.append(max_f_score)
-        return np.mean(avg_f_scores), np.mean(max_f_scores)
+        """Mean over videos of the (average, maximum) F-score of the generated key-shot summary against the annotators."""
+        f = np.array([ev.evaluate_summary(summ, m.user_summary)
+                      for m, summ in (self._machine_summary(k, machine_summary_activations[k]) for k in test_keys)])
+        return np.mean(f[:, 0]), np.mean(f[:, 1])
+
+    # ------------------------------------------------------------------ logging helpers
+    def _histogram(self, tag, key, values):
+        self.hps.writer.add_histogram(f"{self.dataset_name}/{tag}", values, int(key.split("_")[1]))
 
     def draw_gtscores(self, fold, keys, norm=True):
-        """Draw datasets ground truth scores distribution in Tensorboard histograms"""
+        """Ground-truth score distributions of the training videos as TensorBoard histograms."""
         for key in keys:
-            d = self.dataset[key]
-            i = int(key.split("_")[1])
-            gtscore = d["gtscore"][...]
+            gt = self.dataset[key]["gtscore"][...]
             if norm:
-                gtscore -= gtscore.min()
-                gtscore /= gtscore.max() - gtscore.min()
-            self.hps.writer.add_histogram(f"{self.dataset_name}/Fold_{fold+1}/Train/gtscores", gtscore, i)
+                gt = (gt - gt.min()) / (gt.max() - gt.min())
+            self._histogram(f"Fold_{fold+1}/Train/gtscores", key, gt)
 
     def draw_scores(self, fold, dist_scores):
-        """Draw predicted scores distribution in Tensorboard histograms"""
+        """Predicted score distributions (last epoch) as TensorBoard histograms."""
         for key, scores in dist_scores.items():
-            i = int(key.split("_")[1])
-            if torch.is_tensor(scores):
-                scores = scores.detach().cpu().numpy()
-            self.hps.writer.add_histogram(f"{self.dataset_name}/Fold_{fold+1}/Train/final_scores", scores, i)
+            self._histogram(f"Fold_{fold+1}/Train/final_scores", key,
+                            scores.detach().cpu().numpy() if torch.is_tensor(scores) else scores)
 
+    # ------------------------------------------------------------------ predictions / checkpoints
     def predict_dataset(self, pred_path):
-        """Predict on all videos in the dataset and save them (HDF5 when h5py is present, else the same groups in an .npz)"""
+        """Scores + machine summary of EVERY video of the dataset with the best weights, written under
+        `<dataset_file>/<key>/{scores,user_summary,machine_summary,machine_scores}` (HDF5, or an .npz with those paths)."""
         self.model.load_state_dict(self.best_weights)
         self.model.eval()
         keys = list(self.dataset.keys())
         with torch.no_grad():
-            all_scores = self._score_keys(keys)
-        with open_dataset(pred_path, "w") as f:
-            dataset_file = os.path.basename(str(self.hps.dataset_of_file[self.splits_file]))
-            g = f.create_group(dataset_file)
+            activations = self._score_keys(keys)
+        root_name = os.path.basename(str(self.hps.dataset_of_file[self.splits_file]))
+        with open_dataset(pred_path, "w") as sink:
+            root = sink.create_group(root_name)
             for key in keys:
-                d = self.dataset[key]
-                cps = d["change_points"][...]
-                n_frames = d["n_frames"][()]
-                nfps = d["n_frame_per_seg"][...].tolist()
-                positions = d["picks"][...]
-                user_summary = d["user_summary"][...]
-                scores = all_scores[key]
-                machine_summary = generate_summary(scores, cps, n_frames, nfps, positions, self.hps.summary_proportion,
-                                                   self.hps.selection_algorithm)
-                machine_scores = generate_scores(scores, n_frames, positions)
-                k = g.create_group(key)
-                k.create_dataset("scores", data=scores)
-                k.create_dataset("user_summary", data=user_summary)
-                k.create_dataset("machine_summary", data=machine_summary)
-                k.create_dataset("machine_scores", data=machine_scores)
+                m, summary = self._machine_summary(key, activations[key])
+                grp = root.create_group(key)
+                for name, value in (("scores", activations[key]), ("user_summary", m.user_summary),
+                                    ("machine_summary", summary),
+                                    ("machine_scores", ev.generate_scores(activations[key], m.n_frames, m.picks))):
+                    grp.create_dataset(name, data=value)
 
     def save_best_weights(self, weights_path):
-        """Dump current best weights"""
         if self.best_weights is None:
             raise Exception("best_weights property is empty, can't save model's weights")
         torch.save(self.best_weights, weights_path)
 
     def load_weights(self, weights_path):
-        """Load weights"""
         self.model.load_state_dict(torch.load(weights_path))

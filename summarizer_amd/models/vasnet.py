@@ -211,7 +211,7 @@ class VASNetTrainer(Trainer):
                     else:
                         loss = 0
                         for k, (seq, target) in zip(keys, vids):
-                            sc = self.model(seq.unsqueeze(1))
+                            sc = self.model(seq.unsqueeze(1).clone())   # clone: the positional add is in place, seq is the HBM-cached copy
                             loss = loss + torch.mean((sc.view(-1) - target) ** 2) / len(vids)
                             dist_scores[k] = sc.detach()
                     loss.backward()

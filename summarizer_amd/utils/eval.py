@@ -74,30 +74,35 @@ def rank_users(user_scores):
     return np.stack([stats.rankdata(-user_scores[i]) for i in range(user_scores.shape[0])])
 
 
-def generate_summary(scores, cps, n_frames, nfps, positions, proportion=0.15, method="knapsack"):
-    """Generate keyshot-based video summary i.e. a binary vector of shape (sum(nfps),) (eval.py:74-123)."""
-    n_segs = cps.shape[0]
-    frame_scores = upsample(scores, n_frames, positions)
-    seg_score = []
-    for seg_idx in range(n_segs):                                # float32 mean per segment, as python floats
-        start, end = int(cps[seg_idx, 0]), int(cps[seg_idx, 1] + 1)
-        seg_score.append(float(frame_scores[start:end].mean()))
-    limits = int(math.floor(n_frames * proportion))
+def _segment_scores(frame_scores, cps):
+    """float32 mean of the frame scores over each [start, end] change-point interval, as python floats (eval.py:88-94)."""
+    return [float(frame_scores[int(lo):int(hi) + 1].mean()) for lo, hi in cps[:, :2]]
+
+
+def _select_segments(seg_score, nfps, n_segs, budget, method):
+    """Indices of the segments kept under the frame budget: 0/1 knapsack (native DP) or greedy by score (eval.py:98-110)."""
     if method == "knapsack":
-        picks = knapsack_ortools(seg_score, nfps, n_segs, limits)
-    elif method == "rank":
-        order = np.argsort(seg_score)[::-1].tolist()
-        picks = []
-        total_len = 0
-        for i in order:
-            if total_len + nfps[i] < limits:                     # strict, eval.py:105
-                picks.append(i)
-                total_len += nfps[i]
-    else:
+        return knapsack_ortools(seg_score, nfps, n_segs, budget)
+    if method != "rank":
         raise KeyError(f"Unknown method {method}")
-    chosen = np.zeros(n_segs, dtype=np.float32)
-    chosen[np.asarray(picks, dtype=np.int64)] = 1
-    return np.repeat(chosen, np.asarray(nfps[:n_segs], dtype=np.int64))
+    kept, used = [], 0
+    for i in np.argsort(seg_score)[::-1].tolist():
+        if used + nfps[i] < budget:                 # strict, eval.py:105
+            kept.append(i)
+            used += nfps[i]
+    return kept
+
+
+def generate_summary(scores, cps, n_frames, nfps, positions, proportion=0.15, method="knapsack"):
+    """Keyshot-based video summary: binary float32 vector of length sum(nfps) (eval.py:74-123).
+    scores: per-step importance; cps: (n_segs, 2) change points; nfps: frames per segment; positions: sampled-frame
+    positions; proportion: summary length budget; method: 'knapsack' | 'rank'."""
+    n_segs = cps.shape[0]
+    seg_score = _segment_scores(upsample(scores, n_frames, positions), cps)
+    kept = _select_segments(seg_score, nfps, n_segs, int(math.floor(n_frames * proportion)), method)
+    flags = np.zeros(n_segs, dtype=np.float32)
+    flags[np.asarray(kept, dtype=np.int64)] = 1
+    return np.repeat(flags, np.asarray(nfps[:n_segs], dtype=np.int64))
 
 
 def evaluate_summary(machine_summary, user_summary):
