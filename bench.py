@@ -187,12 +187,21 @@ def main():
         ach = qkv_flops / avg_s / 1e12
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc = {}
         if os.path.exists(tp) and args.workload == "tvsum" and args.model == "vasnet" and args.videos == 50:
-            traffic = json.load(open(tp)).get("gemm_qkv_hbm_bytes_per_launch")   # PMC pass of this exact launch shape
+            pmc = json.load(open(tp))                                              # PMC passes of this exact launch shape
+            traffic = pmc.get("gemm_qkv_hbm_bytes_per_launch")
         roof = dict(bound="mfma", kernel="gemm_f32_kernel<128,NT> (QKV projection)", achieved=round(ach, 2),
                     peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     traffic=traffic, avg_launch_us=round(avg_s * 1e6, 2), launches=int(n.value),
                     flops_per_launch=qkv_flops)
+        if traffic:
+            c = pmc.get("counters_mean_per_launch", {})
+            roof["hbm_gbs"] = round(traffic / avg_s / 1e9, 1)
+            roof["hbm_frac_of_8TBs"] = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+            if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+                roof["pmc_mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)
+            roof["pmc_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 note)"
 
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
