@@ -125,7 +125,7 @@ int sumk_frame_head_backward(const float* h, const float* scores, const float* d
                              size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ Transformer scorer
- * Inference of the reference's Transformer-encoder scorer (summarizer/models/transformer.py:74-103): n_layers stock
+ * The reference's Transformer-encoder scorer (summarizer/models/transformer.py:74-103): n_layers stock
  * nn.TransformerEncoderLayer (post-norm, ReLU, dim_feedforward F), final norm = the SHARED layer_norm (also applied after
  * k1), optional extra residual (more_residuals), k1 + ReLU + LN + k2 + sigmoid.  Weights as torch stores them. */
 typedef struct sumk_tf_layer_weights {
@@ -140,14 +140,37 @@ typedef struct sumk_tf_head_weights {
   const float* k1_w; const float* k1_b;               /* (D,D),(D)                                     transformer.py:52 */
   const float* k2_w; const float* k2_b;               /* (D),(1)                                       transformer.py:53 */
 } sumk_tf_head_weights;
-size_t sumk_transformer_workspace_bytes(int32_t D, int32_t F, int32_t n_heads, int32_t n_seq, const int32_t* seq_off_host);
+typedef struct sumk_tf_opts {
+  float layer_eps;        /* LayerNorm eps inside the encoder layers (torch default 1e-5)                       */
+  float final_eps;        /* eps of the shared layer_norm (constructor argument `epsilon`)    transformer.py:47  */
+  int32_t more_residuals; /* encoder_out += x                                                  transformer.py:94  */
+  float layer_dropout_p;  /* training: dropout inside the encoder layers (0.1)                 transformer.py:49  */
+  float head_dropout_p;   /* training: dropout after relu(k1) (0.5)                            transformer.py:46,99 */
+  uint64_t seed;          /* keep-masks are a pure function of (seed, site, element), as for VASNet               */
+} sumk_tf_opts;
+size_t sumk_transformer_workspace_bytes(int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
+                                        const int32_t* seq_off_host, int32_t training);
 /* x (n_rows,D) packed -> scores (n_rows,).  pos_table/pos_rows as in sumk_vasnet_forward (in-place add, transformer.py:83-89).
- * layer_eps: LayerNorm eps inside the encoder layers (torch default 1e-5); final_eps: eps of the shared layer_norm. */
+ * training != 0 keeps every layer's activations in the workspace for sumk_transformer_backward. */
 int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
                              const int32_t* seq_off_host, const int32_t* seq_off_dev,
                              const sumk_tf_layer_weights* layers, const sumk_tf_head_weights* head,
-                             float layer_eps, float final_eps, int32_t more_residuals, const float* pos_table,
-                             const int32_t* pos_rows, float* scores, void* workspace, size_t workspace_bytes, void* stream);
+                             const sumk_tf_opts* opts, const float* pos_table, const int32_t* pos_rows, float* scores,
+                             void* workspace, size_t workspace_bytes, int32_t training, void* stream);
+/* Gradient targets, same shapes as the weights; ACCUMULATED into (caller zeroes them). */
+typedef struct sumk_tf_layer_grads {
+  float* in_proj_w; float* in_proj_b; float* out_proj_w; float* out_proj_b; float* lin1_w; float* lin1_b;
+  float* lin2_w; float* lin2_b; float* norm1_w; float* norm1_b; float* norm2_w; float* norm2_b;
+} sumk_tf_layer_grads;
+typedef struct sumk_tf_head_grads { float* ln_w; float* ln_b; float* k1_w; float* k1_b; float* k2_w; float* k2_b; } sumk_tf_head_grads;
+/* Backward of sum_r dscores[r]*scores[r] (loss.backward(), transformer.py:163); must follow a training-mode forward on the
+ * same workspace.  dx (n_rows,D) is written if non-NULL. */
+int sumk_transformer_backward(const float* x, int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
+                              const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                              const sumk_tf_layer_weights* layers, const sumk_tf_head_weights* head,
+                              const sumk_tf_opts* opts, const float* dscores, const sumk_tf_layer_grads* layer_grads,
+                              const sumk_tf_head_grads* head_grads, float* dx, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------------ DSN reward
  * DSNTrainer.compute_reward (dsn.py:185-236) for E episodes of one or more packed videos:

@@ -37,6 +37,11 @@ class TfHeadWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln_w", "ln_b", "k1_w", "k1_b", "k2_w", "k2_b")]
 
 
+class TfOpts(C.Structure):
+    _fields_ = [("layer_eps", C.c_float), ("final_eps", C.c_float), ("more_residuals", C.c_int32),
+                ("layer_dropout_p", C.c_float), ("head_dropout_p", C.c_float), ("seed", C.c_uint64)]
+
+
 class LstmLayerWeights(C.Structure):
     _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2)]
 
@@ -69,10 +74,13 @@ _SIGS = {
     "sumk_frame_head_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "sumk_frame_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
                                            c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "sumk_transformer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P]),
+    "sumk_transformer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_transformer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
-                                           C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, c_f32p, c_i32p, c_f32p,
-                                           C.c_void_p, C.c_size_t, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
+                                           C.c_int32, C.c_void_p]),
+    "sumk_transformer_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, C.c_void_p, c_f32p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_dsn_reward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_dsn_reward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, c_f32p, C.c_int32, C.c_int32,
                                   C.c_int32, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -86,3 +86,33 @@ class BiLstmScorerFunction(torch.autograd.Function):
         gx = dh if ctx.needs_input_grad[0] else None
         ctx.params = None
         return (gx, None, None, None, None, None, None, None) + tuple(ret)
+
+
+class TransformerFunction(torch.autograd.Function):
+    """scores = Transformer-encoder scorer(x) for a packed batch (transformer.py:74-103)."""
+
+    @staticmethod
+    def forward(ctx, xp, sb, cfg, opts, table, rows, names, *params):
+        p = dict(zip(names, params))
+        scores, ws = kernels.transformer_forward_packed(xp, sb, p, cfg["n_layers"], cfg["n_heads"], cfg["dff"], opts, table,
+                                                        rows, training=True)
+        ctx.meta = (sb, cfg, opts, names, rows)
+        ctx.ws, ctx.params, ctx.table = ws, params, table
+        ctx.table_is_param = isinstance(table, torch.nn.Parameter) and table.requires_grad
+        ctx.save_for_backward(xp)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        (xp,) = ctx.saved_tensors
+        sb, cfg, opts, names, rows = ctx.meta
+        p = dict(zip(names, ctx.params))
+        grads, ret = _grad_targets(names, ctx.params)
+        want_dx = ctx.needs_input_grad[0] or ctx.table_is_param
+        dx = kernels.transformer_backward_packed(xp, sb, p, grads, cfg["n_layers"], cfg["n_heads"], cfg["dff"], opts, dscores,
+                                                 ctx.ws, want_dx=want_dx)
+        if ctx.table_is_param:
+            tg = torch.zeros_like(ctx.table).index_add_(0, rows.long(), dx)
+            ctx.table.grad = tg if ctx.table.grad is None else ctx.table.grad + tg
+        ctx.ws = ctx.params = None
+        return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + tuple(ret)

@@ -40,6 +40,7 @@ struct GemmKArgs {
   int32_t nprob;
   int32_t n_group;
   int32_t total_tiles;   // loop bound of the persistent tile walk (virtual tiles when xcd_tiles_m > 0)
+  Drop drop; uint32_t drop_site;   // epilogue dropout (drop.thr == 0: none); mask index = row * N + col
   int32_t xcd_tiles_m;   // > 0: single-problem launch with the XCD-aware tile map below; value = tiles along M
   float alpha;
 };
@@ -285,9 +286,16 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
           float* cp = ka.C + cur.c_off + (int64_t)row * cur.ldc + col;
           if constexpr (EPI == EPI_NONE) v *= ka.alpha;
           if constexpr (EPI == EPI_RESIDUAL) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
-          if constexpr (EPI == EPI_BIAS_RELU) { v += bsum; v = (v < 0.f) ? 0.f : v; }  // NaN-propagating, like torch.relu
+          if constexpr (EPI == EPI_BIAS_RELU) {
+            v += bsum; v = (v < 0.f) ? 0.f : v;   // NaN-propagating, like torch.relu
+            if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
+          }
           if constexpr (EPI == EPI_BIAS2) v += bsum;
-          if constexpr (EPI == EPI_BIAS_RESIDUAL) v += bsum + ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+          if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+            v += bsum;
+            if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
+            v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+          }
           if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
           *cp = v;
         }
@@ -333,6 +341,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = g.nprob; ka.n_group = g.n_group; ka.alpha = g.alpha;
   ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0;
+  ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
   static const bool xcd_map = !(getenv("SUMK_XCD_MAP") && getenv("SUMK_XCD_MAP")[0] == '0');

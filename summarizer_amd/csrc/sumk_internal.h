@@ -61,6 +61,9 @@ struct GemmLaunch {
   int32_t small_tile = 0;  // tile config: 0 -> 128x128, 1 -> 64x64 (ragged per-video problems), 2 -> 128x64
   int32_t prof_tag = -1;
   int32_t xcd_M = 0, xcd_N = 0;  // single-problem launches: (M,N) so the kernel may use the XCD-aware tile map
+  // training-mode dropout fused in the epilogue (EPI_BIAS_RELU: after the ReLU; EPI_BIAS_RESIDUAL: on acc+bias, before +R);
+  // drop_thr == 0 disables it.  Element index of the mask = row * N + col.
+  uint64_t drop_seed = 0; uint32_t drop_thr = 0, drop_site = 0; float drop_scale = 1.f;
 };
 
 // number of tiles an (M,N) problem takes with the chosen tile size
@@ -99,6 +102,17 @@ inline uint32_t dropout_threshold(float p) {
   double t = (double)p * 4294967296.0;
   return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
+struct Drop {  // dropout descriptor of one call; thr == 0 means "no dropout"
+  uint64_t seed; uint32_t thr; float scale;
+};
+inline Drop make_drop(float p, uint64_t seed) {
+  Drop d; d.seed = seed; d.thr = 0; d.scale = 1.f;
+  if (p > 0.f) { d.thr = dropout_threshold(p); d.scale = 1.0f / (1.0f - p); }
+  return d;
+}
+__host__ __device__ inline float drop_apply(const Drop& d, uint32_t site, uint64_t idx, float v) {
+  return dropout_keep(d.seed, site, idx, d.thr) ? v * d.scale : 0.f;
+}
 
 // ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
 // Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.
@@ -107,6 +121,21 @@ int launch_layernorm(const float* X, float* Y, const float* g, const float* b, i
 // scores[r] = sigmoid(LayerNorm(Z[r]) . w2 + b2)
 int launch_ln_head(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
                    int n_rows, int D, float eps, hipStream_t stream);
+// training-mode variants: dropout `site` applied to X on load; stats (mean, rstd per row) saved for the backward
+int launch_layernorm_drop(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
+                          Drop drop, uint32_t site, hipStream_t stream);
+int launch_ln_head_drop(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
+                        int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream);
+// Backward of Y = LN(drop(X)) * g + b: dX from dY; per-wave partial sums of (dgamma, dbeta) go to `part`
+// ([n_waves][3*D + 4] floats, n_waves <= LNB_MAX_WAVES returned in *n_waves) for partial_reduce_accum.
+constexpr int LNB_MAX_WAVES = 1024;
+int launch_ln_bwd_rows(int D, int R, const float* X, const float* stats, const float* g, const float* b, const float* dY,
+                       float* dX, float* part, Drop drop, uint32_t site, int* n_waves, hipStream_t stream);
+// Backward of scores = sigmoid(LN(drop(Z)) . w2 + b2) with Z = post-ReLU activations: dZ (ReLU + dropout masks applied),
+// partials of (dgamma, dbeta, dw2) and db2 in slot [3*D].
+int launch_ln_head_bwd(int D, int R, const float* Z, const float* stats, const float* g, const float* b, const float* w2,
+                       const float* scores, const float* dscores, float* dZ, float* part, Drop drop, uint32_t site,
+                       int* n_waves, hipStream_t stream);
 // x[r,:] += table[pos_rows[r],:]  in place
 int launch_add_pos(float* x, const float* table, const int32_t* pos_rows, int n_rows, int D, hipStream_t stream);
 

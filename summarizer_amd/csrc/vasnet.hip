@@ -28,7 +28,6 @@ struct SeqInfo {
 enum { TB_S = 0, TB_PV = 1, TB_DV = 2, TB_DP = 3, TB_DQ = 4, TB_DK = 5, TB_COUNT = 6 };
 constexpr int ROW_PROBS = 8;
 constexpr int SPLITK_PROBS = 64;
-constexpr int LNB_MAX_WAVES = 1024;  // partial-sum slots of the LayerNorm backward kernels
 constexpr int COLSUM_CHUNKS = 128;
 
 // Workspace carve-up, computed identically by the size query and by forward/backward.
@@ -184,13 +183,6 @@ __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int
     if (lo * up == 0.f) e = -INFINITY;
   }
   return e;
-}
-
-struct Drop {  // dropout site descriptor; thr == 0 means "no dropout"
-  uint64_t seed; uint32_t thr; float scale;
-};
-__device__ __forceinline__ float drop_apply(const Drop& d, uint32_t site, uint64_t idx, float v) {
-  return dropout_keep(d.seed, site, idx, d.thr) ? v * d.scale : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------- softmax rows
@@ -470,11 +462,7 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2), dim3(64), 0, stream, a);
 }
 
-static Drop make_drop(const sumk_vasnet_opts* o) {
-  Drop d; d.seed = o->seed; d.thr = 0; d.scale = 1.f;
-  if (o->dropout_p > 0.f) { d.thr = dropout_threshold(o->dropout_p); d.scale = 1.0f / (1.0f - o->dropout_p); }
-  return d;
-}
+static Drop make_drop(const sumk_vasnet_opts* o) { return make_drop(o->dropout_p, o->seed); }
 
 int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
                      hipStream_t stream) {
@@ -489,6 +477,20 @@ int launch_ln_head(const float* Z, const float* g, const float* b, const float* 
   Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, Z, nullptr, g, b, w2, b2, scores,
                      n_rows, D, eps, nullptr, none, 0u);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+int launch_layernorm_drop(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
+                          Drop drop, uint32_t site, hipStream_t stream) {
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, X, Y, g, b, nullptr, nullptr,
+                     nullptr, n_rows, D, eps, stats, drop, site);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+int launch_ln_head_drop(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
+                        int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream) {
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, Z, nullptr, g, b, w2, b2, scores,
+                     n_rows, D, eps, stats, drop, site);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -612,6 +614,18 @@ static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
+
+namespace sumk {
+int launch_ln_bwd_rows(int D, int R, const float* X, const float* stats, const float* g, const float* b, const float* dY,
+                       float* dX, float* part, Drop drop, uint32_t site, int* n_waves, hipStream_t stream) {
+  return launch_ln_bwd<false>(D, R, X, stats, g, b, dY, nullptr, nullptr, nullptr, dX, part, drop, site, n_waves, stream);
+}
+int launch_ln_head_bwd(int D, int R, const float* Z, const float* stats, const float* g, const float* b, const float* w2,
+                       const float* scores, const float* dscores, float* dZ, float* part, Drop drop, uint32_t site,
+                       int* n_waves, hipStream_t stream) {
+  return launch_ln_bwd<true>(D, R, Z, stats, g, b, nullptr, w2, scores, dscores, dZ, part, drop, site, n_waves, stream);
+}
+}  // namespace sumk
 
 extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
                                     const int32_t* seq_off_dev, const sumk_vasnet_weights* w,

@@ -276,39 +276,75 @@ def dsn_reward(x, sb, actions, far_sim=False, temp_dist_thre=20):
 
 
 # ------------------------------------------------------------------------------------------------ Transformer scorer
-def transformer_forward_packed(x, sb, params, n_layers, n_heads, dff, layer_eps, final_eps, more_residuals=False,
-                               pos_table=None, pos_rows=None):
-    """x: (n_rows, D) packed -> scores (n_rows,).  params: state_dict-keyed tensors of the reference Transformer."""
+TF_LAYER_FIELDS = (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_attn.in_proj_bias"),
+                   ("out_proj_w", "self_attn.out_proj.weight"), ("out_proj_b", "self_attn.out_proj.bias"),
+                   ("lin1_w", "linear1.weight"), ("lin1_b", "linear1.bias"), ("lin2_w", "linear2.weight"),
+                   ("lin2_b", "linear2.bias"), ("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
+                   ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"))
+TF_HEAD_FIELDS = (("ln_w", "layer_norm.weight"), ("ln_b", "layer_norm.bias"), ("k1_w", "k1.weight"), ("k1_b", "k1.bias"),
+                  ("k2_w", "k2.weight"), ("k2_b", "k2.bias"))
+
+
+def transformer_param_names(n_layers):
+    """state_dict keys the HIP path reads (the prototype `transformer_encoder_layer.*` copy is never used)."""
+    names = [f"transformer_encoder.layers.{l}.{k}" for l in range(n_layers) for _, k in TF_LAYER_FIELDS]
+    return names + [k for _, k in TF_HEAD_FIELDS]
+
+
+def _tf_structs(tensors, n_layers, what, layer_cls, head_cls):
+    def ptr(k):
+        t = tensors[k]
+        _require_gpu(t, f"Transformer {what} {k}")
+        if not t.is_contiguous():
+            raise SumkError(f"Transformer {what} {k} must be contiguous")
+        return t.data_ptr()
+    layers = (layer_cls * n_layers)()
+    for l in range(n_layers):
+        for f, k in TF_LAYER_FIELDS:
+            setattr(layers[l], f, ptr(f"transformer_encoder.layers.{l}.{k}"))
+    head = head_cls(*[ptr(k) for _, k in TF_HEAD_FIELDS])
+    return layers, head
+
+
+def _tf_opts(o):
+    return _lib.TfOpts(float(o["layer_eps"]), float(o["final_eps"]), int(bool(o.get("more_residuals", False))),
+                       float(o.get("layer_dropout_p", 0.0)), float(o.get("head_dropout_p", 0.0)), int(o.get("seed", 0)))
+
+
+def transformer_forward_packed(x, sb, params, n_layers, n_heads, dff, opts, pos_table=None, pos_rows=None, training=False):
+    """x: (n_rows, D) packed -> (scores (n_rows,), workspace or None).  params: state_dict-keyed tensors."""
     lib = _lib.load()
     _require_gpu(x, "transformer input")
     if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
         raise SumkError(f"transformer input must be contiguous (n_rows={sb.n_rows}, D), got {tuple(x.shape)}")
     D = x.shape[1]
-    def ptr(k):
-        t = params[k]
-        _require_gpu(t, f"Transformer weight {k}")
-        if not t.is_contiguous():
-            raise SumkError(f"Transformer weight {k} must be contiguous")
-        return t.data_ptr()
-    layers = (_lib.TfLayerWeights * n_layers)()
-    for l in range(n_layers):
-        pre = f"transformer_encoder.layers.{l}."
-        for f, k in (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_attn.in_proj_bias"),
-                     ("out_proj_w", "self_attn.out_proj.weight"), ("out_proj_b", "self_attn.out_proj.bias"),
-                     ("lin1_w", "linear1.weight"), ("lin1_b", "linear1.bias"), ("lin2_w", "linear2.weight"),
-                     ("lin2_b", "linear2.bias"), ("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"),
-                     ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias")):
-            setattr(layers[l], f, ptr(pre + k))
-    head = _lib.TfHeadWeights(ptr("layer_norm.weight"), ptr("layer_norm.bias"), ptr("k1.weight"), ptr("k1.bias"),
-                              ptr("k2.weight"), ptr("k2.bias"))
-    nbytes = lib.sumk_transformer_workspace_bytes(D, dff, n_heads, sb.n_seq, sb.off_host_p)
+    layers, head = _tf_structs(params, n_layers, "weight", _lib.TfLayerWeights, _lib.TfHeadWeights)
+    o = _tf_opts(opts)
+    nbytes = lib.sumk_transformer_workspace_bytes(D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, int(training))
     if nbytes == 0:
         _lib.check(-1, "sumk_transformer_workspace_bytes")
-    ws = workspace(nbytes, x.device)
+    ws = workspace(nbytes, x.device, persistent=training)
     scores = torch.empty(sb.n_rows, dtype=torch.float32, device=x.device)
     rc = lib.sumk_transformer_forward(_p(x), D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, sb.off_dev_p,
-                                      C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p), float(layer_eps),
-                                      float(final_eps), int(bool(more_residuals)), _p(pos_table), _p(pos_rows), _p(scores),
-                                      _p(ws), ws.numel(), _stream())
+                                      C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p),
+                                      C.cast(C.pointer(o), C.c_void_p), _p(pos_table), _p(pos_rows), _p(scores), _p(ws),
+                                      ws.numel(), int(training), _stream())
     _lib.check(rc, "sumk_transformer_forward")
-    return scores
+    return scores, (ws if training else None)
+
+
+def transformer_backward_packed(x, sb, params, grads, n_layers, n_heads, dff, opts, dscores, ws, want_dx=False):
+    lib = _lib.load()
+    D = x.shape[1]
+    layers, head = _tf_structs(params, n_layers, "weight", _lib.TfLayerWeights, _lib.TfHeadWeights)
+    glayers, ghead = _tf_structs(grads, n_layers, "grad", _lib.TfLayerWeights, _lib.TfHeadWeights)   # same field layout
+    o = _tf_opts(opts)
+    dx = torch.empty_like(x) if want_dx else None
+    if not dscores.is_contiguous():
+        dscores = dscores.contiguous()
+    rc = lib.sumk_transformer_backward(_p(x), D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, sb.off_dev_p,
+                                       C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p),
+                                       C.cast(C.pointer(o), C.c_void_p), _p(dscores), C.cast(glayers, C.c_void_p),
+                                       C.cast(C.pointer(ghead), C.c_void_p), _p(dx), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "sumk_transformer_backward")
+    return dx

@@ -1,12 +1,14 @@
-"""Transformer-encoder scorer on MI355X -- drop-in for the model class of `summarizer/models/transformer.py` (reference),
-INFERENCE path (the first "next" model after the north_star scorers).
+"""Transformer-encoder scorer on MI355X -- drop-in for `summarizer/models/transformer.py` (reference): model class and
+trainer (the first "next" model after the north_star scorers).
 
 Same constructor (transformer.py:19), same parameter names / state_dict keys (the stock `nn.TransformerEncoder` objects are
 kept as PARAMETER CONTAINERS and never called), same forward contract x (seq_len, batch, input_size) -> (seq_len, batch, 1).
 Quirks reproduced: one `layer_norm` used as the encoder's final norm AND after k1 (transformer.py:47,50,100); the in-place
-positional add with the sinusoid table's batch re-view (transformer.py:83-89).  Training (`loss.backward()`) is not
-implemented for this scorer: calling it with grad enabled raises.
+positional add with the sinusoid table's batch re-view (transformer.py:83-89).  Training runs through HIP backward kernels;
+its dropouts (0.1 inside the encoder layers, 0.5 after k1) use the deterministic hash masks of the VASNet path.
 """
+import math
+import random
 import numpy as np
 import torch
 import torch.nn as nn
@@ -16,6 +18,7 @@ from .. import kernels
 from .._lib import SumkError
 from . import Trainer
 from .vasnet import _sinusoid_table
+from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
 
 
 class Transformer(nn.Module):
@@ -53,6 +56,7 @@ class Transformer(nn.Module):
                     fn(self.transformer_encoder.layers[i].linear2.weight)
                 fn(self.k1.weight); fn(self.k2.weight)
         self._pos_rows_cache = {}
+        self._seed_counter = 0
 
     def _pos(self, T, B, device):
         if self.max_length is None:
@@ -90,17 +94,27 @@ class Transformer(nn.Module):
         return self._score(x_packed, kernels.SeqBatch.get(lens, x_packed.device), None, None)
 
     def _score(self, xp, sb, table, rows):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise SumkError("summarizer_amd.Transformer is an inference scorer: wrap the call in torch.no_grad() "
-                            "(its backward kernels are not implemented; see DESIGN.md section 7)")
         p = dict(self.named_parameters())
-        return kernels.transformer_forward_packed(xp, sb, p, self.encoder_layers, self.attention_heads, self.input_size,
-                                                  1e-5, self.epsilon, self.more_residuals, table, rows)
+        opts = dict(layer_eps=1e-5, final_eps=self.epsilon, more_residuals=self.more_residuals)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            from ..autograd import TransformerFunction
+            if self.training:
+                self._seed_counter += 1
+                opts.update(layer_dropout_p=float(self.transformer_encoder.layers[0].dropout.p),
+                            head_dropout_p=float(self.dropout.p),
+                            seed=(torch.initial_seed() * 1000003 + self._seed_counter) & (2**63 - 1))
+            names = kernels.transformer_param_names(self.encoder_layers)
+            cfg = dict(n_layers=self.encoder_layers, n_heads=self.attention_heads, dff=self.input_size)
+            return TransformerFunction.apply(xp, sb, cfg, opts, table, rows, names, *[p[n] for n in names])
+        scores, _ = kernels.transformer_forward_packed(xp, sb, p, self.encoder_layers, self.attention_heads, self.input_size,
+                                                       opts, table, rows)
+        return scores
 
 
 class TransformerTrainer(Trainer):
-    """Scoring / evaluation half of the reference trainer (transformer.py:106-124 `_init_model`; `Trainer.test`,
-    `predict_dataset`, `load_weights` from the base class).  `train()` is not provided on the HIP path."""
+    """Mirror of the reference trainer (transformer.py:106-192): per-video MSE regression with Adam, periodic test, best-
+    correlation weights; same `extra_params`.  Extensions as for VASNetTrainer: `batch_videos`, video sharding + one
+    flat-bucket gradient all-reduce per step under torch.distributed."""
     def _init_model(self):
         ep = self.hps.extra_params
         model = Transformer(
@@ -118,5 +132,59 @@ class TransformerTrainer(Trainer):
         return model
 
     def train(self, fold):
-        raise SumkError("TransformerTrainer.train: training of the Transformer scorer is not implemented on the HIP path "
-                        "(inference/evaluation only); train it with the reference and load the checkpoint with load_weights()")
+        self.model.train()
+        train_keys, _ = self._get_train_test_keys(fold)
+        self.draw_gtscores(fold, train_keys)
+        dev = self._device()
+        rank, world = dist_info()
+        broadcast_parameters(self.model)
+        bv = int(self.hps.extra_params.get("batch_videos", 1))
+        used = set(kernels.transformer_param_names(self.model.encoder_layers)) | {"pos_embed.weight"}
+        self.optimizer = FlatAdam([p for n, p in self.model.named_parameters() if n in used and p.requires_grad],
+                                  lr=self.hps.lr, weight_decay=self.hps.weight_decay)
+        if world > 1:
+            lens = [self.dataset[k]["features"].shape[0] for k in train_keys]
+            my_keys = shard_keys(train_keys, lens, rank, world)
+            steps_per_epoch = max(1, math.ceil(max(len(shard_keys(train_keys, lens, r, world)) for r in range(world)) / bv))
+        else:
+            my_keys, steps_per_epoch = train_keys, math.ceil(len(train_keys) / bv)
+        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        packed = self.model.max_length is None
+        for epoch in range(self.hps.epochs):
+            losses, dist_scores = [], {}
+            random.shuffle(my_keys)
+            for step in range(steps_per_epoch):
+                keys = my_keys[step * bv:(step + 1) * bv]
+                self.optimizer.zero_grad()
+                if keys:
+                    vids = [self._video_on_device(k, dev, want_target=True) for k in keys]
+                    if packed:
+                        lens_b = [v[0].shape[0] for v in vids]
+                        x = vids[0][0] if len(vids) == 1 else torch.cat([v[0] for v in vids])
+                        target = vids[0][1] if len(vids) == 1 else torch.cat([v[1] for v in vids])
+                        scores = self.model.score_packed(x, lens_b)
+                        loss = kernels.SeqBatch.get(lens_b, dev).segment_mean((scores - target) ** 2).mean()   # MSE per video (transformer.py:161)
+                        for k, piece in zip(keys, torch.split(scores.detach(), lens_b)):
+                            dist_scores[k] = piece.view(-1, 1, 1)
+                    else:
+                        loss = 0
+                        for k, (seq, target) in zip(keys, vids):
+                            sc = self.model(seq.unsqueeze(1).clone())
+                            loss = loss + torch.mean((sc.view(-1) - target) ** 2) / len(vids)
+                            dist_scores[k] = sc.detach()
+                    loss.backward()
+                    losses.append(loss.detach())
+                self.optimizer.step(grad_scale=self.optimizer.all_reduce_grads())
+            train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")
+            self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Loss: {train_avg_loss:.05f}")
+            self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", train_avg_loss, epoch)
+            if epoch % self.hps.test_every_epochs == 0:
+                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
+                self.model.train()
+                for tag, val in (("Correlation", avg_corr), ("F-score_avg", avg_f_score), ("F-score_max", max_f_score)):
+                    self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/{tag}", val, epoch)
+                best_avg_f_score, best_max_f_score = max(best_avg_f_score, avg_f_score), max(best_max_f_score, max_f_score)
+                if avg_corr > best_corr:
+                    best_corr, self.best_weights = avg_corr, self.model.state_dict()
+        self.draw_scores(fold, dist_scores)
+        return best_corr, best_avg_f_score, best_max_f_score

@@ -49,3 +49,36 @@ for ci, (T, B, layers) in enumerate([(200, 1, 6), (61, 2, 2)]):
                                                      wdigest=R.digest(w))).encode(), dtype=np.uint8)
 np.savez_compressed(os.path.join(HERE, "transformer_full.npz"), **out)
 print("full", os.path.getsize(os.path.join(HERE, "transformer_full.npz")) / 1024, "KB")
+
+# ----------------------------------------------------------------------------- training steps (all dropouts forced to 0)
+def no_dropout(m):
+    m.dropout.p = 0.0
+    for lyr in m.transformer_encoder.layers:
+        lyr.dropout.p = lyr.dropout1.p = lyr.dropout2.p = 0.0
+        lyr.self_attn.dropout = 0.0
+    return m
+
+out = {}
+T, D = 37, 64
+tgt = np.random.default_rng(5).random((T, 1, 1)).astype(np.float32)
+x = R.features(T, 1, D, 4242) - 0.2
+for name, kw in {"tf": dict(input_size=D, encoder_layers=2, attention_heads=4),
+                 "tf_res": dict(input_size=D, encoder_layers=1, attention_heads=8, more_residuals=True)}.items():
+    m = no_dropout(Transformer(**kw)).train()
+    w = R.transformer_weights(D, kw["encoder_layers"], 4100)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    used = [(k, p) for k, p in m.named_parameters() if not k.startswith("transformer_encoder_layer.") and not k.startswith("transformer_encoder.norm.")]
+    opt = torch.optim.Adam([p for _, p in used], lr=5e-5, weight_decay=1e-5)
+    for s in range(3):
+        loss = torch.nn.functional.mse_loss(m(torch.from_numpy(x.copy())), torch.from_numpy(tgt))
+        opt.zero_grad(); loss.backward()
+        if s == 0:
+            out[f"{name}/loss0"] = np.float32(loss.item())
+            for k, p in used: out[f"{name}/grad0/{k}"] = p.grad.numpy().copy()
+        opt.step()
+        if s in (0, 2):
+            for k, p in used: out[f"{name}/param{s+1}/{k}"] = p.detach().numpy().copy()
+    for k, v in w.items(): out[f"{name}/w/{k}"] = v
+out["x"] = x; out["target"] = tgt
+np.savez_compressed(os.path.join(HERE, "transformer_train.npz"), **out)
+print("train", os.path.getsize(os.path.join(HERE, "transformer_train.npz")) / 1024, "KB")

@@ -58,3 +58,58 @@ def test_transformer_full_size_goldens_and_packed_batch():
     for i, x in enumerate(xs):
         ref = transformer_np.transformer_forward(x, w, L, Hh)[:, 0, 0]
         np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i}")
+
+
+@pytest.mark.parametrize("tag,kw", [("tf", dict(input_size=64, encoder_layers=2, attention_heads=4)),
+                                    ("tf_res", dict(input_size=64, encoder_layers=1, attention_heads=8, more_residuals=True))])
+def test_transformer_train_step_goldens(tag, kw):
+    """MSE + Adam for 3 steps with every dropout forced to 0, vs the real reference (loss, all gradients, parameters)."""
+    from summarizer_amd.models.transformer import Transformer
+    from summarizer_amd import kernels
+    dev = torch.device("cuda:0")
+    g = load_golden("transformer_train")
+    w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{tag}/w/")}
+    m = Transformer(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    m = m.to(dev).train()
+    m.dropout.p = 0.0
+    for lyr in m.transformer_encoder.layers:
+        lyr.dropout.p = 0.0                       # the HIP path reads layers[0].dropout.p as the layer dropout rate
+    used = [(k, p) for k, p in m.named_parameters() if k in set(kernels.transformer_param_names(kw["encoder_layers"]))]
+    x = torch.from_numpy(g["x"]).to(dev); tgt = torch.from_numpy(g["target"]).to(dev)
+    opt = torch.optim.Adam([p for _, p in used], lr=5e-5, weight_decay=1e-5)
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+    for s in range(3):
+        loss = torch.nn.functional.mse_loss(m(x.clone()), tgt)
+        opt.zero_grad(); loss.backward()
+        if s == 0:
+            np.testing.assert_allclose(loss.item(), g[f"{tag}/loss0"], rtol=2e-5)
+            for k, p in used:
+                assert rel(p.grad.cpu().numpy(), g[f"{tag}/grad0/{k}"]) < 3e-4, (k, rel(p.grad.cpu().numpy(), g[f"{tag}/grad0/{k}"]))
+        opt.step()
+        if s in (0, 2):
+            for k, p in used:
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"{tag}/param{s+1}/{k}"], atol=3e-6, err_msg=f"{k} step {s+1}")
+
+
+def test_transformer_trainer_with_dropout_runs():
+    import random
+    from summarizer_amd.models.transformer import TransformerTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    ds = synthetic_dataset(9, seed=3, D=128, t_range=(40, 90), n_users=5)
+    keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
+    hps = make_hps(ds, [{"train_keys": keys[2:], "test_keys": keys[:2]}], epochs=3, test_every_epochs=2, lr=3e-4,
+                   selection_algorithm="rank",
+                   extra_params={"input_size": "128", "encoder_layers": "2", "attention_heads": "4", "batch_videos": "3"})
+    torch.manual_seed(4); random.seed(4)
+    tr = TransformerTrainer(hps, hps.splits_files[0]).reset()
+    best = tr.train(0)                                  # dropout ON (0.1 in the layers, 0.5 before the head)
+    losses = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Train/Loss"]]
+    assert all(np.isfinite(best)) and np.isfinite(losses).all() and losses[-1] < losses[0]
+    # two forwards in training mode draw different masks; eval mode is deterministic
+    x = torch.from_numpy(ds[keys[0]]["features"][...]).unsqueeze(1).cuda()
+    with torch.no_grad():
+        tr.model.train(); a = tr.model(x.clone()); b = tr.model(x.clone())
+        tr.model.eval(); c = tr.model(x.clone()); d = tr.model(x.clone())
+    assert torch.equal(c, d)
