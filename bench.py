@@ -106,7 +106,6 @@ def main():
     elif args.model == "transformer":
         from summarizer_amd.models.transformer import Transformer
         model = Transformer(input_size=D).to(dev)
-        assert args.mode == "score", "the Transformer scorer is inference-only"
     else:
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)
