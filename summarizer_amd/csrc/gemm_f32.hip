@@ -26,8 +26,6 @@ namespace sumk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int KC_PITCH = BK + 4;
 
 struct GemmKArgs {
   const float* A;
@@ -58,11 +56,13 @@ struct TileCtx {
 // LAST k-tile of a tile is being multiplied, the block already decodes its next tile and issues that tile's first global
 // loads, so the epilogue stores of tile i and the prologue latency of tile i+1 overlap instead of leaving the MFMA pipe
 // idle (measured before: ~19k idle cycles per tile per SIMD at K=1024, because co-resident blocks run in lockstep).
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
+  constexpr int KC_PITCH = BK + 4;            // +4 floats: conflict-free ds_read_b128 (pitch 36 or 68 dwords: 16 rows hit 16 distinct slots)
+  constexpr int TPK = BK / 4, RPP = 256 / TPK;  // KC image: threads per row, rows covered per pass
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32; // MFMA tiles per wave along M / N
-  constexpr int NLDA = BM / 32, NLDB = BN / 32;  // float4 loads per thread per operand per k-tile
+  constexpr int NLDA = BM * BK / 1024, NLDB = BN * BK / 1024;  // float4 loads per thread per operand per k-tile
   constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : BK * BM;
   constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : BK * BN;
   __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   const int li = lane & 31, lh = lane >> 5;
   constexpr int TPRA = BM / 4, TPRB = BN / 4;              // MC image: threads per k-row
   constexpr int KROWSA = 256 / TPRA, KROWSB = 256 / TPRB;  // MC image: k-rows covered per pass
-  const int kq4 = (tid & 7) * 4;       // KC image: this thread's k offset inside a k-tile
+  const int kq4 = (tid % TPK) * 4;     // KC image: this thread's k offset inside a k-tile
 
   // Per-thread global source descriptors of the tile whose operands are being LOADED.  Loads are UNCONDITIONAL:
   // addresses are clamped into the operand so the compiler can issue all of a k-tile's 16-B loads back to back and wait
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     if constexpr (A_KC) {
 #pragma unroll
       for (int p = 0; p < NLDA; ++p) {
-        int r = min(c.m0 + (tid >> 3) + 32 * p, P.M - 1);
+        int r = min(c.m0 + tid / TPK + RPP * p, P.M - 1);
         pa[p] = ka.A + P.a_off + (int64_t)r * P.lda;
       }
     } else {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     if constexpr (B_KC) {
 #pragma unroll
       for (int p = 0; p < NLDB; ++p) {
-        int n = min(c.n0 + (tid >> 3) + 32 * p, P.N - 1);
+        int n = min(c.n0 + tid / TPK + RPP * p, P.N - 1);
         int g = 0, nl = n;
         if (ka.n_group > 0) { g = n / ka.n_group; nl = n - g * ka.n_group; }
         const float* bg = g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3];
@@ -188,12 +188,12 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   auto swrite = [&]() {
 #pragma unroll
     for (int p = 0; p < NLDA; ++p) {
-      if constexpr (A_KC) *reinterpret_cast<float4*>(&sA[((tid >> 3) + 32 * p) * KC_PITCH + kq4]) = ra[p];
+      if constexpr (A_KC) *reinterpret_cast<float4*>(&sA[(tid / TPK + RPP * p) * KC_PITCH + kq4]) = ra[p];
       else *reinterpret_cast<float4*>(&sA[(tid / TPRA + KROWSA * p) * BM + (tid % TPRA) * 4]) = ra[p];
     }
 #pragma unroll
     for (int p = 0; p < NLDB; ++p) {
-      if constexpr (B_KC) *reinterpret_cast<float4*>(&sB[((tid >> 3) + 32 * p) * KC_PITCH + kq4]) = rb[p];
+      if constexpr (B_KC) *reinterpret_cast<float4*>(&sB[(tid / TPK + RPP * p) * KC_PITCH + kq4]) = rb[p];
       else *reinterpret_cast<float4*>(&sB[(tid / TPRB + KROWSB * p) * BN + (tid % TPRB) * 4]) = rb[p];
     }
   };
@@ -307,30 +307,30 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
 static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
   // every block then loops over tiles  b, b+grid, ...
-  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : 8);
+  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : 8));
   static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
   dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
   switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
-    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
-    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
-    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
-    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
-    case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI_BIAS_RESIDUAL>), grid, block, 0, s, ka); break;
+    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
+    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
+    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RESIDUAL>), grid, block, 0, s, ka); break;
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static int launch_layout(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
-  if (layout == GEMM_NT) return launch_epi<BM, BN, true, true>(epi, ka, tiles, s);
-  if (layout == GEMM_NN) return launch_epi<BM, BN, true, false>(epi, ka, tiles, s);
-  return launch_epi<BM, BN, false, false>(epi, ka, tiles, s);
+  if (layout == GEMM_NT) return launch_epi<BM, BN, BK, true, true>(epi, ka, tiles, s);
+  if (layout == GEMM_NN) return launch_epi<BM, BN, BK, true, false>(epi, ka, tiles, s);
+  return launch_epi<BM, BN, BK, false, false>(epi, ka, tiles, s);
 }
 
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream) {
@@ -351,9 +351,12 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
-  if (g.small_tile == 1) rc = launch_layout<64, 64>(layout, epi, ka, ka.total_tiles, stream);
-  else if (g.small_tile == 2) rc = launch_layout<128, 64>(layout, epi, ka, ka.total_tiles, stream);
-  else rc = launch_layout<128, 128>(layout, epi, ka, ka.total_tiles, stream);
+  // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
+  static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
+  if (g.small_tile == 1) rc = bk64 ? launch_layout<64, 64, 64>(layout, epi, ka, ka.total_tiles, stream)
+                                   : launch_layout<64, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
+  else if (g.small_tile == 2) rc = launch_layout<128, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
+  else rc = launch_layout<128, 128, 32>(layout, epi, ka, ka.total_tiles, stream);
   prof_end(SUMK_PROF_GEMM_ALL, stream);
   if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
   if (rc != SUMK_OK) return rc;
