@@ -226,7 +226,7 @@ struct PersistArgs {
   const float* G; const float* whh[2]; float* Hout;
   float* gates; float* c_all; float* hprev;   // training-mode saves (nullptr in inference)
   const int32_t* off; unsigned* state;
-  int32_t n_seq, H, gsize, n_groups, upm, n_active, hout_bytes;
+  int32_t n_seq, H, gsize, n_groups, upm, n_active, hout_bytes, n_teams;
 };
 
 constexpr int PK_THREADS = 512;
@@ -236,17 +236,20 @@ constexpr unsigned PK_SPIN_LIMIT = 1u << 20;   // ~1 s of polling; after one tim
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// CPW = 8-wide k chunks per wave: the block's 8 waves cover K = 64 * CPW >= H (4 for DSN's H = 256, 16 for sLSTM's 1024).
+// The member's W_hh fragments (32 gate rows x its wave's k range) live in REGISTERS for the whole work item -- exactly the
+// MFMA B operands every step needs -- so LDS holds only the staged h_{t-1} panel and the split-K partial tiles.
+template <int CPW>
 __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, P = H + 4;
-  float* sW = smem;                       // [32][P]   W_hh rows of this member: row = gate*8 + unit
-  float* sH = sW + 32 * P;                // [32][P]   h_{t-1} of the group's videos
-  float* part = sH + 32 * P;              // [8][32][33] split-K partial tiles
+  float* sH = smem;                       // [gsize][P]  h_{t-1} of the group's videos
+  float* part = sH + a.gsize * P;         // [8][32][33] split-K partial tiles
   int* sR0 = reinterpret_cast<int*>(part + 8 * 32 * 33);   // [32] first row of each video
   int* sT = sR0 + 32;                     // [32] length of each video
   int* sTg = sT + 32;                     // [1]  longest video of the group
 
-  const int team = blockIdx.x % PK_TEAMS, slot = blockIdx.x / PK_TEAMS;
+  const int team = blockIdx.x % a.n_teams, slot = blockIdx.x / a.n_teams;
   if (slot >= a.n_active) return;
   // buffer descriptor over the output/exchange matrix (wave-uniform: built from kernel arguments only)
   const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(a.Hout, (short)0, a.hout_bytes, 0x00020000);
@@ -257,17 +260,18 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
   int loaded_dir = -1;
   bool dead = false;   // (thread 0 only) a wait timed out: results are invalid, state[0] says so
 
-  for (int item = team; item < n_items; item += PK_TEAMS) {
+  float4 wreg[CPW];
+  for (int item = team; item < n_items; item += a.n_teams) {
     const int g = item >> 1, d = item & 1;
     const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
     unsigned* bar = a.state + 16 + item;
     __syncthreads();   // previous item fully done with LDS
-    if (loaded_dir != d) {   // this member's W_hh rows -> LDS (plain loads: weights are never written in this launch)
-      for (int idx = tid; idx < 32 * (H >> 2); idx += PK_THREADS) {
-        const int r = idx / (H >> 2), k4 = (idx % (H >> 2)) * 4;
-        const int unit = min(u0 + (r & 7), H - 1);
-        *reinterpret_cast<float4*>(&sW[r * P + k4]) =
-            *reinterpret_cast<const float4*>(a.whh[d] + (int64_t)((r >> 3) * H + unit) * H + k4);
+    if (loaded_dir != d) {   // this lane's W_hh fragments -> registers (plain loads: weights are never written in this launch)
+      const float* wrow = a.whh[d] + (int64_t)((li >> 3) * H + min(u0 + (li & 7), H - 1)) * H;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int k = (wave * CPW + c) * 8 + 4 * lh;
+        wreg[c] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       loaded_dir = d;
     }
@@ -339,14 +343,12 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int nchunk = (H + 7) >> 3;
-        for (int kk = wave; kk < nchunk; kk += 8) {
-          const int k = kk * 8 + 4 * lh;
-          float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
-          if (k < H) {
-            bv = *reinterpret_cast<const float4*>(&sW[li * P + k]);
-            if (li < nv) av = *reinterpret_cast<const float4*>(&sH[li * P + k]);
-          }
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+          const int k = (wave * CPW + c) * 8 + 4 * lh;
+          float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 bv = wreg[c];
+          if (k < H && li < nv) av = *reinterpret_cast<const float4*>(&sH[li * P + k]);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
@@ -708,6 +710,8 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
   SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
   static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
+  // H > 256 (sLSTM): measured 41 us/step with 2 teams of 128 CUs (every member must gather 24 videos x 4 KB of h per step,
+  // 32 MB chip-wide) versus 36 us/step for the launch chain -- so the persistent kernel is used for H <= 256 only.
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
     PersistArgs pa;
     pa.G = G; pa.whh[0] = w->w_hh[0]; pa.whh[1] = w->w_hh[1]; pa.Hout = h_out;
@@ -716,20 +720,24 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     pa.hprev = training ? (float*)(ws + L.hprev) : nullptr;
     pa.off = seq_off_dev; pa.state = (unsigned*)(ws + L.pstate);
     pa.n_seq = n_seq; pa.H = H; pa.hout_bytes = (int32_t)std::min<size_t>((size_t)R * 2 * H * 4, 0x7fffffff);
-    pa.upm = std::min(8, (H + 31) / 32); pa.n_active = (H + pa.upm - 1) / pa.upm;
-    int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));
+    // H <= 256: 8 teams of 32 CUs (one XCD each); larger H: 2 teams of 128 CUs so every member still owns only 8 units
+    pa.n_teams = H <= 256 ? PK_TEAMS : 2;
+    const int team_size = 256 / pa.n_teams;
+    pa.upm = std::min(8, (H + team_size - 1) / team_size); pa.n_active = (H + pa.upm - 1) / pa.upm;
+    const int gmax = H <= 256 ? 32 : 24;       // videos per work item, bounded by the LDS panel gsize x (H+4) floats
+    int gsize = std::min(gmax, std::max(1, (2 * n_seq + pa.n_teams - 1) / pa.n_teams));
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize;
-    if (2 * pa.n_groups <= PSTATE_WORDS - 16) {
-      const size_t shmem = std::max<size_t>(((size_t)2 * 32 * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
+    if (2 * pa.n_groups <= PSTATE_WORDS - 16 && pa.n_active <= team_size) {
+      const size_t shmem = std::max<size_t>(((size_t)gsize * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
+      const void* fn = (const void*)lstm_persist_kernel<4>;
       static bool attr_set = false;
       if (!attr_set) {
-        SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
       }
       void* kargs[] = {&pa};
       prof_begin(SUMK_PROF_LSTM_REC, stream);
-      SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_persist_kernel, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs,
-                                          (unsigned)shmem, stream));
+      SUMK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(PK_THREADS), kargs, (unsigned)shmem, stream));
       prof_end(SUMK_PROF_LSTM_REC, stream);
       return SUMK_OK;
     }
