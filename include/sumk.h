@@ -210,6 +210,24 @@ int sumk_gemm_tn(const float* A, const float* B, float* C, int32_t M, int32_t N,
 int sumk_knapsack_dp(const int64_t* values, const int64_t* weights, int32_t n_items, int64_t capacity,
                      uint8_t* selected);
 
+/* HOST function, natively threaded (no GPU work): the evaluation tail of `Trainer.test` for a batch of videos --
+ * upsample (summarizer/utils/eval.py:15-35), generate_summary (eval.py:74-123), evaluate_summary (eval.py:125-165) and
+ * evaluate_scores with metric "spearmanr" (eval.py:49-72).  Machine summaries and F-scores are bit-identical to the numpy
+ * implementation (numpy's float32 pairwise summation is reproduced); the rank correlation is float64, equal to ~1e-15. */
+typedef struct sumk_eval_video {
+  const float* scores; int32_t n_steps;        /* in: per-step importance scores                                      */
+  const int32_t* picks; int32_t n_picks;       /* in: positions of the sampled frames                                 */
+  int32_t n_frames;
+  const int32_t* cps; const int32_t* nfps; int32_t n_segs;   /* in: change points (n_segs,2), frames per segment; n_segs 0: skip summary */
+  const float* user_summary; int32_t n_users;  /* in: (n_users, n_frames), > 0 means selected                         */
+  const double* user_ranks;                    /* in: (n_users, n_frames) average ranks of -user_scores, or NULL: skip correlation */
+  float* machine_summary;                      /* out (optional): (sum nfps) 0/1 floats                               */
+  int32_t summary_len;                         /* out: sum nfps                                                        */
+  double corr, f_avg, f_max;                   /* out: mean Spearman over annotators; mean / max F-score (NaN if skipped) */
+} sumk_eval_video;
+/* method: 0 = knapsack (sumk_knapsack_dp), 1 = rank.  n_threads <= 0: min(16, hardware threads). */
+int sumk_eval_videos(sumk_eval_video* videos, int32_t n_videos, double proportion, int32_t method, int32_t n_threads);
+
 /* Per-kernel timing for bench.py's roofline object: when enabled, launches of the tagged kernel are
  * bracketed with hipEvents ON THE LAUNCH STREAM.  sumk_prof_read synchronises and returns the sums. */
 #define SUMK_PROF_GEMM_QKV 0

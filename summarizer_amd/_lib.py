@@ -42,6 +42,14 @@ class TfOpts(C.Structure):
                 ("layer_dropout_p", C.c_float), ("head_dropout_p", C.c_float), ("seed", C.c_uint64)]
 
 
+class EvalVideo(C.Structure):
+    _fields_ = [("scores", C.c_void_p), ("n_steps", C.c_int32), ("picks", C.c_void_p), ("n_picks", C.c_int32),
+                ("n_frames", C.c_int32), ("cps", C.c_void_p), ("nfps", C.c_void_p), ("n_segs", C.c_int32),
+                ("user_summary", C.c_void_p), ("n_users", C.c_int32), ("user_ranks", C.c_void_p),
+                ("machine_summary", C.c_void_p), ("summary_len", C.c_int32), ("corr", C.c_double), ("f_avg", C.c_double),
+                ("f_max", C.c_double)]
+
+
 class LstmLayerWeights(C.Structure):
     _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2)]
 
@@ -93,6 +101,7 @@ _SIGS = {
     "sumk_gemm_tn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_knapsack_dp": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int64,
                                    C.POINTER(C.c_uint8)]),
+    "sumk_eval_videos": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
     "sumk_prof_enable": (C.c_int, [C.c_int32]),
     "sumk_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from ..utils import eval as ev
+from ..utils import eval_native
 from ..utils.datasets import open_dataset
 
 _HBM_CACHE_LIMIT = 16 << 30      # bytes of features kept resident per trainer (a whole dataset is ~0.1 GB)
@@ -135,12 +136,26 @@ class Trainer:
         return out
 
     def test(self, fold):
-        """Score the fold's test videos, then rank correlation and key-shot F-scores: (avg_corr, (avg_f, max_f))."""
+        """Score the fold's test videos, then rank correlation and key-shot F-scores: (avg_corr, (avg_f, max_f)).
+        The whole evaluation tail of all videos runs in ONE native, multi-threaded call (utils/eval_native.py); the
+        per-video numpy methods below (`_eval_scores`, `_eval_summary`) compute the same numbers and remain available."""
         self.model.eval()
         test_keys = self._get_train_test_keys(fold)[1]
         with torch.no_grad():
             activations = self._score_keys(test_keys)
-        return self._eval_scores(activations, test_keys), self._eval_summary(activations, test_keys)
+        corr, f_avg, f_max, _ = self._evaluate_native(activations, test_keys)
+        return np.mean(corr), (np.mean(f_avg), np.mean(f_max))
+
+    def _native_meta(self, key):
+        m = self._video_meta(key, "scores")
+        m = self._video_meta(key, "summary")
+        if "native" not in m.__dict__:
+            m.native = eval_native.prepare_video(m.n_frames, m.picks, m.cps, m.nfps, m.user_summary, m.user_ranks)
+        return m.native
+
+    def _evaluate_native(self, activations, keys, want_summaries=False):
+        return eval_native.evaluate_batch([self._native_meta(k) for k in keys], [activations[k] for k in keys],
+                                          self.hps.summary_proportion, self.hps.selection_algorithm, want_summaries)
 
     def _eval_scores(self, machine_summary_activations, test_keys):
         """Mean over videos of the mean Spearman correlation with each annotator's scores."""
@@ -190,10 +205,11 @@ class Trainer:
         with torch.no_grad():
             activations = self._score_keys(keys)
         root_name = os.path.basename(str(self.hps.dataset_of_file[self.splits_file]))
+        summaries = dict(zip(keys, self._evaluate_native(activations, keys, want_summaries=True)[3]))   # all videos, one native call
         with open_dataset(pred_path, "w") as sink:
             root = sink.create_group(root_name)
             for key in keys:
-                m, summary = self._machine_summary(key, activations[key])
+                m, summary = self._video_meta(key, "summary"), summaries[key]
                 grp = root.create_group(key)
                 for name, value in (("scores", activations[key]), ("user_summary", m.user_summary),
                                     ("machine_summary", summary),

@@ -75,3 +75,33 @@ def test_knapsack_summary_budget_and_equality_with_oracle():
         np.testing.assert_array_equal(a, b)
         assert a.sum() <= int(np.floor(v["n_frames"] * 0.15))
         assert a.shape == (v["n_frames"],)
+
+
+def test_native_eval_tail_is_bit_identical_to_numpy():
+    """sumk_eval_videos vs utils/eval.py: summaries and F-scores bit for bit (incl. the float64 promotion when the summary is
+    shorter than the video, and trimming when longer), Spearman to 1e-12, for both selection methods."""
+    from summarizer_amd.utils import eval_native
+    vids, scores, refs = [], [], []
+    for ci, (T, U, tweak) in enumerate([(300, 15, 0), (120, 18, 0), (17, 3, 0), (640, 20, 0), (200, 7, -9), (150, 5, +6), (90, 4, 0)]):
+        v = R.synthetic_video(T, 300 + ci, n_users=U)
+        nfps = v["n_frame_per_seg"].copy()
+        nfps[-1] += tweak                                     # sum(nfps) != n_frames: padding / trimming branches
+        sc = np.random.default_rng(400 + ci).random(T).astype(np.float32)
+        if ci == 6:
+            sc[:] = np.float32(0.25)                          # all ties: average ranks, constant machine vector -> NaN corr
+        ranks = E.rank_users(v["user_scores"])
+        vids.append(eval_native.prepare_video(v["n_frames"], v["picks"], v["change_points"], nfps, v["user_summary"], ranks))
+        scores.append(sc)
+        refs.append((v, nfps, sc))
+    for method in ("knapsack", "rank"):
+        corr, f_avg, f_max, summ = eval_native.evaluate_batch(vids, scores, 0.15, method, want_summaries=True, n_threads=3)
+        for i, (v, nfps, sc) in enumerate(refs):
+            s_ref = E.generate_summary(sc, v["change_points"], v["n_frames"], nfps.tolist(), v["picks"], 0.15, method)
+            np.testing.assert_array_equal(summ[i], s_ref)
+            fa, fm = E.evaluate_summary(s_ref, v["user_summary"])
+            assert float(fa) == f_avg[i] and float(fm) == f_max[i], (method, i, fa, f_avg[i], fm, f_max[i])
+            with np.errstate(invalid="ignore"):
+                c_ref = E.evaluate_scores(E.upsample(sc, v["n_frames"], v["picks"]), v["user_scores"])
+            np.testing.assert_allclose(corr[i], c_ref, rtol=1e-12, atol=1e-14, equal_nan=True)
+    with pytest.raises(KeyError):
+        eval_native.evaluate_batch(vids, scores, 0.15, "greedy")
