@@ -2,7 +2,6 @@
 SumGAN (`summarizer/models/sumgan.py:23-46`; `SumGAN.forward` is exactly `s_lstm(x)`, sumgan.py:251-258).
 Same constructor and state_dict keys (`lstm.*`, `out.weight`, `out.bias`).  The VAE/GAN training harness of
 sumgan.py:48-533 is out of scope."""
-import torch
 import torch.nn as nn
 
 from .. import kernels

@@ -15,7 +15,6 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from .. import kernels
-from .._lib import SumkError
 from . import Trainer
 from .vasnet import _sinusoid_table
 from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters

@@ -17,7 +17,6 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from .. import kernels
-from .._lib import SumkError
 from . import Trainer
 from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
 

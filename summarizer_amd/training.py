@@ -3,7 +3,6 @@ data-parallel (one process per GPU, RCCL over xGMI) pieces -- video->rank shardi
 gradient bucket per optimiser step.  The reference has no distributed code; this is the MI355X-native
 scale-out of its per-video loop: videos are the independent units, gradients are the only exchange."""
 import math
-import os
 import torch
 
 from . import kernels

@@ -5,7 +5,6 @@
 `open_dataset(path)` returns an h5py.File when h5py is importable and the path is an HDF5 file; otherwise a dict-backed
 object with the same protocol (`DictDataset`), loadable from an .npz whose keys are "<video>/<field>".  The synthetic
 SumMe/TVSum-shaped sets used by tests and bench.py are DictDatasets (no datasets can be downloaded here)."""
-import os
 import numpy as np
 
 
