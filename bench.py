@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -65,6 +66,27 @@ def cpu_baseline(lens, D, budget_s=20.0):
                        ", ".join(f"{k}t={v[0]:.0f} ({v[1]} videos/{v[2]:.1f}s)" for k, v in res.items()))
 
 
+def alt_precision_leg(model, x, lens, ref_scores, steps, frames):
+    """Opt-in bf16x3 arithmetic on the same batch, reported NEXT TO the fp32 headline (never as `value`): this rank's
+    frames/s and the largest score difference from the fp32 path (gate: 1e-4)."""
+    model.precision = "bf16x3"
+    try:
+        with torch.no_grad():
+            for _ in range(5):
+                s = model.score_packed(x, lens)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                s = model.score_packed(x, lens)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+    finally:
+        model.precision = "fp32"
+    return dict(frames_per_s_this_gpu=round(frames / dt, 1), ms_per_step=round(dt * 1e3, 4),
+                max_abs_score_diff_vs_fp32=float((s - ref_scores).abs().max()),
+                note="products as bf16 hi/lo splits (3 bf16 MFMAs), fp32 accumulate; select with --precision bf16x3")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +99,9 @@ def main():
                     help="headline = score (frames scored/sec); train = MSE step; reinforce = DSN REINFORCE step (BASELINE config 4)")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="GEMM arithmetic: fp32 = exact fp32 MFMA (headline); bf16x3 = fp32 operands split into bf16 hi+lo, "
+                         "3 bf16 MFMAs per product, fp32 accumulate (scores within ~1e-5 of fp32; DESIGN.md)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,6 +134,7 @@ def main():
     else:
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)
+    model.precision = args.precision
     model.train(args.mode != "score")
     if args.workload == "stress":
         g = torch.Generator(device=dev); g.manual_seed(rank)
@@ -187,11 +213,13 @@ def main():
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         pmc = {}
-        if os.path.exists(tp) and args.workload == "tvsum" and args.model == "vasnet" and args.videos == 50:
+        if os.path.exists(tp) and args.workload == "tvsum" and args.model == "vasnet" and args.videos == 50 and args.precision == "fp32":
             pmc = json.load(open(tp))                                              # PMC passes of this exact launch shape
             traffic = pmc.get("gemm_qkv_hbm_bytes_per_launch")
-        roof = dict(bound="mfma", kernel="gemm_f32_kernel<128,NT> (QKV projection)", achieved=round(ach, 2),
-                    peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+        # bf16x3 issues 3 dense-bf16 MFMA flops per algorithmic flop: its ceiling is the bf16 peak / 3
+        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+        roof = dict(bound="mfma", kernel="gemm_f32_kernel<128,NT> (QKV projection)" + ("" if args.precision == "fp32" else " [bf16x3]"),
+                    achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                     traffic=traffic, avg_launch_us=round(avg_s * 1e6, 2), launches=int(n.value),
                     flops_per_launch=qkv_flops)
         if traffic:
@@ -207,7 +235,8 @@ def main():
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
+                   vs_baseline=None, dtype="f32" if args.precision == "fp32" else "f32 storage/accumulate, bf16x3 split products",
+                   data="synthetic",
                    config=dict(workload=(f"{args.model} {args.mode}, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch"
                                          if args.workload == "tvsum" else
                                          f"{args.model} {args.mode}, S-stress (BASELINE config 5): 8 sequences/GPU, T=10000, D=2048, packed batch"),
@@ -216,6 +245,8 @@ def main():
                    roofline=roof)
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
+        if args.model == "vasnet" and args.mode == "score" and args.precision == "fp32":
+            out["bf16x3_mode"] = alt_precision_leg(model, x, lens, s, args.steps, frames)
         if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum":
             out["cpu_baseline"] = cpu_baseline(lens, D)
         print(json.dumps(out), flush=True)

@@ -45,6 +45,9 @@ typedef struct sumk_vasnet_weights {
   const float* ln_w; const float* ln_b;              /* (D)        layer_norm           vasnet.py:54   */
 } sumk_vasnet_weights;
 
+#define SUMK_PRECISION_FP32 0
+#define SUMK_PRECISION_BF16X3 1
+
 typedef struct sumk_vasnet_opts {
   float scale;          /* logits multiplier, 1/sqrt(D) by default      vasnet.py:34,119 */
   float eps;            /* LayerNorm epsilon                            vasnet.py:18,54  */
@@ -55,6 +58,10 @@ typedef struct sumk_vasnet_opts {
      of (seed, site, element index) -- see DESIGN.md "Dropout" -- so backward regenerates them. */
   float dropout_p;
   uint64_t seed;
+  /* arithmetic of the x.W^T / Q.K^T GEMMs: SUMK_PRECISION_FP32 (exact fp32 MFMA, the default everywhere) or
+     SUMK_PRECISION_BF16X3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: ~2^-16 relative
+     per product, scores stay within ~1e-5 of the fp32 path -- DESIGN.md "bf16x3").  Storage is fp32 either way. */
+  int32_t precision;
 } sumk_vasnet_opts;
 
 /* Bytes of workspace sumk_vasnet_forward / _backward need for this batch (seq_off_host has n_seq+1 entries). */
@@ -147,6 +154,7 @@ typedef struct sumk_tf_opts {
   float layer_dropout_p;  /* training: dropout inside the encoder layers (0.1)                 transformer.py:49  */
   float head_dropout_p;   /* training: dropout after relu(k1) (0.5)                            transformer.py:46,99 */
   uint64_t seed;          /* keep-masks are a pure function of (seed, site, element), as for VASNet               */
+  int32_t precision;      /* SUMK_PRECISION_*, as in sumk_vasnet_opts                                             */
 } sumk_tf_opts;
 size_t sumk_transformer_workspace_bytes(int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
                                         const int32_t* seq_off_host, int32_t training);
@@ -198,6 +206,8 @@ int sumk_sumsq(const float* v, int64_t n, float* out, void* workspace, void* str
  * fp32 MFMA GEMM (the dominant kernel), exposed for tests and for bench.py's roofline probe:
  * C(M,N) = A(M,K) * B^T  with B given as (N,K) row-major ("NT", both operands K-contiguous). */
 int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
+/* the same product in the selected arithmetic (SUMK_PRECISION_FP32 | SUMK_PRECISION_BF16X3) */
+int sumk_gemm_nt_prec(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t precision, void* stream);
 /* C(M,N) = A(M,K) * B(K,N) */
 int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 /* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */

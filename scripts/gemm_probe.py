@@ -9,12 +9,16 @@ shapes = [("qkv", 12003, 3072, 1024), ("proj", 12003, 1024, 1024), ("big", 8192,
 bufs = {}
 for name, M, N, K in shapes:
     bufs[name] = (torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev))
+PREC = 1 if "bf16x3" in sys.argv[1:] else 0
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run(name, M, N, K):
     a, b, c = bufs[name]
     fn = lib.sumk_gemm_tn if name.startswith("tn") else lib.sumk_gemm_nt
     if name.startswith("tn"):
         a = a.t().contiguous() if False else a   # layouts only matter for timing here
+    if PREC and not name.startswith("tn"):
+        _lib.check(lib.sumk_gemm_nt_prec(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, PREC, st), "gemm")
+        return
     _lib.check(fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, st), "gemm")
 res = {n: [] for n, *_ in shapes}
 for rnd in range(5):

@@ -25,7 +25,7 @@ class VasnetGrads(C.Structure):
 
 class VasnetOpts(C.Structure):
     _fields_ = [("scale", C.c_float), ("eps", C.c_float), ("ignore_self", C.c_int32), ("aperture", C.c_int32),
-                ("dropout_p", C.c_float), ("seed", C.c_uint64)]
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32)]
 
 
 class TfLayerWeights(C.Structure):
@@ -39,7 +39,7 @@ class TfHeadWeights(C.Structure):
 
 class TfOpts(C.Structure):
     _fields_ = [("layer_eps", C.c_float), ("final_eps", C.c_float), ("more_residuals", C.c_int32),
-                ("layer_dropout_p", C.c_float), ("head_dropout_p", C.c_float), ("seed", C.c_uint64)]
+                ("layer_dropout_p", C.c_float), ("head_dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32)]
 
 
 class EvalVideo(C.Structure):
@@ -97,6 +97,7 @@ _SIGS = {
     "sumk_sumsq_workspace_bytes": (C.c_size_t, []),
     "sumk_sumsq": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_void_p]),
     "sumk_gemm_nt": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_gemm_nt_prec": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_nn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_tn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_knapsack_dp": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int64,

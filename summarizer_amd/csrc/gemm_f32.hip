@@ -25,6 +25,9 @@
 namespace sumk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 
 struct GemmKArgs {
@@ -56,8 +59,15 @@ struct TileCtx {
 // LAST k-tile of a tile is being multiplied, the block already decodes its next tile and issues that tile's first global
 // loads, so the epilogue stores of tile i and the prologue latency of tile i+1 overlap instead of leaving the MFMA pipe
 // idle (measured before: ~19k idle cycles per tile per SIMD at K=1024, because co-resident blocks run in lockstep).
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI>
+// X3 (NT layout only): "bf16x3" arithmetic.  Each fp32 operand is split on its way into LDS into hi = bf16(x) and
+// lo = bf16(x - hi); the product is accumulated in fp32 as  lo.hi + hi.lo + hi.hi  with v_mfma_f32_32x32x16_bf16 (16x the
+// fp32 MFMA rate, 3 MFMAs per 16-deep k step instead of 8 fp32 ones): the dropped lo.lo term is ~2^-16 relative, which keeps
+// VASNet scores within ~1e-5 of the fp32 path (scripts/bf16x3_emulation.py; the 1e-4 gate holds, plain bf16 misses it by
+// 20-100x).  The LDS row becomes [hi: BK bf16 | lo: BK bf16] -- the same BK*4 bytes and the same +16 B pad, so the
+// conflict-free ds_read_b128 argument is unchanged; a lane's 16-B fragment is 8 consecutive k of one plane.
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
+  static_assert(!X3 || (A_KC && B_KC), "bf16x3 is implemented for the NT layout");
   constexpr int KC_PITCH = BK + 4;            // +4 floats: conflict-free ds_read_b128 (pitch 36 or 68 dwords: 16 rows hit 16 distinct slots)
   constexpr int TPK = BK / 4, RPP = 256 / TPK;  // KC image: threads per row, rows covered per pass
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
@@ -185,7 +195,22 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       }
     }
   };
+  auto split_store = [&](float* row, float4 v) {   // row: LDS row start; this thread's 4 k values -> hi | lo planes
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    const bf16x4 hi = __builtin_convertvector(x, bf16x4);
+    const bf16x4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4);
+    char* r8 = reinterpret_cast<char*>(row);
+    *reinterpret_cast<bf16x4*>(r8 + 2 * kq4) = hi;
+    *reinterpret_cast<bf16x4*>(r8 + 2 * BK + 2 * kq4) = lo;
+  };
   auto swrite = [&]() {
+    if constexpr (X3) {
+#pragma unroll
+      for (int p = 0; p < NLDA; ++p) split_store(&sA[(tid / TPK + RPP * p) * KC_PITCH], ra[p]);
+#pragma unroll
+      for (int p = 0; p < NLDB; ++p) split_store(&sB[(tid / TPK + RPP * p) * KC_PITCH], rb[p]);
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NLDA; ++p) {
       if constexpr (A_KC) *reinterpret_cast<float4*>(&sA[(tid / TPK + RPP * p) * KC_PITCH + kq4]) = ra[p];
@@ -227,6 +252,30 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
         has_next = setup(next_tile, nxt);
         if (has_next) gload(nxt, 0);
       }
+      if constexpr (X3) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            const char* rp = reinterpret_cast<const char*>(&sA[(wm * WTM + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
+            ah[t] = *reinterpret_cast<const bf16x8*>(rp); al[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+          }
+#pragma unroll
+          for (int t = 0; t < TN; ++t) {
+            const char* rp = reinterpret_cast<const char*>(&sB[(wn * WTN + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
+            bh[t] = *reinterpret_cast<const bf16x8*>(rp); bl[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+          }
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {   // small cross terms first, then the main product
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
+      } else {
 #pragma unroll
       for (int kk = 0; kk < BK / 8; ++kk) {
         float av[TM][4], bv[TN][4];
@@ -257,6 +306,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
+      }
       }
     }
 
@@ -307,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   }
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool X3 = false>
 static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
   // every block then loops over tiles  b, b+grid, ...
@@ -315,12 +365,12 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
   static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
   dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
   switch (epi) {
-    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
-    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
-    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
-    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS2>), grid, block, 0, s, ka); break;
-    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
-    case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RESIDUAL>), grid, block, 0, s, ka); break;
+    case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>), grid, block, 0, s, ka); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL, X3>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RELU, X3>), grid, block, 0, s, ka); break;
+    case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS2, X3>), grid, block, 0, s, ka); break;
+    case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_ACCUM, X3>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RESIDUAL, X3>), grid, block, 0, s, ka); break;
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;
@@ -353,6 +403,11 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   int rc;
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
+  if (g.precision == SUMK_PRECISION_BF16X3 && layout == GEMM_NT) {   // bf16x3 arithmetic (same tiles, same k order per tile shape)
+    if (g.small_tile == 1) rc = launch_epi<64, 64, 32, true, true, true>(epi, ka, ka.total_tiles, stream);
+    else if (g.small_tile == 2) rc = launch_epi<128, 64, 32, true, true, true>(epi, ka, ka.total_tiles, stream);
+    else rc = launch_epi<128, 128, 32, true, true, true>(epi, ka, ka.total_tiles, stream);
+  } else
   if (g.small_tile == 1) rc = bk64 ? launch_layout<64, 64, 64>(layout, epi, ka, ka.total_tiles, stream)
                                    : launch_layout<64, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
   else if (g.small_tile == 2) rc = launch_layout<128, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
@@ -496,7 +551,7 @@ sumk::GemmProb* scratch_prob() {
   return p;
 }
 int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C, int M, int N, int K, int lda,
-               int ldb, void* stream) {
+               int ldb, void* stream, int precision = SUMK_PRECISION_FP32) {
   using namespace sumk;
   SUMK_ARG(A && B && C, "gemm: null pointer");
   SUMK_ARG(M > 0 && N > 0 && K > 0, "gemm: non-positive size M=%d N=%d K=%d", M, N, K);
@@ -509,13 +564,18 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
   SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, small, s));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = small;
-  g.total_tiles = gemm_tiles(M, N, small); g.xcd_M = M; g.xcd_N = N;
+  g.total_tiles = gemm_tiles(M, N, small); g.xcd_M = M; g.xcd_N = N; g.precision = precision;
   return launch_gemm(layout, EPI_NONE, g, s);
 }
 }  // namespace
 
 extern "C" int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
   return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream);
+}
+extern "C" int sumk_gemm_nt_prec(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t precision,
+                                 void* stream) {
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "gemm: unknown precision %d", precision);
+  return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream, precision);
 }
 extern "C" int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
   return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream);

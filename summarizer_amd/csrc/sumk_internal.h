@@ -60,6 +60,7 @@ struct GemmLaunch {
   float alpha = 1.f;
   int32_t small_tile = 0;  // tile config: 0 -> 128x128, 1 -> 64x64 (ragged per-video problems), 2 -> 128x64
   int32_t prof_tag = -1;
+  int32_t precision = 0;   // 0: exact fp32 MFMA; 1: bf16x3 split on bf16 MFMA (NT layout only; other layouts stay fp32)
   int32_t xcd_M = 0, xcd_N = 0;  // single-problem launches: (M,N) so the kernel may use the XCD-aware tile map
   // training-mode dropout fused in the epilogue (EPI_BIAS_RELU: after the ReLU; EPI_BIAS_RESIDUAL: on acc+bias, before +R);
   // drop_thr == 0 disables it.  Element index of the mask = row * N + col.

@@ -268,26 +268,26 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     }
     const uint32_t site = 10u * (uint32_t)l;
     {  // packed in-projection  [Q|K|V] = h Win^T + bin
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = hin; g.B[0] = W.in_proj_w; g.bias0[0] = W.in_proj_b; g.C = QKV; g.probs = prow + P_QKV; g.small_tile = G.c_qkv;
       g.total_tiles = gemm_tiles(R, 3 * D, G.c_qkv); g.xcd_M = R; g.xcd_N = 3 * D;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
     }
     {  // logits per (video, head)
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + (size_t)TT_S * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_s;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
     }
     hipLaunchKernelGGL(tf_softmax_kernel, dim3((unsigned)(((int64_t)R * n_heads + 3) / 4)), dim3(256), 0, stream, E, E2, seq,
                        seq_off_dev, n_seq, R, n_heads, att_scale, dl, site + 0);
     {  // context, heads written side by side
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = E2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + (size_t)TT_PV * np; g.nprob = np; g.small_tile = 1;
       g.total_tiles = G.tiles_pv;
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
     }
     {  // out-projection + bias (+dropout1) + residual
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = CTX; g.B[0] = W.out_proj_w; g.bias0[0] = W.out_proj_b; g.R = hin; g.C = T1a; g.probs = prow + P_DD; g.small_tile = G.c_dd;
       g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D;
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 1;
@@ -295,14 +295,14 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     }
     SUMK_TRY(launch_layernorm(T1a, hmid, W.norm1_w, W.norm1_b, R, D, opts->layer_eps, stats, stream));
     {  // feed-forward 1: bias + ReLU (+dropout)
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = hmid; g.B[0] = W.lin1_w; g.bias0[0] = W.lin1_b; g.C = FF; g.probs = prow + P_DF; g.small_tile = G.c_df;
       g.total_tiles = gemm_tiles(R, F, G.c_df); g.xcd_M = R; g.xcd_N = F;
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 2;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
     }
     {  // feed-forward 2: bias (+dropout2) + residual
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = FF; g.B[0] = W.lin2_w; g.bias0[0] = W.lin2_b; g.R = hmid; g.C = T1b; g.probs = prow + P_FD; g.small_tile = G.c_dd;
       g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D;
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 3;
@@ -321,7 +321,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, hfin, x, n4);
   }
   {
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = hfin; g.B[0] = head->k1_w; g.bias0[0] = head->k1_b; g.C = Z; g.probs = prow + P_DD; g.small_tile = G.c_dd;
     g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
@@ -363,7 +363,7 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
   int nw = 0;
   auto blocks = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
   auto nn = [&](const float* A, const float* B, float* C, int prob, GemmEpi epi, int N) -> int {   // C (op)= A . B, B stored (K, N)
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = A; g.B[0] = B; g.C = C; g.probs = prow + prob; g.small_tile = (N == F ? G.c_df : G.c_dd);
     g.total_tiles = gemm_tiles(R, N, g.small_tile);
     return launch_gemm(GEMM_NN, epi, g, stream);
@@ -431,24 +431,24 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
     // multi-head attention backward, per (video, head)
     const float* Pd = dl.thr ? (const float*)E2 : P;
     {
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = Pd; g.B[0] = fa; g.C = dQKV; g.probs = tabs + (size_t)TT_DV * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_pv;
       SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
     }
     {
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = fa; g.B[0] = QKV; g.C = E2; g.probs = tabs + (size_t)TT_DP * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_s;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
     }
     hipLaunchKernelGGL(tf_softmax_bwd_kernel, dim3((unsigned)(((int64_t)R * n_heads + 3) / 4)), dim3(256), 0, stream, P, E2, seq,
                        seq_off_dev, n_seq, R, n_heads, att_scale, dl, site + 0);
     {
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + (size_t)TT_DQ * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_pv;
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
     }
     {
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + (size_t)TT_DK * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_pv;
       SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
     }

@@ -523,6 +523,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   SUMK_ARG((pos_table == nullptr) == (pos_rows == nullptr), "vasnet_forward: pos_table and pos_rows go together");
   SUMK_ARG(opts->dropout_p >= 0.f && opts->dropout_p < 1.f, "vasnet_forward: dropout_p=%f out of [0,1)", opts->dropout_p);
   SUMK_ARG(opts->dropout_p == 0.f || training, "vasnet_forward: dropout needs training mode");
+  SUMK_ARG(opts->precision == SUMK_PRECISION_FP32 || opts->precision == SUMK_PRECISION_BF16X3, "vasnet_forward: unknown precision %d", opts->precision);
   Geometry G;
   SUMK_TRY(geometry(D, n_seq, seq_off_host, training, &G));
   const VasnetWs& L = G.L;
@@ -553,14 +554,14 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
 
   {  // 1: QKV projection
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
     g.total_tiles = G.tiles_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
@@ -569,13 +570,13 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   hipLaunchKernelGGL(vasnet_softmax_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, use_e2 ? E2 : nullptr, seq,
                      seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop);
   {  // 4: context
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {  // 5: output projection + residual
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
@@ -584,7 +585,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   hipLaunchKernelGGL(layernorm_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, stream, Y0, Y1, w->ln_w, w->ln_b, nullptr,
                      nullptr, nullptr, R, D, opts->eps, stats, drop, 1u);
   {  // 7: k1 + bias + ReLU
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
@@ -682,7 +683,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
-    GemmLaunch g;  // dY1 = dZ . W1
+    GemmLaunch g; g.precision = opts->precision;  // dY1 = dZ . W1
     g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
@@ -694,19 +695,19 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dY0, D, CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
-    GemmLaunch g;  // dCTX = dY0 . Wo
+    GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // 4': dV = alphaD^T dC ; dAlphaD = dC V^T
   const float* Pd = use_e2 ? E2 : E;
   {
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   {
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = dCTX; g.B[0] = QKV; g.C = E2; g.probs = tabs + TB_DP * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s; g.total_tiles = G.tiles_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
@@ -715,12 +716,12 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
                      opts->scale, drop);
   // 2': dQ = dS K ; dK = dS^T Q
   {
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {
-    GemmLaunch g;
+    GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
@@ -733,7 +734,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     SUMK_HIP(hipMemcpyAsync(dx, dY0, (size_t)R * D * 4, hipMemcpyDeviceToDevice, stream));
     const float* Ws[3] = {w->Wq, w->Wk, w->Wv};
     for (int part = 0; part < 3; ++part) {
-      GemmLaunch g;
+      GemmLaunch g; g.precision = opts->precision;
       g.A = dQKV + (size_t)part * D; g.B[0] = Ws[part]; g.C = dx; g.probs = prow + RP_DX; g.small_tile = G.st_d;
       g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_ACCUM, g, stream));

@@ -90,6 +90,18 @@ VASNET_FIELDS = [("Wk", "K.weight"), ("Wq", "Q.weight"), ("Wv", "V.weight"), ("W
                  ("ln_w", "layer_norm.weight"), ("ln_b", "layer_norm.bias")]
 
 
+PRECISIONS = {"fp32": 0, "bf16x3": 1}      # SUMK_PRECISION_* of include/sumk.h
+
+
+def precision_code(p):
+    """"fp32" (default: exact fp32 MFMA) or "bf16x3" (hi+lo bf16 split, 3 bf16 MFMAs per product, fp32 accumulate)."""
+    if p is None:
+        return 0
+    if p not in PRECISIONS:
+        raise SumkError(f"unknown precision {p!r}; expected one of {sorted(PRECISIONS)}")
+    return PRECISIONS[p]
+
+
 def _vasnet_structs(params, opts):
     w = _lib.VasnetWeights()
     for f, k in VASNET_FIELDS:
@@ -100,7 +112,7 @@ def _vasnet_structs(params, opts):
         setattr(w, f, t.data_ptr())
     o = _lib.VasnetOpts(float(opts["scale"]), float(opts["eps"]), int(bool(opts.get("ignore_self", False))),
                         -1 if opts.get("aperture") is None else int(opts["aperture"]),
-                        float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)))
+                        float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)), precision_code(opts.get("precision")))
     return w, o
 
 
@@ -308,7 +320,8 @@ def _tf_structs(tensors, n_layers, what, layer_cls, head_cls):
 
 def _tf_opts(o):
     return _lib.TfOpts(float(o["layer_eps"]), float(o["final_eps"]), int(bool(o.get("more_residuals", False))),
-                       float(o.get("layer_dropout_p", 0.0)), float(o.get("head_dropout_p", 0.0)), int(o.get("seed", 0)))
+                       float(o.get("layer_dropout_p", 0.0)), float(o.get("head_dropout_p", 0.0)), int(o.get("seed", 0)),
+                       precision_code(o.get("precision")))
 
 
 def transformer_forward_packed(x, sb, params, n_layers, n_heads, dff, opts, pos_table=None, pos_rows=None, training=False):

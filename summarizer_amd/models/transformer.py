@@ -94,7 +94,8 @@ class Transformer(nn.Module):
 
     def _score(self, xp, sb, table, rows):
         p = dict(self.named_parameters())
-        opts = dict(layer_eps=1e-5, final_eps=self.epsilon, more_residuals=self.more_residuals)
+        opts = dict(layer_eps=1e-5, final_eps=self.epsilon, more_residuals=self.more_residuals,
+                    precision=getattr(self, "precision", "fp32"))
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             from ..autograd import TransformerFunction
             if self.training:
@@ -125,6 +126,7 @@ class TransformerTrainer(Trainer):
             epsilon=float(ep.get("epsilon", 1e-5)),
             weight_init=ep.get("weight_init", None),
             **({"input_size": int(ep["input_size"])} if "input_size" in ep else {}))
+        model.precision = ep.get("precision", "fp32")      # "fp32" | "bf16x3" (kernels.precision_code)
         if self.hps.use_cuda:
             torch.cuda.set_device(self.hps.cuda_device)
             model.cuda()

@@ -23,8 +23,9 @@ from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
 
 class VASNet(nn.Module):
     def __init__(self, input_size=1024, max_length=None, pos_embed="simple", ignore_self=False,
-                 attention_aperture=None, scale=None, epsilon=1e-6, weight_init="xavier"):
+                 attention_aperture=None, scale=None, epsilon=1e-6, weight_init="xavier", precision="fp32"):
         super().__init__()
+        self.precision = precision      # GEMM arithmetic: "fp32" (exact) | "bf16x3" (kernels.precision_code); not in the reference
         self.input_size = input_size
         self.aperture = attention_aperture
         self.ignore_self = ignore_self
@@ -67,7 +68,7 @@ class VASNet(nn.Module):
 
     def _opts(self, training):
         o = dict(scale=float(self.scale), eps=float(self.epsilon), ignore_self=bool(self.ignore_self),
-                 aperture=self.aperture)
+                 aperture=self.aperture, precision=self.precision)
         if self.aperture is not None:
             assert isinstance(self.aperture, int)      # vasnet.py:125
         if training:
@@ -159,6 +160,7 @@ class VASNetTrainer(Trainer):
             scale=float(ep["scale"]) if "scale" in ep else None,
             epsilon=float(ep.get("epsilon", 1e-6)),
             weight_init=ep.get("weight_init", "xavier"),
+            precision=ep.get("precision", "fp32"),
             **({"input_size": int(ep["input_size"])} if "input_size" in ep else {}))
         if self.hps.use_cuda:
             self.log.info(f"Setting CUDA device: {self.hps.cuda_device}")

@@ -53,6 +53,35 @@ def test_gemm_layouts_vs_float64(dev, M, N, K):
             assert (np.abs(got - ref) <= tol).all(), f"TN max err {np.abs(got-ref).max()}"
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (37, 64, 64), (130, 192, 100), (129, 128, 1024), (300, 3072, 1024), (64, 1000, 36), (257, 260, 8)])
+def test_gemm_bf16x3_vs_float64(dev, M, N, K):
+    """Opt-in bf16x3 arithmetic (hi+lo bf16 splits, 3 bf16 MFMAs, fp32 accumulate): each product carries ~2^-16 relative
+    error (dropped lo*lo term and the rounding of lo), so the bound is 2^-15 * |A|.|B|^T -- and it must be far tighter
+    than plain bf16 (2^-8)."""
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bt = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ Bt.astype(np.float64).T
+    bound = np.abs(A).astype(np.float64) @ np.abs(Bt).astype(np.float64).T
+    a = torch.from_numpy(A).to(dev); b = torch.from_numpy(Bt).to(dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    _lib.check(lib.sumk_gemm_nt_prec(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    torch.cuda.synchronize()
+    err = np.abs(c.cpu().numpy() - ref)
+    assert (err <= 2.0 ** -15 * bound + 1e-6).all(), f"bf16x3 max err {err.max()}"
+    # exact on data that bf16 represents exactly (small integers): fragment / plane mapping check
+    Ai = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)
+    Bi = ((np.arange(N * K).reshape(N, K) % 5 - 2) + (np.arange(N)[:, None] % 3)).astype(np.float32)
+    a.copy_(torch.from_numpy(Ai)); b.copy_(torch.from_numpy(Bi))
+    _lib.check(lib.sumk_gemm_nt_prec(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(c.cpu().numpy(), Ai.astype(np.int64) @ Bi.astype(np.int64).T)
+
+
 def test_gemm_exact_integer_data_asymmetric(dev):
     # exact small-integer operands: any mis-mapped fragment / k pairing shows up as an exact mismatch
     from summarizer_amd import _lib
@@ -66,13 +95,14 @@ def test_gemm_exact_integer_data_asymmetric(dev):
     np.testing.assert_array_equal(_gemm(lib.sumk_gemm_tn, np.ascontiguousarray(A.T), np.ascontiguousarray(Bt.T), M, N, K, dev), ref)
 
 
-def test_vasnet_small_goldens_all_variants(dev):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_vasnet_small_goldens_all_variants(dev, precision):
     g = load_golden("vasnet_small")
     meta = js(g["meta"])
     worst = 0.0
     for vname, m in meta.items():
         w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{vname}/w/")}
-        model = _model(dev, 64, w, **m)
+        model = _model(dev, 64, w, precision=precision, **m)
         for c in sorted(k.split("/")[-1] for k in g.files if k.startswith(f"{vname}/x/")):
             x = torch.from_numpy(g[f"{vname}/x/{c}"].copy()).to(dev)
             with torch.no_grad():
@@ -95,17 +125,19 @@ def test_vasnet_pos_embed_mutates_callers_tensor_like_reference(dev):
     np.testing.assert_allclose(x.cpu().numpy()[:, 0, :], x0[:, 0, :] + w["pos_embed.weight"][:37], atol=1e-6)
 
 
-def test_vasnet_full_size_goldens(dev):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_vasnet_full_size_goldens(dev, precision):
     g = load_golden("vasnet_full")
     n = len([k for k in g.files if k.endswith("/cfg")])
     for ci in range(n):
         cfg = js(g[f"c{ci}/cfg"])
         w = R.vasnet_weights(cfg["D"], cfg["wseed"]); x = R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"])
         assert R.digest(w) == cfg["wdigest"] and R.digest({"x": x}) == cfg["xdigest"]
-        model = _model(dev, cfg["D"], w, **cfg["kw"])
+        model = _model(dev, cfg["D"], w, precision=precision, **cfg["kw"])
         with torch.no_grad():
             y = model(torch.from_numpy(x).to(dev)).cpu().numpy()
         np.testing.assert_allclose(y, g[f"c{ci}/y"], atol=TOL, rtol=0, err_msg=str(cfg))
+        print(precision, cfg["T"], "max |d| vs reference:", float(np.abs(y - g[f"c{ci}/y"]).max()))
 
 
 def test_vasnet_packed_ragged_batch_vs_oracle(dev):
