@@ -206,8 +206,10 @@ int sumk_sumsq(const float* v, int64_t n, float* out, void* workspace, void* str
  * fp32 MFMA GEMM (the dominant kernel), exposed for tests and for bench.py's roofline probe:
  * C(M,N) = A(M,K) * B^T  with B given as (N,K) row-major ("NT", both operands K-contiguous). */
 int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
-/* the same product in the selected arithmetic (SUMK_PRECISION_FP32 | SUMK_PRECISION_BF16X3) */
-int sumk_gemm_nt_prec(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t precision, void* stream);
+/* any of the three products (layout 0 = NT, 1 = NN, 2 = TN, operands as above) in the selected arithmetic
+ * (SUMK_PRECISION_FP32 | SUMK_PRECISION_BF16X3) */
+int sumk_gemm_prec(int32_t layout, const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t precision,
+                   void* stream);
 /* C(M,N) = A(M,K) * B(K,N) */
 int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 /* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */

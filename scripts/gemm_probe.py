@@ -16,8 +16,8 @@ def run(name, M, N, K):
     fn = lib.sumk_gemm_tn if name.startswith("tn") else lib.sumk_gemm_nt
     if name.startswith("tn"):
         a = a.t().contiguous() if False else a   # layouts only matter for timing here
-    if PREC and not name.startswith("tn"):
-        _lib.check(lib.sumk_gemm_nt_prec(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, PREC, st), "gemm")
+    if PREC:
+        _lib.check(lib.sumk_gemm_prec(2 if name.startswith("tn") else 0, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, PREC, st), "gemm")
         return
     _lib.check(fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, st), "gemm")
 res = {n: [] for n, *_ in shapes}

@@ -28,6 +28,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 
 struct GemmKArgs {
@@ -54,27 +56,43 @@ struct TileCtx {
   int32_t M, N, K, lda, ldb, ldc, ldr, m0, n0, klast;
 };
 
+// hi / lo fragments (8 consecutive k of this lane's row) of a [k][row] bf16 image: 2 transposing reads per plane
+__device__ __forceinline__ void tr_frag(const char* p, int pitch, int plane, bf16x8& hi, bf16x8& lo) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+  const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * pitch));
+  const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + plane));
+  const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + plane + 4 * pitch));
+  hi = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+  lo = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // __launch_bounds__(256, 3): three blocks per CU (152 VGPRs, 36 KB LDS for the 128x128 tile).
 // PERSISTENT tile loop: the grid is at most (resident slots) blocks and block b walks tiles b, b+grid, ...  While the
 // LAST k-tile of a tile is being multiplied, the block already decodes its next tile and issues that tile's first global
 // loads, so the epilogue stores of tile i and the prologue latency of tile i+1 overlap instead of leaving the MFMA pipe
 // idle (measured before: ~19k idle cycles per tile per SIMD at K=1024, because co-resident blocks run in lockstep).
-// X3 (NT layout only): "bf16x3" arithmetic.  Each fp32 operand is split on its way into LDS into hi = bf16(x) and
+// X3: "bf16x3" arithmetic.  Each fp32 operand is split on its way into LDS into hi = bf16(x) and
 // lo = bf16(x - hi); the product is accumulated in fp32 as  lo.hi + hi.lo + hi.hi  with v_mfma_f32_32x32x16_bf16 (16x the
 // fp32 MFMA rate, 3 MFMAs per 16-deep k step instead of 8 fp32 ones): the dropped lo.lo term is ~2^-16 relative, which keeps
 // VASNet scores within ~1e-5 of the fp32 path (scripts/bf16x3_emulation.py; the 1e-4 gate holds, plain bf16 misses it by
 // 20-100x).  The LDS row becomes [hi: BK bf16 | lo: BK bf16] -- the same BK*4 bytes and the same +16 B pad, so the
 // conflict-free ds_read_b128 argument is unchanged; a lane's 16-B fragment is 8 consecutive k of one plane.
+// An operand whose rows are NOT K-contiguous in memory (the "MC" side of NN / TN) keeps its natural [k][row] order in LDS,
+// as two bf16 planes with a (2*BT + 64)-byte pitch, and is read with ds_read_b64_tr_b16 -- gfx950's transposing LDS read
+// hands lane (i, h) the 4 consecutive k of column i, two reads per 8-k fragment (4 k-rows x 64 B per 32-lane half land on
+// 4 distinct 16-bank groups with that pitch).  The kernel has no divergent lanes in its main loop (EXEC all ones, as the
+// instruction requires).
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
-  static_assert(!X3 || (A_KC && B_KC), "bf16x3 is implemented for the NT layout");
   constexpr int KC_PITCH = BK + 4;            // +4 floats: conflict-free ds_read_b128 (pitch 36 or 68 dwords: 16 rows hit 16 distinct slots)
   constexpr int TPK = BK / 4, RPP = 256 / TPK;  // KC image: threads per row, rows covered per pass
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32; // MFMA tiles per wave along M / N
   constexpr int NLDA = BM * BK / 1024, NLDB = BN * BK / 1024;  // float4 loads per thread per operand per k-tile
-  constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : BK * BM;
-  constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : BK * BN;
+  constexpr int MCP_A = 2 * BM + 64, MCP_B = 2 * BN + 64;   // X3: byte pitch of one k-row of a [k][row] bf16 plane
+  constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : (X3 ? 2 * BK * MCP_A / 4 : BK * BM);
+  constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : (X3 ? 2 * BK * MCP_B / 4 : BK * BN);
   __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
   float* sA = lds;
   float* sB = lds + A_ELEMS;
@@ -203,12 +221,26 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     *reinterpret_cast<bf16x4*>(r8 + 2 * kq4) = hi;
     *reinterpret_cast<bf16x4*>(r8 + 2 * BK + 2 * kq4) = lo;
   };
+  auto split_store_mc = [&](float* img, int krow, int col4, int pitch, float4 v) {   // 4 consecutive rows at one k
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    const bf16x4 hi = __builtin_convertvector(x, bf16x4);
+    const bf16x4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4);
+    char* r8 = reinterpret_cast<char*>(img) + krow * pitch + 2 * col4;
+    *reinterpret_cast<bf16x4*>(r8) = hi;
+    *reinterpret_cast<bf16x4*>(r8 + BK * pitch) = lo;
+  };
   auto swrite = [&]() {
     if constexpr (X3) {
 #pragma unroll
-      for (int p = 0; p < NLDA; ++p) split_store(&sA[(tid / TPK + RPP * p) * KC_PITCH], ra[p]);
+      for (int p = 0; p < NLDA; ++p) {
+        if constexpr (A_KC) split_store(&sA[(tid / TPK + RPP * p) * KC_PITCH], ra[p]);
+        else split_store_mc(sA, tid / TPRA + KROWSA * p, (tid % TPRA) * 4, MCP_A, ra[p]);
+      }
 #pragma unroll
-      for (int p = 0; p < NLDB; ++p) split_store(&sB[(tid / TPK + RPP * p) * KC_PITCH], rb[p]);
+      for (int p = 0; p < NLDB; ++p) {
+        if constexpr (B_KC) split_store(&sB[(tid / TPK + RPP * p) * KC_PITCH], rb[p]);
+        else split_store_mc(sB, tid / TPRB + KROWSB * p, (tid % TPRB) * 4, MCP_B, rb[p]);
+      }
       return;
     }
 #pragma unroll
@@ -258,13 +290,23 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
           bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
-            const char* rp = reinterpret_cast<const char*>(&sA[(wm * WTM + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
-            ah[t] = *reinterpret_cast<const bf16x8*>(rp); al[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+            if constexpr (A_KC) {
+              const char* rp = reinterpret_cast<const char*>(&sA[(wm * WTM + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
+              ah[t] = *reinterpret_cast<const bf16x8*>(rp); al[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+            } else {
+              tr_frag(reinterpret_cast<const char*>(sA) + (16 * ks + 8 * lh + ((lane & 15) >> 2)) * MCP_A +
+                          2 * (wm * WTM + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)), MCP_A, BK * MCP_A, ah[t], al[t]);
+            }
           }
 #pragma unroll
           for (int t = 0; t < TN; ++t) {
-            const char* rp = reinterpret_cast<const char*>(&sB[(wn * WTN + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
-            bh[t] = *reinterpret_cast<const bf16x8*>(rp); bl[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+            if constexpr (B_KC) {
+              const char* rp = reinterpret_cast<const char*>(&sB[(wn * WTN + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
+              bh[t] = *reinterpret_cast<const bf16x8*>(rp); bl[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+            } else {
+              tr_frag(reinterpret_cast<const char*>(sB) + (16 * ks + 8 * lh + ((lane & 15) >> 2)) * MCP_B +
+                          2 * (wn * WTN + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)), MCP_B, BK * MCP_B, bh[t], bl[t]);
+            }
           }
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
@@ -376,11 +418,11 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
   return SUMK_OK;
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool X3 = false>
 static int launch_layout(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
-  if (layout == GEMM_NT) return launch_epi<BM, BN, BK, true, true>(epi, ka, tiles, s);
-  if (layout == GEMM_NN) return launch_epi<BM, BN, BK, true, false>(epi, ka, tiles, s);
-  return launch_epi<BM, BN, BK, false, false>(epi, ka, tiles, s);
+  if (layout == GEMM_NT) return launch_epi<BM, BN, BK, true, true, X3>(epi, ka, tiles, s);
+  if (layout == GEMM_NN) return launch_epi<BM, BN, BK, true, false, X3>(epi, ka, tiles, s);
+  return launch_epi<BM, BN, BK, false, false, X3>(epi, ka, tiles, s);
 }
 
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream) {
@@ -403,10 +445,10 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   int rc;
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
-  if (g.precision == SUMK_PRECISION_BF16X3 && layout == GEMM_NT) {   // bf16x3 arithmetic (same tiles, same k order per tile shape)
-    if (g.small_tile == 1) rc = launch_epi<64, 64, 32, true, true, true>(epi, ka, ka.total_tiles, stream);
-    else if (g.small_tile == 2) rc = launch_epi<128, 64, 32, true, true, true>(epi, ka, ka.total_tiles, stream);
-    else rc = launch_epi<128, 128, 32, true, true, true>(epi, ka, ka.total_tiles, stream);
+  if (g.precision == SUMK_PRECISION_BF16X3) {   // bf16x3 arithmetic (same tiles, same k order per tile shape)
+    if (g.small_tile == 1) rc = launch_layout<64, 64, 32, true>(layout, epi, ka, ka.total_tiles, stream);
+    else if (g.small_tile == 2) rc = launch_layout<128, 64, 32, true>(layout, epi, ka, ka.total_tiles, stream);
+    else rc = launch_layout<128, 128, 32, true>(layout, epi, ka, ka.total_tiles, stream);
   } else
   if (g.small_tile == 1) rc = bk64 ? launch_layout<64, 64, 64>(layout, epi, ka, ka.total_tiles, stream)
                                    : launch_layout<64, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
@@ -468,7 +510,7 @@ __global__ void slab_reduce_kernel(SlabReduceArgs a) {
 
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream) {
+                         int ldo, float alpha, hipStream_t stream, int precision) {
   SUMK_ARG(M > 0 && N > 0 && K > 0, "splitk: bad shape");
   SUMK_ARG(slab_elems >= (size_t)M * N, "splitk: slab too small");
   const int small = gemm_tiles(M, N, 0) >= 64 ? 0 : 1;
@@ -483,6 +525,7 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
                      gemm_tile_dim(small));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = slab; g.probs = probs_dev; g.nprob = S; g.small_tile = small; g.total_tiles = S * tiles;
+  g.precision = precision;
   SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   SlabReduceArgs r;
   r.slab = slab; for (int i = 0; i < 4; ++i) r.out[i] = out[i];
@@ -572,10 +615,13 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
 extern "C" int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
   return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream);
 }
-extern "C" int sumk_gemm_nt_prec(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t precision,
-                                 void* stream) {
+extern "C" int sumk_gemm_prec(int32_t layout, const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
+                              int32_t precision, void* stream) {
   SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "gemm: unknown precision %d", precision);
-  return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream, precision);
+  SUMK_ARG(layout >= 0 && layout <= 2, "gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
+  if (layout == 0) return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream, precision);
+  if (layout == 1) return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream, precision);
+  return plain_gemm(sumk::GEMM_TN, A, B, C, M, N, K, M, N, stream, precision);
 }
 extern "C" int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
   return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream);

@@ -84,7 +84,7 @@ int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, 
 // for row = g*rows_per_out + rl.  probs_dev must hold probs_cap entries; slab holds slab_elems floats.
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream);
+                         int ldo, float alpha, hipStream_t stream, int precision = 0);
 // out[c] += sum_r X[r*ld + c]; partial must hold max_chunks*N floats.
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream);
 // out[c] += sum_p partial[p*stride + c]

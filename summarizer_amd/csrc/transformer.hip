@@ -371,7 +371,7 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
   auto wgrad = [&](const float* dY, int ldy, int M, const float* Xin, int ldx, int N, float* out0, float* out1, float* out2,
                    int rows_per_out) -> int {   // out[M,N] += dY^T Xin
     float* out[4] = {out0, out1, out2, nullptr};
-    return gemm_tn_splitk_accum(dY, ldy, Xin, ldx, M, N, R, slab, L.slab_elems, psk, TF_SPLITK_PROBS, out, rows_per_out, N, 1.f, stream);
+    return gemm_tn_splitk_accum(dY, ldy, Xin, ldx, M, N, R, slab, L.slab_elems, psk, TF_SPLITK_PROBS, out, rows_per_out, N, 1.f, stream, opts->precision);
   };
 
   // ---- scoring head: dZ (ReLU + head dropout masks applied), dk2, db2, shared-LN grads

@@ -682,7 +682,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   SUMK_TRY(colsum_accum(dZ, D, R, D, colpart, COLSUM_CHUNKS, gr->b1, stream));
   {
     float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
+    SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
     GemmLaunch g; g.precision = opts->precision;  // dY1 = dZ . W1
     g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
@@ -694,7 +694,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   // 5': output projection (+ residual branch into dx)
   {
     float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dY0, D, CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
+    SUMK_TRY(gemm_tn_splitk_accum(dY0, D, CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
@@ -728,7 +728,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X
   {
     float* out[4] = {gr->Wq, gr->Wk, gr->Wv, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dQKV, 3 * D, x, D, 3 * D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream));
+    SUMK_TRY(gemm_tn_splitk_accum(dQKV, 3 * D, x, D, 3 * D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
   }
   if (dx) {  // dX = dY0 (residual) + dQ Wq + dK Wk + dV Wv
     SUMK_HIP(hipMemcpyAsync(dx, dY0, (size_t)R * D * 4, hipMemcpyDeviceToDevice, stream));

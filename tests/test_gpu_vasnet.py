@@ -53,33 +53,35 @@ def test_gemm_layouts_vs_float64(dev, M, N, K):
             assert (np.abs(got - ref) <= tol).all(), f"TN max err {np.abs(got-ref).max()}"
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (37, 64, 64), (130, 192, 100), (129, 128, 1024), (300, 3072, 1024), (64, 1000, 36), (257, 260, 8)])
+@pytest.mark.parametrize("M,N,K", [(4, 4, 4), (36, 64, 64), (132, 192, 100), (128, 128, 1024), (300, 3072, 1024), (64, 1000, 36), (260, 260, 8),
+                                   (200, 1024, 260)])
 def test_gemm_bf16x3_vs_float64(dev, M, N, K):
-    """Opt-in bf16x3 arithmetic (hi+lo bf16 splits, 3 bf16 MFMAs, fp32 accumulate): each product carries ~2^-16 relative
-    error (dropped lo*lo term and the rounding of lo), so the bound is 2^-15 * |A|.|B|^T -- and it must be far tighter
-    than plain bf16 (2^-8)."""
+    """Opt-in bf16x3 arithmetic (hi+lo bf16 splits, 3 bf16 MFMAs, fp32 accumulate), all three layouts: each product carries
+    ~2^-16 relative error (dropped lo*lo term and the rounding of lo), so the bound is 2^-15 * |A|.|B|^T -- far tighter
+    than plain bf16 (2^-8) -- and data that bf16 represents exactly must come out exact (fragment / plane mapping)."""
     from summarizer_amd import _lib
     lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(M * 7 + N)
     A = rng.standard_normal((M, K)).astype(np.float32)
     Bt = rng.standard_normal((N, K)).astype(np.float32)
-    ref = A.astype(np.float64) @ Bt.astype(np.float64).T
-    bound = np.abs(A).astype(np.float64) @ np.abs(Bt).astype(np.float64).T
-    a = torch.from_numpy(A).to(dev); b = torch.from_numpy(Bt).to(dev)
-    c = torch.full((M, N), float("nan"), device=dev)
-    _lib.check(lib.sumk_gemm_nt_prec(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1,
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
-    torch.cuda.synchronize()
-    err = np.abs(c.cpu().numpy() - ref)
-    assert (err <= 2.0 ** -15 * bound + 1e-6).all(), f"bf16x3 max err {err.max()}"
-    # exact on data that bf16 represents exactly (small integers): fragment / plane mapping check
     Ai = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)
     Bi = ((np.arange(N * K).reshape(N, K) % 5 - 2) + (np.arange(N)[:, None] % 3)).astype(np.float32)
-    a.copy_(torch.from_numpy(Ai)); b.copy_(torch.from_numpy(Bi))
-    _lib.check(lib.sumk_gemm_nt_prec(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1,
-                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(c.cpu().numpy(), Ai.astype(np.int64) @ Bi.astype(np.int64).T)
+    for a_np, b_np, exact in ((A, Bt, False), (Ai, Bi, True)):
+        ref = a_np.astype(np.float64) @ b_np.astype(np.float64).T
+        bound = 2.0 ** -15 * (np.abs(a_np).astype(np.float64) @ np.abs(b_np).astype(np.float64).T) + 1e-6
+        for layout, name in ((0, "NT"), (1, "NN"), (2, "TN")):
+            a_host = a_np if layout < 2 else np.ascontiguousarray(a_np.T)
+            b_host = b_np if layout == 0 else np.ascontiguousarray(b_np.T)
+            a = torch.from_numpy(a_host).to(dev); b = torch.from_numpy(b_host).to(dev)
+            c = torch.full((M, N), float("nan"), device=dev)
+            _lib.check(lib.sumk_gemm_prec(layout, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1, st), "gemm")
+            torch.cuda.synchronize()
+            got = c.cpu().numpy()
+            if exact:
+                np.testing.assert_array_equal(got, ref, err_msg=name)
+            else:
+                assert (np.abs(got - ref) <= bound).all(), f"{name} bf16x3 max err {np.abs(got - ref).max()}"
 
 
 def test_gemm_exact_integer_data_asymmetric(dev):
