@@ -230,6 +230,10 @@ def main():
                 roof["pmc_mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)
             roof["pmc_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc, separate passes; FETCH_SIZE doubled per the gfx950 note)"
 
+    alt = None
+    if args.model == "vasnet" and args.mode == "score" and args.precision == "fp32":
+        alt = alt_precision_leg(model, x, lens, s, args.steps, frames)     # every rank runs it, so ranks stay in step
+        barrier()
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
@@ -245,8 +249,8 @@ def main():
                    roofline=roof)
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
-        if args.model == "vasnet" and args.mode == "score" and args.precision == "fp32":
-            out["bf16x3_mode"] = alt_precision_leg(model, x, lens, s, args.steps, frames)
+        if alt is not None:
+            out["bf16x3_mode"] = alt
         if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum":
             out["cpu_baseline"] = cpu_baseline(lens, D)
         print(json.dumps(out), flush=True)
