@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["vasnet", "dsn", "transformer"], default="vasnet", help="headline = vasnet")
+    ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer"], default="vasnet",
+                    help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024")
     ap.add_argument("--mode", choices=["score", "train", "reinforce"], default="score",
                     help="headline = score (frames scored/sec); train = MSE step; reinforce = DSN REINFORCE step (BASELINE config 4)")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
@@ -131,6 +132,9 @@ def main():
     elif args.model == "transformer":
         from summarizer_amd.models.transformer import Transformer
         model = Transformer(input_size=D).to(dev)
+    elif args.model == "slstm":
+        from summarizer_amd.models.sumgan import sLSTM
+        model = sLSTM(input_size=D).to(dev)
     else:
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)

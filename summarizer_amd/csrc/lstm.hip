@@ -22,6 +22,7 @@ namespace sumk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one step counter per work item
 
@@ -397,6 +398,182 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------- wide persistent recurrence
+// The same one-launch recurrence for 256 < H <= 1024 (sLSTM: H = 1024, W_hh = 16 MB per direction -- the launch chain
+// re-reads it from the Infinity Cache every step, 28 us per step).  Here W_hh never moves: the 256 CUs split into TWO teams
+// of 128 (team = direction; XCDs 0-3 / 4-7 under the observed round-robin dispatch -- speed only, as above), member m keeps
+// the 32 gate rows of its 8 hidden units as MFMA B fragments in registers (64 VGPRs per lane: 32 rows x the wave's 128 k),
+// and a work item is a group of up to 64 videos = two 32-row MFMA tiles.  A 64 x 1024 fp32 panel of h_{t-1} (256 KB) does
+// not fit in LDS, so the A fragments are loaded straight into registers (sc1 16-B buffer loads, 32 in flight per lane; a
+// lane pair covers 32 contiguous bytes of one video's row, L2-served after the first CU of the XCD has pulled the line).
+// Hand-off protocol, bounded spins and error word are exactly those of lstm_persist_kernel (Guideline 16 R1).
+// Per step and CU: 2 x 16 x 4 fp32 MFMAs per wave = 6.8 us of MFMA time at 2 waves per SIMD -- the fp32 floor of this
+// shape -- plus the panel load and one hand-off.
+struct WideArgs {
+  const float* G; const float* whh[2]; float* Hout;
+  float* gates; float* c_all; float* hprev;   // training-mode saves (nullptr in inference)
+  const int32_t* off; unsigned* state;
+  int32_t n_seq, H, n_groups, upm, n_active, hout_bytes;
+};
+constexpr int WK_GROUP = 64;    // videos per work item
+constexpr int WK_CPW = 16;      // 8-wide k chunks per wave: 8 waves x 16 x 8 = 1024 >= H
+
+__global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H;
+  float* part = smem;                                     // [8 waves][64 videos][33] split-K partial tiles
+  int* sR0 = reinterpret_cast<int*>(part + 8 * 64 * 33);  // [64] first row of each video
+  int* sT = sR0 + 64;                                     // [64] length of each video (0 past the group)
+  int* sTg = sT + 64;                                     // [1]  longest video of the group
+
+  const int d = (blockIdx.x & 7) >> 2;                    // team = direction
+  const int slot = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
+  if (slot >= a.n_active) return;
+  const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(a.Hout, (short)0, a.hout_bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
+  bool dead = false;   // (thread 0 only) a wait timed out: results are invalid, state[0] says so
+
+  // this lane's W_hh fragments -> registers for the whole launch (plain loads: weights are never written here)
+  float4 wreg[WK_CPW];
+  {
+    const float* wrow = a.whh[d] + (int64_t)((li >> 3) * H + min(u0 + (li & 7), H - 1)) * H;
+#pragma unroll
+    for (int c = 0; c < WK_CPW; ++c) {
+      const int k = (wave * WK_CPW + c) * 8 + 4 * lh;
+      wreg[c] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  constexpr unsigned OOB = 0x7ffffff0u;   // beyond num_records: the buffer load returns zeros
+
+  for (int g = 0; g < a.n_groups; ++g) {
+    const int item = 2 * g + d;
+    const int v0 = g * WK_GROUP, nv = min(WK_GROUP, a.n_seq - v0);
+    unsigned* bar = a.state + 16 + item;
+    __syncthreads();   // previous item fully done with LDS
+    if (tid == 0) *sTg = 0;
+    __syncthreads();
+    if (tid < 64) {
+      int r0 = 0, T = 0;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; atomicMax(sTg, T); }
+      sR0[tid] = r0; sT[tid] = T;
+    }
+    __syncthreads();
+    const int Tg = *sTg;
+    const int r0a = sR0[li], Ta = sT[li], r0b = sR0[32 + li], Tb = sT[32 + li];   // the two videos this lane feeds to the MFMAs
+
+    // epilogue role: thread (video ei, unit eu); cell state and last h live in registers for the whole item
+    const int ei = tid >> 3, eu = tid & 7;
+    const bool erole = ei < nv && eu < nu;
+    const int er0 = erole ? sR0[ei] : 0, eT = erole ? sT[ei] : 0;
+    const int j = u0 + eu;
+    float c = 0.f, hlast = 0.f;
+    float gcur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (erole && eT > 0) {
+      const int64_t row = d == 0 ? er0 : er0 + eT - 1;
+      const float* gp = a.G + row * (8 * H) + d * 4 * H;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+    }
+
+    for (int t = 0; t < Tg; ++t) {
+      if (t > 0) {
+        if (tid == 0 && !dead) {   // wait until every member published step t-1
+          const unsigned want = (unsigned)t * (unsigned)a.n_active;
+          unsigned spins = 0;
+          while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
+                 __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicOr(a.state, 1u); dead = true; break;   // never hang the GPU: flag the failure and stop waiting
+            }
+          }
+        }
+        __syncthreads();
+        // A fragments: h_{t-1}[video][k..k+3], sc1 (L1-bypassing) 16-B buffer loads ONLY; finished videos read zeros
+        const unsigned basea = t < Ta ? (unsigned)(((int64_t)(d == 0 ? r0a + t - 1 : r0a + Ta - t) * (2 * H) + d * H) * 4) : OOB;
+        const unsigned baseb = t < Tb ? (unsigned)(((int64_t)(d == 0 ? r0b + t - 1 : r0b + Tb - t) * (2 * H) + d * H) * 4) : OOB;
+        u32x4 va[WK_CPW], vb[WK_CPW];
+#pragma unroll
+        for (int cc = 0; cc < WK_CPW; ++cc) {
+          const int k = (wave * WK_CPW + cc) * 8 + 4 * lh;
+          va[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? basea + 4u * k : OOB, 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int cc = 0; cc < WK_CPW; ++cc) {
+          const int k = (wave * WK_CPW + cc) * 8 + 4 * lh;
+          vb[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? baseb + 4u * k : OOB, 0, 16 /* sc1 */);
+        }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int cc = 0; cc < WK_CPW; ++cc) {
+          const float4 bv = wreg[cc];
+          const f32x4 av = __builtin_bit_cast(f32x4, va[cc]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int cc = 0; cc < WK_CPW; ++cc) {
+          const float4 bv = wreg[cc];
+          const f32x4 av = __builtin_bit_cast(f32x4, vb[cc]);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          part[(wave * 64 + row) * 33 + li] = acc0[r];
+          part[(wave * 64 + 32 + row) * 33 + li] = acc1[r];
+        }
+        __syncthreads();
+      }
+      if (erole && t < eT) {
+        const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = gcur[q];
+          if (t > 0) {
+            float ps = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) ps += part[(w8 * 64 + ei) * 33 + q * 8 + eu];
+            v += ps;
+          }
+          pre[q] = v;
+        }
+        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+        c = fg * c + ig * gg;
+        const float h = og * tanhf(c);
+        st_sc1(a.Hout + row * (2 * H) + d * H + j, h);
+        if (a.gates) {
+          float* gs = a.gates + row * (8 * H) + d * 4 * H;
+          gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
+          a.c_all[row * (2 * H) + d * H + j] = c;
+          a.hprev[row * (2 * H) + d * H + j] = hlast;
+        }
+        hlast = h;
+        if (t + 1 < eT) {   // next step's input-projection slice, one step ahead
+          const int64_t nrow = d == 0 ? row + 1 : row - 1;
+          const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+        }
+      }
+      // publish step t: every storing wave drains its stores, then one lane signals
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- BPTT step kernel
 // Step t (run for t = t_max-1 .. 0).  Block = (32 videos) x (32 hidden units) x direction, 512 threads = 8 waves that
 // split the K = 4H contraction  dh_rec[video, j] = sum_k dG[next row][k] * W_hh[k][j]  (MFMA, fragments straight from
@@ -741,6 +918,30 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
       prof_end(SUMK_PROF_LSTM_REC, stream);
       return SUMK_OK;
     }
+  }
+  if (persist_ok && H > 256 && H <= 64 * WK_CPW && (size_t)R * 2 * H * 4 < 0x7fffffe0 &&
+      2 * ((n_seq + WK_GROUP - 1) / WK_GROUP) <= PSTATE_WORDS - 16) {
+    WideArgs wa;
+    wa.G = G; wa.whh[0] = w->w_hh[0]; wa.whh[1] = w->w_hh[1]; wa.Hout = h_out;
+    wa.gates = training ? (float*)(ws + L.gates) : nullptr;
+    wa.c_all = training ? (float*)(ws + L.call) : nullptr;
+    wa.hprev = training ? (float*)(ws + L.hprev) : nullptr;
+    wa.off = seq_off_dev; wa.state = (unsigned*)(ws + L.pstate);
+    wa.n_seq = n_seq; wa.H = H; wa.hout_bytes = (int32_t)((size_t)R * 2 * H * 4);
+    wa.n_groups = (n_seq + WK_GROUP - 1) / WK_GROUP;
+    wa.upm = (H + 127) / 128; wa.n_active = (H + wa.upm - 1) / wa.upm;     // <= 8 units per member, <= 128 members per team
+    const size_t shmem = 96 * 1024;   // 68 KB used; > 80 KB keeps one block per CU
+    const void* fn = (const void*)lstm_wide_kernel;
+    static bool wide_attr_set = false;
+    if (!wide_attr_set) {
+      SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      wide_attr_set = true;
+    }
+    void* kargs[] = {&wa};
+    prof_begin(SUMK_PROF_LSTM_REC, stream);
+    SUMK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(PK_THREADS), kargs, (unsigned)shmem, stream));
+    prof_end(SUMK_PROF_LSTM_REC, stream);
+    return SUMK_OK;
   }
   StepArgs a;
   a.G = G; a.whh[0] = w->w_hh[0]; a.whh[1] = w->w_hh[1]; a.Hout = h_out;

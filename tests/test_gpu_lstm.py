@@ -80,6 +80,43 @@ def test_dsn_packed_ragged_batch_vs_oracle(dev):
         np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i} T={lens[i]}")
 
 
+def test_wide_recurrence_ragged_batch_vs_oracle(dev):
+    """256 < H <= 1024 runs the two-team register-resident recurrence (lstm_wide_kernel): H = 320 is not a multiple of
+    128 (3 units per member, last member short), 70 videos = two work items per direction, lengths 1 ... 90."""
+    from oracle import lstm_np
+    from summarizer_amd.models.dsn import DSN
+    D, H = 64, 320
+    w = R.lstm_weights("rnn.", D, H, 1, 78, "out.0.")
+    m = _load(DSN(D, H, 1), w, dev)
+    lens = [1, 2, 33, 64, 5, 90] + [3, 7] * 32
+    xs = [R.features(T, 1, D, 900 + i) - 0.2 for i, T in enumerate(lens)]
+    with torch.no_grad():
+        s = m.score_packed(torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev), lens).cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, x in enumerate(xs):
+        ref = lstm_np.dsn_forward(x, w)[:, 0, 0]
+        np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i} T={lens[i]}")
+
+
+def test_slstm_batch_properties_full_size(dev):
+    """sLSTM (2 layers, H = 1024) at BASELINE size: a video's scores do not depend on what it is batched with, bit for bit."""
+    from summarizer_amd.models.sumgan import sLSTM
+    torch.manual_seed(4)
+    m = sLSTM().eval().to(dev)
+    lens = [int(np.ceil(v)) for v in np.random.default_rng(2).uniform(150, 320, 6)]
+    xs = [torch.from_numpy(R.features(T, 1, 1024, 800 + i)[:, 0, :]).to(dev) for i, T in enumerate(lens)]
+    with torch.no_grad():
+        a = m.score_packed(torch.cat(xs), lens)
+        b = m.score_packed(torch.cat(xs[::-1]), lens[::-1])
+        single = m(xs[2].unsqueeze(1))[:, 0, 0]
+    off = np.concatenate([[0], np.cumsum(lens)]); offr = np.concatenate([[0], np.cumsum(lens[::-1])])
+    for i in range(len(lens)):
+        j = len(lens) - 1 - i
+        assert torch.equal(b[offr[j]:offr[j + 1]], a[off[i]:off[i + 1]])
+    assert torch.equal(single, a[off[2]:off[3]])
+    assert bool(((a > 0) & (a < 1)).all())
+
+
 def test_dsn_batch_properties_full_size(dev):
     from summarizer_amd.models.dsn import DSN
     torch.manual_seed(3)

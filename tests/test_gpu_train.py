@@ -143,7 +143,8 @@ def test_dsn_bce_grads_golden(dev):
         assert _rel(p.grad.cpu().numpy(), g[f"dsn_bce/grad0/{k}"]) < 2e-4, k
 
 
-@pytest.mark.parametrize("kind,D,H,L,lens", [("dsn", 128, 40, 1, [50, 1, 33, 7] + [4] * 30), ("slstm", 64, 32, 2, [37, 90, 2])])
+@pytest.mark.parametrize("kind,D,H,L,lens", [("dsn", 128, 40, 1, [50, 1, 33, 7] + [4] * 30), ("slstm", 64, 32, 2, [37, 90, 2]),
+                                              ("slstm", 64, 264, 2, [21, 40, 2, 1] + [3] * 64)])   # H > 256: wide persistent forward, > 64 videos
 def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens):
     from oracle import torch_port
     from summarizer_amd.models.dsn import DSN
