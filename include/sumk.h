@@ -34,6 +34,10 @@ int sumk_version(void);
 /* number of HIP devices visible; <0 if the runtime cannot be initialised (the library never falls back to CPU) */
 int sumk_device_count(void);
 
+/* GEMM arithmetic selectors (see sumk_vasnet_opts.precision) */
+#define SUMK_PRECISION_FP32 0
+#define SUMK_PRECISION_BF16X3 1
+
 /* ------------------------------------------------------------------------------------------------ VASNet
  * Weights of summarizer/models/vasnet.py:56-66, each as stored by nn.Linear ([out][in]).
  * The SAME layer_norm (ln_w, ln_b) is applied twice (vasnet.py:137 and :143). */
@@ -44,9 +48,6 @@ typedef struct sumk_vasnet_weights {
   const float* w2; const float* b2;                  /* (D),(1)    k2                   vasnet.py:65   */
   const float* ln_w; const float* ln_b;              /* (D)        layer_norm           vasnet.py:54   */
 } sumk_vasnet_weights;
-
-#define SUMK_PRECISION_FP32 0
-#define SUMK_PRECISION_BF16X3 1
 
 typedef struct sumk_vasnet_opts {
   float scale;          /* logits multiplier, 1/sqrt(D) by default      vasnet.py:34,119 */
@@ -89,10 +90,12 @@ typedef struct sumk_lstm_layer_weights {
 } sumk_lstm_layer_weights;
 
 size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
+/* precision: SUMK_PRECISION_FP32, or SUMK_PRECISION_BF16X3 for the input projection (and, for 256 < H <= 1024, the
+ * recurrent product) in the bf16 hi/lo split arithmetic described at sumk_vasnet_opts. */
 int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq,
                               const int32_t* seq_off_host, const int32_t* seq_off_dev,
                               const sumk_lstm_layer_weights* w, float* h_out,
-                              void* workspace, size_t workspace_bytes, int32_t training, void* stream);
+                              void* workspace, size_t workspace_bytes, int32_t training, int32_t precision, void* stream);
 
 /* Per-frame head shared by DSN (dsn.py:34-36,46: Linear(2H,1)+Sigmoid) and sLSTM (sumgan.py:33-34,44-45):
  * scores[r] = sigmoid(dot(h[r,:F], w) + b[0]). */
@@ -123,7 +126,7 @@ typedef struct sumk_lstm_layer_grads {
 int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* dh_out, int32_t In, int32_t H,
                                int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
                                const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* grads, float* dx,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
 
 /* dh[r,:] = ds[r]*s(1-s)*w ; dw += sum_r ds*s(1-s)*h[r,:] ; db += sum_r ds*s(1-s) */
 size_t sumk_frame_head_workspace_bytes(int32_t F);

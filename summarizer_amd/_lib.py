@@ -73,11 +73,11 @@ _SIGS = {
     "sumk_bilstm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_bilstm_layer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
                                             C.POINTER(LstmLayerWeights), c_f32p, C.c_void_p, C.c_size_t, C.c_int32,
-                                            C.c_void_p]),
+                                            C.c_int32, C.c_void_p]),
     "sumk_bilstm_check": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_bilstm_layer_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P,
                                              c_i32p, C.POINTER(LstmLayerWeights), C.POINTER(LstmLayerGrads), c_f32p,
-                                             C.c_void_p, C.c_size_t, C.c_void_p]),
+                                             C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "sumk_frame_head_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sumk_frame_head_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "sumk_frame_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,

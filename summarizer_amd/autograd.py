@@ -57,14 +57,14 @@ class BiLstmScorerFunction(torch.autograd.Function):
     """scores = sigmoid(Linear(BiLSTM_stack(x))) for a packed batch (DSN: dsn.py:45-46, sLSTM: sumgan.py:43-45)."""
 
     @staticmethod
-    def forward(ctx, xp, sb, prefix, num_layers, H, head_w, head_b, names, *params):
+    def forward(ctx, xp, sb, prefix, num_layers, H, head_w, head_b, precision, names, *params):
         p = dict(zip(names, params))
         acts, wss = [xp], []
         for layer in range(num_layers):
-            h, ws = kernels.bilstm_layer_forward(acts[-1], sb, p, prefix, layer, H, training=True)
+            h, ws = kernels.bilstm_layer_forward(acts[-1], sb, p, prefix, layer, H, training=True, precision=precision)
             acts.append(h); wss.append(ws)
         scores = kernels.frame_head_forward(acts[-1], p[head_w], p[head_b])
-        ctx.meta = (sb, prefix, num_layers, H, head_w, head_b, names)
+        ctx.meta = (sb, prefix, num_layers, H, head_w, head_b, precision, names)
         ctx.wss = wss
         ctx.params = params
         ctx.save_for_backward(scores, *acts)
@@ -72,7 +72,7 @@ class BiLstmScorerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dscores):
-        sb, prefix, num_layers, H, head_w, head_b, names = ctx.meta
+        sb, prefix, num_layers, H, head_w, head_b, precision, names = ctx.meta
         saved = ctx.saved_tensors
         scores, acts, params = saved[0], saved[1:2 + num_layers], ctx.params
         p = dict(zip(names, params))
@@ -81,11 +81,11 @@ class BiLstmScorerFunction(torch.autograd.Function):
         for layer in range(num_layers - 1, -1, -1):
             want_dx = layer > 0 or ctx.needs_input_grad[0]
             dh = kernels.bilstm_layer_backward(acts[layer], acts[layer + 1], dh, sb, p, grads, prefix, layer, H,
-                                               ctx.wss[layer], want_dx)
+                                               ctx.wss[layer], want_dx, precision=precision)
         ctx.wss = None
         gx = dh if ctx.needs_input_grad[0] else None
         ctx.params = None
-        return (gx, None, None, None, None, None, None, None) + tuple(ret)
+        return (gx, None, None, None, None, None, None, None, None) + tuple(ret)
 
 
 class TransformerFunction(torch.autograd.Function):

@@ -23,6 +23,8 @@ namespace sumk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one step counter per work item
 
@@ -418,6 +420,16 @@ struct WideArgs {
 constexpr int WK_GROUP = 64;    // videos per work item
 constexpr int WK_CPW = 16;      // 8-wide k chunks per wave: 8 waves x 16 x 8 = 1024 >= H
 
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the operand split of the bf16x3 arithmetic (gemm_f32.hip)
+__device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, bf16x8& hi, bf16x8& lo) {
+  const f32x8 x = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  hi = __builtin_convertvector(x, bf16x8);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+
+// X3: the recurrent product in bf16x3 arithmetic (3 v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 fp32 MFMAs): W_hh is
+// split once into hi/lo bf16 fragments (the same 64 VGPRs), h_{t-1} is split in registers after the load.
+template <bool X3>
 __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H;
@@ -436,13 +448,26 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
   bool dead = false;   // (thread 0 only) a wait timed out: results are invalid, state[0] says so
 
   // this lane's W_hh fragments -> registers for the whole launch (plain loads: weights are never written here)
-  float4 wreg[WK_CPW];
+  // fp32: chunk c of 8 k, this lane holds k = 8c + 4 lh .. +3.  X3: k16-step s, this lane holds k = 16s + 8 lh .. +7.
+  constexpr int NS = WK_CPW / 2;    // k16 steps per wave
+  float4 wreg[X3 ? 1 : WK_CPW];
+  bf16x8 whi[X3 ? NS : 1], wlo[X3 ? NS : 1];
   {
     const float* wrow = a.whh[d] + (int64_t)((li >> 3) * H + min(u0 + (li & 7), H - 1)) * H;
+    if constexpr (X3) {
 #pragma unroll
-    for (int c = 0; c < WK_CPW; ++c) {
-      const int k = (wave * WK_CPW + c) * 8 + 4 * lh;
-      wreg[c] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        const int k = (wave * NS + sidx) * 16 + 8 * lh;
+        const float4 w0 = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 w1 = k + 4 < H ? *reinterpret_cast<const float4*>(wrow + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        split8(f32x4{w0.x, w0.y, w0.z, w0.w}, f32x4{w1.x, w1.y, w1.z, w1.w}, whi[sidx], wlo[sidx]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < WK_CPW; ++c) {
+        const int k = (wave * WK_CPW + c) * 8 + 4 * lh;
+        wreg[c] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   constexpr unsigned OOB = 0x7ffffff0u;   // beyond num_records: the buffer load returns zeros
@@ -494,37 +519,68 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
         // A fragments: h_{t-1}[video][k..k+3], sc1 (L1-bypassing) 16-B buffer loads ONLY; finished videos read zeros
         const unsigned basea = t < Ta ? (unsigned)(((int64_t)(d == 0 ? r0a + t - 1 : r0a + Ta - t) * (2 * H) + d * H) * 4) : OOB;
         const unsigned baseb = t < Tb ? (unsigned)(((int64_t)(d == 0 ? r0b + t - 1 : r0b + Tb - t) * (2 * H) + d * H) * 4) : OOB;
-        u32x4 va[WK_CPW], vb[WK_CPW];
-#pragma unroll
-        for (int cc = 0; cc < WK_CPW; ++cc) {
-          const int k = (wave * WK_CPW + cc) * 8 + 4 * lh;
-          va[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? basea + 4u * k : OOB, 0, 16 /* sc1 */);
-        }
-#pragma unroll
-        for (int cc = 0; cc < WK_CPW; ++cc) {
-          const int k = (wave * WK_CPW + cc) * 8 + 4 * lh;
-          vb[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? baseb + 4u * k : OOB, 0, 16 /* sc1 */);
-        }
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        u32x4 va[WK_CPW], vb[WK_CPW];
+        if constexpr (X3) {
 #pragma unroll
-        for (int cc = 0; cc < WK_CPW; ++cc) {
-          const float4 bv = wreg[cc];
-          const f32x4 av = __builtin_bit_cast(f32x4, va[cc]);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc0, 0, 0, 0);
-        }
+          for (int cc = 0; cc < WK_CPW; ++cc) {     // [2 sidx + half]: 32 contiguous bytes per lane, 64 per lane pair
+            const int k = (wave * NS + (cc >> 1)) * 16 + 8 * lh + 4 * (cc & 1);
+            va[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? basea + 4u * k : OOB, 0, 16 /* sc1 */);
+          }
 #pragma unroll
-        for (int cc = 0; cc < WK_CPW; ++cc) {
-          const float4 bv = wreg[cc];
-          const f32x4 av = __builtin_bit_cast(f32x4, vb[cc]);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc1, 0, 0, 0);
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const int k = (wave * NS + (cc >> 1)) * 16 + 8 * lh + 4 * (cc & 1);
+            vb[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? baseb + 4u * k : OOB, 0, 16 /* sc1 */);
+          }
+#pragma unroll
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            bf16x8 ah, al;
+            split8(__builtin_bit_cast(f32x4, va[2 * sidx]), __builtin_bit_cast(f32x4, va[2 * sidx + 1]), ah, al);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, whi[sidx], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wlo[sidx], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, whi[sidx], acc0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            bf16x8 bh, bl;
+            split8(__builtin_bit_cast(f32x4, vb[2 * sidx]), __builtin_bit_cast(f32x4, vb[2 * sidx + 1]), bh, bl);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, whi[sidx], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wlo[sidx], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, whi[sidx], acc1, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const int k = (wave * WK_CPW + cc) * 8 + 4 * lh;
+            va[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? basea + 4u * k : OOB, 0, 16 /* sc1 */);
+          }
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const int k = (wave * WK_CPW + cc) * 8 + 4 * lh;
+            vb[cc] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? baseb + 4u * k : OOB, 0, 16 /* sc1 */);
+          }
+          // (the whole vector is bit-cast before its elements are taken: bit-casting va[cc][j] element-wise made hipcc narrow
+          //  the load to one dword and feed element 0 to all four MFMAs)
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const float4 bv = wreg[cc];
+            const f32x4 av = __builtin_bit_cast(f32x4, va[cc]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const float4 bv = wreg[cc];
+            const f32x4 av = __builtin_bit_cast(f32x4, vb[cc]);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc1, 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -858,9 +914,10 @@ extern "C" size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_s
 extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq,
                                          const int32_t* seq_off_host, const int32_t* seq_off_dev,
                                          const sumk_lstm_layer_weights* w, float* h_out, void* workspace,
-                                         size_t workspace_bytes, int32_t training, void* stream_) {
+                                         size_t workspace_bytes, int32_t training, int32_t precision, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && seq_off_dev && w && h_out && workspace, "bilstm_forward: null pointer");
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "bilstm_forward: unknown precision %d", precision);
   for (int d = 0; d < 2; ++d)
     SUMK_ARG(w->w_ih[d] && w->w_hh[d] && w->b_ih[d] && w->b_hh[d], "bilstm_forward: null weight (dir %d)", d);
   LstmWs L;
@@ -882,13 +939,13 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     g.A = x; g.B[0] = w->w_ih[0]; g.B[1] = w->w_ih[1]; g.n_group = 4 * H;
     g.bias0[0] = w->b_ih[0]; g.bias0[1] = w->b_ih[1]; g.bias1[0] = w->b_hh[0]; g.bias1[1] = w->b_hh[1];
     g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 8 * H, small);
+    g.precision = precision;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
   SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
   static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
-  // H > 256 (sLSTM): measured 41 us/step with 2 teams of 128 CUs (every member must gather 24 videos x 4 KB of h per step,
-  // 32 MB chip-wide) versus 36 us/step for the launch chain -- so the persistent kernel is used for H <= 256 only.
+  // H <= 256: 8 XCD teams with an LDS panel; 256 < H <= 1024: the two-team register-resident kernel; otherwise the launch chain
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
     PersistArgs pa;
     pa.G = G; pa.whh[0] = w->w_hh[0]; pa.whh[1] = w->w_hh[1]; pa.Hout = h_out;
@@ -931,11 +988,12 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     wa.n_groups = (n_seq + WK_GROUP - 1) / WK_GROUP;
     wa.upm = (H + 127) / 128; wa.n_active = (H + wa.upm - 1) / wa.upm;     // <= 8 units per member, <= 128 members per team
     const size_t shmem = 96 * 1024;   // 68 KB used; > 80 KB keeps one block per CU
-    const void* fn = (const void*)lstm_wide_kernel;
-    static bool wide_attr_set = false;
-    if (!wide_attr_set) {
+    const bool x3 = precision == SUMK_PRECISION_BF16X3;
+    const void* fn = x3 ? (const void*)lstm_wide_kernel<true> : (const void*)lstm_wide_kernel<false>;
+    static bool wide_attr_set[2] = {false, false};
+    if (!wide_attr_set[x3]) {
       SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      wide_attr_set = true;
+      wide_attr_set[x3] = true;
     }
     void* kargs[] = {&wa};
     prof_begin(SUMK_PROF_LSTM_REC, stream);
@@ -975,7 +1033,8 @@ extern "C" int sumk_frame_head_forward(const float* h, int32_t n_rows, int32_t F
 extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* dh_out, int32_t In, int32_t H,
                                           int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
                                           const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* gr, float* dx,
-                                          void* workspace, size_t workspace_bytes, void* stream_) {
+                                          void* workspace, size_t workspace_bytes, int32_t precision, void* stream_) {
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "bilstm_backward: unknown precision %d", precision);
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && h_out && dh_out && seq_off_dev && w && gr && workspace, "bilstm_backward: null pointer");
   for (int d = 0; d < 2; ++d)
@@ -1037,12 +1096,12 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   // weight gradients: dW_ih[d] += dG_d^T X (both directions in one split-K launch), dW_hh[d] += dG_d^T h_prev_d
   {
     float* out[4] = {gr->w_ih[0], gr->w_ih[1], nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dG, 8 * H, x, In, 8 * H, In, R, slab, L.slab_elems, psk, 64, out, 4 * H, In, 1.f, stream));
+    SUMK_TRY(gemm_tn_splitk_accum(dG, 8 * H, x, In, 8 * H, In, R, slab, L.slab_elems, psk, 64, out, 4 * H, In, 1.f, stream, precision));
   }
   for (int d = 0; d < 2; ++d) {
     float* out[4] = {gr->w_hh[d], nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dG + (size_t)d * 4 * H, 8 * H, hprev + (size_t)d * H, 2 * H, 4 * H, H, R, slab, L.slab_elems,
-                                  psk, 64, out, 4 * H, H, 1.f, stream));
+                                  psk, 64, out, 4 * H, H, 1.f, stream, precision));
     SUMK_TRY(colsum_accum(dG + (size_t)d * 4 * H, 8 * H, R, 4 * H, colpart, 128, gr->b_ih[d], stream));
     SUMK_TRY(colsum_accum(dG + (size_t)d * 4 * H, 8 * H, R, 4 * H, colpart, 128, gr->b_hh[d], stream));
   }
@@ -1052,7 +1111,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     for (int d = 0; d < 2; ++d) {
       GemmLaunch g;
       g.A = dG + (size_t)d * 4 * H; g.B[0] = w->w_ih[d]; g.C = dx; g.probs = prob + 1; g.small_tile = small;
-      g.total_tiles = gemm_tiles(R, In, small);
+      g.total_tiles = gemm_tiles(R, In, small); g.precision = precision;
       SUMK_TRY(launch_gemm(GEMM_NN, d == 0 ? EPI_NONE : EPI_ACCUM, g, stream));
     }
   }

@@ -154,7 +154,7 @@ def _lstm_layer_struct(params, prefix, layer):
     return w
 
 
-def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False):
+def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False, precision=None):
     """x: (n_rows, In) packed -> h (n_rows, 2H) = [h_fwd || h_rev].  Returns (h, workspace or None)."""
     lib = _lib.load()
     _require_gpu(x, "bilstm input")
@@ -168,7 +168,7 @@ def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False):
     ws = workspace(nbytes, x.device, persistent=training)
     h = torch.empty(sb.n_rows, 2 * H, dtype=torch.float32, device=x.device)
     rc = lib.sumk_bilstm_layer_forward(_p(x), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), _p(h), _p(ws),
-                                       ws.numel(), int(training), _stream())
+                                       ws.numel(), int(training), precision_code(precision), _stream())
     _lib.check(rc, "sumk_bilstm_layer_forward")
     if CHECK_LSTM:
         _lib.check(lib.sumk_bilstm_check(_p(ws), In, H, sb.n_seq, sb.off_host_p, int(training), 0, _stream()), "sumk_bilstm_check")
@@ -233,7 +233,7 @@ def sumsq(v, out=None):
     return out
 
 
-def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, want_dx):
+def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, want_dx, precision=None):
     """BPTT of one bidirectional layer; accumulates into grads[<prefix>{weight,bias}_{ih,hh}_l{layer}[_reverse]]."""
     lib = _lib.load()
     In = x.shape[1]
@@ -246,7 +246,7 @@ def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, wan
     if not dh.is_contiguous():
         dh = dh.contiguous()
     rc = lib.sumk_bilstm_layer_backward(_p(x), _p(h), _p(dh), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w),
-                                        C.byref(g), _p(dx), _p(ws), ws.numel(), _stream())
+                                        C.byref(g), _p(dx), _p(ws), ws.numel(), precision_code(precision), _stream())
     _lib.check(rc, "sumk_bilstm_layer_backward")
     if CHECK_LSTM:
         _lib.check(lib.sumk_bilstm_check(_p(ws), In, H, sb.n_seq, sb.off_host_p, 1, 1, _stream()), "sumk_bilstm_check")

@@ -15,14 +15,15 @@ def pack_time_major(x):
 
 
 def bilstm_scores(model, xp, sb, prefix, num_layers, H, head_w, head_b):
+    precision = getattr(model, "precision", "fp32")     # "fp32" | "bf16x3" (kernels.precision_code)
     training = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if training:
         from ..autograd import BiLstmScorerFunction
         names = [n for n, _ in model.named_parameters()]
         p = dict(model.named_parameters())
-        return BiLstmScorerFunction.apply(xp, sb, prefix, num_layers, H, head_w, head_b, names, *[p[n] for n in names])
+        return BiLstmScorerFunction.apply(xp, sb, prefix, num_layers, H, head_w, head_b, precision, names, *[p[n] for n in names])
     p = dict(model.named_parameters())
     h = xp
     for layer in range(num_layers):
-        h, _ = kernels.bilstm_layer_forward(h, sb, p, prefix, layer, H, training=False)
+        h, _ = kernels.bilstm_layer_forward(h, sb, p, prefix, layer, H, training=False, precision=precision)
     return kernels.frame_head_forward(h, p[head_w], p[head_b])

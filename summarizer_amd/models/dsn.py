@@ -26,6 +26,7 @@ class DSN(nn.Module):
             raise SumkError("summarizer_amd.DSN: only cell='lstm' has a HIP kernel (the reference's optional GRU "
                             "cell, dsn.py:28-33, is not on the scored path: DSNTrainer always builds DSN())")
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.precision = "fp32"          # GEMM arithmetic: "fp32" (exact) | "bf16x3" (kernels.precision_code); not in the reference
         self.rnn = nn.LSTM(input_size, hidden_size, num_layers=num_layers, bidirectional=True)
         self.out = nn.Sequential(nn.Linear(hidden_size * 2, 1), nn.Sigmoid())
 
@@ -64,6 +65,7 @@ class DSNTrainer(Trainer):
         self.sup = bool(ep.get("sup", False))
         model = DSN(**({"input_size": int(ep["input_size"])} if "input_size" in ep else {}),
                     **({"hidden_size": int(ep["hidden_size"])} if "hidden_size" in ep else {}))
+        model.precision = ep.get("precision", "fp32")
         return model
 
     def compute_reward(self, seq, actions, far_sim=False, temp_dist_thre=20):

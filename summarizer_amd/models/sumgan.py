@@ -13,6 +13,7 @@ class sLSTM(nn.Module):
         """Selector LSTM"""
         super().__init__()
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.precision = "fp32"          # GEMM arithmetic: "fp32" (exact) | "bf16x3" (kernels.precision_code); not in the reference
         self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, bidirectional=True)
         self.out = nn.Linear(hidden_size * 2, 1)
         self.sig = nn.Sigmoid()

@@ -47,7 +47,8 @@ def test_lstm_hidden_states_vs_golden(dev):
     np.testing.assert_allclose(h.detach().cpu().numpy(), g["dsn_small/h/T37B1"][:, 0, :], atol=2e-5)
 
 
-def test_lstm_full_size_goldens(dev):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_lstm_full_size_goldens(dev, precision):
     from summarizer_amd.models.dsn import DSN
     from summarizer_amd.models.sumgan import sLSTM
     g = load_golden("lstm_full")
@@ -59,9 +60,11 @@ def test_lstm_full_size_goldens(dev):
             w = R.lstm_weights("lstm.", cfg["D"], cfg["H"], cfg["L"], cfg["wseed"], "out."); m = sLSTM(cfg["D"], cfg["H"], cfg["L"])
         assert R.digest(w) == cfg["wdigest"]
         m = _load(m, w, dev)
+        m.precision = precision     # bf16x3: input projections (and the H = 1024 recurrent product) in split-bf16 arithmetic
         with torch.no_grad():
             y = m(torch.from_numpy(R.features(cfg["T"], 1, cfg["D"], cfg["xseed"])).to(dev)).cpu().numpy()
         np.testing.assert_allclose(y, g[f"c{ci}/y"], atol=TOL, rtol=0, err_msg=str(cfg))
+        print(precision, cfg["kind"], cfg["T"], "max |d| vs reference:", float(np.abs(y - g[f"c{ci}/y"]).max()))
 
 
 def test_dsn_packed_ragged_batch_vs_oracle(dev):
@@ -80,7 +83,8 @@ def test_dsn_packed_ragged_batch_vs_oracle(dev):
         np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i} T={lens[i]}")
 
 
-def test_wide_recurrence_ragged_batch_vs_oracle(dev):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_wide_recurrence_ragged_batch_vs_oracle(dev, precision):
     """256 < H <= 1024 runs the two-team register-resident recurrence (lstm_wide_kernel): H = 320 is not a multiple of
     128 (3 units per member, last member short), 70 videos = two work items per direction, lengths 1 ... 90."""
     from oracle import lstm_np
@@ -88,6 +92,7 @@ def test_wide_recurrence_ragged_batch_vs_oracle(dev):
     D, H = 64, 320
     w = R.lstm_weights("rnn.", D, H, 1, 78, "out.0.")
     m = _load(DSN(D, H, 1), w, dev)
+    m.precision = precision
     lens = [1, 2, 33, 64, 5, 90] + [3, 7] * 32
     xs = [R.features(T, 1, D, 900 + i) - 0.2 for i, T in enumerate(lens)]
     with torch.no_grad():

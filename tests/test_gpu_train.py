@@ -143,9 +143,10 @@ def test_dsn_bce_grads_golden(dev):
         assert _rel(p.grad.cpu().numpy(), g[f"dsn_bce/grad0/{k}"]) < 2e-4, k
 
 
+@pytest.mark.parametrize("precision,gtol", [("fp32", 3e-4), ("bf16x3", 1e-3)])
 @pytest.mark.parametrize("kind,D,H,L,lens", [("dsn", 128, 40, 1, [50, 1, 33, 7] + [4] * 30), ("slstm", 64, 32, 2, [37, 90, 2]),
                                               ("slstm", 64, 264, 2, [21, 40, 2, 1] + [3] * 64)])   # H > 256: wide persistent forward, > 64 videos
-def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens):
+def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens, precision, gtol):
     from oracle import torch_port
     from summarizer_amd.models.dsn import DSN
     from summarizer_amd.models.sumgan import sLSTM
@@ -153,6 +154,7 @@ def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens):
     w = R.lstm_weights(pre, D, H, L, 21, hw[:-6])
     m = DSN(D, H, L) if kind == "dsn" else sLSTM(D, H, L)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    m.precision = precision
     xs = [R.features(T, 1, D, 80 + i) - 0.2 for i, T in enumerate(lens)]
     xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev).requires_grad_(True)
     s = m.score_packed(xp, lens)
@@ -171,10 +173,10 @@ def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens):
     ref_grads = {f"{pre}{k}": v.grad.numpy() for k, v in lstm.named_parameters()}
     ref_grads[hw] = pt[hw].grad.numpy(); ref_grads[hb] = pt[hb].grad.numpy()
     for k, p in m.named_parameters():
-        assert _rel(p.grad.cpu().numpy(), ref_grads[k]) < 3e-4, (k, _rel(p.grad.cpu().numpy(), ref_grads[k]))
+        assert _rel(p.grad.cpu().numpy(), ref_grads[k]) < gtol, (k, _rel(p.grad.cpu().numpy(), ref_grads[k]))
     gx = xp.grad.cpu().numpy()
     for i, xt in enumerate(xrefs):
-        assert _rel(gx[off[i]:off[i + 1]], xt.grad.numpy()[:, 0, :]) < 3e-4
+        assert _rel(gx[off[i]:off[i + 1]], xt.grad.numpy()[:, 0, :]) < gtol
 
 
 def test_lstm_launch_chain_path_still_matches(dev):
