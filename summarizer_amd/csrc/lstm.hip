@@ -242,7 +242,9 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p
 // CPW = 8-wide k chunks per wave: the block's 8 waves cover K = 64 * CPW >= H (4 for DSN's H = 256, 16 for sLSTM's 1024).
 // The member's W_hh fragments (32 gate rows x its wave's k range) live in REGISTERS for the whole work item -- exactly the
 // MFMA B operands every step needs -- so LDS holds only the staged h_{t-1} panel and the split-K partial tiles.
-template <int CPW>
+// DIRECT: the A fragments (h_{t-1}[video li][k..k+3]) go straight from the sc1 buffer loads into the MFMAs, as in
+// lstm_wide_kernel below -- no LDS panel, one workgroup barrier less per step.
+template <int CPW, bool DIRECT>
 __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, P = H + 4;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
     const bool erole = tid < 256 && ei < nv && eu < nu;
     const int er0 = erole ? sR0[ei] : 0, eT = erole ? sT[ei] : 0;
     const int j = u0 + eu;
-    float c = 0.f;
+    float c = 0.f, hlast = 0.f;
     float gcur[4] = {0.f, 0.f, 0.f, 0.f};
     if (erole && eT > 0) {
       const int64_t row = d == 0 ? er0 : er0 + eT - 1;
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
     }
+    const int r0l = sR0[li], Tl = sT[li];      // the video this lane feeds to the MFMAs (DIRECT)
 
     for (int t = 0; t < Tg; ++t) {
       if (t > 0) {
@@ -316,6 +319,28 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           }
         }
         __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (DIRECT) {
+          constexpr unsigned OOB = 0x7ffffff0u;   // beyond num_records: the buffer load returns zeros
+          const unsigned basel = t < Tl ? (unsigned)(((int64_t)(d == 0 ? r0l + t - 1 : r0l + Tl - t) * (2 * H) + d * H) * 4) : OOB;
+          u32x4 va[CPW];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const int k = (wave * CPW + c) * 8 + 4 * lh;
+            va[c] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, k < H ? basel + 4u * k : OOB, 0, 16 /* sc1 */);
+          }
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const float4 bv = wreg[c];
+            const f32x4 av = __builtin_bit_cast(f32x4, va[c]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc, 0, 0, 0);
+          }
+        } else {
         // h_{t-1} of every video of the group -> LDS.  sc1 (write-through / L1-bypassing) 16-B buffer loads ONLY, four in
         // flight per thread before the first LDS write.
         {
@@ -343,9 +368,6 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           }
         }
         __syncthreads();
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
           const int k = (wave * CPW + c) * 8 + 4 * lh;
@@ -356,6 +378,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
@@ -383,8 +406,9 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           float* gs = a.gates + row * (8 * H) + d * 4 * H;
           gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
           a.c_all[row * (2 * H) + d * H + j] = c;
-          a.hprev[row * (2 * H) + d * H + j] = t > 0 ? sH[ei * P + j] : 0.f;
+          a.hprev[row * (2 * H) + d * H + j] = hlast;
         }
+        hlast = h;
         if (t + 1 < eT) {   // next step's input-projection slice, one step ahead
           const int64_t nrow = d == 0 ? row + 1 : row - 1;
           const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
@@ -963,11 +987,12 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize;
     if (2 * pa.n_groups <= PSTATE_WORDS - 16 && pa.n_active <= team_size) {
       const size_t shmem = std::max<size_t>(((size_t)gsize * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
-      const void* fn = (const void*)lstm_persist_kernel<4>;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static const bool direct = !(getenv("SUMK_LSTM_PANEL") && getenv("SUMK_LSTM_PANEL")[0] == '1');   // 1: stage h through LDS
+      const void* fn = direct ? (const void*)lstm_persist_kernel<4, true> : (const void*)lstm_persist_kernel<4, false>;
+      static bool attr_set[2] = {false, false};
+      if (!attr_set[direct]) {
         SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[direct] = true;
       }
       void* kargs[] = {&pa};
       prof_begin(SUMK_PROF_LSTM_REC, stream);
