@@ -79,6 +79,11 @@ class DSNTrainer(Trainer):
     def _load_video(self, key, dev):
         return self._video_on_device(key, dev, want_target=True)
 
+    def _sample_actions(self, dist, n_episodes, keys):
+        """(n_episodes, n_rows) 0/1 draws from the frame-selection distribution (dsn.py:125, one `dist.sample()` per
+        episode there).  A separate method so tests can replay the draws the reference's torch-CPU generator made."""
+        return dist.sample((n_episodes,))
+
     def train(self, fold):
         self.model.train()
         train_keys, _ = self._get_train_test_keys(fold)
@@ -115,7 +120,7 @@ class DSNTrainer(Trainer):
                     sb = kernels.SeqBatch.get(lens_b, dev)
                     probs = self.model.score_packed(x, lens_b)            # (sum T,)
                     dist = Bernoulli(probs)
-                    actions = dist.sample((E,))                           # (E, sum T)   dsn.py:125
+                    actions = self._sample_actions(dist, E, keys)         # (E, sum T)   dsn.py:125
                     log_probs = dist.log_prob(actions)                    # dsn.py:126
                     rewards = kernels.dsn_reward(x, sb, actions.contiguous(), far_sim=self.far_sim,
                                                  temp_dist_thre=self.temp_dist_thre)       # (E, n_videos)  dsn.py:129-131

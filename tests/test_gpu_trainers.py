@@ -172,3 +172,55 @@ def test_vasnet_trainer_reproduces_the_reference_trainer_end_to_end():
     assert np.abs(np.array(f_avg) - g["f_avg"]).max() < 0.1 and np.abs(np.array(f_max) - g["f_max"]).max() < 0.1   # north_star bar
     np.testing.assert_allclose(f_avg, g["f_avg"], atol=2e-2); np.testing.assert_allclose(f_max, g["f_max"], atol=2e-2)
     np.testing.assert_allclose(best[0], g["best"][0], atol=5e-3)
+
+
+def test_dsn_trainer_reproduces_the_reference_trainer_end_to_end():
+    """G8: the REAL reference DSNTrainer (CPU; REINFORCE with 3 episodes + supervised BCE + length penalty beta=1; rank
+    selection) was run in the build container (tests/golden/make_golden_e2e_dsn.py) with every Bernoulli draw recorded.
+    Replaying those draws, the HIP trainer must start from the same weights, follow the same per-epoch loss and reward
+    trajectory (reward kernel, log-prob loss, baselines, grad-norm clip, Adam), end at the same weights and report the
+    same test metrics."""
+    from conftest import load_golden
+    from summarizer_amd.models.dsn import DSNTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    g = load_golden("e2e_dsn")
+    D, H, SEED, n, dseed, t0, t1, nu, E = [int(v) for v in g["meta"]]
+    ds = synthetic_dataset(n, seed=dseed, D=D, t_range=(t0, t1), n_users=nu)
+    keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
+    hps = make_hps(ds, [{"train_keys": keys[3:], "test_keys": keys[:3]}], epochs=3, test_every_epochs=1, lr=1e-3,
+                   selection_algorithm="rank",
+                   extra_params={"beta": "1", "sup": True, "num_episodes": str(E), "input_size": str(D), "hidden_size": str(H)})
+    bounds = np.concatenate([[0], np.cumsum(g["actions_len"])])
+    recorded = [g["actions"][bounds[i]:bounds[i + 1]] for i in range(int(g["n_actions"][0]))]
+    cursor = [0]
+
+    class Replay(DSNTrainer):
+        def _sample_actions(self, dist, n_episodes, keys):
+            assert len(keys) == 1                       # reference schedule: one video per optimiser step
+            rows = recorded[cursor[0]:cursor[0] + n_episodes]; cursor[0] += n_episodes
+            a = torch.from_numpy(np.stack(rows).astype(np.float32)).cuda()
+            assert a.shape[1] == dist.probs.shape[0]
+            return a
+
+    torch.manual_seed(SEED); random.seed(SEED)
+    tr = Replay(hps, hps.splits_files[0]).reset()
+    assert (tr.beta, tr.sup, tr.num_episodes) == (1, True, E)
+    for k, v in tr.model.state_dict().items():
+        np.testing.assert_array_equal(v.detach().cpu().numpy(), g[f"w0/{k}"], err_msg=f"initial {k}")
+    best = tr.train(0)
+    assert cursor[0] == len(recorded)
+    sc = hps.writer.scalars
+    np.testing.assert_allclose([v for _, v in sc["synthetic/Fold_1/Train/Loss"]], g["losses"], rtol=1e-3)
+    np.testing.assert_allclose([v for _, v in sc["synthetic/Fold_1/Train/Reward"]], g["rewards"], rtol=1e-4)
+    for k, v in tr.model.state_dict().items():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"w1/{k}"], atol=3e-4, err_msg=f"final {k}")
+    tr.model.eval()
+    with torch.no_grad():
+        for k in keys[:3]:
+            s = tr.model(torch.from_numpy(ds[k]["features"][...]).unsqueeze(1).cuda()).squeeze().cpu().numpy()
+            np.testing.assert_allclose(s, g[f"scores/{k}"], atol=1e-3)     # after 21 optimiser steps of fp32 drift
+    np.testing.assert_allclose([v for _, v in sc["synthetic/Fold_1/Test/Correlation"]], g["corr"], atol=5e-3)
+    f_avg = [v for _, v in sc["synthetic/Fold_1/Test/F-score_avg"]]; f_max = [v for _, v in sc["synthetic/Fold_1/Test/F-score_max"]]
+    np.testing.assert_allclose(f_avg, g["f_avg"], atol=2e-2); np.testing.assert_allclose(f_max, g["f_max"], atol=2e-2)
+    np.testing.assert_allclose(best[0], g["best"][0], atol=5e-3)
