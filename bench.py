@@ -96,8 +96,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer"], default="vasnet",
                     help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024")
-    ap.add_argument("--mode", choices=["score", "train", "reinforce"], default="score",
-                    help="headline = score (frames scored/sec); train = MSE step; reinforce = DSN REINFORCE step (BASELINE config 4)")
+    ap.add_argument("--mode", choices=["score", "train", "reinforce", "stream"], default="score",
+                    help="headline = score (frames scored/sec, features resident in HBM); train = MSE step; reinforce = DSN "
+                         "REINFORCE step (BASELINE config 4); stream = PCIe-inclusive scoring: features start in pageable host "
+                         "memory and scores end there (summarizer_amd/ingest.py) -- never the headline value")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
@@ -139,7 +141,7 @@ def main():
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)
     model.precision = args.precision
-    model.train(args.mode != "score")
+    model.train(args.mode not in ("score", "stream"))
     if args.workload == "stress":
         g = torch.Generator(device=dev); g.manual_seed(rank)
         x = torch.randn(frames, D, device=dev, generator=g) * 0.05
@@ -179,6 +181,22 @@ def main():
             opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
             base = 0.9 * base + 0.1 * rewards.mean(dim=0)
             return loss.detach()
+    elif args.mode == "stream":
+        # host -> host: every step ships the batch again (packed pinned staging, one H2D, packed scoring, one D2H), two slots deep
+        from summarizer_amd.ingest import StreamingScorer
+        xh = x.cpu().numpy()
+        off = np.concatenate([[0], np.cumsum(lens)])
+        vids = [(i, xh[off[i]:off[i + 1]]) for i in range(len(lens))]
+        scorer = StreamingScorer(model, max_frames=frames, depth=3)
+        last = [None]
+        def run_steps(n):
+            def feed():
+                for _ in range(n):
+                    yield from vids
+            for _, sc in scorer.score(feed()):
+                last[0] = sc
+            return torch.from_numpy(last[0])
+        run_step = None
     else:
         def run_step():
             with torch.no_grad():
@@ -189,14 +207,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        s = run_step()
+    if run_step is None:
+        s = run_steps(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            s = run_step()
     barrier()
     lib.sumk_prof_read(_lib.PROF_GEMM_QKV, None, None, 1)
     lib.sumk_prof_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s = run_step()
+    if run_step is None:
+        s = run_steps(args.steps)
+    else:
+        for _ in range(args.steps):
+            s = run_step()
     barrier()
     t1 = time.perf_counter()
     lib.sumk_prof_enable(0)
@@ -253,6 +277,9 @@ def main():
                    roofline=roof)
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
+        if args.mode == "stream":
+            out["note"] = ("PCIe-inclusive: features start in pageable host memory and scores end in host memory every step "
+                           "(native threaded pack into pinned staging + one H2D + packed scoring + one D2H, 3 slots in flight)")
         if alt is not None:
             out["bf16x3_mode"] = alt
         if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum":

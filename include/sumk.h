@@ -243,6 +243,12 @@ typedef struct sumk_eval_video {
 /* method: 0 = knapsack (sumk_knapsack_dp), 1 = rank.  n_threads <= 0: min(16, hardware threads). */
 int sumk_eval_videos(sumk_eval_video* videos, int32_t n_videos, double proportion, int32_t method, int32_t n_threads);
 
+/* ------------------------------------------------------------------------------------------------ feature ingest (host)
+ * Packs the (n_rows[i], D) fp32 feature matrices srcs[i] back to back into dst (normally a pinned staging buffer that ONE
+ * H2D copy then ships) with a pool of memcpy threads; replaces the per-video host->device uploads of the reference's loops
+ * (summarizer/models/__init__.py:47-51, vasnet.py:194-205, dsn.py:98-110).  n_threads <= 0: min(16, hardware threads). */
+int sumk_pack_rows(float* dst, const float* const* srcs, const int32_t* n_rows, int32_t n_videos, int32_t D, int32_t n_threads);
+
 /* Per-kernel timing for bench.py's roofline object: when enabled, launches of the tagged kernel are
  * bracketed with hipEvents ON THE LAUNCH STREAM.  sumk_prof_read synchronises and returns the sums. */
 #define SUMK_PROF_GEMM_QKV 0

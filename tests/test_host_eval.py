@@ -105,3 +105,24 @@ def test_native_eval_tail_is_bit_identical_to_numpy():
             np.testing.assert_allclose(corr[i], c_ref, rtol=1e-12, atol=1e-14, equal_nan=True)
     with pytest.raises(KeyError):
         eval_native.evaluate_batch(vids, scores, 0.15, "greedy")
+
+
+def test_pack_rows_native_threads():
+    """sumk_pack_rows (host): ragged videos packed back to back, any thread count, chunk seams inside and across videos."""
+    import ctypes as C
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    D = 24
+    lens = [1, 7, 300, 2, 4500, 64, 1, 9000]
+    arrs = [rng.standard_normal((T, D)).astype(np.float32) for T in lens]
+    want = np.concatenate(arrs)
+    for nt in (0, 1, 2, 5, 16):
+        dst = np.full_like(want, np.nan)
+        srcs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        rc = lib.sumk_pack_rows(C.c_void_p(dst.ctypes.data), srcs, _lib.host_i32(np.asarray(lens, np.int32)), len(arrs), D, nt)
+        assert rc == 0
+        np.testing.assert_array_equal(dst, want)
+    assert lib.sumk_pack_rows(None, None, None, 0, D, 0) == 0
+    bad = (C.c_void_p * 1)(None)
+    assert lib.sumk_pack_rows(C.c_void_p(dst.ctypes.data), bad, _lib.host_i32(np.asarray([3], np.int32)), 1, D, 1) != 0
