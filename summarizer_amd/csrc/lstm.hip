@@ -928,6 +928,19 @@ __global__ __launch_bounds__(256) void frame_head_bwd_kernel(const float* __rest
 
 using namespace sumk;
 
+// The persistent recurrences are written for the full chip: 256 co-resident blocks, one per CU.  On a partitioned device
+// (CPX / fewer CUs) or with SUMK_LSTM_PERSIST=0 the launch-per-step kernels run instead -- same arithmetic.
+static bool persistent_kernels_usable() {
+  static const bool ok = [] {
+    if (getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0') return false;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return cus >= 256;
+  }();
+  return ok;
+}
+
 extern "C" size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host,
                                               int32_t training) {
   LstmWs w;
@@ -968,7 +981,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
   }
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
   SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
-  static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
+  static const bool persist_ok = persistent_kernels_usable();
   // H <= 256: 8 XCD teams with an LDS panel; 256 < H <= 1024: the two-team register-resident kernel; otherwise the launch chain
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
     PersistArgs pa;
@@ -1080,7 +1093,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   GemmProb* prob = (GemmProb*)(ws + L.prob);
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
 
-  static const bool persist_ok = !(getenv("SUMK_LSTM_PERSIST") && getenv("SUMK_LSTM_PERSIST")[0] == '0');
+  static const bool persist_ok = persistent_kernels_usable();
   SUMK_HIP(hipMemsetAsync(ws + L.pstate_b, 0, (size_t)PSTATE_WORDS * 4, stream));
   bool done = false;
   if (persist_ok && H <= 256 && L.xchg_bytes > 0) {
