@@ -128,6 +128,32 @@ int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* 
                                const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* grads, float* dx,
                                void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ unidirectional LSTM layer
+ * One forward-running nn.LSTM(bidirectional=False) layer with an optional initial state and the final state as an output:
+ * the layers of SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-111,216-233).  Packed batch as above;
+ * h0 / c0 / h_last / c_last / dh_last / dc_last / dh0 / dc0 are (n_seq, H) and may be NULL (zeros / not wanted). */
+typedef struct sumk_lstm_dir_weights { const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh; } sumk_lstm_dir_weights;
+typedef struct sumk_lstm_dir_grads { float* w_ih; float* w_hh; float* b_ih; float* b_hh; } sumk_lstm_dir_grads;
+size_t sumk_lstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
+int sumk_lstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host,
+                            const int32_t* seq_off_dev, const sumk_lstm_dir_weights* w, const float* h0, const float* c0,
+                            float* h_out, float* h_last, float* c_last, void* workspace, size_t workspace_bytes,
+                            int32_t training, int32_t precision, void* stream);
+/* Gradients ACCUMULATE into grads; dx (n_rows, In) written if non-NULL; dh_out may be NULL (no per-step upstream gradient).
+ * Needs the workspace of a training-mode sumk_lstm_layer_forward, that call's h_out and the same c0. */
+int sumk_lstm_layer_backward(const float* x, const float* h_out, const float* dh_out, const float* dh_last, const float* dc_last,
+                             int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                             const sumk_lstm_dir_weights* w, const float* c0, const sumk_lstm_dir_grads* grads, float* dx,
+                             float* dh0, float* dc0, void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
+
+/* Dense layer y (M,N) = x (M,K) w^T + b for the small Linear layers around the LSTM stacks (sumgan.py:59-60,86); w is (N,K)
+ * as in nn.Linear, b may be NULL.  backward: dx (M,K) written if non-NULL, dw (N,K) / db (N) ACCUMULATED if non-NULL. */
+size_t sumk_linear_workspace_bytes(int32_t N, int32_t K);
+int sumk_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t N, int32_t K,
+                        void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
+int sumk_linear_backward(const float* x, const float* w, const float* dy, int32_t M, int32_t N, int32_t K, float* dx, float* dw,
+                         float* db, void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
+
 /* dh[r,:] = ds[r]*s(1-s)*w ; dw += sum_r ds*s(1-s)*h[r,:] ; db += sum_r ds*s(1-s) */
 size_t sumk_frame_head_workspace_bytes(int32_t F);
 int sumk_frame_head_backward(const float* h, const float* scores, const float* dscores, int32_t n_rows,

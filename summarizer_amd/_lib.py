@@ -28,6 +28,14 @@ class VasnetOpts(C.Structure):
                 ("dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32)]
 
 
+class LstmDirWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "b_ih", "b_hh")]
+
+
+class LstmDirGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "b_ih", "b_hh")]
+
+
 class TfLayerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b",
                                           "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
@@ -78,6 +86,18 @@ _SIGS = {
     "sumk_bilstm_layer_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P,
                                              c_i32p, C.POINTER(LstmLayerWeights), C.POINTER(LstmLayerGrads), c_f32p,
                                              C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "sumk_lstm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_lstm_layer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(LstmDirWeights),
+                                          c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32,
+                                          C.c_void_p]),
+    "sumk_lstm_layer_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P,
+                                           c_i32p, C.POINTER(LstmDirWeights), c_f32p, C.POINTER(LstmDirGrads), c_f32p, c_f32p,
+                                           c_f32p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "sumk_linear_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sumk_linear_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                      C.c_int32, C.c_void_p]),
+    "sumk_linear_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
+                                       C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "sumk_frame_head_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sumk_frame_head_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "sumk_frame_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,

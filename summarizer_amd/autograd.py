@@ -116,3 +116,88 @@ class TransformerFunction(torch.autograd.Function):
             ctx.table.grad = tg if ctx.table.grad is None else ctx.table.grad + tg
         ctx.ws = ctx.params = None
         return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + tuple(ret)
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = x W^T + b on the MFMA GEMM (the small Linear layers around SumGAN's LSTM stacks, sumgan.py:59-60,86)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, precision):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        y = kernels.linear_forward(x2, w, b, precision)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (shape, b is not None, precision)
+        ctx.params = (w, b)
+        return y.view(*shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        shape, has_b, precision = ctx.meta
+        names = ["w", "b"] if has_b else ["w"]
+        grads, ret = _grad_targets(names, [p for p in ctx.params if p is not None])
+        dx = kernels.linear_backward(x2, w, dy.reshape(-1, w.shape[0]), grads["w"], grads.get("b"), ctx.needs_input_grad[0], precision)
+        ctx.params = None
+        return (dx.view(shape) if dx is not None else None, ret[0], ret[1] if has_b else None, None)
+
+
+class LstmStackFunction(torch.autograd.Function):
+    """Stacked forward-running LSTM layers (nn.LSTM(num_layers=L, bidirectional=False)) on a packed batch, with optional
+    initial state: (x (n_rows, In), h0 (L, n_seq, H) | None, c0 | None) -> (out (n_rows, H), h_n (L, n_seq, H), c_n)."""
+
+    @staticmethod
+    def forward(ctx, xp, sb, H, precision, h0, c0, *params):
+        L = len(params) // 4
+        acts, wss, hn, cn = [xp], [], [], []
+        for l in range(L):
+            h, hl, cl, ws = kernels.lstm_layer_forward(acts[-1], sb, params[4 * l:4 * l + 4], H,
+                                                       None if h0 is None else h0[l].contiguous(),
+                                                       None if c0 is None else c0[l].contiguous(), training=True, precision=precision)
+            acts.append(h); wss.append(ws); hn.append(hl); cn.append(cl)
+        ctx.meta = (sb, H, precision, L, h0 is not None, c0 is not None)
+        ctx.wss, ctx.params = wss, params
+        ctx.c0 = None if c0 is None else c0.detach()
+        ctx.save_for_backward(*acts)
+        return acts[-1], torch.stack(hn), torch.stack(cn)
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn):
+        sb, H, precision, L, has_h0, has_c0 = ctx.meta
+        acts, params = ctx.saved_tensors, ctx.params
+        grads, ret = _grad_targets([str(i) for i in range(len(params))], params)
+        want_d0 = (has_h0 and ctx.needs_input_grad[4]) or (has_c0 and ctx.needs_input_grad[5])
+        dh, dh0s, dc0s = dout, [], []
+        for l in range(L - 1, -1, -1):
+            want_dx = l > 0 or ctx.needs_input_grad[0]
+            g4 = [grads[str(4 * l + i)] for i in range(4)]
+            dh, dh0, dc0 = kernels.lstm_layer_backward(acts[l], acts[l + 1], dh, None if dhn is None else dhn[l],
+                                                       None if dcn is None else dcn[l], sb, params[4 * l:4 * l + 4],
+                                                       None if ctx.c0 is None else ctx.c0[l].contiguous(), g4, H, ctx.wss[l],
+                                                       want_dx, want_d0, precision)
+            dh0s.append(dh0); dc0s.append(dc0)
+        ctx.wss = ctx.params = None
+        gx = dh if ctx.needs_input_grad[0] else None
+        gh0 = torch.stack(dh0s[::-1]) if (has_h0 and ctx.needs_input_grad[4]) else None
+        gc0 = torch.stack(dc0s[::-1]) if (has_c0 and ctx.needs_input_grad[5]) else None
+        return (gx, None, None, None, gh0, gc0) + tuple(ret)
+
+
+class FrameHeadFunction(torch.autograd.Function):
+    """probs = sigmoid(h w^T + b) for h (n, F): the Linear(F,1)+Sigmoid heads (cLSTM.out, sumgan.py:228-231)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        h = h.contiguous()
+        s = kernels.frame_head_forward(h, w, b)
+        ctx.save_for_backward(h, s, w)
+        ctx.params = (w, b)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        h, s, w = ctx.saved_tensors
+        grads, ret = _grad_targets(["w", "b"], ctx.params)
+        dh = kernels.frame_head_backward(h, s, ds, w, grads["w"], grads["b"])
+        ctx.params = None
+        return dh, ret[0], ret[1]

@@ -93,14 +93,20 @@ struct StepArgs {
   float* hprev;          // (R, 2H) or nullptr
   const int32_t* off;
   int32_t n_seq, H, t, n_ublk;
+  // nd = 2: bidirectional layer (row layouts (R, 2H) / (R, 8H), dir 1 runs backwards in time); nd = 1: one forward-running
+  // direction (row layouts (R, H) / (R, 4H)).  h0 / c0: optional initial state (n_seq, nd, H); nullptr = zeros.
+  int32_t nd = 2;
+  const float* h0 = nullptr;
+  const float* c0 = nullptr;
 };
 
 __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
   __shared__ float part[4][32][33];
-  const int H = a.H;
-  const int d = blockIdx.x & 1;
-  const int ublk = (blockIdx.x >> 1) % a.n_ublk;
-  const int mtile = (blockIdx.x >> 1) / a.n_ublk;
+  const int H = a.H, nd = a.nd, S1 = nd * H, S4 = nd * 4 * H;
+  const int d = blockIdx.x % nd;
+  const int ublk = (blockIdx.x / nd) % a.n_ublk;
+  const int mtile = (blockIdx.x / nd) / a.n_ublk;
+  const bool rec = a.t > 0 || a.h0 != nullptr;      // a recurrent term exists at this step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int j0 = ublk * 8;
@@ -120,14 +126,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
       eact = true;
       row = d == 0 ? r0 + t : r0 + T - 1 - t;
       prow = d == 0 ? row - 1 : row + 1;
-      const float* g = a.G + row * (8 * H) + d * 4 * H;
+      const float* g = a.G + row * S4 + d * 4 * H;
 #pragma unroll
       for (int q = 0; q < 4; ++q) pre[q] = g[q * H + j];
-      if (t > 0) cprev = a.c_all ? a.c_all[prow * (2 * H) + d * H + j] : a.cstate[((int64_t)esv * 2 + d) * H + j];
+      if (t > 0) cprev = a.c_all ? a.c_all[prow * S1 + d * H + j] : a.cstate[((int64_t)esv * nd + d) * H + j];
+      else if (a.c0) cprev = a.c0[((int64_t)esv * nd + d) * H + j];
     }
   }
 
-  if (t > 0) {
+  if (rec) {
     // A operand: h_prev of video (mtile*32 + li); B operand: W_hh row of gate-column li = g*8 + u.
     // Fragments come straight from memory (L2 does not survive the kernel boundary: Infinity Cache / HBM).  Measured
     // alternatives: staging the 32x128 panels through LDS in 128-B-coalesced segments was SLOWER (12.3 vs 10.5 us per
@@ -137,7 +144,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
     const float* hp = a.Hout;  // clamped to a legal row when inactive
     if (sv < a.n_seq) {
       int r0 = a.off[sv], T = a.off[sv + 1] - r0;
-      if (t < T) { act = true; hp = a.Hout + (int64_t)(d == 0 ? r0 + t - 1 : r0 + T - t) * (2 * H) + d * H; }
+      if (t < T) {
+        act = true;
+        hp = t > 0 ? a.Hout + (int64_t)(d == 0 ? r0 + t - 1 : r0 + T - t) * S1 + d * H : a.h0 + ((int64_t)sv * nd + d) * H;
+      }
     }
     const int gcol = li >> 3, u = li & 7;
     const int unit = min(j0 + u, H - 1);
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
   // ---- cell update: thread = (video ei, unit eu)
   if (!eact) return;
   const int i = ei, u = eu;
-  if (t > 0) {
+  if (rec) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       pre[q] += (part[0][i][q * 8 + u] + part[1][i][q * 8 + u]) + (part[2][i][q * 8 + u] + part[3][i][q * 8 + u]);
@@ -183,13 +193,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs a) {
   const int sv = esv;
   const float c = fg * cprev + ig * gg;
   const float h = og * tanhf(c);
-  a.Hout[row * (2 * H) + d * H + j] = h;
-  if (a.c_all) a.c_all[row * (2 * H) + d * H + j] = c; else a.cstate[((int64_t)sv * 2 + d) * H + j] = c;
+  a.Hout[row * S1 + d * H + j] = h;
+  if (a.c_all) a.c_all[row * S1 + d * H + j] = c; else a.cstate[((int64_t)sv * nd + d) * H + j] = c;
   if (a.gates) {
-    float* gs = a.gates + row * (8 * H) + d * 4 * H;
+    float* gs = a.gates + row * S4 + d * 4 * H;
     gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
   }
-  if (a.hprev) a.hprev[row * (2 * H) + d * H + j] = t > 0 ? a.Hout[prow * (2 * H) + d * H + j] : 0.f;
+  if (a.hprev) a.hprev[row * S1 + d * H + j] = t > 0 ? a.Hout[prow * S1 + d * H + j] : (a.h0 ? a.h0[((int64_t)sv * nd + d) * H + j] : 0.f);
 }
 
 // scores[r] = sigmoid(h[r,:] . w + b)       dsn.py:34-36,46 / sumgan.py:33-34,44-45
@@ -667,14 +677,22 @@ struct BwdStepArgs {
   float* dcstate;        // (n_seq, 2, H) running dc
   const int32_t* off;
   int32_t n_seq, H, t, n_jblk;
+  // nd as in StepArgs.  Optional (n_seq, nd, H) tensors: c0 = initial cell state of the forward pass; dh_last / dc_last =
+  // upstream gradients of the final (h, c); dh0 / dc0 = outputs written by the extra pass t = -1.  dHout may be nullptr.
+  int32_t nd = 2;
+  const float* c0 = nullptr;
+  const float* dh_last = nullptr;
+  const float* dc_last = nullptr;
+  float* dh0 = nullptr;
+  float* dc0 = nullptr;
 };
 
 __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(BwdStepArgs a) {
   __shared__ float part[8][32][33];
-  const int H = a.H, H4 = 4 * H;
-  const int d = blockIdx.x & 1;
-  const int jblk = (blockIdx.x >> 1) % a.n_jblk;
-  const int mtile = (blockIdx.x >> 1) / a.n_jblk;
+  const int H = a.H, H4 = 4 * H, nd = a.nd, S1 = nd * H, S4 = nd * H4;
+  const int d = blockIdx.x % nd;
+  const int jblk = (blockIdx.x / nd) % a.n_jblk;
+  const int mtile = (blockIdx.x / nd) / a.n_jblk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int j0 = jblk * 32;
@@ -686,7 +704,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(BwdStepArgs a) {
     const float* gp = a.dG;
     if (sv < a.n_seq) {
       int r0 = a.off[sv], T = a.off[sv + 1] - r0;
-      if (t + 1 < T) { act = true; gp = a.dG + (int64_t)(d == 0 ? r0 + t + 1 : r0 + T - 2 - t) * (8 * H) + d * H4; }
+      if (t + 1 < T) { act = true; gp = a.dG + (int64_t)(d == 0 ? r0 + t + 1 : r0 + T - 2 - t) * S4 + d * H4; }
     }
     const int jc = min(j0 + li, H - 1);
     const float* wp = a.whh[d] + jc;
@@ -727,20 +745,27 @@ __global__ __launch_bounds__(512) void lstm_bwd_step_kernel(BwdStepArgs a) {
     if (sv >= a.n_seq || j >= H) continue;
     const int r0 = a.off[sv], T = a.off[sv + 1] - r0;
     if (t >= T) continue;
-    const int64_t row = d == 0 ? r0 + t : r0 + T - 1 - t;
-    float dh = a.dHout[row * (2 * H) + d * H + j];
+    const int64_t sidx = ((int64_t)sv * nd + d) * H + j;
     float rec = 0.f;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) rec += part[w8][i][u];
+    float* dcs = a.dcstate + sidx;
+    if (t < 0) {   // extra pass: gradient of the initial state
+      if (a.dh0) a.dh0[sidx] = rec;
+      if (a.dc0) a.dc0[sidx] = *dcs;
+      continue;
+    }
+    const int64_t row = d == 0 ? r0 + t : r0 + T - 1 - t;
+    float dh = a.dHout ? a.dHout[row * S1 + d * H + j] : 0.f;
     if (t + 1 < T) dh += rec;
-    const float* gs = a.gates + row * (8 * H) + d * H4;
+    else if (a.dh_last) dh += a.dh_last[sidx];
+    const float* gs = a.gates + row * S4 + d * H4;
     const float ig = gs[j], fg = gs[H + j], gg = gs[2 * H + j], og = gs[3 * H + j];
-    const float c = a.c_all[row * (2 * H) + d * H + j];
-    const float cprev = t > 0 ? a.c_all[(d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j] : 0.f;
+    const float c = a.c_all[row * S1 + d * H + j];
+    const float cprev = t > 0 ? a.c_all[(d == 0 ? row - 1 : row + 1) * S1 + d * H + j] : (a.c0 ? a.c0[sidx] : 0.f);
     const float tc = tanhf(c);
-    float* dcs = a.dcstate + ((int64_t)sv * 2 + d) * H + j;
-    float dc = (t + 1 < T ? *dcs : 0.f) + dh * og * (1.f - tc * tc);
-    float* dg = a.dG + row * (8 * H) + d * H4;
+    float dc = (t + 1 < T ? *dcs : (a.dc_last ? a.dc_last[sidx] : 0.f)) + dh * og * (1.f - tc * tc);
+    float* dg = a.dG + row * S4 + d * H4;
     dg[j] = dc * gg * ig * (1.f - ig);
     dg[H + j] = dc * cprev * fg * (1.f - fg);
     dg[2 * H + j] = dc * ig * (1.f - gg * gg);
@@ -1152,6 +1177,236 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
       g.total_tiles = gemm_tiles(R, In, small); g.precision = precision;
       SUMK_TRY(launch_gemm(GEMM_NN, d == 0 ? EPI_NONE : EPI_ACCUM, g, stream));
     }
+  }
+  return SUMK_OK;
+}
+
+// ------------------------------------------------------------------------------------------- unidirectional layer
+// One forward-running LSTM direction with an optional initial state and the final state as an output -- the layers of
+// SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-111,216-233: nn.LSTM(bidirectional=False), `(h_0, c_0)`
+// inputs, `(h_n, c_n)` outputs).  Runs the launch-per-step kernels with nd = 1 (row layouts (R, H) / (R, 4H)).
+struct Lstm1Ws {
+  size_t g, cstate, prob, gates, call, hprev, dg, dcstate, slab, prob_sk, colpart, total;
+  size_t slab_elems;
+  int32_t n_rows, t_max;
+};
+
+static int lstm1_carve(int In, int H, int n_seq, const int32_t* off, int training, Lstm1Ws* w) {
+  SUMK_ARG(In > 0 && In % 4 == 0, "lstm: input size %d must be a positive multiple of 4", In);
+  SUMK_ARG(H > 0 && H % 4 == 0, "lstm: hidden size %d must be a positive multiple of 4", H);
+  SUMK_ARG(n_seq > 0 && off != nullptr && off[0] == 0, "lstm: empty batch / seq_off[0] != 0");
+  int tmax = 0;
+  for (int s = 0; s < n_seq; ++s) {
+    int T = off[s + 1] - off[s];
+    SUMK_ARG(T > 0, "lstm: sequence %d has %d steps", s, T);
+    tmax = T > tmax ? T : tmax;
+  }
+  const size_t R = (size_t)off[n_seq];
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  w->n_rows = (int32_t)R; w->t_max = tmax;
+  w->g = take(R * 4 * H * 4);
+  w->cstate = take((size_t)n_seq * H * 4);
+  w->prob = take(8 * sizeof(GemmProb));
+  w->gates = w->call = w->hprev = w->dg = w->dcstate = w->slab = w->prob_sk = w->colpart = 0;
+  w->slab_elems = 0;
+  if (training) {
+    w->gates = take(R * 4 * H * 4);
+    w->call = take(R * H * 4);
+    w->hprev = take(R * H * 4);
+    w->dg = take(R * 4 * H * 4);
+    w->dcstate = take((size_t)n_seq * H * 4);
+    w->slab_elems = (size_t)8 * (4 * H) * (size_t)(In > H ? In : H);
+    w->slab = take(w->slab_elems * 4);
+    w->prob_sk = take(64 * sizeof(GemmProb));
+    w->colpart = take((size_t)128 * 4 * H * 4);
+  }
+  w->total = p;
+  return SUMK_OK;
+}
+
+// h_last[s][j] = h_out[last row of s][j]; c_last from the per-row cell states (training) or the running state (inference)
+__global__ void lstm_last_state_kernel(const float* __restrict__ h_out, const float* __restrict__ c_all,
+                                       const float* __restrict__ cstate, const int32_t* __restrict__ off, int n_seq, int H,
+                                       float* __restrict__ h_last, float* __restrict__ c_last) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_seq * H) return;
+  const int s = (int)(idx / H), j = (int)(idx % H);
+  const int64_t row = off[s + 1] - 1;
+  if (h_last) h_last[idx] = h_out[row * H + j];
+  if (c_last) c_last[idx] = c_all ? c_all[row * H + j] : cstate[idx];
+}
+
+extern "C" size_t sumk_lstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training) {
+  Lstm1Ws w;
+  if (lstm1_carve(In, H, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
+  return w.total;
+}
+
+extern "C" int sumk_lstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host,
+                                       const int32_t* seq_off_dev, const sumk_lstm_dir_weights* w, const float* h0,
+                                       const float* c0, float* h_out, float* h_last, float* c_last, void* workspace,
+                                       size_t workspace_bytes, int32_t training, int32_t precision, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(x && seq_off_dev && w && h_out && workspace, "lstm_forward: null pointer");
+  SUMK_ARG(w->w_ih && w->w_hh && w->b_ih && w->b_hh, "lstm_forward: null weight");
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "lstm_forward: unknown precision %d", precision);
+  Lstm1Ws L;
+  SUMK_TRY(lstm1_carve(In, H, n_seq, seq_off_host, training, &L));
+  if (workspace_bytes < L.total) {
+    set_error("lstm_forward: workspace %zu < required %zu", workspace_bytes, L.total);
+    return SUMK_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  const int R = L.n_rows;
+  float* G = (float*)(ws + L.g);
+  GemmProb* prob = (GemmProb*)(ws + L.prob);
+  const int small = gemm_tiles(R, 4 * H, 0) >= 512 ? 0 : 1;
+  SUMK_TRY(fill_single_prob(prob, R, 4 * H, In, In, In, 4 * H, 0, small, stream));
+  {
+    GemmLaunch g;   // G = X W_ih^T + b_ih + b_hh
+    g.A = x; g.B[0] = w->w_ih; g.bias0[0] = w->b_ih; g.bias1[0] = w->b_hh;
+    g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 4 * H, small); g.precision = precision;
+    SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
+  }
+  StepArgs a;
+  a.G = G; a.whh[0] = w->w_hh; a.whh[1] = nullptr; a.Hout = h_out;
+  a.cstate = training ? nullptr : (float*)(ws + L.cstate);
+  a.gates = training ? (float*)(ws + L.gates) : nullptr;
+  a.c_all = training ? (float*)(ws + L.call) : nullptr;
+  a.hprev = training ? (float*)(ws + L.hprev) : nullptr;
+  a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_ublk = (H + 7) / 8;
+  a.nd = 1; a.h0 = h0; a.c0 = c0;
+  const int n_mtiles = (n_seq + 31) / 32;
+  const dim3 grid((unsigned)(n_mtiles * a.n_ublk)), block(256);
+  for (int t = 0; t < L.t_max; ++t) {
+    a.t = t;
+    hipLaunchKernelGGL(lstm_step_kernel, grid, block, 0, stream, a);
+  }
+  if (h_last || c_last) {
+    const int64_t n = (int64_t)n_seq * H;
+    hipLaunchKernelGGL(lstm_last_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, h_out,
+                       (const float*)a.c_all, (const float*)a.cstate, seq_off_dev, n_seq, H, h_last, c_last);
+  }
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, const float* dh_out, const float* dh_last,
+                                        const float* dc_last, int32_t In, int32_t H, int32_t n_seq,
+                                        const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                                        const sumk_lstm_dir_weights* w, const float* c0, const sumk_lstm_dir_grads* gr,
+                                        float* dx, float* dh0, float* dc0, void* workspace, size_t workspace_bytes,
+                                        int32_t precision, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(x && h_out && seq_off_dev && w && gr && workspace, "lstm_backward: null pointer");
+  SUMK_ARG(w->w_ih && w->w_hh && gr->w_ih && gr->w_hh && gr->b_ih && gr->b_hh, "lstm_backward: null weight/grad");
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "lstm_backward: unknown precision %d", precision);
+  Lstm1Ws L;
+  SUMK_TRY(lstm1_carve(In, H, n_seq, seq_off_host, 1, &L));
+  if (workspace_bytes < L.total) {
+    set_error("lstm_backward: workspace %zu < required %zu (needs the training-mode forward's workspace)", workspace_bytes, L.total);
+    return SUMK_ERR_WORKSPACE;
+  }
+  char* ws = (char*)workspace;
+  const int R = L.n_rows;
+  float* dG = (float*)(ws + L.dg);
+  float* hprev = (float*)(ws + L.hprev);
+  float* slab = (float*)(ws + L.slab);
+  float* colpart = (float*)(ws + L.colpart);
+  GemmProb* prob = (GemmProb*)(ws + L.prob);
+  GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
+  BwdStepArgs a;
+  a.whh[0] = w->w_hh; a.whh[1] = nullptr; a.dHout = dh_out; a.gates = (const float*)(ws + L.gates);
+  a.c_all = (const float*)(ws + L.call); a.dG = dG; a.dcstate = (float*)(ws + L.dcstate);
+  a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_jblk = (H + 31) / 32;
+  a.nd = 1; a.c0 = c0; a.dh_last = dh_last; a.dc_last = dc_last; a.dh0 = dh0; a.dc0 = dc0;
+  const int n_mtiles = (n_seq + 31) / 32;
+  const dim3 grid((unsigned)(n_mtiles * a.n_jblk)), block(512);
+  for (int t = L.t_max - 1; t >= ((dh0 || dc0) ? -1 : 0); --t) {
+    a.t = t;
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, 0, stream, a);
+  }
+  SUMK_HIP(hipGetLastError());
+  {
+    float* out[4] = {gr->w_ih, nullptr, nullptr, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum(dG, 4 * H, x, In, 4 * H, In, R, slab, L.slab_elems, psk, 64, out, 4 * H, In, 1.f, stream, precision));
+  }
+  {
+    float* out[4] = {gr->w_hh, nullptr, nullptr, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum(dG, 4 * H, hprev, H, 4 * H, H, R, slab, L.slab_elems, psk, 64, out, 4 * H, H, 1.f, stream, precision));
+    SUMK_TRY(colsum_accum(dG, 4 * H, R, 4 * H, colpart, 128, gr->b_ih, stream));
+    SUMK_TRY(colsum_accum(dG, 4 * H, R, 4 * H, colpart, 128, gr->b_hh, stream));
+  }
+  if (dx) {
+    const int small = gemm_tiles(R, In, 0) >= 512 ? 0 : 1;
+    SUMK_TRY(fill_single_prob(prob + 1, R, In, 4 * H, 4 * H, In, In, 0, small, stream));
+    GemmLaunch g;
+    g.A = dG; g.B[0] = w->w_ih; g.C = dx; g.probs = prob + 1; g.small_tile = small;
+    g.total_tiles = gemm_tiles(R, In, small); g.precision = precision;
+    SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+  }
+  return SUMK_OK;
+}
+
+// ------------------------------------------------------------------------------------------- dense layer
+// y = x W^T + b and its backward, for the small Linear layers around the LSTM stacks (eLSTM mu / logvar, dLSTM recons:
+// sumgan.py:59-60,86) -- the MFMA GEMM with the bias in its epilogue, split-K weight gradient, column-sum bias gradient.
+struct LinWs { size_t prob, prob_sk, slab, colpart, total, slab_elems; };
+static void linear_carve(int N, int K, LinWs* w) {
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  w->prob = take(4 * sizeof(GemmProb));
+  w->prob_sk = take(64 * sizeof(GemmProb));
+  w->slab_elems = (size_t)8 * N * K;
+  w->slab = take(w->slab_elems * 4);
+  w->colpart = take((size_t)128 * N * 4);
+  w->total = p;
+}
+extern "C" size_t sumk_linear_workspace_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0) return 0;
+  LinWs w; linear_carve(N, K, &w); return w.total;
+}
+extern "C" int sumk_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t N, int32_t K,
+                                   void* workspace, size_t workspace_bytes, int32_t precision, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(x && w && y && workspace, "linear_forward: null pointer");
+  SUMK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0, "linear_forward: bad shape M=%d N=%d K=%d (K must be a multiple of 4)", M, N, K);
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "linear_forward: unknown precision %d", precision);
+  LinWs L; linear_carve(N, K, &L);
+  if (workspace_bytes < L.total) { set_error("linear_forward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
+  GemmProb* prob = (GemmProb*)((char*)workspace + L.prob);
+  const int small = gemm_tiles(M, N, 0) >= 512 ? 0 : 1;
+  SUMK_TRY(fill_single_prob(prob, M, N, K, K, K, N, 0, small, stream));
+  GemmLaunch g;
+  g.A = x; g.B[0] = w; g.bias0[0] = b; g.C = y; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(M, N, small);
+  g.precision = precision;
+  return launch_gemm(GEMM_NT, b ? EPI_BIAS2 : EPI_NONE, g, stream);
+}
+extern "C" int sumk_linear_backward(const float* x, const float* w, const float* dy, int32_t M, int32_t N, int32_t K, float* dx,
+                                    float* dw, float* db, void* workspace, size_t workspace_bytes, int32_t precision,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(x && w && dy && workspace, "linear_backward: null pointer");
+  SUMK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0 && N % 4 == 0, "linear_backward: bad shape M=%d N=%d K=%d (N, K multiples of 4)", M, N, K);
+  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "linear_backward: unknown precision %d", precision);
+  LinWs L; linear_carve(N, K, &L);
+  if (workspace_bytes < L.total) { set_error("linear_backward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
+  char* ws = (char*)workspace;
+  GemmProb* prob = (GemmProb*)(ws + L.prob);
+  if (dw) {   // dW (N, K) += dY^T X
+    float* out[4] = {dw, nullptr, nullptr, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum(dy, N, x, K, N, K, M, (float*)(ws + L.slab), L.slab_elems, (GemmProb*)(ws + L.prob_sk), 64, out, N, K,
+                                  1.f, stream, precision));
+  }
+  if (db) SUMK_TRY(colsum_accum(dy, N, M, N, (float*)(ws + L.colpart), 128, db, stream));
+  if (dx) {   // dX (M, K) = dY W
+    const int small = gemm_tiles(M, K, 0) >= 512 ? 0 : 1;
+    SUMK_TRY(fill_single_prob(prob + 1, M, K, N, N, K, K, 0, small, stream));
+    GemmLaunch g;
+    g.A = dy; g.B[0] = w; g.C = dx; g.probs = prob + 1; g.small_tile = small; g.total_tiles = gemm_tiles(M, K, small);
+    g.precision = precision;
+    SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   return SUMK_OK;
 }

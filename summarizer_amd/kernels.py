@@ -361,3 +361,99 @@ def transformer_backward_packed(x, sb, params, grads, n_layers, n_heads, dff, op
                                        C.cast(C.pointer(ghead), C.c_void_p), _p(dx), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "sumk_transformer_backward")
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ unidirectional LSTM layer / dense layer
+def _lstm_dir_struct(cls, tensors):
+    s = cls()
+    for f, t in zip(("w_ih", "w_hh", "b_ih", "b_hh"), tensors):
+        _require_gpu(t, f"LSTM {f}")
+        if not t.is_contiguous():
+            raise SumkError(f"LSTM {f} must be contiguous")
+        setattr(s, f, t.data_ptr())
+    return s
+
+
+def _state(t, n_seq, H, what):
+    if t is None:
+        return None
+    _require_gpu(t, what)
+    if tuple(t.shape) != (n_seq, H) or not t.is_contiguous():
+        raise SumkError(f"{what} must be contiguous ({n_seq}, {H}), got {tuple(t.shape)}")
+    return t
+
+
+def lstm_layer_forward(x, sb, weights, H, h0=None, c0=None, training=False, precision=None):
+    """One forward-running LSTM layer (nn.LSTM(bidirectional=False) semantics) on a packed batch.
+    x (n_rows, In); weights = (w_ih (4H,In), w_hh (4H,H), b_ih, b_hh); h0 / c0 (n_seq, H) or None.
+    Returns (h_out (n_rows, H), h_last (n_seq, H), c_last (n_seq, H), workspace or None)."""
+    lib = _lib.load()
+    _require_gpu(x, "lstm input")
+    if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
+        raise SumkError(f"lstm input must be contiguous (n_rows={sb.n_rows}, In), got {tuple(x.shape)}")
+    In = x.shape[1]
+    w = _lstm_dir_struct(_lib.LstmDirWeights, weights)
+    h0, c0 = _state(h0, sb.n_seq, H, "h0"), _state(c0, sb.n_seq, H, "c0")
+    nbytes = lib.sumk_lstm_workspace_bytes(In, H, sb.n_seq, sb.off_host_p, int(training))
+    if nbytes == 0:
+        _lib.check(-1, "sumk_lstm_workspace_bytes")
+    ws = workspace(nbytes, x.device, persistent=training)
+    h = torch.empty(sb.n_rows, H, dtype=torch.float32, device=x.device)
+    h_last = torch.empty(sb.n_seq, H, dtype=torch.float32, device=x.device)
+    c_last = torch.empty(sb.n_seq, H, dtype=torch.float32, device=x.device)
+    rc = lib.sumk_lstm_layer_forward(_p(x), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), _p(h0), _p(c0), _p(h),
+                                     _p(h_last), _p(c_last), _p(ws), ws.numel(), int(training), precision_code(precision), _stream())
+    _lib.check(rc, "sumk_lstm_layer_forward")
+    return h, h_last, c_last, (ws if training else None)
+
+
+def lstm_layer_backward(x, h, dh, dh_last, dc_last, sb, weights, c0, grads, H, ws, want_dx, want_d0, precision=None):
+    """BPTT of one forward-running layer; ACCUMULATES into grads = (dw_ih, dw_hh, db_ih, db_hh).  dh (n_rows, H), dh_last,
+    dc_last (n_seq, H) may be None.  Returns (dx or None, dh0 or None, dc0 or None)."""
+    lib = _lib.load()
+    In = x.shape[1]
+    w = _lstm_dir_struct(_lib.LstmDirWeights, weights)
+    g = _lstm_dir_struct(_lib.LstmDirGrads, grads)
+    dx = torch.empty_like(x) if want_dx else None
+    dh0 = torch.empty(sb.n_seq, H, dtype=torch.float32, device=x.device) if want_d0 else None
+    dc0 = torch.empty(sb.n_seq, H, dtype=torch.float32, device=x.device) if want_d0 else None
+    dh = dh.contiguous() if dh is not None else None
+    dh_last = dh_last.contiguous() if dh_last is not None else None
+    dc_last = dc_last.contiguous() if dc_last is not None else None
+    rc = lib.sumk_lstm_layer_backward(_p(x), _p(h), _p(dh), _p(dh_last), _p(dc_last), In, H, sb.n_seq, sb.off_host_p, sb.off_dev_p,
+                                      C.byref(w), _p(c0), C.byref(g), _p(dx), _p(dh0), _p(dc0), _p(ws), ws.numel(),
+                                      precision_code(precision), _stream())
+    _lib.check(rc, "sumk_lstm_layer_backward")
+    return dx, dh0, dc0
+
+
+def _linear_ws(N, K, device):
+    nb = _lib.load().sumk_linear_workspace_bytes(N, K)
+    return torch.empty(nb, dtype=torch.uint8, device=device)
+
+
+def linear_forward(x, w, b, precision=None):
+    """y (M, N) = x (M, K) w^T + b, w (N, K) as in nn.Linear."""
+    lib = _lib.load()
+    _require_gpu(x, "linear input")
+    x = x.contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    ws = _linear_ws(N, K, x.device)
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    _lib.check(lib.sumk_linear_forward(_p(x), _p(w), _p(b), _p(y), M, N, K, _p(ws), ws.numel(), precision_code(precision), _stream()),
+               "sumk_linear_forward")
+    return y
+
+
+def linear_backward(x, w, dy, dw, db, want_dx, precision=None):
+    """dw (N, K) / db (N) ACCUMULATED if given; returns dx (M, K) or None."""
+    lib = _lib.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    ws = _linear_ws(N, K, x.device)
+    dx = torch.empty_like(x) if want_dx else None
+    _lib.check(lib.sumk_linear_backward(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), _p(ws), ws.numel(),
+                                        precision_code(precision), _stream()), "sumk_linear_backward")
+    return dx

@@ -27,3 +27,24 @@ def bilstm_scores(model, xp, sb, prefix, num_layers, H, head_w, head_b):
     for layer in range(num_layers):
         h, _ = kernels.bilstm_layer_forward(h, sb, p, prefix, layer, H, training=False, precision=precision)
     return kernels.frame_head_forward(h, p[head_w], p[head_b])
+
+
+def lstm_stack(lstm, xp, sb, h0=None, c0=None, precision="fp32"):
+    """nn.LSTM(bidirectional=False) container `lstm` applied to packed rows xp: -> (out (n_rows, H), h_n, c_n (L, n_seq, H)).
+    The nn.LSTM object only holds the parameters (same names / shapes / init as the reference); it is never called."""
+    H, L = lstm.hidden_size, lstm.num_layers
+    params = []
+    for l in range(L):
+        params += [getattr(lstm, f"weight_ih_l{l}"), getattr(lstm, f"weight_hh_l{l}"), getattr(lstm, f"bias_ih_l{l}"),
+                   getattr(lstm, f"bias_hh_l{l}")]
+    needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or xp.requires_grad or
+                                              (h0 is not None and h0.requires_grad) or (c0 is not None and c0.requires_grad))
+    if needs_grad:
+        from ..autograd import LstmStackFunction
+        return LstmStackFunction.apply(xp, sb, H, precision, h0, c0, *params)
+    h, hn, cn = xp, [], []
+    for l in range(L):
+        h, hl, cl, _ = kernels.lstm_layer_forward(h, sb, params[4 * l:4 * l + 4], H, None if h0 is None else h0[l].contiguous(),
+                                                  None if c0 is None else c0[l].contiguous(), training=False, precision=precision)
+        hn.append(hl); cn.append(cl)
+    return h, torch.stack(hn), torch.stack(cn)
