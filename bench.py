@@ -87,6 +87,54 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames):
                 note="products as bf16 hi/lo splits (3 bf16 MFMAs), fp32 accumulate; select with --precision bf16x3")
 
 
+def bench_sumgan(args, dev, rank, world, dist):
+    """One step = the three updates of ONE video (T = 300, D = 1024) through SumGANTrainer.train_video at the reference's
+    default sizes.  Non-headline: reported as frames of the video per second."""
+    assert args.mode == "train", "--model sumgan measures the training step (scoring is --model slstm)"
+    import recipes as R
+    from summarizer_amd.models.sumgan import SumGANTrainer
+    from summarizer_amd.utils.datasets import DictDataset
+    from summarizer_amd.utils.hps import make_hps
+    T, D = 300, 1024
+    hps = make_hps(DictDataset({}), [{"train_keys": [], "test_keys": []}], epochs=1, extra_params={})
+    torch.manual_seed(1234)
+    tr = SumGANTrainer(hps, hps.splits_files[0]).reset()
+    tr.model.train()
+    tr.setup_optimizers()
+    x = torch.from_numpy(R.features(T, 1, D, 1000 * rank)).to(dev)
+    y = torch.rand(T, 1, 1, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        vals = tr.train_video(x, y, noisy=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vals = tr.train_video(x, y, noisy=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(bool(torch.isfinite(v).all()) for v in vals)
+    if rank == 0:
+        n_params = sum(p.numel() for p in tr.model.parameters())
+        print(json.dumps(dict(metric="frames scored/sec (T x 1024)", value=round(T * world * args.steps / elapsed, 1), unit="frames/s",
+                              n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                              config=dict(workload=f"sumgan train: one video (T={T}, D={D}) per step = selector+encoder, decoder and "
+                                                   f"discriminator updates, reference default sizes ({n_params/1e6:.0f} M parameters)",
+                                          frames_per_step_per_gpu=T, parallelism=f"replicas x{world}"),
+                              roofline=None, note="non-headline mode (SURVEY section 8f rank 4)")), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,8 +142,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer"], default="vasnet",
-                    help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024")
+    ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer", "sumgan"], default="vasnet",
+                    help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024; "
+                         "sumgan (--mode train only) = one SumGANTrainer video step: selector+encoder, decoder and "
+                         "discriminator updates at the reference's default sizes (350 M parameters)")
     ap.add_argument("--mode", choices=["score", "train", "reinforce", "stream"], default="score",
                     help="headline = score (frames scored/sec, features resident in HBM); train = MSE step; reinforce = DSN "
                          "REINFORCE step (BASELINE config 4); stream = PCIe-inclusive scoring: features start in pageable host "
@@ -123,6 +173,8 @@ def main():
     from summarizer_amd.models.vasnet import VASNet
     lib = _lib.load()
 
+    if args.model == "sumgan":
+        return bench_sumgan(args, dev, rank, world, dist)
     D = 1024
     lens = tvsum_lens(args.videos)
     if args.workload == "stress":

@@ -146,6 +146,19 @@ int sumk_lstm_layer_backward(const float* x, const float* h_out, const float* dh
                              const sumk_lstm_dir_weights* w, const float* c0, const sumk_lstm_dir_grads* grads, float* dx,
                              float* dh0, float* dc0, void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
 
+/* Step-wise decoder = SumGAN's dLSTM (sumgan.py:75-111): an n_layers-deep forward-running LSTM (input size == H) whose
+ * input at step t is its own top-layer output of step t-1 (zeros at t = 0), started from (h0, c0) (n_layers, n_seq, H) or
+ * NULL.  out (n_rows, H) = top-layer outputs in time order (the module flips them, sumgan.py:110).  w / grads: n_layers
+ * entries.  backward: needs the forward's workspace and out; grads ACCUMULATE; dh0 / dc0 (n_layers, n_seq, H) or NULL. */
+size_t sumk_lstm_decoder_workspace_bytes(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host);
+int sumk_lstm_decoder_forward(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                              const sumk_lstm_dir_weights* w, const float* h0, const float* c0, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                               const sumk_lstm_dir_weights* w, const float* c0, const float* out, const float* dout,
+                               const sumk_lstm_dir_grads* grads, float* dh0, float* dc0, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* Dense layer y (M,N) = x (M,K) w^T + b for the small Linear layers around the LSTM stacks (sumgan.py:59-60,86); w is (N,K)
  * as in nn.Linear, b may be NULL.  backward: dx (M,K) written if non-NULL, dw (N,K) / db (N) ACCUMULATED if non-NULL. */
 size_t sumk_linear_workspace_bytes(int32_t N, int32_t K);

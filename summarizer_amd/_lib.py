@@ -93,6 +93,12 @@ _SIGS = {
     "sumk_lstm_layer_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P,
                                            c_i32p, C.POINTER(LstmDirWeights), c_f32p, C.POINTER(LstmDirGrads), c_f32p, c_f32p,
                                            c_f32p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "sumk_lstm_decoder_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P]),
+    "sumk_lstm_decoder_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(LstmDirWeights), c_f32p,
+                                            c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sumk_lstm_decoder_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(LstmDirWeights), c_f32p,
+                                             c_f32p, c_f32p, C.POINTER(LstmDirGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p]),
     "sumk_linear_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sumk_linear_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                       C.c_int32, C.c_void_p]),

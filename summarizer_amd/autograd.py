@@ -201,3 +201,33 @@ class FrameHeadFunction(torch.autograd.Function):
         dh = kernels.frame_head_backward(h, s, ds, w, grads["w"], grads["b"])
         ctx.params = None
         return dh, ret[0], ret[1]
+
+
+class LstmDecoderFunction(torch.autograd.Function):
+    """SumGAN's step-wise dLSTM loop (sumgan.py:98-109) as one op: (h0, c0 (L, n_seq, H), *params) -> top-layer outputs
+    (n_rows, H) in time order."""
+
+    @staticmethod
+    def forward(ctx, sb, H, h0, c0, *params):
+        L = len(params) // 4
+        layers = [params[4 * l:4 * l + 4] for l in range(L)]
+        h0c = None if h0 is None else h0.contiguous()
+        c0c = None if c0 is None else c0.contiguous()
+        out, ws = kernels.lstm_decoder_forward(sb, layers, H, h0c, c0c)
+        ctx.meta = (sb, H, L, h0 is not None, c0 is not None)
+        ctx.ws, ctx.params, ctx.c0 = ws, params, (None if c0c is None else c0c.detach())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sb, H, L, has_h0, has_c0 = ctx.meta
+        (out,) = ctx.saved_tensors
+        params = ctx.params
+        grads, ret = _grad_targets([str(i) for i in range(len(params))], params)
+        want_d0 = (has_h0 and ctx.needs_input_grad[2]) or (has_c0 and ctx.needs_input_grad[3])
+        dh0, dc0 = kernels.lstm_decoder_backward(sb, [params[4 * l:4 * l + 4] for l in range(L)], H, ctx.c0, out, dout,
+                                                 [[grads[str(4 * l + i)] for i in range(4)] for l in range(L)], ctx.ws, want_d0)
+        ctx.ws = ctx.params = None
+        return (None, None, dh0 if (has_h0 and ctx.needs_input_grad[2]) else None,
+                dc0 if (has_c0 and ctx.needs_input_grad[3]) else None) + tuple(ret)

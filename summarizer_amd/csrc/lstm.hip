@@ -1349,6 +1349,314 @@ extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, cons
   return SUMK_OK;
 }
 
+// ------------------------------------------------------------------------------------------- step-wise decoder
+// SumGAN's dLSTM (summarizer/models/sumgan.py:75-111): an L-layer forward-running LSTM driven one step at a time, whose
+// input at step t is its own top-layer output of step t-1 (zeros at t = 0) -- so no input projection can be hoisted and
+// every (layer, step) is a cell with TWO mat-vecs:  pre = W_ih a1 + W_hh a2 + b_ih + b_hh  with
+//   a1 = h_{top}[t-1] (layer 0)  or  h_{l-1}[t] (layer l > 0),   a2 = h_l[t-1]  (h0_l at t = 0).
+// One launch per (layer, step); block = (32 sequences) x (8 hidden units x 4 gates), 4 waves split K, fragments straight
+// from memory, exactly like lstm_step_kernel.  Everything the backward pass needs is kept per row.
+struct DecStepArgs {
+  const float* a1;       // (R, H) source rows of the first operand, or nullptr (layer 0 at t = 0: zeros)
+  int32_t a1_shift;      // row offset of a1 relative to this step's row: -1 (previous step) or 0 (same step)
+  const float* w1;       // (4H, H)
+  const float* w2;       // (4H, H)
+  const float* b1; const float* b2;   // (4H)
+  const float* h0; const float* c0;   // (n_seq, H) or nullptr
+  float* hseq;           // (R, H) this layer's outputs (a2 = previous row)
+  float* c_all;          // (R, H)
+  float* gates;          // (R, 4H)
+  float* hprev;          // (R, H) a2 as used (for dW_hh)
+  float* xin;            // (R, H) a1 as used (for dW_ih), or nullptr when a1 rows are addressable directly
+  const int32_t* off;
+  int32_t n_seq, H, t, n_ublk;
+};
+
+__global__ __launch_bounds__(256) void lstm_dec_step_kernel(DecStepArgs a) {
+  __shared__ float part[4][32][33];
+  const int H = a.H, t = a.t;
+  const int ublk = blockIdx.x % a.n_ublk, mtile = blockIdx.x / a.n_ublk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int j0 = ublk * 8;
+  {
+    const int sv = mtile * 32 + li;
+    bool act = false;
+    int64_t row = 0;
+    if (sv < a.n_seq) { const int r0 = a.off[sv], T = a.off[sv + 1] - r0; if (t < T) { act = true; row = r0 + t; } }
+    const float* p1 = (act && a.a1 && (a.a1_shift == 0 || t > 0)) ? a.a1 + (row + a.a1_shift) * H : nullptr;
+    const float* p2 = act ? (t > 0 ? a.hseq + (row - 1) * H : (a.h0 ? a.h0 + (int64_t)sv * H : nullptr)) : nullptr;
+    const int gcol = li >> 3, unit = min(j0 + (li & 7), H - 1);
+    const float* wp1 = a.w1 + (int64_t)(gcol * H + unit) * H;
+    const float* wp2 = a.w2 + (int64_t)(gcol * H + unit) * H;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = (H + 7) >> 3;
+    for (int pair = 0; pair < 2; ++pair) {
+      const float* ap = pair == 0 ? p1 : p2;
+      const float* wp = pair == 0 ? wp1 : wp2;
+      const float* asafe = ap ? ap : wp;           // a legal address for the unconditional loads; masked below
+      for (int kb = wave; kb < nchunk; kb += 16) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kc = min((kb + 4 * q) * 8 + 4 * lh, H - 4);
+          bv[q] = *reinterpret_cast<const float4*>(wp + kc);
+          av[q] = *reinterpret_cast<const float4*>(asafe + kc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = (kb + 4 * q) * 8 + 4 * lh;
+          if (ap == nullptr || k >= H) av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k >= H) bv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+    __syncthreads();
+  }
+  const int i = tid >> 3, u = tid & 7;
+  const int sv = mtile * 32 + i, j = j0 + u;
+  if (sv >= a.n_seq || j >= H) return;
+  const int r0 = a.off[sv], T = a.off[sv + 1] - r0;
+  if (t >= T) return;
+  const int64_t row = r0 + t;
+  float pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    pre[q] = a.b1[q * H + j] + a.b2[q * H + j] +
+             ((part[0][i][q * 8 + u] + part[1][i][q * 8 + u]) + (part[2][i][q * 8 + u] + part[3][i][q * 8 + u]));
+  const float cprev = t > 0 ? a.c_all[(row - 1) * H + j] : (a.c0 ? a.c0[(int64_t)sv * H + j] : 0.f);
+  const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+  const float c = fg * cprev + ig * gg;
+  const float h = og * tanhf(c);
+  a.hprev[row * H + j] = t > 0 ? a.hseq[(row - 1) * H + j] : (a.h0 ? a.h0[(int64_t)sv * H + j] : 0.f);
+  if (a.xin) a.xin[row * H + j] = (a.a1 && (a.a1_shift == 0 || t > 0)) ? a.a1[(row + a.a1_shift) * H + j] : 0.f;
+  a.hseq[row * H + j] = h;
+  a.c_all[row * H + j] = c;
+  float* gs = a.gates + row * 4 * H;
+  gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
+}
+
+// Backward of one (layer, step), run for t = T-1 .. 0 (and t = -1 for the initial-state gradients).
+//   dh[i][j] = dext[row][j] + sum_k dGa[row + 1][k] Wa[k][j]  (pair A: own recurrence, needs step t+1)
+//                           + sum_k dGb[row + sb][k] Wb[k][j]  (pair B: the consumer of this output: the layer above at the same
+//                                                               step (sb = 0) or layer 0 at the next step (sb = 1))
+struct DecBwdArgs {
+  const float* dext;     // (R, H) external gradient of this layer's outputs, or nullptr
+  const float* dGa; const float* wa;                     // own dG (R, 4H) and W_hh (4H, H)
+  const float* dGb; const float* wb; int32_t b_shift;    // consumer's dG and W_ih; nullptr = none
+  const float* gates; const float* c_all; const float* c0;
+  float* dG;             // (R, 4H) output
+  float* dcstate;        // (n_seq, H)
+  float* dh0; float* dc0;// (n_seq, H) outputs of the pass t = -1
+  const int32_t* off;
+  int32_t n_seq, H, t, n_jblk;
+};
+
+__global__ __launch_bounds__(512) void lstm_dec_bwd_step_kernel(DecBwdArgs a) {
+  __shared__ float part[8][32][33];
+  const int H = a.H, H4 = 4 * H, t = a.t;
+  const int jblk = blockIdx.x % a.n_jblk, mtile = blockIdx.x / a.n_jblk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int j0 = jblk * 32;
+  {
+    const int sv = mtile * 32 + li;
+    const float* pa = nullptr; const float* pb = nullptr;
+    if (sv < a.n_seq) {
+      const int r0 = a.off[sv], T = a.off[sv + 1] - r0;
+      if (t + 1 < T) pa = a.dGa + (int64_t)(r0 + t + 1) * H4;
+      if (a.dGb && t >= 0 && t + a.b_shift < T) pb = a.dGb + (int64_t)(r0 + t + a.b_shift) * H4;
+    }
+    const int jc = min(j0 + li, H - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = H4 >> 3;
+    for (int pair = 0; pair < 2; ++pair) {
+      const float* gp = pair == 0 ? pa : pb;
+      const float* wsrc = pair == 0 ? a.wa : a.wb;
+      if (wsrc == nullptr) continue;                 // (uniform: kernel argument)
+      const float* wp = wsrc + jc;
+      const float* gsafe = gp ? gp : a.dGa;
+      for (int kb = wave; kb < nchunk; kb += 32) {
+        float4 av[4];
+        float bq[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = min((kb + 8 * q) * 8 + 4 * lh, H4 - 4);
+          av[q] = *reinterpret_cast<const float4*>(gsafe + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bq[q][e] = wp[(int64_t)(k + e) * H];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool live = gp != nullptr && (kb + 8 * q) < nchunk;
+          if (!live) av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bq[q][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bq[q][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bq[q][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bq[q][3], acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int i = (tid >> 5) + 16 * rep, u = tid & 31;
+    const int sv = mtile * 32 + i, j = j0 + u;
+    if (sv >= a.n_seq || j >= H) continue;
+    const int r0 = a.off[sv], T = a.off[sv + 1] - r0;
+    if (t >= T) continue;
+    float rec = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) rec += part[w8][i][u];
+    float* dcs = a.dcstate + (int64_t)sv * H + j;
+    if (t < 0) {
+      if (a.dh0) a.dh0[(int64_t)sv * H + j] = rec;
+      if (a.dc0) a.dc0[(int64_t)sv * H + j] = *dcs;
+      continue;
+    }
+    const int64_t row = r0 + t;
+    const float dh = (a.dext ? a.dext[row * H + j] : 0.f) + rec;
+    const float* gs = a.gates + row * H4;
+    const float ig = gs[j], fg = gs[H + j], gg = gs[2 * H + j], og = gs[3 * H + j];
+    const float c = a.c_all[row * H + j];
+    const float cprev = t > 0 ? a.c_all[(row - 1) * H + j] : (a.c0 ? a.c0[(int64_t)sv * H + j] : 0.f);
+    const float tc = tanhf(c);
+    const float dc = (t + 1 < T ? *dcs : 0.f) + dh * og * (1.f - tc * tc);
+    float* dg = a.dG + row * H4;
+    dg[j] = dc * gg * ig * (1.f - ig);
+    dg[H + j] = dc * cprev * fg * (1.f - fg);
+    dg[2 * H + j] = dc * ig * (1.f - gg * gg);
+    dg[3 * H + j] = dh * tc * og * (1.f - og);
+    *dcs = dc * fg;
+  }
+}
+
+struct DecWs {
+  size_t hseq, call, gates, hprev, dg, dcstate;   // per layer: offset of layer 0, layer l at + l * stride
+  size_t s_hseq, s_gates, s_dcstate;
+  size_t xin0, slab, prob_sk, colpart, total, slab_elems;
+  int32_t n_rows, t_max;
+};
+static int dec_carve(int H, int Lr, int n_seq, const int32_t* off, DecWs* w) {
+  SUMK_ARG(H > 0 && H % 4 == 0, "lstm_decoder: hidden size %d must be a positive multiple of 4", H);
+  SUMK_ARG(Lr >= 1 && Lr <= 8, "lstm_decoder: %d layers (supported: 1..8)", Lr);
+  SUMK_ARG(n_seq > 0 && off != nullptr && off[0] == 0, "lstm_decoder: empty batch / seq_off[0] != 0");
+  int tmax = 0;
+  for (int s = 0; s < n_seq; ++s) { int T = off[s + 1] - off[s]; SUMK_ARG(T > 0, "lstm_decoder: sequence %d has %d steps", s, T); tmax = T > tmax ? T : tmax; }
+  const size_t R = (size_t)off[n_seq];
+  size_t p = 0;
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  w->n_rows = (int32_t)R; w->t_max = tmax;
+  w->s_hseq = align_up(R * H * 4, 256); w->s_gates = align_up(R * 4 * H * 4, 256); w->s_dcstate = align_up((size_t)n_seq * H * 4, 256);
+  w->hseq = take(w->s_hseq * Lr); w->call = take(w->s_hseq * Lr); w->hprev = take(w->s_hseq * Lr);
+  w->gates = take(w->s_gates * Lr); w->dg = take(w->s_gates * Lr); w->dcstate = take(w->s_dcstate * Lr);
+  w->xin0 = take(R * H * 4);
+  w->slab_elems = (size_t)8 * (4 * H) * H;
+  w->slab = take(w->slab_elems * 4);
+  w->prob_sk = take(64 * sizeof(GemmProb));
+  w->colpart = take((size_t)128 * 4 * H * 4);
+  w->total = p;
+  return SUMK_OK;
+}
+
+extern "C" size_t sumk_lstm_decoder_workspace_bytes(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host) {
+  DecWs w;
+  if (dec_carve(H, n_layers, n_seq, seq_off_host, &w) != SUMK_OK) return 0;
+  return w.total;
+}
+
+extern "C" int sumk_lstm_decoder_forward(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host,
+                                         const int32_t* seq_off_dev, const sumk_lstm_dir_weights* w, const float* h0,
+                                         const float* c0, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(seq_off_dev && w && out && workspace, "lstm_decoder_forward: null pointer");
+  DecWs L;
+  SUMK_TRY(dec_carve(H, n_layers, n_seq, seq_off_host, &L));
+  for (int l = 0; l < n_layers; ++l) SUMK_ARG(w[l].w_ih && w[l].w_hh && w[l].b_ih && w[l].b_hh, "lstm_decoder_forward: null weight (layer %d)", l);
+  if (workspace_bytes < L.total) { set_error("lstm_decoder_forward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
+  char* ws = (char*)workspace;
+  const int top = n_layers - 1;
+  auto hseq = [&](int l) { return l == top ? out : (float*)(ws + L.hseq + L.s_hseq * l); };   // the top layer writes the output itself
+  DecStepArgs a;
+  a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_ublk = (H + 7) / 8;
+  const dim3 grid((unsigned)(((n_seq + 31) / 32) * a.n_ublk)), block(256);
+  for (int t = 0; t < L.t_max; ++t) {
+    a.t = t;
+    for (int l = 0; l < n_layers; ++l) {
+      a.a1 = l == 0 ? hseq(top) : hseq(l - 1); a.a1_shift = l == 0 ? -1 : 0;
+      a.w1 = w[l].w_ih; a.w2 = w[l].w_hh; a.b1 = w[l].b_ih; a.b2 = w[l].b_hh;
+      a.h0 = h0 ? h0 + (size_t)l * n_seq * H : nullptr; a.c0 = c0 ? c0 + (size_t)l * n_seq * H : nullptr;
+      a.hseq = hseq(l); a.c_all = (float*)(ws + L.call + L.s_hseq * l); a.gates = (float*)(ws + L.gates + L.s_gates * l);
+      a.hprev = (float*)(ws + L.hprev + L.s_hseq * l); a.xin = l == 0 ? (float*)(ws + L.xin0) : nullptr;
+      hipLaunchKernelGGL(lstm_dec_step_kernel, grid, block, 0, stream, a);
+    }
+  }
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+extern "C" int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host,
+                                          const int32_t* seq_off_dev, const sumk_lstm_dir_weights* w, const float* c0,
+                                          const float* out, const float* dout, const sumk_lstm_dir_grads* gr, float* dh0,
+                                          float* dc0, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(seq_off_dev && w && out && dout && gr && workspace, "lstm_decoder_backward: null pointer");
+  DecWs L;
+  SUMK_TRY(dec_carve(H, n_layers, n_seq, seq_off_host, &L));
+  if (workspace_bytes < L.total) { set_error("lstm_decoder_backward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
+  char* ws = (char*)workspace;
+  const int R = L.n_rows, top = n_layers - 1;
+  auto dG = [&](int l) { return (float*)(ws + L.dg + L.s_gates * l); };
+  auto hseq = [&](int l) { return l == top ? out : (const float*)(ws + L.hseq + L.s_hseq * l); };
+  DecBwdArgs a;
+  a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_jblk = (H + 31) / 32;
+  const dim3 grid((unsigned)(((n_seq + 31) / 32) * a.n_jblk)), block(512);
+  const bool want0 = dh0 || dc0;
+  for (int t = L.t_max - 1; t >= (want0 ? -1 : 0); --t) {
+    a.t = t;
+    for (int l = top; l >= 0; --l) {
+      a.dext = l == top ? dout : nullptr;
+      a.dGa = dG(l); a.wa = w[l].w_hh;
+      if (l == top) { a.dGb = dG(0); a.wb = w[0].w_ih; a.b_shift = 1; }          // x_{t+1} = h_top[t] feeds layer 0 at the next step
+      else { a.dGb = dG(l + 1); a.wb = w[l + 1].w_ih; a.b_shift = 0; }            // feeds the layer above at the same step
+      a.gates = (const float*)(ws + L.gates + L.s_gates * l); a.c_all = (const float*)(ws + L.call + L.s_hseq * l);
+      a.c0 = c0 ? c0 + (size_t)l * n_seq * H : nullptr;
+      a.dG = dG(l); a.dcstate = (float*)(ws + L.dcstate + L.s_dcstate * l);
+      a.dh0 = dh0 ? dh0 + (size_t)l * n_seq * H : nullptr; a.dc0 = dc0 ? dc0 + (size_t)l * n_seq * H : nullptr;
+      hipLaunchKernelGGL(lstm_dec_bwd_step_kernel, grid, block, 0, stream, a);
+    }
+  }
+  SUMK_HIP(hipGetLastError());
+  float* slab = (float*)(ws + L.slab);
+  GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
+  float* colpart = (float*)(ws + L.colpart);
+  for (int l = 0; l < n_layers; ++l) {
+    SUMK_ARG(gr[l].w_ih && gr[l].w_hh && gr[l].b_ih && gr[l].b_hh, "lstm_decoder_backward: null grad (layer %d)", l);
+    const float* xin = l == 0 ? (const float*)(ws + L.xin0) : hseq(l - 1);
+    { float* o[4] = {gr[l].w_ih, nullptr, nullptr, nullptr};
+      SUMK_TRY(gemm_tn_splitk_accum(dG(l), 4 * H, xin, H, 4 * H, H, R, slab, L.slab_elems, psk, 64, o, 4 * H, H, 1.f, stream)); }
+    { float* o[4] = {gr[l].w_hh, nullptr, nullptr, nullptr};
+      SUMK_TRY(gemm_tn_splitk_accum(dG(l), 4 * H, (const float*)(ws + L.hprev + L.s_hseq * l), H, 4 * H, H, R, slab, L.slab_elems, psk, 64, o,
+                                    4 * H, H, 1.f, stream)); }
+    SUMK_TRY(colsum_accum(dG(l), 4 * H, R, 4 * H, colpart, 128, gr[l].b_ih, stream));
+    SUMK_TRY(colsum_accum(dG(l), 4 * H, R, 4 * H, colpart, 128, gr[l].b_hh, stream));
+  }
+  return SUMK_OK;
+}
+
 // ------------------------------------------------------------------------------------------- dense layer
 // y = x W^T + b and its backward, for the small Linear layers around the LSTM stacks (eLSTM mu / logvar, dLSTM recons:
 // sumgan.py:59-60,86) -- the MFMA GEMM with the bias in its epilogue, split-K weight gradient, column-sum bias gradient.

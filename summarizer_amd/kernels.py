@@ -457,3 +457,49 @@ def linear_backward(x, w, dy, dw, db, want_dx, precision=None):
     _lib.check(lib.sumk_linear_backward(_p(x), _p(w), _p(dy), M, N, K, _p(dx), _p(dw), _p(db), _p(ws), ws.numel(),
                                         precision_code(precision), _stream()), "sumk_linear_backward")
     return dx
+
+
+def _dir_array(cls, per_layer):
+    arr = (cls * len(per_layer))()
+    for l, tensors in enumerate(per_layer):
+        for f, t in zip(("w_ih", "w_hh", "b_ih", "b_hh"), tensors):
+            _require_gpu(t, f"decoder LSTM {f} (layer {l})")
+            if not t.is_contiguous():
+                raise SumkError(f"decoder LSTM {f} (layer {l}) must be contiguous")
+            setattr(arr[l], f, t.data_ptr())
+    return arr
+
+
+def lstm_decoder_forward(sb, layers, H, h0=None, c0=None):
+    """Step-wise autoregressive decoder (SumGAN's dLSTM): layers = [(w_ih (4H,H), w_hh, b_ih, b_hh)] * L; h0 / c0 (L, n_seq, H)
+    or None.  Returns (top-layer outputs (n_rows, H) in time order, workspace)."""
+    lib = _lib.load()
+    L = len(layers)
+    dev = layers[0][0].device
+    w = _dir_array(_lib.LstmDirWeights, layers)
+    for name, t in (("h0", h0), ("c0", c0)):
+        if t is not None:
+            _require_gpu(t, f"decoder {name}")
+            if tuple(t.shape) != (L, sb.n_seq, H) or not t.is_contiguous():
+                raise SumkError(f"decoder {name} must be contiguous ({L}, {sb.n_seq}, {H}), got {tuple(t.shape)}")
+    nbytes = lib.sumk_lstm_decoder_workspace_bytes(H, L, sb.n_seq, sb.off_host_p)
+    if nbytes == 0:
+        _lib.check(-1, "sumk_lstm_decoder_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(sb.n_rows, H, dtype=torch.float32, device=dev)
+    _lib.check(lib.sumk_lstm_decoder_forward(H, L, sb.n_seq, sb.off_host_p, sb.off_dev_p, w, _p(h0), _p(c0), _p(out), _p(ws), nbytes,
+                                             _stream()), "sumk_lstm_decoder_forward")
+    return out, ws
+
+
+def lstm_decoder_backward(sb, layers, H, c0, out, dout, grads, ws, want_d0):
+    """grads = [(dw_ih, dw_hh, db_ih, db_hh)] * L, ACCUMULATED.  Returns (dh0, dc0) (L, n_seq, H) or (None, None)."""
+    lib = _lib.load()
+    L = len(layers)
+    w = _dir_array(_lib.LstmDirWeights, layers)
+    g = _dir_array(_lib.LstmDirGrads, grads)
+    dh0 = torch.empty(L, sb.n_seq, H, dtype=torch.float32, device=out.device) if want_d0 else None
+    dc0 = torch.empty(L, sb.n_seq, H, dtype=torch.float32, device=out.device) if want_d0 else None
+    _lib.check(lib.sumk_lstm_decoder_backward(H, L, sb.n_seq, sb.off_host_p, sb.off_dev_p, w, _p(c0), _p(out), _p(dout.contiguous()), g,
+                                              _p(dh0), _p(dc0), _p(ws), ws.numel(), _stream()), "sumk_lstm_decoder_backward")
+    return dh0, dc0

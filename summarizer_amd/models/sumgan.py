@@ -1,13 +1,18 @@
 """SumGAN's LSTM modules on MI355X (`summarizer/models/sumgan.py`): the sLSTM selector -- the scorer, `SumGAN.forward` is
-exactly `s_lstm(x)` (sumgan.py:23-46,251-258) -- and the forward-running stacks of the VAE / GAN side: eLSTM (sumgan.py:48-73)
-and cLSTM / GAN (sumgan.py:213-250).  Same constructors, forward signatures and state_dict keys; every module is
-differentiable through the HIP backward kernels, so a reference-style training loop can call `.backward()` on losses built
-from their outputs.  The GAN training harness itself (SumGANTrainer, sumgan.py:262-533) is not mirrored."""
+exactly `s_lstm(x)` (sumgan.py:23-46,251-258) -- and the forward-running stacks of the VAE / GAN side: eLSTM (sumgan.py:48-73),
+the step-wise decoder dLSTM (sumgan.py:75-111), VAE, Summarizer, cLSTM / GAN and the SumGAN container (sumgan.py:113-258).  Same constructors, forward signatures and state_dict keys; every module is
+differentiable through the HIP backward kernels.  `SumGANTrainer` follows the reference trainer (sumgan.py:262-533): VAE
+pre-training, then per video the selector+encoder, decoder and discriminator updates with their three Adam optimisers."""
+import random
+
+import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import kernels
+from . import Trainer
 from ._bilstm import pack_time_major, bilstm_scores, lstm_stack
+from ..training import FlatAdam
 
 
 class sLSTM(nn.Module):
@@ -58,6 +63,70 @@ class eLSTM(nn.Module):
         return (h_mu, h_logvar), c_last
 
 
+class dLSTM(nn.Module):
+    def __init__(self, input_size=1024, hidden_size=2048, num_layers=2):
+        """Decoder LSTM"""
+        super().__init__()
+        self.precision = "fp32"
+        self.lstm = nn.LSTM(input_size=hidden_size, hidden_size=hidden_size, num_layers=num_layers, bidirectional=False)
+        self.recons = nn.Linear(hidden_size, input_size)
+
+    def forward(self, seq_len, h_0, c_0):
+        """Decode the entire sequence (the reference's step-by-step loop, sumgan.py:98-111, as ONE op).
+        h_0, c_0: (num_layers, batch_size, hidden_size) -> x_hat: (seq_len, batch_size, input_size)"""
+        from ..autograd import LstmDecoderFunction, LinearFunction
+        kernels._require_gpu(h_0, "dLSTM.forward")
+        B, H, L = h_0.size(1), h_0.size(2), self.lstm.num_layers
+        sb = kernels.SeqBatch.get([int(seq_len)] * B, h_0.device)
+        params = []
+        for l in range(L):
+            params += [getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}"),
+                       getattr(self.lstm, f"bias_ih_l{l}"), getattr(self.lstm, f"bias_hh_l{l}")]
+        rows = LstmDecoderFunction.apply(sb, H, h_0, c_0, *params)                  # (B*T, H) batch-major, time order
+        x_hat = LinearFunction.apply(rows, self.recons.weight, self.recons.bias, self.precision)
+        return torch.flip(_unpack_time_major(x_hat, int(seq_len), B), (0,))         # reverse (sumgan.py:110)
+
+
+class VAE(nn.Module):
+    def __init__(self, input_size=1024, hidden_size=2048, num_layers=2):
+        """Variational Auto Encoder LSTM"""
+        super().__init__()
+        self.e_lstm = eLSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+        self.d_lstm = dLSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers)
+
+    def reparameterize(self, mu, logvar):
+        std = torch.exp(0.5 * logvar)
+        eps = torch.randn_like(std)
+        return mu + eps * std
+
+    def forward(self, x):
+        """x: (seq_len, batch_size, input_size) -> x_hat (seq_len, batch_size, input_size), (h_mu, h_logvar)"""
+        (h_mu, h_logvar), c = self.e_lstm(x)
+        h = self.reparameterize(h_mu, h_logvar)
+        x_hat = self.d_lstm(x.size(0), h, c)
+        return x_hat, (h_mu, h_logvar)
+
+
+class Summarizer(nn.Module):
+    def __init__(self, input_size=1024, sLSTM_hidden_size=1024, sLSTM_num_layers=2, edLSTM_hidden_size=2048,
+                 edLSTM_num_layers=2):
+        """Summarizer: Selector (sLSTM) + VAE (eLSTM/dLSTM)."""
+        super().__init__()
+        self.s_lstm = sLSTM(input_size=input_size, hidden_size=sLSTM_hidden_size, num_layers=sLSTM_num_layers)
+        self.vae = VAE(input_size=input_size, hidden_size=edLSTM_hidden_size, num_layers=edLSTM_num_layers)
+
+    def forward(self, x, uniform=False):
+        """-> x_hat (seq_len, batch_size, input_size), (h_mu, h_logvar), scores (seq_len, batch_size, 1)"""
+        if uniform:
+            seq_len, batch_size, _ = x.size()
+            scores = torch.rand((seq_len, batch_size, 1)).to(x.device)
+        else:
+            scores = self.s_lstm(x)
+        x_weighted = x * scores
+        x_hat, (h_mu, h_logvar) = self.vae(x_weighted)
+        return x_hat, (h_mu, h_logvar), scores
+
+
 class cLSTM(nn.Module):
     def __init__(self, input_size=1024, hidden_size=1024, num_layers=2):
         """Discriminator as a classifier LSTM"""
@@ -85,3 +154,192 @@ class GAN(nn.Module):
 
     def forward(self, x):
         return self.c_lstm(x)
+
+
+class SumGAN(nn.Module):
+    def __init__(self, input_size=1024, sLSTM_hidden_size=1024, sLSTM_num_layers=2, edLSTM_hidden_size=2048,
+                 edLSTM_num_layers=2, cLSTM_hidden_size=1024, cLSTM_num_layers=2):
+        """SumGAN: Summarizer + GAN"""
+        super().__init__()
+        self.summarizer = Summarizer(input_size=input_size, sLSTM_hidden_size=sLSTM_hidden_size, sLSTM_num_layers=sLSTM_num_layers,
+                                     edLSTM_hidden_size=edLSTM_hidden_size, edLSTM_num_layers=edLSTM_num_layers)
+        self.gan = GAN(input_size=input_size, hidden_size=cLSTM_hidden_size, num_layers=cLSTM_num_layers)
+
+    def forward(self, x):
+        """x: (seq_len, batch_size, input_size) -> scores (seq_len, batch_size, 1)"""
+        return self.summarizer.s_lstm(x)
+
+    def score_packed(self, x_packed, lens):
+        return self.summarizer.s_lstm.score_packed(x_packed, lens)
+
+
+class SumGANTrainer(Trainer):
+    """Mirror of the reference trainer (sumgan.py:262-533), same `extra_params` (`sigma`, `input_size`, `*_hidden_size`,
+    `*_num_layers`, `sup`, `pretrain_vae`, `epoch_noise`).  Per video three updates, each with its own Adam:
+      selector + encoder:  ||phi(x) - phi(x_hat)||_2 + KL prior + sparsity (|mean(s) - sigma|, or BCE to gtscore with `sup`)
+      decoder:             ||phi(x) - phi(x_hat)||_2 + BCE(D(x_hat), 0.9) + BCE(D(x_hat_p), 0.9)      (x_hat_p: uniform scores)
+      discriminator:       BCE(D(x), 0.9) + BCE(D(x_hat), 0.1) + BCE(D(x_hat_p), 0.1)   (inputs multiplied by noise early on)
+    where phi / D are the cLSTM's last hidden state / probability.  As in the reference, `zero_grad` only clears the group
+    being updated and the gradient-norm clip (5.0) spans EVERY parameter of the model -- gradients left in the other groups
+    by earlier backward passes count towards the norm and are rescaled with it.  The optimiser math runs in the HIP Adam
+    kernel over one flat bucket per group."""
+
+    def _init_model(self):
+        ep = self.hps.extra_params
+        self.sigma = float(ep.get("sigma", 0.3))
+        self.sup = bool(ep.get("sup", False))
+        self.pretrain_vae = int(ep.get("pretrain_vae", 20))
+        self.epoch_noise = int(ep.get("epoch_noise", 0.2 * self.hps.epochs))
+        sizes = {name: int(ep.get(name, default)) for name, default in
+                 (("input_size", 1024), ("sLSTM_hidden_size", 1024), ("sLSTM_num_layers", 2), ("edLSTM_hidden_size", 2048),
+                  ("edLSTM_num_layers", 2), ("cLSTM_hidden_size", 1024), ("cLSTM_num_layers", 2))}
+        model = SumGAN(**sizes)
+        self.log.debug("Generator params: {}".format(sum(p.numel() for p in model.summarizer.parameters())))
+        self.log.debug("Discriminator params: {}".format(sum(p.numel() for p in model.gan.parameters())))
+        return model
+
+    # ---- losses (sumgan.py:288-321)
+    @staticmethod
+    def loss_recons(h_real, h_fake):
+        return torch.norm(h_real - h_fake, p=2)
+
+    @staticmethod
+    def loss_prior(mu, logvar):
+        return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
+
+    def loss_vae(self, x, x_hat, mu, logvar):
+        return self.loss_recons(x, x_hat) + self.loss_prior(mu, logvar)
+
+    @staticmethod
+    def _bce(p, label):
+        return torch.nn.functional.binary_cross_entropy(p, torch.full_like(p, label))
+
+    # ---- optimiser plumbing
+    @staticmethod
+    def _clip_all(buckets, max_norm=5.0):
+        """torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0): one norm over every bucket, every bucket rescaled."""
+        acc = torch.zeros(1, dtype=torch.float32, device=buckets[0].flat_grad.device)
+        for b in buckets:
+            kernels.sumsq(b.flat_grad, out=acc)
+        coef = min(1.0, max_norm / (float(acc.item()) ** 0.5 + 1e-6))
+        if coef < 1.0:
+            for b in buckets:
+                b.flat_grad.mul_(coef)
+
+    def _video(self, key, dev):
+        feats, target = self._video_on_device(key, dev, want_target=True)
+        return feats.unsqueeze(1), target.view(-1, 1, 1)
+
+    def pretrain(self, fold):
+        """VAE alone before the adversarial game (sumgan.py:323-360)."""
+        train_keys, _ = self._get_train_test_keys(fold)
+        dev = self._device()
+        vae = self.model.summarizer.vae
+        opt = FlatAdam(vae.parameters(), lr=self.hps.lr, weight_decay=self.hps.weight_decay)
+        for epoch in range(self.pretrain_vae):
+            losses = []
+            random.shuffle(train_keys)
+            for key in train_keys:
+                x, _ = self._video(key, dev)
+                x_hat, (mu, logvar) = vae(x)
+                loss = self.loss_vae(x, x_hat, mu, logvar)
+                opt.zero_grad()
+                loss.backward()
+                self._clip_all([opt])
+                opt.step()
+                losses.append(loss.detach())
+            if epoch % 10 == 0 or epoch == self.pretrain_vae - 1:
+                self.log.info(f"Pretrain: {epoch+1:3}/{self.pretrain_vae:3}   Lvae: {float(torch.stack(losses).mean()):.05f}")
+
+    def setup_optimizers(self):
+        """The three Adam groups of sumgan.py:372-386 as flat buckets; together they cover every parameter."""
+        summ, gan = self.model.summarizer, self.model.gan
+        mk = lambda params: FlatAdam(params, lr=self.hps.lr, weight_decay=self.hps.weight_decay)
+        self.s_e_optimizer = mk(list(summ.s_lstm.parameters()) + list(summ.vae.e_lstm.parameters()))
+        self.d_optimizer = mk(summ.vae.d_lstm.parameters())
+        self.c_optimizer = mk(gan.c_lstm.parameters())
+        self._buckets = [self.s_e_optimizer, self.d_optimizer, self.c_optimizer]
+        for b in self._buckets:
+            b.zero_grad()                                  # fresh buckets start empty, like the reference's grad=None
+
+    def _update(self, opt, loss):
+        opt.zero_grad()
+        loss.backward()
+        self._clip_all(self._buckets)
+        opt.step()
+
+    def train_video(self, x, y, noisy):
+        """The three updates of one video (sumgan.py:413-479).  x (T,1,D), y (T,1,1) normalised gtscore; `noisy`: multiply the
+        discriminator's inputs by Gaussian noise (epoch < epoch_noise).  Returns (Lse, Ld, Lc, D(x), D(x_hat), D(x_hat_p),
+        scores) as device tensors."""
+        summ, gan = self.model.summarizer, self.model.gan
+        # -- selector and encoder
+        x_hat, (mu, logvar), scores = summ(x)
+        _, h_real = gan(x)
+        _, h_fake = gan(x_hat)
+        sparsity = torch.nn.functional.binary_cross_entropy(scores, y) if self.sup else torch.abs(torch.mean(scores) - self.sigma)
+        loss_s_e = self.loss_recons(h_real, h_fake) + self.loss_prior(mu, logvar) + sparsity
+        self._update(self.s_e_optimizer, loss_s_e)
+        # -- decoder
+        x_hat, _, _ = summ(x)
+        x_hat_p, _, _ = summ(x, uniform=True)
+        _, h_real = gan(x)
+        probs_fake, h_fake = gan(x_hat)
+        probs_uniform, _ = gan(x_hat_p)
+        loss_d = self.loss_recons(h_real, h_fake) + self._bce(probs_fake, 0.9) + self._bce(probs_uniform, 0.9)
+        self._update(self.d_optimizer, loss_d)
+        # -- discriminator
+        x_hat, _, scores = summ(x)
+        x_hat_p, _, _ = summ(x, uniform=True)
+        x_real = x
+        if noisy:
+            x_real = torch.randn_like(x) * x
+            x_hat = x_hat * torch.randn_like(x_hat)
+            x_hat_p = x_hat_p * torch.randn_like(x_hat_p)
+        probs_real, _ = gan(x_real)
+        probs_fake, _ = gan(x_hat)
+        probs_uniform, _ = gan(x_hat_p)
+        loss_c = self._bce(probs_real, 0.9) + self._bce(probs_fake, 0.1) + self._bce(probs_uniform, 0.1)
+        self._update(self.c_optimizer, loss_c)
+        return (loss_s_e.detach(), loss_d.detach(), loss_c.detach(), probs_real.mean().detach(), probs_fake.mean().detach(),
+                probs_uniform.mean().detach(), scores.detach())
+
+    def train(self, fold):
+        self.model.train()
+        train_keys, _ = self._get_train_test_keys(fold)
+        self.draw_gtscores(fold, train_keys)
+        if self.pretrain_vae > 0:
+            self.pretrain(fold)
+        dev = self._device()
+        self.setup_optimizers()
+        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        tags = ("Lse", "Ld", "Lc", "D_x", "D_x_hat", "D_x_hat_p")
+        for epoch in range(self.hps.epochs):
+            log = {t: [] for t in tags}
+            dist_scores = {}
+            random.shuffle(train_keys)
+            for key in train_keys:
+                x, y = self._video(key, dev)
+                *vals, scores = self.train_video(x, y, noisy=epoch < self.epoch_noise)
+                for t, v in zip(tags, vals):
+                    log[t].append(v)
+                dist_scores[key] = scores
+            means = {t: float(torch.stack(v).mean()) for t, v in log.items()}
+            self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   " + "  ".join(
+                f"{n}: {means[t]:.05f}" for n, t in (("Lse", "Lse"), ("Ld", "Ld"), ("Lc", "Lc"), ("D(x)", "D_x"),
+                                                     ("D(x_hat)", "D_x_hat"), ("D(x_hat_p)", "D_x_hat_p"))))
+            for t in tags:
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/{t}", means[t], epoch)
+            if epoch % self.hps.test_every_epochs == 0:
+                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
+                self.model.train()
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/Correlation", avg_corr, epoch)
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_avg", avg_f_score, epoch)
+                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_max", max_f_score, epoch)
+                best_avg_f_score = max(best_avg_f_score, avg_f_score)
+                best_max_f_score = max(best_max_f_score, max_f_score)
+                if avg_corr > best_corr:
+                    best_corr = avg_corr
+                    self.best_weights = self.model.state_dict()
+        self.draw_scores(fold, dist_scores)
+        return best_corr, best_avg_f_score, best_max_f_score

@@ -40,5 +40,17 @@ for T, B in ((37, 1), (20, 3)):
            lambda m, x: (lambda r: [r[0][0], r[0][1], r[1]])(m(x)))
     c = ref.cLSTM(input_size=D, hidden_size=H, num_layers=L)
     record(f"clstm_T{T}B{B}", c, rng.standard_normal((T, B, D)).astype(np.float32) * 0.5, lambda m, x: list(m(x)))
+    torch.manual_seed(200 + T)
+    dl = ref.dLSTM(input_size=D, hidden_size=H, num_layers=L)
+    h0 = torch.from_numpy(rng.standard_normal((L, B, H)).astype(np.float32) * 0.4).requires_grad_(True)
+    c0 = torch.from_numpy(rng.standard_normal((L, B, H)).astype(np.float32) * 0.4).requires_grad_(True)
+    tag = f"dlstm_T{T}B{B}"
+    xh = dl(T, h0, c0)
+    cw = torch.from_numpy(rng.standard_normal(tuple(xh.shape)).astype(np.float32))
+    (xh * cw).sum().backward()
+    out[f"{tag}/h0"] = h0.detach().numpy(); out[f"{tag}/c0"] = c0.detach().numpy(); out[f"{tag}/cw"] = cw.numpy()
+    out[f"{tag}/y"] = xh.detach().numpy(); out[f"{tag}/dh0"] = h0.grad.numpy(); out[f"{tag}/dc0"] = c0.grad.numpy()
+    for k, p in dl.named_parameters():
+        out[f"{tag}/w/{k}"] = p.detach().numpy().copy(); out[f"{tag}/g/{k}"] = p.grad.numpy().copy()
 np.savez_compressed(os.path.join(HERE, "sumgan_lstm.npz"), **out)
 print(sorted(k for k in out if k.endswith("y0")), os.path.getsize(os.path.join(HERE, "sumgan_lstm.npz")) / 1024, "KB")

@@ -134,3 +134,43 @@ def vasnet_drop_masks(seed, p, lens, D):
         out.append(tuple((dropout_keep(seed, site, ix, p).astype(np.float32) * sc) for site, ix in ((0, ia), (1, iy), (2, iy))))
         row0 += T
     return out
+
+
+class DetRandom:
+    """Counter-based stand-in for torch.randn_like / torch.rand, used to run the reference's SumGAN trainer and the HIP one
+    on the SAME draws (their generators -- torch CPU vs device -- cannot be matched): draw n comes from
+    numpy.random.default_rng([seed, n]) whatever the device."""
+
+    def __init__(self, seed):
+        self.seed, self.n = int(seed), 0
+
+    def _next(self, shape, kind):
+        import torch
+        self.n += 1
+        g = np.random.default_rng([self.seed, self.n])
+        a = g.standard_normal(tuple(shape)) if kind == "normal" else g.random(tuple(shape))
+        return torch.from_numpy(a.astype(np.float32))
+
+    def randn_like(self, t, **kw):
+        return self._next(t.shape, "normal").to(t.device)
+
+    def rand(self, *size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list)):
+            size = tuple(size[0])
+        out = self._next(size, "uniform")
+        return out.to(kw["device"]) if kw.get("device") is not None else out
+
+    def patch(self):
+        """Context manager: torch.randn_like / torch.rand -> this generator."""
+        import contextlib
+        import torch
+
+        @contextlib.contextmanager
+        def cm():
+            old = torch.randn_like, torch.rand
+            torch.randn_like, torch.rand = self.randn_like, self.rand
+            try:
+                yield self
+            finally:
+                torch.randn_like, torch.rand = old
+        return cm()
