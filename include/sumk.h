@@ -130,7 +130,7 @@ int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* 
 
 /* ------------------------------------------------------------------------------------------------ unidirectional LSTM layer
  * One forward-running nn.LSTM(bidirectional=False) layer with an optional initial state and the final state as an output:
- * the layers of SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-111,216-233).  Packed batch as above;
+ * the layers of SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-115,185-210).  Packed batch as above;
  * h0 / c0 / h_last / c_last / dh_last / dc_last / dh0 / dc0 are (n_seq, H) and may be NULL (zeros / not wanted). */
 typedef struct sumk_lstm_dir_weights { const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh; } sumk_lstm_dir_weights;
 typedef struct sumk_lstm_dir_grads { float* w_ih; float* w_hh; float* b_ih; float* b_hh; } sumk_lstm_dir_grads;
@@ -146,9 +146,9 @@ int sumk_lstm_layer_backward(const float* x, const float* h_out, const float* dh
                              const sumk_lstm_dir_weights* w, const float* c0, const sumk_lstm_dir_grads* grads, float* dx,
                              float* dh0, float* dc0, void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
 
-/* Step-wise decoder = SumGAN's dLSTM (sumgan.py:75-111): an n_layers-deep forward-running LSTM (input size == H) whose
+/* Step-wise decoder = SumGAN's dLSTM (sumgan.py:74-115): an n_layers-deep forward-running LSTM (input size == H) whose
  * input at step t is its own top-layer output of step t-1 (zeros at t = 0), started from (h0, c0) (n_layers, n_seq, H) or
- * NULL.  out (n_rows, H) = top-layer outputs in time order (the module flips them, sumgan.py:110).  w / grads: n_layers
+ * NULL.  out (n_rows, H) = top-layer outputs in time order (the module flips them, sumgan.py:114).  w / grads: n_layers
  * entries.  backward: needs the forward's workspace and out; grads ACCUMULATE; dh0 / dc0 (n_layers, n_seq, H) or NULL. */
 size_t sumk_lstm_decoder_workspace_bytes(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host);
 int sumk_lstm_decoder_forward(int32_t H, int32_t n_layers, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
@@ -159,7 +159,7 @@ int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n_seq, const
                                const sumk_lstm_dir_grads* grads, float* dh0, float* dc0, void* workspace, size_t workspace_bytes,
                                void* stream);
 
-/* Dense layer y (M,N) = x (M,K) w^T + b for the small Linear layers around the LSTM stacks (sumgan.py:59-60,86); w is (N,K)
+/* Dense layer y (M,N) = x (M,K) w^T + b for the small Linear layers around the LSTM stacks (sumgan.py:58-59,84); w is (N,K)
  * as in nn.Linear, b may be NULL.  backward: dx (M,K) written if non-NULL, dw (N,K) / db (N) ACCUMULATED if non-NULL. */
 size_t sumk_linear_workspace_bytes(int32_t N, int32_t K);
 int sumk_linear_forward(const float* x, const float* w, const float* b, float* y, int32_t M, int32_t N, int32_t K,

@@ -119,7 +119,7 @@ class TransformerFunction(torch.autograd.Function):
 
 
 class LinearFunction(torch.autograd.Function):
-    """y = x W^T + b on the MFMA GEMM (the small Linear layers around SumGAN's LSTM stacks, sumgan.py:59-60,86)."""
+    """y = x W^T + b on the MFMA GEMM (the small Linear layers around SumGAN's LSTM stacks, sumgan.py:58-59,84)."""
 
     @staticmethod
     def forward(ctx, x, w, b, precision):
@@ -184,7 +184,7 @@ class LstmStackFunction(torch.autograd.Function):
 
 
 class FrameHeadFunction(torch.autograd.Function):
-    """probs = sigmoid(h w^T + b) for h (n, F): the Linear(F,1)+Sigmoid heads (cLSTM.out, sumgan.py:228-231)."""
+    """probs = sigmoid(h w^T + b) for h (n, F): the Linear(F,1)+Sigmoid heads (cLSTM.out, sumgan.py:195-197,209)."""
 
     @staticmethod
     def forward(ctx, h, w, b):
@@ -204,7 +204,7 @@ class FrameHeadFunction(torch.autograd.Function):
 
 
 class LstmDecoderFunction(torch.autograd.Function):
-    """SumGAN's step-wise dLSTM loop (sumgan.py:98-109) as one op: (h0, c0 (L, n_seq, H), *params) -> top-layer outputs
+    """SumGAN's step-wise dLSTM loop (sumgan.py:98-115) as one op: (h0, c0 (L, n_seq, H), *params) -> top-layer outputs
     (n_rows, H) in time order."""
 
     @staticmethod

@@ -1183,7 +1183,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
 
 // ------------------------------------------------------------------------------------------- unidirectional layer
 // One forward-running LSTM direction with an optional initial state and the final state as an output -- the layers of
-// SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-111,216-233: nn.LSTM(bidirectional=False), `(h_0, c_0)`
+// SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-115,185-210: nn.LSTM(bidirectional=False), `(h_0, c_0)`
 // inputs, `(h_n, c_n)` outputs).  Runs the launch-per-step kernels with nd = 1 (row layouts (R, H) / (R, 4H)).
 struct Lstm1Ws {
   size_t g, cstate, prob, gates, call, hprev, dg, dcstate, slab, prob_sk, colpart, total;
@@ -1350,7 +1350,7 @@ extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, cons
 }
 
 // ------------------------------------------------------------------------------------------- step-wise decoder
-// SumGAN's dLSTM (summarizer/models/sumgan.py:75-111): an L-layer forward-running LSTM driven one step at a time, whose
+// SumGAN's dLSTM (summarizer/models/sumgan.py:74-115): an L-layer forward-running LSTM driven one step at a time, whose
 // input at step t is its own top-layer output of step t-1 (zeros at t = 0) -- so no input projection can be hoisted and
 // every (layer, step) is a cell with TWO mat-vecs:  pre = W_ih a1 + W_hh a2 + b_ih + b_hh  with
 //   a1 = h_{top}[t-1] (layer 0)  or  h_{l-1}[t] (layer l > 0),   a2 = h_l[t-1]  (h0_l at t = 0).
@@ -1659,7 +1659,7 @@ extern "C" int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n
 
 // ------------------------------------------------------------------------------------------- dense layer
 // y = x W^T + b and its backward, for the small Linear layers around the LSTM stacks (eLSTM mu / logvar, dLSTM recons:
-// sumgan.py:59-60,86) -- the MFMA GEMM with the bias in its epilogue, split-K weight gradient, column-sum bias gradient.
+// sumgan.py:58-59,84) -- the MFMA GEMM with the bias in its epilogue, split-K weight gradient, column-sum bias gradient.
 struct LinWs { size_t prob, prob_sk, slab, colpart, total, slab_elems; };
 static void linear_carve(int N, int K, LinWs* w) {
   size_t p = 0;

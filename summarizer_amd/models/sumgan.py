@@ -1,7 +1,7 @@
 """SumGAN's LSTM modules on MI355X (`summarizer/models/sumgan.py`): the sLSTM selector -- the scorer, `SumGAN.forward` is
-exactly `s_lstm(x)` (sumgan.py:23-46,251-258) -- and the forward-running stacks of the VAE / GAN side: eLSTM (sumgan.py:48-73),
-the step-wise decoder dLSTM (sumgan.py:75-111), VAE, Summarizer, cLSTM / GAN and the SumGAN container (sumgan.py:113-258).  Same constructors, forward signatures and state_dict keys; every module is
-differentiable through the HIP backward kernels.  `SumGANTrainer` follows the reference trainer (sumgan.py:262-533): VAE
+exactly `s_lstm(x)` (sumgan.py:23-46,251-258) -- and the forward-running stacks of the VAE / GAN side: eLSTM (sumgan.py:48-72),
+the step-wise decoder dLSTM (sumgan.py:74-115), VAE, Summarizer, cLSTM / GAN and the SumGAN container (sumgan.py:117-258).  Same constructors, forward signatures and state_dict keys; every module is
+differentiable through the HIP backward kernels.  `SumGANTrainer` follows the reference trainer (sumgan.py:261-533): VAE
 pre-training, then per video the selector+encoder, decoder and discriminator updates with their three Adam optimisers."""
 import random
 
@@ -72,7 +72,7 @@ class dLSTM(nn.Module):
         self.recons = nn.Linear(hidden_size, input_size)
 
     def forward(self, seq_len, h_0, c_0):
-        """Decode the entire sequence (the reference's step-by-step loop, sumgan.py:98-111, as ONE op).
+        """Decode the entire sequence (the reference's step-by-step loop, sumgan.py:98-115, as ONE op).
         h_0, c_0: (num_layers, batch_size, hidden_size) -> x_hat: (seq_len, batch_size, input_size)"""
         from ..autograd import LstmDecoderFunction, LinearFunction
         kernels._require_gpu(h_0, "dLSTM.forward")
@@ -84,7 +84,7 @@ class dLSTM(nn.Module):
                        getattr(self.lstm, f"bias_ih_l{l}"), getattr(self.lstm, f"bias_hh_l{l}")]
         rows = LstmDecoderFunction.apply(sb, H, h_0, c_0, *params)                  # (B*T, H) batch-major, time order
         x_hat = LinearFunction.apply(rows, self.recons.weight, self.recons.bias, self.precision)
-        return torch.flip(_unpack_time_major(x_hat, int(seq_len), B), (0,))         # reverse (sumgan.py:110)
+        return torch.flip(_unpack_time_major(x_hat, int(seq_len), B), (0,))         # reverse (sumgan.py:114)
 
 
 class VAE(nn.Module):
@@ -141,7 +141,7 @@ class cLSTM(nn.Module):
         kernels._require_gpu(x, "cLSTM.forward")
         xp, lens = pack_time_major(x)
         _, h_n, _ = lstm_stack(self.lstm, xp, kernels.SeqBatch.get(lens, x.device), precision=self.precision)
-        h_last = h_n[-1]                                   # output[-1] of the top layer (sumgan.py:231)
+        h_last = h_n[-1]                                   # output[-1] of the top layer (sumgan.py:208)
         probs = FrameHeadFunction.apply(h_last, self.out[0].weight, self.out[0].bias)
         return probs.view(-1, 1), h_last
 
