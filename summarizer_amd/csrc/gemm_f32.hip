@@ -75,7 +75,7 @@ __device__ __forceinline__ void tr_frag(const char* p, int pitch, int plane, bf1
 // X3: "bf16x3" arithmetic.  Each fp32 operand is split on its way into LDS into hi = bf16(x) and
 // lo = bf16(x - hi); the product is accumulated in fp32 as  lo.hi + hi.lo + hi.hi  with v_mfma_f32_32x32x16_bf16 (16x the
 // fp32 MFMA rate, 3 MFMAs per 16-deep k step instead of 8 fp32 ones): the dropped lo.lo term is ~2^-16 relative, which keeps
-// VASNet scores within ~1e-5 of the fp32 path (scripts/bf16x3_emulation.py; the 1e-4 gate holds, plain bf16 misses it by
+// VASNet scores within ~1e-5 of the fp32 path (tests/probes/bf16x3_emulation.py; the 1e-4 gate holds, plain bf16 misses it by
 // 20-100x).  The LDS row becomes [hi: BK bf16 | lo: BK bf16] -- the same BK*4 bytes and the same +16 B pad, so the
 // conflict-free ds_read_b128 argument is unchanged; a lane's 16-B fragment is 8 consecutive k of one plane.
 // An operand whose rows are NOT K-contiguous in memory (the "MC" side of NN / TN) keeps its natural [k][row] order in LDS,

@@ -1,8 +1,8 @@
 """CPU emulation: would a bf16x3 split (a = hi + lo, a*b ~= hi*hi + hi*lo + lo*hi, fp32 accumulate) keep VASNet scores
 within the 1e-4 parity gate?  Compares against the float64 oracle on full-size (D=1024) cases."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden"))
 import numpy as np, torch
 import recipes as R
 from oracle import vasnet_np
