@@ -69,3 +69,30 @@ def test_single_frame_videos_everywhere():
     for i, x in enumerate(xs):
         np.testing.assert_allclose(sv[i], vasnet_np.vasnet_forward(x, wv)[0, 0, 0], atol=1e-4)
         np.testing.assert_allclose(sl[i], lstm_np.dsn_forward(x, wl)[0, 0, 0], atol=1e-4)
+
+
+def test_integration_md_binding_stub_runs():
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed verbatim against libsumk.so: it must score a batch
+    exactly like the Python mirror does (keeps the document honest when the ABI moves)."""
+    import os, re
+    import numpy as np
+    import torch
+    from conftest import ROOT
+    from summarizer_amd.models.vasnet import VASNet
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "def vasnet_scores" in b)
+    cwd = os.getcwd()
+    os.chdir(ROOT)                      # the stub loads "summarizer_amd/libsumk.so" relative to the repo root
+    try:
+        ns = {}
+        exec(stub, ns)
+        torch.manual_seed(2)
+        m = VASNet().cuda().eval()
+        feats = [torch.rand(T, 1024, device="cuda") * 0.5 for T in (40, 7, 130)]
+        got = ns["vasnet_scores"](m, feats)
+        with torch.no_grad():
+            want = m.score_packed(torch.cat(feats), [f.shape[0] for f in feats])
+        assert torch.equal(torch.cat(list(got)), want)
+    finally:
+        os.chdir(cwd)
