@@ -29,11 +29,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one step counter per work item
 
 struct LstmWs {
-  size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, pstate_b, xchg, total;
+  size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, pstate_b, xchg, partial, total;
   size_t xchg_bytes;
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
+
+constexpr int GV_MAXB = 8;      // "a few sequences": the small-batch mat-vec step kernels below take over up to this many
+// geometry of the transposed mat-vec: strips of 256 columns x k splits sized for ~512 blocks
+struct TGemvGeom { int strips, n_ksplit, rows_per_split; };
+static TGemvGeom tgemv_geom(int H) {
+  TGemvGeom g;
+  g.strips = (H + 255) / 256;
+  const int H4 = 4 * H;
+  int want = std::max(1, 512 / g.strips);
+  want = std::min(want, std::max(1, H4 / 32));            // at least 32 rows per split (8 per wave)
+  want = std::min(want, 128);
+  g.rows_per_split = ((H4 + want - 1) / want + 3) / 4 * 4;
+  g.n_ksplit = (H4 + g.rows_per_split - 1) / g.rows_per_split;
+  return g;
+}
+static size_t tgemv_partial_bytes(int H, int n_seq, int nd = 1) {
+  return (size_t)tgemv_geom(H).n_ksplit * (size_t)std::min(n_seq, GV_MAXB) * nd * H * 4;
+}
 
 static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training, LstmWs* w) {
   SUMK_ARG(In > 0 && In % 4 == 0, "bilstm: input size %d must be a positive multiple of 4", In);
@@ -74,12 +92,243 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
       w->xchg_bytes = H <= 256 ? (size_t)2 * items * 32 * 32 * H * 4 : 0;
       w->xchg = take(w->xchg_bytes);
     }
+    w->partial = take(n_seq <= GV_MAXB ? tgemv_partial_bytes(H, n_seq, 2) : 0);   // small-batch transposed mat-vec (H > 256 at a few videos)
   }
   w->total = p;
   return SUMK_OK;
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// ------------------------------------------------------------------------------------------- small-batch (mat-vec) steps
+// With a handful of sequences (SumGAN trains one video at a time) a recurrence step is a matrix-VECTOR product: nothing to
+// feed an MFMA tile with, and the step time is the time to stream the weights (up to 134 MB per decoder step) once.  The
+// MFMA step kernels above read them in 32-byte (forward) or 128-byte-strided (backward, transposed) pieces from at most
+// 64 blocks; these kernels are shaped for bandwidth instead (n_seq <= GV_MAXB):
+//   forward:  one WAVE per hidden unit streams its 4 gate rows of W_ih / W_hh, lanes along k (1 KB contiguous per load),
+//             dot products on the VALU, butterfly reduction across the wave, lane b finishes the cell of sequence b;
+//   backward: the transposed product dh = dG W is cut into (256-column strip) x (k split) blocks, lanes along the columns
+//             (1 KB contiguous per row), partial sums per split; a second tiny kernel sums the splits and does the cell backward.
+
+struct GemvStepArgs {
+  const float* a1; int32_t a1_shift;     // first operand rows (R, H): row + shift (-1: previous step, 0: same step); nullptr = none
+  const float* w1;                       // (4H, H) or nullptr
+  const float* G;                        // (R, 4H) hoisted input projection incl. both biases, or nullptr
+  const float* b1; const float* b2;      // (4H) biases when G == nullptr
+  const float* w2;                       // (4H, H) recurrent weights
+  const float* h0; const float* c0;      // (n_seq, H) or nullptr
+  float* hseq;                           // (R, H)
+  float* c_all; float* cstate;           // (R, H) per-row cell states, or (n_seq, H) running state when c_all == nullptr
+  float* gates; float* hprev; float* xin;// saves for the backward pass (nullptr in inference)
+  const int32_t* off;
+  int32_t n_seq, H, t;
+};
+
+__global__ __launch_bounds__(256) void lstm_gemv_step_kernel(GemvStepArgs a) {
+  const int H = a.H, t = a.t, nb = a.n_seq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= H) return;                    // whole wave
+  int64_t row[GV_MAXB]; bool act[GV_MAXB];
+#pragma unroll
+  for (int b = 0; b < GV_MAXB; ++b) {
+    act[b] = false; row[b] = 0;
+    if (b < nb) { const int r0 = a.off[b], T = a.off[b + 1] - r0; if (t < T) { act[b] = true; row[b] = r0 + t; } }
+  }
+  float acc[4][GV_MAXB];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b) acc[q][b] = 0.f;
+  for (int pair = 0; pair < 2; ++pair) {
+    const float* w = pair == 0 ? a.w1 : a.w2;
+    if (w == nullptr) continue;
+    const float* src[GV_MAXB];
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b) {
+      src[b] = nullptr;
+      if (b < nb && act[b]) {
+        if (pair == 0) { if (a.a1 && (a.a1_shift == 0 || t > 0)) src[b] = a.a1 + (row[b] + a.a1_shift) * H; }
+        else src[b] = t > 0 ? a.hseq + (row[b] - 1) * H : (a.h0 ? a.h0 + (int64_t)b * H : nullptr);
+      }
+    }
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b) any |= src[b] != nullptr;
+    if (!any) continue;                  // uniform: e.g. layer 0 of the decoder at t = 0, or no initial state
+    for (int k = 4 * lane; k < H; k += 256) {
+      float4 wq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(w + (int64_t)(q * H + j) * H + k);
+#pragma unroll
+      for (int b = 0; b < GV_MAXB; ++b) {
+        if (b < nb && src[b] != nullptr) {
+          const float4 x = *reinterpret_cast<const float4*>(src[b] + k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q][b] += (wq[q].x * x.x + wq[q].y * x.y) + (wq[q].z * x.z + wq[q].w * x.w);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b)
+      if (b < nb) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[q][b] += __shfl_xor(acc[q][b], m, 64);
+      }
+  // lane b finishes sequence b
+#pragma unroll
+  for (int b = 0; b < GV_MAXB; ++b) {
+    if (lane != b || b >= nb || !act[b]) continue;
+    const int64_t r = row[b];
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      pre[q] = acc[q][b] + (a.G ? a.G[r * 4 * H + q * H + j] : a.b1[q * H + j] + a.b2[q * H + j]);
+    float cprev;
+    if (t > 0) cprev = a.c_all ? a.c_all[(r - 1) * H + j] : a.cstate[(int64_t)b * H + j];
+    else cprev = a.c0 ? a.c0[(int64_t)b * H + j] : 0.f;
+    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+    const float c = fg * cprev + ig * gg;
+    const float h = og * tanhf(c);
+    if (a.hprev) a.hprev[r * H + j] = t > 0 ? a.hseq[(r - 1) * H + j] : (a.h0 ? a.h0[(int64_t)b * H + j] : 0.f);
+    if (a.xin) a.xin[r * H + j] = (a.a1 && (a.a1_shift == 0 || t > 0)) ? a.a1[(r + a.a1_shift) * H + j] : 0.f;
+    a.hseq[r * H + j] = h;
+    if (a.c_all) a.c_all[r * H + j] = c; else a.cstate[(int64_t)b * H + j] = c;
+    if (a.gates) { float* gs = a.gates + r * 4 * H; gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og; }
+  }
+}
+
+// partial[split][b][j] = sum over this split's k of  dGa[row_b + 1][k] Wa[k][j]  (+ dGb[row_b + b_shift][k] Wb[k][j])
+struct TGemvArgs {
+  const float* dGa; const float* wa;                    // own dG (R, nd*4H), W_hh (4H, H) of direction 0
+  const float* dGb; const float* wb; int32_t b_shift;   // consumer's dG and W_ih, or nullptr (nd = 1 only)
+  float* partial;                                       // (n_ksplit, n_seq, nd, H)
+  const int32_t* off;
+  int32_t n_seq, H, t, rows_per_split;
+  int32_t nd = 1;                                       // 2: bidirectional layer, blockIdx.z = direction (1 runs backwards in time)
+  const float* wa1 = nullptr;                           // W_hh of direction 1
+};
+
+__global__ __launch_bounds__(256) void lstm_tgemv_partial_kernel(TGemvArgs a) {
+  __shared__ float4 red[3][GV_MAXB][64];
+  const int H = a.H, H4 = 4 * H, t = a.t, nb = a.n_seq, nd = a.nd, d = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jq = blockIdx.x * 256 + 4 * lane;            // this lane's 4 columns
+  const bool jok = jq < H;
+  const int kbeg = blockIdx.y * a.rows_per_split, kend = min(H4, kbeg + a.rows_per_split);
+  float4 acc[GV_MAXB];
+#pragma unroll
+  for (int b = 0; b < GV_MAXB; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int pair = 0; pair < 2; ++pair) {
+    const float* w = pair == 0 ? (d == 0 ? a.wa : a.wa1) : a.wb;
+    const float* dG = pair == 0 ? a.dGa : a.dGb;
+    if (w == nullptr || dG == nullptr) continue;
+    const float* g[GV_MAXB];
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b) {
+      g[b] = nullptr;
+      if (b < nb) {
+        const int r0 = a.off[b], T = a.off[b + 1] - r0;
+        const int sh = pair == 0 ? 1 : a.b_shift;
+        if ((pair == 0 || t >= 0) && t + sh < T && t + sh >= 0) {
+          const int64_t row = d == 0 ? r0 + t + sh : r0 + T - 1 - (t + sh);     // the row of step t + sh in this direction
+          g[b] = dG + row * (nd * H4) + d * H4; any = true;
+        }
+      }
+    }
+    if (!any) continue;
+    for (int k = kbeg + wave; k < kend; k += 4) {
+      const float4 w4 = jok ? *reinterpret_cast<const float4*>(w + (int64_t)k * H + jq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int b = 0; b < GV_MAXB; ++b) {
+        if (b < nb && g[b] != nullptr) {
+          const float gv = g[b][k];
+          acc[b].x += gv * w4.x; acc[b].y += gv * w4.y; acc[b].z += gv * w4.z; acc[b].w += gv * w4.w;
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b) if (b < nb) red[wave - 1][b][lane] = acc[b];
+  }
+  __syncthreads();
+  if (wave == 0 && jok) {
+#pragma unroll
+    for (int b = 0; b < GV_MAXB; ++b) {
+      if (b >= nb) continue;
+      float4 v = acc[b];
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3) { const float4 o = red[w3][b][lane]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *reinterpret_cast<float4*>(a.partial + (((int64_t)blockIdx.y * nb + b) * nd + d) * H + jq) = v;
+    }
+  }
+}
+
+// cell backward of one (layer, step) for n_seq <= GV_MAXB: dh = dext + dh_last (last step) + sum of the mat-vec partials
+struct CellBwdArgs {
+  const float* dext;                     // (R, H) or nullptr
+  const float* dh_last; const float* dc_last;   // (n_seq, H) or nullptr
+  const float* partial; int32_t n_ksplit;
+  const float* gates; const float* c_all; const float* c0;
+  float* dG; float* dcstate; float* dh0; float* dc0;
+  const int32_t* off;
+  int32_t n_seq, H, t;
+  int32_t nd = 1;                        // 2: bidirectional layer (blockIdx.z = direction; state tensors are (n_seq, nd, H))
+};
+
+// block = 64 columns x 4 split groups: the n_ksplit partial sums of a column are added by 4 threads (independent,
+// unrolled loads) and combined through LDS -- a single thread walking 64-128 dependent loads made this kernel 22 us.
+__global__ __launch_bounds__(256) void lstm_cellbwd_kernel(CellBwdArgs a) {
+  __shared__ float red[4][64];
+  const int H = a.H, H4 = 4 * H, t = a.t, nd = a.nd, d = blockIdx.z, S1 = nd * H, S4 = nd * H4;
+  const int b = blockIdx.y, jl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
+  const int r0 = a.off[b], T = a.off[b + 1] - r0;
+  if (t >= T) return;                                   // whole block
+  float rec = 0.f;
+  if (j < H) {
+    const float* p = a.partial + ((int64_t)b * nd + d) * H + j;
+    const int64_t stride = (int64_t)a.n_seq * nd * H;
+    int s = grp;
+    for (; s + 12 < a.n_ksplit; s += 16) {
+      const float v0 = p[s * stride], v1 = p[(s + 4) * stride], v2 = p[(s + 8) * stride], v3 = p[(s + 12) * stride];
+      rec += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < a.n_ksplit; s += 4) rec += p[s * stride];
+  }
+  red[grp][jl] = rec;
+  __syncthreads();
+  if (grp != 0 || j >= H) return;
+  rec = (red[0][jl] + red[1][jl]) + (red[2][jl] + red[3][jl]);
+  const int64_t idx = ((int64_t)b * nd + d) * H + j;
+  float* dcs = a.dcstate + idx;
+  if (t < 0) {
+    if (a.dh0) a.dh0[idx] = rec;
+    if (a.dc0) a.dc0[idx] = *dcs;
+    return;
+  }
+  const int64_t row = d == 0 ? r0 + t : r0 + T - 1 - t;
+  float dh = (a.dext ? a.dext[row * S1 + d * H + j] : 0.f) + rec;   // rec is zero by construction when no later step feeds this one
+  if (t + 1 == T && a.dh_last) dh += a.dh_last[idx];
+  const float* gs = a.gates + row * S4 + d * H4;
+  const float ig = gs[j], fg = gs[H + j], gg = gs[2 * H + j], og = gs[3 * H + j];
+  const float c = a.c_all[row * S1 + d * H + j];
+  const float cprev = t > 0 ? a.c_all[(d == 0 ? row - 1 : row + 1) * S1 + d * H + j] : (a.c0 ? a.c0[idx] : 0.f);
+  const float tc = tanhf(c);
+  const float dc = (t + 1 < T ? *dcs : (a.dc_last ? a.dc_last[idx] : 0.f)) + dh * og * (1.f - tc * tc);
+  float* dg = a.dG + row * S4 + d * H4;
+  dg[j] = dc * gg * ig * (1.f - ig);
+  dg[H + j] = dc * cprev * fg * (1.f - fg);
+  dg[2 * H + j] = dc * ig * (1.f - gg * gg);
+  dg[3 * H + j] = dh * tc * og * (1.f - og);
+  *dcs = dc * fg;
+}
+
 
 // ------------------------------------------------------------------------------------------- step kernel
 // grid.x = n_mtiles * n_ublk * 2 ; block = 256
@@ -1143,6 +1392,24 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
       done = true;
     }
   }
+  if (!done && n_seq <= GV_MAXB) {   // a few videos and no persistent BPTT (H > 256): bandwidth-shaped transposed mat-vec per step
+    const TGemvGeom tg = tgemv_geom(H);
+    TGemvArgs ta;
+    ta.dGa = dG; ta.wa = w->w_hh[0]; ta.wa1 = w->w_hh[1]; ta.dGb = nullptr; ta.wb = nullptr; ta.b_shift = 0; ta.nd = 2;
+    ta.partial = (float*)(ws + L.partial); ta.off = seq_off_dev; ta.n_seq = n_seq; ta.H = H; ta.rows_per_split = tg.rows_per_split;
+    CellBwdArgs ca;
+    ca.dext = dh_out; ca.dh_last = ca.dc_last = nullptr; ca.partial = ta.partial; ca.n_ksplit = tg.n_ksplit; ca.nd = 2;
+    ca.gates = (const float*)(ws + L.gates); ca.c_all = (const float*)(ws + L.call); ca.c0 = nullptr;
+    ca.dG = dG; ca.dcstate = (float*)(ws + L.dcstate); ca.dh0 = ca.dc0 = nullptr;
+    ca.off = seq_off_dev; ca.n_seq = n_seq; ca.H = H;
+    for (int t = L.t_max - 1; t >= 0; --t) {
+      ta.t = ca.t = t;
+      hipLaunchKernelGGL(lstm_tgemv_partial_kernel, dim3((unsigned)tg.strips, (unsigned)tg.n_ksplit, 2), dim3(256), 0, stream, ta);
+      hipLaunchKernelGGL(lstm_cellbwd_kernel, dim3((unsigned)((H + 63) / 64), (unsigned)n_seq, 2), dim3(256), 0, stream, ca);
+    }
+    SUMK_HIP(hipGetLastError());
+    done = true;
+  }
   if (!done) {
     BwdStepArgs a;
     a.whh[0] = w->w_hh[0]; a.whh[1] = w->w_hh[1]; a.dHout = dh_out; a.gates = (const float*)(ws + L.gates);
@@ -1186,7 +1453,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
 // SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-115,185-210: nn.LSTM(bidirectional=False), `(h_0, c_0)`
 // inputs, `(h_n, c_n)` outputs).  Runs the launch-per-step kernels with nd = 1 (row layouts (R, H) / (R, 4H)).
 struct Lstm1Ws {
-  size_t g, cstate, prob, gates, call, hprev, dg, dcstate, slab, prob_sk, colpart, total;
+  size_t g, cstate, prob, gates, call, hprev, dg, dcstate, slab, prob_sk, colpart, partial, total;
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
@@ -1208,7 +1475,7 @@ static int lstm1_carve(int In, int H, int n_seq, const int32_t* off, int trainin
   w->g = take(R * 4 * H * 4);
   w->cstate = take((size_t)n_seq * H * 4);
   w->prob = take(8 * sizeof(GemmProb));
-  w->gates = w->call = w->hprev = w->dg = w->dcstate = w->slab = w->prob_sk = w->colpart = 0;
+  w->gates = w->call = w->hprev = w->dg = w->dcstate = w->slab = w->prob_sk = w->colpart = w->partial = 0;
   w->slab_elems = 0;
   if (training) {
     w->gates = take(R * 4 * H * 4);
@@ -1220,6 +1487,7 @@ static int lstm1_carve(int In, int H, int n_seq, const int32_t* off, int trainin
     w->slab = take(w->slab_elems * 4);
     w->prob_sk = take(64 * sizeof(GemmProb));
     w->colpart = take((size_t)128 * 4 * H * 4);
+    w->partial = take(tgemv_partial_bytes(H, n_seq));     // split partial sums of the small-batch transposed mat-vec
   }
   w->total = p;
   return SUMK_OK;
@@ -1269,6 +1537,24 @@ extern "C" int sumk_lstm_layer_forward(const float* x, int32_t In, int32_t H, in
     g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 4 * H, small); g.precision = precision;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
+  if (n_seq <= GV_MAXB) {      // a few sequences: bandwidth-shaped mat-vec steps
+    GemvStepArgs ga;
+    ga.a1 = nullptr; ga.a1_shift = 0; ga.w1 = nullptr; ga.G = G; ga.b1 = ga.b2 = nullptr; ga.w2 = w->w_hh; ga.h0 = h0; ga.c0 = c0;
+    ga.hseq = h_out; ga.c_all = training ? (float*)(ws + L.call) : nullptr; ga.cstate = training ? nullptr : (float*)(ws + L.cstate);
+    ga.gates = training ? (float*)(ws + L.gates) : nullptr; ga.hprev = training ? (float*)(ws + L.hprev) : nullptr; ga.xin = nullptr;
+    ga.off = seq_off_dev; ga.n_seq = n_seq; ga.H = H;
+    for (int t = 0; t < L.t_max; ++t) {
+      ga.t = t;
+      hipLaunchKernelGGL(lstm_gemv_step_kernel, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, stream, ga);
+    }
+    if (h_last || c_last) {
+      const int64_t n = (int64_t)n_seq * H;
+      hipLaunchKernelGGL(lstm_last_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, h_out,
+                         (const float*)ga.c_all, (const float*)ga.cstate, seq_off_dev, n_seq, H, h_last, c_last);
+    }
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   StepArgs a;
   a.G = G; a.whh[0] = w->w_hh; a.whh[1] = nullptr; a.Hout = h_out;
   a.cstate = training ? nullptr : (float*)(ws + L.cstate);
@@ -1316,6 +1602,22 @@ extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, cons
   float* colpart = (float*)(ws + L.colpart);
   GemmProb* prob = (GemmProb*)(ws + L.prob);
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
+  if (n_seq <= GV_MAXB) {      // a few sequences: bandwidth-shaped transposed mat-vec + cell kernel per step
+    const TGemvGeom tg = tgemv_geom(H);
+    TGemvArgs ta;
+    ta.dGa = dG; ta.wa = w->w_hh; ta.dGb = nullptr; ta.wb = nullptr; ta.b_shift = 0; ta.partial = (float*)(ws + L.partial);
+    ta.off = seq_off_dev; ta.n_seq = n_seq; ta.H = H; ta.rows_per_split = tg.rows_per_split;
+    CellBwdArgs ca;
+    ca.dext = dh_out; ca.dh_last = dh_last; ca.dc_last = dc_last; ca.partial = ta.partial; ca.n_ksplit = tg.n_ksplit;
+    ca.gates = (const float*)(ws + L.gates); ca.c_all = (const float*)(ws + L.call); ca.c0 = c0;
+    ca.dG = dG; ca.dcstate = (float*)(ws + L.dcstate); ca.dh0 = dh0; ca.dc0 = dc0;
+    ca.off = seq_off_dev; ca.n_seq = n_seq; ca.H = H;
+    for (int t = L.t_max - 1; t >= ((dh0 || dc0) ? -1 : 0); --t) {
+      ta.t = ca.t = t;
+      hipLaunchKernelGGL(lstm_tgemv_partial_kernel, dim3((unsigned)tg.strips, (unsigned)tg.n_ksplit), dim3(256), 0, stream, ta);
+      hipLaunchKernelGGL(lstm_cellbwd_kernel, dim3((unsigned)((H + 63) / 64), (unsigned)n_seq), dim3(256), 0, stream, ca);
+    }
+  } else {
   BwdStepArgs a;
   a.whh[0] = w->w_hh; a.whh[1] = nullptr; a.dHout = dh_out; a.gates = (const float*)(ws + L.gates);
   a.c_all = (const float*)(ws + L.call); a.dG = dG; a.dcstate = (float*)(ws + L.dcstate);
@@ -1326,6 +1628,7 @@ extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, cons
   for (int t = L.t_max - 1; t >= ((dh0 || dc0) ? -1 : 0); --t) {
     a.t = t;
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, block, 0, stream, a);
+  }
   }
   SUMK_HIP(hipGetLastError());
   {
@@ -1547,7 +1850,7 @@ __global__ __launch_bounds__(512) void lstm_dec_bwd_step_kernel(DecBwdArgs a) {
 struct DecWs {
   size_t hseq, call, gates, hprev, dg, dcstate;   // per layer: offset of layer 0, layer l at + l * stride
   size_t s_hseq, s_gates, s_dcstate;
-  size_t xin0, slab, prob_sk, colpart, total, slab_elems;
+  size_t xin0, slab, prob_sk, colpart, partial, total, slab_elems;
   int32_t n_rows, t_max;
 };
 static int dec_carve(int H, int Lr, int n_seq, const int32_t* off, DecWs* w) {
@@ -1568,6 +1871,7 @@ static int dec_carve(int H, int Lr, int n_seq, const int32_t* off, DecWs* w) {
   w->slab = take(w->slab_elems * 4);
   w->prob_sk = take(64 * sizeof(GemmProb));
   w->colpart = take((size_t)128 * 4 * H * 4);
+  w->partial = take(tgemv_partial_bytes(H, n_seq));
   w->total = p;
   return SUMK_OK;
 }
@@ -1590,6 +1894,23 @@ extern "C" int sumk_lstm_decoder_forward(int32_t H, int32_t n_layers, int32_t n_
   char* ws = (char*)workspace;
   const int top = n_layers - 1;
   auto hseq = [&](int l) { return l == top ? out : (float*)(ws + L.hseq + L.s_hseq * l); };   // the top layer writes the output itself
+  if (n_seq <= GV_MAXB) {      // a few sequences: bandwidth-shaped mat-vec steps
+    GemvStepArgs ga;
+    ga.G = nullptr; ga.cstate = nullptr; ga.off = seq_off_dev; ga.n_seq = n_seq; ga.H = H;
+    for (int t = 0; t < L.t_max; ++t) {
+      ga.t = t;
+      for (int l = 0; l < n_layers; ++l) {
+        ga.a1 = l == 0 ? hseq(top) : hseq(l - 1); ga.a1_shift = l == 0 ? -1 : 0;
+        ga.w1 = w[l].w_ih; ga.w2 = w[l].w_hh; ga.b1 = w[l].b_ih; ga.b2 = w[l].b_hh;
+        ga.h0 = h0 ? h0 + (size_t)l * n_seq * H : nullptr; ga.c0 = c0 ? c0 + (size_t)l * n_seq * H : nullptr;
+        ga.hseq = hseq(l); ga.c_all = (float*)(ws + L.call + L.s_hseq * l); ga.gates = (float*)(ws + L.gates + L.s_gates * l);
+        ga.hprev = (float*)(ws + L.hprev + L.s_hseq * l); ga.xin = l == 0 ? (float*)(ws + L.xin0) : nullptr;
+        hipLaunchKernelGGL(lstm_gemv_step_kernel, dim3((unsigned)((H + 3) / 4)), dim3(256), 0, stream, ga);
+      }
+    }
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   DecStepArgs a;
   a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_ublk = (H + 7) / 8;
   const dim3 grid((unsigned)(((n_seq + 31) / 32) * a.n_ublk)), block(256);
@@ -1621,10 +1942,32 @@ extern "C" int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n
   const int R = L.n_rows, top = n_layers - 1;
   auto dG = [&](int l) { return (float*)(ws + L.dg + L.s_gates * l); };
   auto hseq = [&](int l) { return l == top ? out : (const float*)(ws + L.hseq + L.s_hseq * l); };
+  const bool want0 = dh0 || dc0;
+  if (n_seq <= GV_MAXB) {      // a few sequences: transposed mat-vec partials + cell kernel per (layer, step)
+    const TGemvGeom tg = tgemv_geom(H);
+    TGemvArgs ta;
+    ta.partial = (float*)(ws + L.partial); ta.off = seq_off_dev; ta.n_seq = n_seq; ta.H = H; ta.rows_per_split = tg.rows_per_split;
+    CellBwdArgs ca;
+    ca.dh_last = ca.dc_last = nullptr; ca.partial = ta.partial; ca.n_ksplit = tg.n_ksplit; ca.off = seq_off_dev; ca.n_seq = n_seq; ca.H = H;
+    for (int t = L.t_max - 1; t >= (want0 ? -1 : 0); --t) {
+      ta.t = ca.t = t;
+      for (int l = top; l >= 0; --l) {
+        ta.dGa = dG(l); ta.wa = w[l].w_hh;
+        if (l == top) { ta.dGb = dG(0); ta.wb = w[0].w_ih; ta.b_shift = 1; }
+        else { ta.dGb = dG(l + 1); ta.wb = w[l + 1].w_ih; ta.b_shift = 0; }
+        ca.dext = l == top ? dout : nullptr;
+        ca.gates = (const float*)(ws + L.gates + L.s_gates * l); ca.c_all = (const float*)(ws + L.call + L.s_hseq * l);
+        ca.c0 = c0 ? c0 + (size_t)l * n_seq * H : nullptr;
+        ca.dG = dG(l); ca.dcstate = (float*)(ws + L.dcstate + L.s_dcstate * l);
+        ca.dh0 = dh0 ? dh0 + (size_t)l * n_seq * H : nullptr; ca.dc0 = dc0 ? dc0 + (size_t)l * n_seq * H : nullptr;
+        hipLaunchKernelGGL(lstm_tgemv_partial_kernel, dim3((unsigned)tg.strips, (unsigned)tg.n_ksplit), dim3(256), 0, stream, ta);
+        hipLaunchKernelGGL(lstm_cellbwd_kernel, dim3((unsigned)((H + 63) / 64), (unsigned)n_seq), dim3(256), 0, stream, ca);
+      }
+    }
+  } else {
   DecBwdArgs a;
   a.off = seq_off_dev; a.n_seq = n_seq; a.H = H; a.n_jblk = (H + 31) / 32;
   const dim3 grid((unsigned)(((n_seq + 31) / 32) * a.n_jblk)), block(512);
-  const bool want0 = dh0 || dc0;
   for (int t = L.t_max - 1; t >= (want0 ? -1 : 0); --t) {
     a.t = t;
     for (int l = top; l >= 0; --l) {
@@ -1638,6 +1981,7 @@ extern "C" int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n
       a.dh0 = dh0 ? dh0 + (size_t)l * n_seq * H : nullptr; a.dc0 = dc0 ? dc0 + (size_t)l * n_seq * H : nullptr;
       hipLaunchKernelGGL(lstm_dec_bwd_step_kernel, grid, block, 0, stream, a);
     }
+  }
   }
   SUMK_HIP(hipGetLastError());
   float* slab = (float*)(ws + L.slab);
