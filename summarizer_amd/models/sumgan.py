@@ -5,7 +5,6 @@ differentiable through the HIP backward kernels.  `SumGANTrainer` follows the re
 pre-training, then per video the selector+encoder, decoder and discriminator updates with their three Adam optimisers."""
 import random
 
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -4,7 +4,6 @@ import ctypes
 import os
 import re
 import subprocess
-import numpy as np
 import pytest
 import torch
 

@@ -3,7 +3,6 @@ all-reduce -- without any compute call (the HIP path needs a GPU)."""
 import os
 import socket
 import numpy as np
-import pytest
 import torch
 import torch.multiprocessing as mp
 

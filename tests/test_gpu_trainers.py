@@ -139,7 +139,6 @@ def test_vasnet_trainer_reproduces_the_reference_trainer_end_to_end():
     container (tests/golden/make_golden_e2e.py).  With the same torch / python seeds the HIP trainer must start from the
     SAME weights (identical module creation order), follow the same loss trajectory, end at the same weights, score the
     test videos within 1e-4 and report the same correlation / F-scores."""
-    import logging
     from conftest import load_golden
     from summarizer_amd.models.vasnet import VASNetTrainer
     from summarizer_amd.utils.datasets import synthetic_dataset

@@ -1,6 +1,5 @@
 """CPU-side host logic that needs no GPU: precision selectors, ingest / model guards, trainer hyper-parameter parsing,
 state_dict key compatibility of the SumGAN containers, the deterministic draw helper of the end-to-end goldens."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,8 +1,6 @@
 """CPU: pins the oracle (numpy restatements + torch port) against vectors produced by the REAL reference
 (tests/golden/make_golden.py).  Tolerances: fp32 restatement vs fp32 reference -> 2e-5 abs on scores in (0,1)."""
-import json
 import numpy as np
-import pytest
 import torch
 
 import recipes as R
