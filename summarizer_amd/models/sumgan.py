@@ -267,8 +267,66 @@ class SumGANTrainer(Trainer):
         self._clip_all(self._buckets)
         opt.step()
 
+    # ---- one video, the independent passes of each update batched along the batch axis
+    def _generate(self, x, scores_list, eps_list):
+        """VAE over several score-weighted copies of one video at once: x (T,1,D), scores_list [(T,1,1)], eps_list
+        [(L,1,H)] -> ([x_hat (T,1,D)], h_mu, h_logvar (L,B,H)).  Same arithmetic per copy as `Summarizer.forward`."""
+        vae = self.model.summarizer.vae
+        xw = torch.cat([x * sc for sc in scores_list], dim=1)
+        (h_mu, h_logvar), c = vae.e_lstm(xw)
+        h = h_mu + torch.cat(eps_list, dim=1) * torch.exp(0.5 * h_logvar)
+        x_hat = vae.d_lstm(x.size(0), h, c)
+        return [x_hat[:, i:i + 1] for i in range(len(scores_list))], h_mu, h_logvar
+
+    def _discriminate(self, xs):
+        """cLSTM over several sequences at once -> ([probs (1,1)], [h_last (1,H)])."""
+        probs, h_last = self.model.gan(torch.cat(xs, dim=1))
+        return [probs[i:i + 1] for i in range(len(xs))], [h_last[i:i + 1] for i in range(len(xs))]
+
     def train_video(self, x, y, noisy):
         """The three updates of one video (sumgan.py:413-479).  x (T,1,D), y (T,1,1) normalised gtscore; `noisy`: multiply the
+        discriminator's inputs by Gaussian noise (epoch < epoch_noise).  Returns (Lse, Ld, Lc, D(x), D(x_hat), D(x_hat_p),
+        scores) as device tensors.
+        The reference runs 5 generator and 8 discriminator passes one after the other; the passes of one update share their
+        weights, so they are batched here (3 + 3 passes: every recurrence step then streams the weights once for 2-3
+        sequences).  The random draws keep the reference's order -- a draw depends only on its shape, so the reparameterisation
+        noise of a pass can be drawn before that pass is computed."""
+        summ = self.model.summarizer
+        L, H = summ.vae.e_lstm.lstm.num_layers, summ.vae.e_lstm.lstm.hidden_size
+        eps_like = torch.empty(L, 1, H, device=x.device)
+        T = x.size(0)
+        # -- selector and encoder
+        scores = summ.s_lstm(x)
+        (x_hat,), mu, logvar = self._generate(x, [scores], [torch.randn_like(eps_like)])
+        _, (h_real, h_fake) = self._discriminate([x, x_hat])
+        sparsity = torch.nn.functional.binary_cross_entropy(scores, y) if self.sup else torch.abs(torch.mean(scores) - self.sigma)
+        loss_s_e = self.loss_recons(h_real, h_fake) + self.loss_prior(mu, logvar) + sparsity
+        self._update(self.s_e_optimizer, loss_s_e)
+        # -- decoder
+        scores = summ.s_lstm(x)
+        eps1 = torch.randn_like(eps_like); uniform = torch.rand((T, 1, 1)).to(x.device); eps2 = torch.randn_like(eps_like)
+        (x_hat, x_hat_p), _, _ = self._generate(x, [scores, uniform], [eps1, eps2])
+        (_, probs_fake, probs_uniform), (h_real, h_fake, _) = self._discriminate([x, x_hat, x_hat_p])
+        loss_d = self.loss_recons(h_real, h_fake) + self._bce(probs_fake, 0.9) + self._bce(probs_uniform, 0.9)
+        self._update(self.d_optimizer, loss_d)
+        # -- discriminator
+        scores = summ.s_lstm(x)
+        eps1 = torch.randn_like(eps_like); uniform = torch.rand((T, 1, 1)).to(x.device); eps2 = torch.randn_like(eps_like)
+        (x_hat, x_hat_p), _, _ = self._generate(x, [scores, uniform], [eps1, eps2])
+        x_real = x
+        if noisy:
+            x_real = torch.randn_like(x) * x
+            x_hat = x_hat * torch.randn_like(x_hat)
+            x_hat_p = x_hat_p * torch.randn_like(x_hat_p)
+        (probs_real, probs_fake, probs_uniform), _ = self._discriminate([x_real, x_hat, x_hat_p])
+        loss_c = self._bce(probs_real, 0.9) + self._bce(probs_fake, 0.1) + self._bce(probs_uniform, 0.1)
+        self._update(self.c_optimizer, loss_c)
+        return (loss_s_e.detach(), loss_d.detach(), loss_c.detach(), probs_real.mean().detach(), probs_fake.mean().detach(),
+                probs_uniform.mean().detach(), scores.detach())
+
+    def train_video_sequential(self, x, y, noisy):
+        """The three updates of one video (sumgan.py:413-479), pass by pass exactly as the reference writes them (13 separate
+        generator / discriminator passes).  `train_video` is the batched equivalent used by `train`.  x (T,1,D), y (T,1,1) normalised gtscore; `noisy`: multiply the
         discriminator's inputs by Gaussian noise (epoch < epoch_noise).  Returns (Lse, Ld, Lc, D(x), D(x_hat), D(x_hat_p),
         scores) as device tensors."""
         summ, gan = self.model.summarizer, self.model.gan

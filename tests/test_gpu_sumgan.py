@@ -199,3 +199,33 @@ def test_sumgan_trainer_reproduces_the_reference_trainer_end_to_end():
         for k in keys[:3]:
             s = tr.model(torch.from_numpy(ds[k]["features"][...]).unsqueeze(1).cuda()).squeeze().cpu().numpy()
             np.testing.assert_allclose(s, g[f"scores/{k}"], atol=5e-3)
+
+
+def test_sumgan_batched_video_step_equals_the_pass_by_pass_one():
+    """`train_video` batches the independent passes of each update; `train_video_sequential` runs the reference's 13 passes
+    one by one.  Same draws -> same losses, same parameters after two video steps (up to summation order in the weight-
+    gradient GEMMs)."""
+    import random
+    import recipes as R
+    from summarizer_amd.models.sumgan import SumGANTrainer
+    from summarizer_amd.utils.datasets import DictDataset
+    from summarizer_amd.utils.hps import make_hps
+    ep = {"input_size": "64", "sLSTM_hidden_size": "32", "edLSTM_hidden_size": "40", "cLSTM_hidden_size": "24", "sup": True}
+    results = []
+    for which in ("train_video", "train_video_sequential"):
+        hps = make_hps(DictDataset({}), [{"train_keys": [], "test_keys": []}], epochs=1, lr=1e-3, extra_params=dict(ep))
+        torch.manual_seed(9); random.seed(9)
+        tr = SumGANTrainer(hps, hps.splits_files[0]).reset()
+        tr.model.train(); tr.setup_optimizers()
+        x = torch.from_numpy(R.features(45, 1, 64, 77)).cuda()
+        y = torch.linspace(0, 1, 45, device="cuda").view(-1, 1, 1)
+        with R.DetRandom(4).patch() as det:
+            vals = [getattr(tr, which)(x, y, noisy=(i == 0)) for i in range(2)]
+            draws = det.n
+        results.append(([[float(v) for v in step[:6]] for step in vals], draws,
+                        {k: v.detach().cpu().numpy().copy() for k, v in tr.model.state_dict().items()}))
+    (la, da, wa), (lb, db, wb) = results
+    assert da == db == 17                                   # 10 draws with noise, 7 without
+    np.testing.assert_allclose(la, lb, rtol=1e-4)
+    for k in wa:
+        np.testing.assert_allclose(wa[k], wb[k], atol=2e-5, err_msg=k)
