@@ -21,6 +21,7 @@ run stress --no-cpu-baseline --workload stress --steps 10 --warmup 3
 run stress_bf16x3 --no-cpu-baseline --workload stress --precision bf16x3 --steps 10 --warmup 3
 run vasnet_stream --no-cpu-baseline --mode stream --steps 100 --warmup 10
 run dsn_stream --no-cpu-baseline --mode stream --model dsn --steps 100 --warmup 10
+run sumgan_train --model sumgan --mode train --steps 5 --warmup 1
 for m in "vasnet_score" "dsn_score --model dsn" "slstm_score --model slstm --steps 10 --warmup 3"; do
   set -- $m; name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o p -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 10 "$@" > $OUT/prof_$name.log 2>&1
