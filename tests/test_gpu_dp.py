@@ -56,3 +56,24 @@ def test_dp_two_ranks_equal_single_process_batch_of_two():
     for k in dp[0]:
         np.testing.assert_array_equal(dp[0][k], dp[1][k], err_msg=f"ranks disagree on {k}")
         np.testing.assert_allclose(dp[0][k], single[k], atol=2e-6, err_msg=f"DP != single-process batch for {k}")
+
+
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """`bench.py` as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) -- here with both ranks on the
+    one GPU of the test box over gloo (SUMK_BENCH_ONE_GPU=1): barriers, max-over-ranks timing, ONE JSON line from rank 0 whose
+    value counts the frames of all ranks."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SUMK_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--videos", "6"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak" and "cpu_baseline" not in out
+    per_rank = out["config"]["frames_per_step_per_gpu"]
+    assert abs(out["value"] - 2 * per_rank * 5 / (out["ms_per_step"] * 5 / 1e3)) / out["value"] < 1e-3
+    assert out["roofline"]["frac"] > 0 and out["bf16x3_mode"]["max_abs_score_diff_vs_fp32"] < 1e-4
