@@ -70,13 +70,15 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, persistent=False):
-    """Caller-owned scratch for one call.  Inference reuses one grow-only buffer per device; a training
-    forward gets its own buffer (it must survive until backward)."""
+    """Caller-owned scratch for one call.  Inference reuses one grow-only buffer per (device, stream) -- calls on one stream
+    are ordered, calls on different streams (e.g. ingest.StreamingScorer's compute stream next to the default one) must not
+    share scratch; a training forward gets its own buffer (it must survive until backward)."""
     if persistent:
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
-    buf = _ws_cache.get(str(device))
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = _ws_cache[str(device)] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        buf = _ws_cache[key] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
     return buf
 
 
