@@ -37,6 +37,7 @@ int sumk_device_count(void);
 /* GEMM arithmetic selectors (see sumk_vasnet_opts.precision) */
 #define SUMK_PRECISION_FP32 0
 #define SUMK_PRECISION_BF16X3 1
+#define SUMK_PRECISION_BF16X6 2   /* x = x1+x2+x3 exactly, 6 bf16 MFMAs per product: fp32-grade results */
 
 /* ------------------------------------------------------------------------------------------------ VASNet
  * Weights of summarizer/models/vasnet.py:56-66, each as stored by nn.Linear ([out][in]).
@@ -59,7 +60,8 @@ typedef struct sumk_vasnet_opts {
      of (seed, site, element index) -- see DESIGN.md "Dropout" -- so backward regenerates them. */
   float dropout_p;
   uint64_t seed;
-  /* arithmetic of the x.W^T / Q.K^T GEMMs: SUMK_PRECISION_FP32 (exact fp32 MFMA, the default everywhere) or
+  /* arithmetic of the GEMMs: SUMK_PRECISION_FP32 (native fp32 MFMA, the default everywhere), SUMK_PRECISION_BF16X6 (operands
+     split exactly into three bf16 planes, 6 bf16 MFMAs per product: fp32-grade results, DESIGN.md "bf16x6") or
      SUMK_PRECISION_BF16X3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: ~2^-16 relative
      per product, scores stay within ~1e-5 of the fp32 path -- DESIGN.md "bf16x3").  Storage is fp32 either way. */
   int32_t precision;

@@ -9,7 +9,7 @@ shapes = [("qkv", 12003, 3072, 1024), ("proj", 12003, 1024, 1024), ("big", 8192,
 bufs = {}
 for name, M, N, K in shapes:
     bufs[name] = (torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev))
-PREC = 1 if "bf16x3" in sys.argv[1:] else 0
+PREC = 2 if "bf16x6" in sys.argv[1:] else 1 if "bf16x3" in sys.argv[1:] else 0
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run(name, M, N, K):
     a, b, c = bufs[name]

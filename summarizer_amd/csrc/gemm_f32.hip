@@ -56,15 +56,12 @@ struct TileCtx {
   int32_t M, N, K, lda, ldb, ldc, ldr, m0, n0, klast;
 };
 
-// hi / lo fragments (8 consecutive k of this lane's row) of a [k][row] bf16 image: 2 transposing reads per plane
-__device__ __forceinline__ void tr_frag(const char* p, int pitch, int plane, bf16x8& hi, bf16x8& lo) {
+// one plane's fragment (8 consecutive k of this lane's row) of a [k][row] bf16 image: 2 transposing reads
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
   typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
   const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
   const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * pitch));
-  const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + plane));
-  const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + plane + 4 * pitch));
-  hi = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-  lo = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // __launch_bounds__(256, 3): three blocks per CU (152 VGPRs, 36 KB LDS for the 128x128 tile).
@@ -83,16 +80,23 @@ __device__ __forceinline__ void tr_frag(const char* p, int pitch, int plane, bf1
 // hands lane (i, h) the 4 consecutive k of column i, two reads per 8-k fragment (4 k-rows x 64 B per 32-lane half land on
 // 4 distinct 16-bank groups with that pitch).  The kernel has no divergent lanes in its main loop (EXEC all ones, as the
 // instruction requires).
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, bool X3 = false>
+// NS = number of bf16 planes an fp32 operand is split into: 0 = none (exact fp32 MFMA), 2 = "bf16x3" (above), 3 = "bf16x6":
+// x = x1 + x2 + x3 EXACTLY (3 x 8 significand bits = fp32's 24), products x_i y_j for i + j <= 4 -- six bf16 MFMAs per 16 k
+// instead of eight fp32 ones at 1/16 of their cost; the three dropped terms are <= 3 * 2^-24 relative, i.e. the result is
+// fp32-grade (the fp32 tolerances of tests/test_gpu_vasnet.py::test_gemm_layouts_vs_float64 hold).  The KC image row
+// becomes [x1 | x2 | x3] = 6 BK bytes + 16 B pad (pitch 52 dwords at BK = 32: 16 rows still hit 16 distinct 16-byte slots).
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
-  constexpr int KC_PITCH = BK + 4;            // +4 floats: conflict-free ds_read_b128 (pitch 36 or 68 dwords: 16 rows hit 16 distinct slots)
+  constexpr bool X3 = NS > 0;
+  static_assert(NS == 0 || NS == 2 || NS == 3, "operand split: 0, 2 or 3 bf16 planes");
+  constexpr int KC_PITCH = (NS == 3 ? 3 * BK / 2 : BK) + 4;   // +4 floats: conflict-free ds_read_b128 (pitch 36 / 52 / 68 dwords: 16 rows hit 16 distinct slots)
   constexpr int TPK = BK / 4, RPP = 256 / TPK;  // KC image: threads per row, rows covered per pass
   constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32; // MFMA tiles per wave along M / N
   constexpr int NLDA = BM * BK / 1024, NLDB = BN * BK / 1024;  // float4 loads per thread per operand per k-tile
   constexpr int MCP_A = 2 * BM + 64, MCP_B = 2 * BN + 64;   // X3: byte pitch of one k-row of a [k][row] bf16 plane
-  constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : (X3 ? 2 * BK * MCP_A / 4 : BK * BM);
-  constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : (X3 ? 2 * BK * MCP_B / 4 : BK * BN);
+  constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : (X3 ? NS * BK * MCP_A / 4 : BK * BM);
+  constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : (X3 ? NS * BK * MCP_B / 4 : BK * BN);
   __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
   float* sA = lds;
   float* sB = lds + A_ELEMS;
@@ -213,21 +217,28 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       }
     }
   };
-  auto split_store = [&](float* row, float4 v) {   // row: LDS row start; this thread's 4 k values -> hi | lo planes
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    const bf16x4 hi = __builtin_convertvector(x, bf16x4);
-    const bf16x4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4);
-    char* r8 = reinterpret_cast<char*>(row);
-    *reinterpret_cast<bf16x4*>(r8 + 2 * kq4) = hi;
-    *reinterpret_cast<bf16x4*>(r8 + 2 * BK + 2 * kq4) = lo;
+  // planes p = 0 .. NS-1 of this thread's 4 values: x_p = bf16(remainder), remainder -= x_p  (each subtraction is exact)
+  auto split_planes = [&](float4 v, bf16x4 (&pl)[3]) {
+    f32x4 r = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < (NS > 0 ? NS : 1); ++q) {
+      pl[q] = __builtin_convertvector(r, bf16x4);
+      if (q + 1 < NS) r = r - __builtin_convertvector(pl[q], f32x4);
+    }
+  };
+  auto split_store = [&](float* row, float4 v) {   // row: LDS row start; this thread's 4 k values -> planes [x1 | x2 (| x3)]
+    bf16x4 pl[3];
+    split_planes(v, pl);
+    char* r8 = reinterpret_cast<char*>(row) + 2 * kq4;
+#pragma unroll
+    for (int q = 0; q < (NS > 0 ? NS : 1); ++q) *reinterpret_cast<bf16x4*>(r8 + q * 2 * BK) = pl[q];
   };
   auto split_store_mc = [&](float* img, int krow, int col4, int pitch, float4 v) {   // 4 consecutive rows at one k
-    const f32x4 x = {v.x, v.y, v.z, v.w};
-    const bf16x4 hi = __builtin_convertvector(x, bf16x4);
-    const bf16x4 lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4);
+    bf16x4 pl[3];
+    split_planes(v, pl);
     char* r8 = reinterpret_cast<char*>(img) + krow * pitch + 2 * col4;
-    *reinterpret_cast<bf16x4*>(r8) = hi;
-    *reinterpret_cast<bf16x4*>(r8 + BK * pitch) = lo;
+#pragma unroll
+    for (int q = 0; q < (NS > 0 ? NS : 1); ++q) *reinterpret_cast<bf16x4*>(r8 + q * BK * pitch) = pl[q];
   };
   auto swrite = [&]() {
     if constexpr (X3) {
@@ -285,36 +296,48 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
         if (has_next) gload(nxt, 0);
       }
       if constexpr (X3) {
+        constexpr int NP = NS > 0 ? NS : 1;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-          bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+          bf16x8 af[NP][TM], bf[NP][TN];      // [plane][tile]: 8 consecutive k of this lane's row
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
             if constexpr (A_KC) {
               const char* rp = reinterpret_cast<const char*>(&sA[(wm * WTM + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
-              ah[t] = *reinterpret_cast<const bf16x8*>(rp); al[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+#pragma unroll
+              for (int q = 0; q < NP; ++q) af[q][t] = *reinterpret_cast<const bf16x8*>(rp + q * 2 * BK);
             } else {
-              tr_frag(reinterpret_cast<const char*>(sA) + (16 * ks + 8 * lh + ((lane & 15) >> 2)) * MCP_A +
-                          2 * (wm * WTM + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)), MCP_A, BK * MCP_A, ah[t], al[t]);
+              const char* rp = reinterpret_cast<const char*>(sA) + (16 * ks + 8 * lh + ((lane & 15) >> 2)) * MCP_A +
+                               2 * (wm * WTM + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+#pragma unroll
+              for (int q = 0; q < NP; ++q) af[q][t] = tr_frag(rp + q * BK * MCP_A, MCP_A);
             }
           }
 #pragma unroll
           for (int t = 0; t < TN; ++t) {
             if constexpr (B_KC) {
               const char* rp = reinterpret_cast<const char*>(&sB[(wn * WTN + t * 32 + li) * KC_PITCH]) + 32 * ks + 16 * lh;
-              bh[t] = *reinterpret_cast<const bf16x8*>(rp); bl[t] = *reinterpret_cast<const bf16x8*>(rp + 2 * BK);
+#pragma unroll
+              for (int q = 0; q < NP; ++q) bf[q][t] = *reinterpret_cast<const bf16x8*>(rp + q * 2 * BK);
             } else {
-              tr_frag(reinterpret_cast<const char*>(sB) + (16 * ks + 8 * lh + ((lane & 15) >> 2)) * MCP_B +
-                          2 * (wn * WTN + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)), MCP_B, BK * MCP_B, bh[t], bl[t]);
+              const char* rp = reinterpret_cast<const char*>(sB) + (16 * ks + 8 * lh + ((lane & 15) >> 2)) * MCP_B +
+                               2 * (wn * WTN + t * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+#pragma unroll
+              for (int q = 0; q < NP; ++q) bf[q][t] = tr_frag(rp + q * BK * MCP_B, MCP_B);
             }
           }
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {   // small cross terms first, then the main product
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn) {   // smallest terms first: planes (i, j) with i + j descending
+#pragma unroll
+              for (int sum = NP; sum >= 0; --sum)          // i + j = sum, 0-based planes; keep i + j <= NP - 1 ... plus (NS = 2) nothing more
+#pragma unroll
+                for (int i = NP - 1; i >= 0; --i) {
+                  const int j = sum - i;
+                  if (j < 0 || j >= NP || i + j > NP - 1) continue;
+                  acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][tm], bf[j][tn], acc[tm][tn], 0, 0, 0);
+                }
             }
         }
       } else {
@@ -399,7 +422,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   }
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool X3 = false>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int X3 = 0>
 static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
   // every block then loops over tiles  b, b+grid, ...
@@ -418,7 +441,7 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
   return SUMK_OK;
 }
 
-template <int BM, int BN, int BK, bool X3 = false>
+template <int BM, int BN, int BK, int X3 = 0>
 static int launch_layout(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   if (layout == GEMM_NT) return launch_epi<BM, BN, BK, true, true, X3>(epi, ka, tiles, s);
   if (layout == GEMM_NN) return launch_epi<BM, BN, BK, true, false, X3>(epi, ka, tiles, s);
@@ -446,9 +469,13 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
   if (g.precision == SUMK_PRECISION_BF16X3) {   // bf16x3 arithmetic (same tiles, same k order per tile shape)
-    if (g.small_tile == 1) rc = launch_layout<64, 64, 32, true>(layout, epi, ka, ka.total_tiles, stream);
-    else if (g.small_tile == 2) rc = launch_layout<128, 64, 32, true>(layout, epi, ka, ka.total_tiles, stream);
-    else rc = launch_layout<128, 128, 32, true>(layout, epi, ka, ka.total_tiles, stream);
+    if (g.small_tile == 1) rc = launch_layout<64, 64, 32, 2>(layout, epi, ka, ka.total_tiles, stream);
+    else if (g.small_tile == 2) rc = launch_layout<128, 64, 32, 2>(layout, epi, ka, ka.total_tiles, stream);
+    else rc = launch_layout<128, 128, 32, 2>(layout, epi, ka, ka.total_tiles, stream);
+  } else if (g.precision == SUMK_PRECISION_BF16X6) {   // fp32-grade emulation on the bf16 MFMA
+    if (g.small_tile == 1) rc = launch_layout<64, 64, 32, 3>(layout, epi, ka, ka.total_tiles, stream);
+    else if (g.small_tile == 2) rc = launch_layout<128, 64, 32, 3>(layout, epi, ka, ka.total_tiles, stream);
+    else rc = launch_layout<128, 128, 32, 3>(layout, epi, ka, ka.total_tiles, stream);
   } else
   if (g.small_tile == 1) rc = bk64 ? launch_layout<64, 64, 64>(layout, epi, ka, ka.total_tiles, stream)
                                    : launch_layout<64, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
@@ -617,7 +644,7 @@ extern "C" int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M,
 }
 extern "C" int sumk_gemm_prec(int32_t layout, const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K,
                               int32_t precision, void* stream) {
-  SUMK_ARG(precision == SUMK_PRECISION_FP32 || precision == SUMK_PRECISION_BF16X3, "gemm: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "gemm: unknown precision %d", precision);
   SUMK_ARG(layout >= 0 && layout <= 2, "gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
   if (layout == 0) return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream, precision);
   if (layout == 1) return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream, precision);

@@ -92,7 +92,7 @@ VASNET_FIELDS = [("Wk", "K.weight"), ("Wq", "Q.weight"), ("Wv", "V.weight"), ("W
                  ("ln_w", "layer_norm.weight"), ("ln_b", "layer_norm.bias")]
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1}      # SUMK_PRECISION_* of include/sumk.h
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}      # SUMK_PRECISION_* of include/sumk.h
 
 
 def precision_code(p):

@@ -22,7 +22,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-@pytest.mark.parametrize("precision,gtol", [("fp32", 2e-4), ("bf16x3", 1e-3)])
+@pytest.mark.parametrize("precision,gtol", [("fp32", 2e-4), ("bf16x3", 1e-3), ("bf16x6", 2e-4)])
 @pytest.mark.parametrize("tag,kw", [("vasnet", dict()), ("vasnet_loc", dict(attention_aperture=4, ignore_self=True))])
 def test_vasnet_train_step_goldens(dev, tag, kw, precision, gtol):
     from summarizer_amd.models.vasnet import VASNet
@@ -38,14 +38,14 @@ def test_vasnet_train_step_goldens(dev, tag, kw, precision, gtol):
         loss = torch.nn.functional.mse_loss(scores, tgt)
         opt.zero_grad(); loss.backward()
         if s == 0:
-            np.testing.assert_allclose(loss.item(), g[f"{tag}/loss0"], rtol=2e-5 if precision == "fp32" else 1e-4)
+            np.testing.assert_allclose(loss.item(), g[f"{tag}/loss0"], rtol=1e-4 if precision == "bf16x3" else 2e-5)
             for k, p in m.named_parameters():
                 ref = g[f"{tag}/grad0/{k}"]
                 assert _rel(p.grad.cpu().numpy(), ref) < gtol, (k, _rel(p.grad.cpu().numpy(), ref))
         opt.step()
         if s in (0, 2):
             for k, p in m.named_parameters():
-                np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"{tag}/param{s+1}/{k}"], atol=2e-6 if precision == "fp32" else 5e-6, err_msg=f"{k} step {s+1}")
+                np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"{tag}/param{s+1}/{k}"], atol=5e-6 if precision == "bf16x3" else 2e-6, err_msg=f"{k} step {s+1}")
 
 
 def test_vasnet_grads_vs_torch_port_ragged_batch_with_dropout(dev):

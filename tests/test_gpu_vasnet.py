@@ -84,6 +84,33 @@ def test_gemm_bf16x3_vs_float64(dev, M, N, K):
                 assert (np.abs(got - ref) <= bound).all(), f"{name} bf16x3 max err {np.abs(got - ref).max()}"
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 4, 4), (36, 64, 64), (132, 192, 100), (128, 128, 1024), (300, 3072, 1024), (64, 1000, 36), (200, 1024, 260)])
+def test_gemm_bf16x6_is_fp32_grade(dev, M, N, K):
+    """bf16x6 (three bf16 planes = fp32's 24 significand bits, six bf16 MFMAs per product) must satisfy the SAME bound as the
+    exact fp32 MFMA path in test_gemm_layouts_vs_float64, in all three layouts."""
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bt = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ Bt.astype(np.float64).T
+    tol = 2e-6 * np.abs(A).astype(np.float64) @ np.abs(Bt).astype(np.float64).T + 1e-6
+    worst = {}
+    for prec in (0, 2):
+        for layout, name in ((0, "NT"), (1, "NN"), (2, "TN")):
+            a_host = A if layout < 2 else np.ascontiguousarray(A.T)
+            b_host = Bt if layout == 0 else np.ascontiguousarray(Bt.T)
+            a = torch.from_numpy(a_host).to(dev); b = torch.from_numpy(b_host).to(dev)
+            c = torch.full((M, N), float("nan"), device=dev)
+            _lib.check(lib.sumk_gemm_prec(layout, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, prec, st), "gemm")
+            torch.cuda.synchronize()
+            err = np.abs(c.cpu().numpy() - ref)
+            assert (err <= tol).all(), f"{name} precision {prec} max err {err.max()}"
+            worst[(prec, name)] = float((err / tol).max())
+    print("worst err / tol:", worst)
+
+
 def test_gemm_exact_integer_data_asymmetric(dev):
     # exact small-integer operands: any mis-mapped fragment / k pairing shows up as an exact mismatch
     from summarizer_amd import _lib
@@ -97,7 +124,7 @@ def test_gemm_exact_integer_data_asymmetric(dev):
     np.testing.assert_array_equal(_gemm(lib.sumk_gemm_tn, np.ascontiguousarray(A.T), np.ascontiguousarray(Bt.T), M, N, K, dev), ref)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x6"])
 def test_vasnet_small_goldens_all_variants(dev, precision):
     g = load_golden("vasnet_small")
     meta = js(g["meta"])
@@ -127,7 +154,7 @@ def test_vasnet_pos_embed_mutates_callers_tensor_like_reference(dev):
     np.testing.assert_allclose(x.cpu().numpy()[:, 0, :], x0[:, 0, :] + w["pos_embed.weight"][:37], atol=1e-6)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x6"])
 def test_vasnet_full_size_goldens(dev, precision):
     g = load_golden("vasnet_full")
     n = len([k for k in g.files if k.endswith("/cfg")])

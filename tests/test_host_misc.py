@@ -10,6 +10,7 @@ def test_precision_selector():
     from summarizer_amd import kernels
     from summarizer_amd._lib import SumkError
     assert kernels.precision_code(None) == 0 and kernels.precision_code("fp32") == 0 and kernels.precision_code("bf16x3") == 1
+    assert kernels.precision_code("bf16x6") == 2
     with pytest.raises(SumkError):
         kernels.precision_code("bf16")
 
