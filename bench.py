@@ -276,14 +276,22 @@ def main():
     barrier()
     lib.sumk_prof_read(_lib.PROF_GEMM_QKV, None, None, 1)
     lib.sumk_prof_enable(1)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if run_step is not None else []
     t0 = time.perf_counter()
     if run_step is None:
         s = run_steps(args.steps)
     else:
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             s = run_step()
+            marks[i + 1].record()          # per-step device time (median and p10 / p90), no host sync inside the loop
     barrier()
     t1 = time.perf_counter()
+    step_ms = None
+    if marks:
+        per = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+        step_ms = dict(median=round(float(np.median(per)), 4), p10=round(float(np.percentile(per, 10)), 4),
+                       p90=round(float(np.percentile(per, 90)), 4))
     lib.sumk_prof_enable(0)
     elapsed = t1 - t0
     if dist is not None:
@@ -337,6 +345,8 @@ def main():
                                frames_per_step_per_gpu=frames, parallelism=f"video-sharded x{world}"),
                    whole_path_tflops=round(frames * world * args.steps / elapsed * flops_frame / 1e12, 2),
                    roofline=roof)
+        if step_ms is not None:
+            out["step_ms_device_events"] = step_ms
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
         if args.mode == "stream":
