@@ -138,3 +138,35 @@ def test_dsn_batch_properties_full_size(dev):
         assert torch.equal(b[offr[j]:offr[j + 1]], a[off[i]:off[i + 1]])
         assert torch.equal(singles[i], a[off[i]:off[i + 1]])
     assert bool(((a > 0) & (a < 1)).all())
+
+
+@pytest.mark.parametrize("kind,T", [("dsn", 3000), ("slstm", 400)])
+def test_bilstm_time_reversal_symmetry_full_size(dev, kind, T):
+    """Size-independent property at BASELINE sizes (D = 1024; DSN H = 256 at T = 3000, sLSTM 2 x H = 1024 at T = 400):
+    a bidirectional LSTM run on the time-reversed video with its forward / reverse weights swapped produces the
+    time-reversed hidden sequence with the two halves swapped -- so, with the head's halves swapped too, the reversed scores."""
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.sumgan import sLSTM
+    torch.manual_seed(6)
+    m = (DSN() if kind == "dsn" else sLSTM()).eval().to(dev)
+    pre, hw = ("rnn.", "out.0.weight") if kind == "dsn" else ("lstm.", "out.weight")
+    H = m.hidden_size
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sw = {}
+    for k, v in sd.items():
+        if k.startswith(pre):
+            other = k[:-8] if k.endswith("_reverse") else k + "_reverse"
+            v = sd[other].clone()
+            layer = int(k.split("_l")[1].split("_")[0])
+            if "weight_ih" in k and layer > 0:                       # deeper layers see [fwd || rev] inputs: swap the halves
+                v = torch.cat([v[:, H:], v[:, :H]], dim=1)
+        elif k == hw:
+            v = torch.cat([v[:, H:], v[:, :H]], dim=1)
+        sw[k] = v
+    m2 = (DSN() if kind == "dsn" else sLSTM()).eval().to(dev)
+    m2.load_state_dict(sw)
+    x = torch.from_numpy(R.features(T, 1, 1024, 4242)[:, 0, :]).to(dev)
+    with torch.no_grad():
+        a = m.score_packed(x, [T])
+        b = m2.score_packed(torch.flip(x, (0,)).contiguous(), [T])
+    np.testing.assert_allclose(torch.flip(b, (0,)).cpu().numpy(), a.cpu().numpy(), atol=1e-6, rtol=0)
