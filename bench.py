@@ -30,7 +30,7 @@ def tvsum_lens(n_videos=50):
     return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
 
 
-def cpu_baseline(lens, D, budget_s=20.0):
+def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet"):
     """Reference-equivalent stock-PyTorch CPU path (oracle/torch_port.py), one video per call as in
     Trainer.test (summarizer/models/__init__.py:45-54).  torch's intra-op pool is swept over a few thread
     counts (a 256-thread pool is far slower than 16-32 threads on (T<=320, 1024) matrices); the BEST setting is
@@ -38,22 +38,33 @@ def cpu_baseline(lens, D, budget_s=20.0):
     import recipes as R
     from oracle import torch_port
     torch.manual_seed(1234)
-    from summarizer_amd.models.vasnet import VASNet
-    m = VASNet(input_size=D)
-    p = {k: v.detach() for k, v in m.named_parameters()}
+    if kind == "vasnet":
+        from summarizer_amd.models.vasnet import VASNet
+        p = {k: v.detach() for k, v in VASNet(input_size=D).named_parameters()}
+        score = lambda x: torch_port.vasnet_scores(x, p)
+    else:                                   # DSN (BiLSTM 1024 -> 2 x 256) or sLSTM (2 layers, 2 x 1024): torch's own nn.LSTM on the CPU
+        from summarizer_amd.models.dsn import DSN
+        from summarizer_amd.models.sumgan import sLSTM
+        m = DSN(input_size=D) if kind == "dsn" else sLSTM(input_size=D)
+        p = {k: v.detach() for k, v in m.named_parameters()}
+        pre, hw, hb = ("rnn.", "out.0.weight", "out.0.bias") if kind == "dsn" else ("lstm.", "out.weight", "out.bias")
+        lstm = torch_port.make_lstm(p, pre, D, m.hidden_size, m.num_layers)
+        score = lambda x: torch_port.bilstm_scores(x, p, pre, hw, hb, D, m.hidden_size, m.num_layers, lstm=lstm)
     ncores = os.cpu_count() or 1
     xs = [torch.from_numpy(R.features(T, 1, D, 1000 + i)) for i, T in enumerate(lens)]
-    cands = sorted({t for t in (1, 8, 16, 32, 64, ncores) if t <= ncores})
+    # (an intra-op pool as wide as a 256-cpu host is pathological on these sizes -- 95 frames/s for VASNet, minutes per video for
+    #  the LSTMs -- so the sweep stops at 64 threads)
+    cands = sorted({t for t in (1, 8, 16, 32, 64, min(ncores, 64)) if t <= ncores})
     per = budget_s / len(cands)
     res = {}
     with torch.no_grad():
         for nt in cands:
             torch.set_num_threads(nt)
-            torch_port.vasnet_scores(xs[0], p)
+            score(xs[0])
             frames, t0, n = 0, time.perf_counter(), 0
             while True:
                 x = xs[n % len(xs)]
-                torch_port.vasnet_scores(x, p)
+                score(x)
                 frames += x.shape[0]; n += 1
                 el = time.perf_counter() - t0
                 if el > per:
@@ -61,7 +72,7 @@ def cpu_baseline(lens, D, budget_s=20.0):
             res[nt] = (frames / el, n, el)
     best = max(res, key=lambda k: res[k][0])
     return dict(value=round(res[best][0], 1), unit="frames/s", cores=best, kind="port",
-                sample=f"single-video VASNet forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops) on a "
+                sample=f"single-video {kind} forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops) on a "
                        f"{ncores}-cpu host; frames/s by intra-op threads: " +
                        ", ".join(f"{k}t={v[0]:.0f} ({v[1]} videos/{v[2]:.1f}s)" for k, v in res.items()))
 
@@ -355,8 +366,8 @@ def main():
         if alt is not None:
             out["bf16x6_mode"] = alt6
             out["bf16x3_mode"] = alt
-        if world == 1 and not args.no_cpu_baseline and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum":
-            out["cpu_baseline"] = cpu_baseline(lens, D)
+        if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
+            out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
