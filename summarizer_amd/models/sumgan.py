@@ -193,6 +193,9 @@ class SumGANTrainer(Trainer):
                  (("input_size", 1024), ("sLSTM_hidden_size", 1024), ("sLSTM_num_layers", 2), ("edLSTM_hidden_size", 2048),
                   ("edLSTM_num_layers", 2), ("cLSTM_hidden_size", 1024), ("cLSTM_num_layers", 2))}
         model = SumGAN(**sizes)
+        for mod in model.modules():                       # "fp32" | "bf16x6" | "bf16x3" for every input projection / dense layer
+            if hasattr(mod, "precision"):
+                mod.precision = ep.get("precision", "fp32")
         self.log.debug("Generator params: {}".format(sum(p.numel() for p in model.summarizer.parameters())))
         self.log.debug("Discriminator params: {}".format(sum(p.numel() for p in model.gan.parameters())))
         return model
