@@ -113,12 +113,21 @@ typedef struct sumk_vasnet_grads {
 int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
                          const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
                          const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* grads,
-                         float* dx, void* workspace, size_t workspace_bytes, void* stream);
+                         float* dx, void* workspace, size_t workspace_bytes, void* stream,
+                         void* tail_grads_ready_event);
+/* tail_grads_ready_event: NULL, or a hipEvent_t recorded on `stream` once the gradients of Wo, W1, b1, w2 and b2 are final
+ * (before the attention backward and the Q/K/V weight gradients run): a data-parallel caller overlaps the all-reduce of
+ * that part of its gradient bucket with the rest of this call (summarizer_amd/training.py: FlatAdam.reduce_tail_async). */
 
 /* Synchronises `stream` and returns an error if a persistent recurrence kernel that used this workspace reported a
- * timed-out hand-off (outputs invalid).  Cheap; the trainers call it once per evaluation, tests after every call. */
+ * timed-out hand-off (outputs invalid).  Per-workspace word: valid until the next call reuses the workspace; the test-suite
+ * (SUMK_CHECK=1) calls it after every recurrent layer.  Production code uses sumk_health_check below. */
 int sumk_bilstm_check(const void* workspace, int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host,
                       int32_t training, int32_t after_backward, void* stream);
+/* Sticky, workspace-free variant: synchronises `stream` and fails if ANY persistent recurrence kernel on the current device
+ * timed out since the previous call (then resets the device-side word).  The Python trainers / scorers call it at the host
+ * synchronisation points they already have (score D2H in Trainer.test / predict_dataset / StreamingScorer, per-epoch loss). */
+int sumk_health_check(void* stream);
 
 typedef struct sumk_lstm_layer_grads {
   float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];

@@ -1,4 +1,4 @@
-"""0/1 knapsack used for key-shot selection.  TEST INFRASTRUCTURE ONLY.  *** PARITY UNPINNED ***
+"""0/1 knapsack used for key-shot selection.  TEST INFRASTRUCTURE ONLY.  *** PARITY PINNED EXCEPT TIES ***
 
 Reference call site: summarizer/utils/knapsack.py:5-23, reached from summarizer/utils/eval.py:99.
 The arithmetic lives in a third-party dependency that is NOT under /root/reference:
@@ -11,8 +11,17 @@ solution reconstruction:
         if profits[c-w]+v > profits[c] (STRICT): profits[c]=..., sel[c]=item;  return sel[cap]
   Solve(): rem=capacity, n=num_items; while rem>0 and n>0: s=SolveSubProblem(rem,n); rem-=w[s]; n=s;
         if rem>=0: best[s]=True
-The optimal VALUE is unique and is what tests check (against brute force); the selected SET under ties is
-solver specific and unverified.  (KnapsackSolver's optional problem reduction pass is not restated.)
+What IS pinned (tests/test_host_eval.py):
+  * the optimal VALUE against brute force;
+  * the selected SET on every instance whose optimum is unique (exhaustive check, S <= 18): any exact solver, OR-tools'
+    included, must return that set;
+  * the whole reference pipeline around the solver -- segment means, trunc(1000 * mean) values, capacity, expansion to
+    frames, F-scores -- against tests/golden/knapsack_e2e.npz, produced by the REAL `generate_summary(method="knapsack")`
+    + `evaluate_summary` with only the solver swapped for an exhaustive one (make_golden_knapsack.py), unique-optimum
+    videos only.
+What remains UNVERIFIED: which of several equally valuable subsets OR-tools returns (tie-breaking; also its optional
+problem-reduction pass).  A tie needs two feasible subsets with the same sum of trunc(1000 * mean) values -- e.g. equal
+segment scores, or zero-valued segments that may be included or not.
 The value/weight conversion IS the reference's: values = trunc(score*1000) as int, weights = int(nfps)
 (knapsack.py:11-15).
 """

@@ -60,3 +60,28 @@ def bilstm_scores(x, p, prefix, head_w, head_b, input_size, hidden_size, num_lay
     lstm = lstm if lstm is not None else make_lstm(p, prefix, input_size, hidden_size, num_layers)
     h, _ = lstm(x)
     return torch.sigmoid(F.linear(h, p[head_w], p[head_b]))
+
+
+class TransformerPort(torch.nn.Module):
+    """Stock-PyTorch restatement of the reference Transformer scorer (transformer.py:19-103) with every dropout at 0:
+    learnable positional table added in place, nn.TransformerEncoder (post-norm, FF = D) whose final norm is the SAME
+    LayerNorm that follows k1, then k1 / ReLU / LayerNorm / k2 / sigmoid.  Autograd-capable checker for the HIP path."""
+
+    def __init__(self, D, n_layers, n_heads, max_length=None, eps=1e-5, more_residuals=False):
+        super().__init__()
+        nn = torch.nn
+        self.pos_embed = nn.Embedding(max_length, D) if max_length else None
+        self.layer_norm = nn.LayerNorm(D, eps)
+        layer = nn.TransformerEncoderLayer(d_model=D, nhead=n_heads, dim_feedforward=D, dropout=0.0, activation="relu")
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=n_layers, norm=self.layer_norm, enable_nested_tensor=False)
+        self.k1, self.k2 = nn.Linear(D, D), nn.Linear(D, 1)
+        self.more_residuals = more_residuals
+
+    def forward(self, x):
+        T, B, D = x.shape
+        if self.pos_embed is not None:
+            x = x + self.pos_embed(torch.arange(T)).unsqueeze(1)          # 'simple' table: row t for every batch entry
+        e = self.transformer_encoder(x)
+        if self.more_residuals:
+            e = e + x
+        return torch.sigmoid(self.k2(self.layer_norm(torch.relu(self.k1(e)))))

@@ -77,12 +77,13 @@ _SIGS = {
                                       C.c_int32, C.c_void_p]),
     "sumk_vasnet_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
                                        C.POINTER(VasnetOpts), c_f32p, C.POINTER(VasnetGrads), c_f32p, C.c_void_p,
-                                       C.c_size_t, C.c_void_p]),
+                                       C.c_size_t, C.c_void_p, C.c_void_p]),
     "sumk_bilstm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_bilstm_layer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
                                             C.POINTER(LstmLayerWeights), c_f32p, C.c_void_p, C.c_size_t, C.c_int32,
                                             C.c_int32, C.c_void_p]),
     "sumk_bilstm_check": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_health_check": (C.c_int, [C.c_void_p]),
     "sumk_bilstm_layer_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P,
                                              c_i32p, C.POINTER(LstmLayerWeights), C.POINTER(LstmLayerGrads), c_f32p,
                                              C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),

@@ -20,6 +20,17 @@ def _grad_targets(names, params):
     return grads, ret
 
 
+def _table_grad(table, rows, dx):
+    """Learnable positional embedding (vasnet.py:42, transformer.py:49): rows of dx scatter-add into the table's gradient.
+    Accumulated IN PLACE when .grad exists -- FlatAdam's .grad is a view of its flat bucket, and rebinding .grad to a new
+    tensor would leave the bucket (what step() and the all-reduce read) at zero.  A few KB of index bookkeeping, done
+    with a torch op rather than a dedicated kernel."""
+    with torch.no_grad():
+        if table.grad is None:
+            table.grad = torch.zeros_like(table)
+        table.grad.index_add_(0, rows.long(), dx)
+
+
 class VasnetFunction(torch.autograd.Function):
     """scores = VASNet(x) for a packed batch.  inputs: x, SeqBatch, opts, pos table/rows, param names, *params."""
 
@@ -44,10 +55,7 @@ class VasnetFunction(torch.autograd.Function):
         dx = kernels.vasnet_backward_packed(xp, ctx.sb, p, ctx.opts, dscores, ctx.ws, grads, want_dx=want_dx)
         ctx.ws = None
         if ctx.table_is_param:
-            # learnable positional embedding (vasnet.py:42): rows of dx scatter-add into the table.  A few KB of
-            # index bookkeeping, done with a torch op rather than a dedicated kernel.
-            tg = torch.zeros_like(ctx.table).index_add_(0, ctx.rows.long(), dx)
-            ctx.table.grad = tg if ctx.table.grad is None else ctx.table.grad + tg
+            _table_grad(ctx.table, ctx.rows, dx)
         gx = dx if ctx.needs_input_grad[0] else None
         ctx.params = None
         return (gx, None, None, None, None, None) + tuple(ret)
@@ -112,8 +120,7 @@ class TransformerFunction(torch.autograd.Function):
         dx = kernels.transformer_backward_packed(xp, sb, p, grads, cfg["n_layers"], cfg["n_heads"], cfg["dff"], opts, dscores,
                                                  ctx.ws, want_dx=want_dx)
         if ctx.table_is_param:
-            tg = torch.zeros_like(ctx.table).index_add_(0, rows.long(), dx)
-            ctx.table.grad = tg if ctx.table.grad is None else ctx.table.grad + tg
+            _table_grad(ctx.table, rows, dx)
         ctx.ws = ctx.params = None
         return (dx if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + tuple(ret)
 

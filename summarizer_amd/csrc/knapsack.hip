@@ -2,8 +2,9 @@
 // Replaces knapsack_ortools (summarizer/utils/knapsack.py:5-23): OR-tools' KNAPSACK_DYNAMIC_PROGRAMMING_SOLVER
 // (ortools==7.5.7466, third party, not vendored).  Restated from the published solver: a 1-D DP over capacity
 // keeping, per capacity, the best profit and the LAST item that improved it (strict '>'), and a reconstruction that
-// re-solves the shrinking sub-problem (items < last selected, remaining capacity).  Parity with OR-tools is
-// UNPINNED (see oracle/knapsack_np.py); the optimal value is checked against brute force in tests.
+// re-solves the shrinking sub-problem (items < last selected, remaining capacity).  Parity is pinned wherever the
+// optimum is unique (selected set == the unique optimal set; the reference pipeline's summaries and F-scores around an
+// exhaustive solver, tests/golden/knapsack_e2e.npz); tie-breaking versus OR-tools stays unverified (oracle/knapsack_np.py).
 #include "sumk_internal.h"
 #include <vector>
 

@@ -491,6 +491,11 @@ struct PersistArgs {
   int32_t n_seq, H, gsize, n_groups, upm, n_active, hout_bytes, n_teams;
 };
 
+// Sticky per-device health word: every persistent kernel ORs 1 into it when a bounded hand-off wait times out, in addition to
+// the per-call word in the workspace (which the next call on a shared inference workspace clears).  sumk_health_check reads
+// and resets it; the Python host calls that at the synchronisation points it already has (score D2H, per-epoch loss).
+__device__ unsigned g_sumk_health = 0u;
+
 constexpr int PK_THREADS = 512;
 constexpr int PK_TEAMS = 8;
 constexpr unsigned PK_SPIN_LIMIT = 1u << 20;   // ~1 s of polling; after one timeout the block stops waiting altogether
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
             __builtin_amdgcn_s_sleep(1);
             if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
                  __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicOr(a.state, 1u); dead = true; break;   // never hang the GPU: flag the failure and stop waiting
+              atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); dead = true; break;   // never hang the GPU: flag the failure and stop waiting
             }
           }
         }
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
                  __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicOr(a.state, 1u); dead = true; break;   // never hang the GPU: flag the failure and stop waiting
+              atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); dead = true; break;   // never hang the GPU: flag the failure and stop waiting
             }
           }
         }
@@ -1107,7 +1112,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
             __builtin_amdgcn_s_sleep(1);
             if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
                  __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicOr(a.state, 1u); dead = true; break;
+              atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); dead = true; break;
             }
           }
         }
@@ -2096,6 +2101,24 @@ extern "C" int sumk_bilstm_check(const void* workspace, int32_t In, int32_t H, i
   if (flags[0] != 0u || flags[1] != 0u) {
     set_error("bilstm: persistent recurrence kernel timed out waiting for a team member (forward flag %u, backward flag %u); "
               "outputs are invalid -- rerun with SUMK_LSTM_PERSIST=0 to use the launch-per-step kernels", flags[0], flags[1]);
+    return SUMK_ERR_HIP;
+  }
+  return SUMK_OK;
+}
+
+// Sticky health check (no workspace needed): synchronises `stream`, then fails if ANY persistent recurrence kernel on this
+// device has timed out since the last check -- every result produced in between is suspect.  Resets the word.
+extern "C" int sumk_health_check(void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  unsigned flag = 0u;
+  SUMK_HIP(hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(g_sumk_health), sizeof(flag), 0, hipMemcpyDeviceToHost, stream));
+  SUMK_HIP(hipStreamSynchronize(stream));
+  if (flag != 0u) {
+    const unsigned zero = 0u;
+    SUMK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sumk_health), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, stream));
+    SUMK_HIP(hipStreamSynchronize(stream));
+    set_error("persistent LSTM recurrence kernel timed out waiting for a team member since the last health check (flag %u): "
+              "scores / gradients produced in between are INVALID -- rerun with SUMK_LSTM_PERSIST=0 (launch-per-step kernels)", flag);
     return SUMK_ERR_HIP;
   }
   return SUMK_OK;

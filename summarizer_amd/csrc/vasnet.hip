@@ -631,7 +631,8 @@ int launch_ln_head_bwd(int D, int R, const float* Z, const float* stats, const f
 extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
                                     const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
                                     const sumk_vasnet_opts* opts, const float* dscores, const sumk_vasnet_grads* gr,
-                                    float* dx, void* workspace, size_t workspace_bytes, void* stream_) {
+                                    float* dx, void* workspace, size_t workspace_bytes, void* stream_,
+                                    void* tail_grads_ready_event) {
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && seq_off_dev && w && opts && dscores && gr && workspace, "vasnet_backward: null pointer");
   SUMK_ARG(gr->Wk && gr->Wq && gr->Wv && gr->Wo && gr->W1 && gr->b1 && gr->w2 && gr->b2 && gr->ln_w && gr->ln_b,
@@ -699,6 +700,9 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
+  // Wo, W1, b1, w2, b2 (the tail of the parameter order) are final from here on: a data-parallel caller starts their
+  // all-reduce on a side stream now, under the attention backward and the QKV weight gradients (60 % of the bucket).
+  if (tail_grads_ready_event) SUMK_HIP(hipEventRecord((hipEvent_t)tail_grads_ready_event, stream));
   // 4': dV = alphaD^T dC ; dAlphaD = dC V^T
   const float* Pd = use_e2 ? E2 : E;
   {

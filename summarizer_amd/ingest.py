@@ -43,6 +43,7 @@ class StreamingScorer:
         self.slots = [_Slot(self.max_frames, self.D, self.dev) for _ in range(max(1, int(depth)))]
         self.copy_stream = torch.cuda.Stream(self.dev)
         self.compute_stream = torch.cuda.Stream(self.dev)
+        self.check_stream = torch.cuda.Stream(self.dev)
         self._lib = _lib.load()
 
     # ------------------------------------------------------------------ one batch through a slot
@@ -76,6 +77,9 @@ class StreamingScorer:
         keys, lens = slot.pending
         slot.pending = None
         slot.all_done.synchronize()
+        # this batch is home: did a persistent recurrence kernel time out?  (own stream: synchronising the compute stream here
+        # would also wait for the batches still in flight behind this one)
+        _lib.check(self._lib.sumk_health_check(C.c_void_p(self.check_stream.cuda_stream)), "sumk_health_check")
         flat = slot.host_s[:sum(lens)].numpy()
         off = np.concatenate([[0], np.cumsum(lens)])
         return [(k, flat[off[i]:off[i + 1]].copy()) for i, k in enumerate(keys)]
@@ -85,6 +89,9 @@ class StreamingScorer:
         """videos: iterable of (key, float32 (T, D) array).  Yields (key, float32 (T,) scores) in input order."""
         was_training = self.model.training
         self.model.eval()
+        # entry ordering: whatever the caller queued on ITS stream (model.to(dev), load_state_dict, the last optimiser step)
+        # must be visible to the scoring kernels that read the weights on the private compute stream
+        self.compute_stream.wait_stream(torch.cuda.current_stream(self.dev))
         try:
             inflight = deque()
             batch, frames, turn = [], 0, 0

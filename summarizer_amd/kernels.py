@@ -177,6 +177,13 @@ def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False, precis
     return h, (ws if training else None)
 
 
+def health_check():
+    """Raises SumkError if a persistent recurrence kernel on the current device timed out since the last check (its
+    outputs, and everything computed from them, are invalid).  Synchronises the current stream; meant for the host
+    synchronisation points callers already have (score D2H, per-epoch loss read-back)."""
+    _lib.check(_lib.load().sumk_health_check(_stream()), "sumk_health_check")
+
+
 def frame_head_forward(h, w, b):
     """scores = sigmoid(h @ w.T + b) for h (n_rows, F), w (1, F) or (F,), b (1,)."""
     lib = _lib.load()
@@ -201,8 +208,12 @@ def vasnet_backward_packed(x, sb, params, opts, dscores, ws, grads, want_dx=Fals
     dx = torch.empty_like(x) if want_dx else None
     if not dscores.is_contiguous():
         dscores = dscores.contiguous()
+    ev = opts.get("tail_grads_ready_event")          # torch.cuda.Event recorded mid-backward (data-parallel overlap) or None
+    if ev is not None:
+        ev.record()                                  # materialise the lazy hipEvent_t handle (re-recorded by the library)
     rc = lib.sumk_vasnet_backward(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o), _p(dscores),
-                                  C.byref(g), _p(dx), _p(ws), ws.numel(), _stream())
+                                  C.byref(g), _p(dx), _p(ws), ws.numel(), _stream(),
+                                  C.c_void_p(ev.cuda_event) if ev is not None else C.c_void_p(0))
     _lib.check(rc, "sumk_vasnet_backward")
     return dx
 

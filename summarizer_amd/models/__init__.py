@@ -16,6 +16,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from .. import kernels
 from ..utils import eval as ev
 from ..utils import eval_native
 from ..utils.datasets import open_dataset
@@ -117,6 +118,7 @@ class Trainer:
             for key in keys:
                 feats = self._video_on_device(key, dev)[0]
                 out[key] = self.model(feats.unsqueeze(1).clone()).squeeze().detach().cpu().numpy()
+            kernels.health_check()
             return out
         groups, cur, frames = [], [], 0
         for key in keys:
@@ -131,6 +133,7 @@ class Trainer:
             lens = [f.shape[0] for f in feats]
             packed = feats[0] if len(feats) == 1 else torch.cat(feats)
             flat = self.model.score_packed(packed, lens).detach().cpu().numpy()
+            kernels.health_check()      # the D2H above synchronised: fail loudly if a persistent recurrence kernel timed out
             for k, piece in zip(grp, np.split(flat, np.cumsum(lens)[:-1])):
                 out[k] = piece.copy() if piece.shape[0] > 1 else piece.reshape(())    # `.squeeze()` of the reference: T == 1 -> 0-d
         return out

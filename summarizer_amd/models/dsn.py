@@ -14,7 +14,7 @@ from .. import kernels
 from .._lib import SumkError
 from . import Trainer
 from ._bilstm import pack_time_major, bilstm_scores
-from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
+from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
 class DSN(nn.Module):
@@ -91,16 +91,10 @@ class DSNTrainer(Trainer):
         self.log.debug("Parameters: {}".format(sum([_.numel() for _ in self.model.parameters()])))
         dev = self._device()
         rank, world = dist_info()
-        broadcast_parameters(self.model)
         bv = int(self.hps.extra_params.get("batch_videos", 1))
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.hps.lr, weight_decay=self.hps.weight_decay)
-        if world > 1:
-            lens = [self.dataset[k]["features"].shape[0] for k in train_keys]
-            my_keys = shard_keys(train_keys, lens, rank, world)
-            steps_per_epoch = max(1, math.ceil(max(len(shard_keys(train_keys, lens, r, world)) for r in range(world)) / bv))
-        else:
-            my_keys = train_keys
-            steps_per_epoch = math.ceil(len(my_keys) / bv)
+        self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
+        my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
 
         baselines = {key: 0. for key in my_keys}                         # dsn.py:81
         reward_writers = {key: [] for key in my_keys}                    # dsn.py:84
@@ -134,7 +128,9 @@ class DSNTrainer(Trainer):
                         l_v = l_v + sb.segment_mean(torch.nn.functional.binary_cross_entropy(probs, target, reduction="none"))  # dsn.py:117-119
                     lp = sb.segment_mean(log_probs)                                                  # (E, n_videos)
                     l_v = l_v - (lp * (rewards - base)).sum(dim=0)                                   # dsn.py:134
-                    loss = (l_v / float(E)).mean()                                                   # dsn.py:140
+                    l_v = l_v / float(E)                                                             # dsn.py:140
+                    # data-parallel: every video of the GLOBAL step weighs 1/n_total (see training.step_video_total)
+                    loss = l_v.mean() if world == 1 else l_v.sum() / step_video_total(sizes, bv, step)
                     for i, k in enumerate(keys):
                         dist_scores[k] = probs[off[i]:off[i + 1]].detach().view(-1, 1, 1)
                     loss.backward()
@@ -143,11 +139,12 @@ class DSNTrainer(Trainer):
                     for i, k in enumerate(keys):
                         baselines[k] = 0.9 * baselines[k] + 0.1 * mean_r[i]                 # dsn.py:149
                         reward_writers[k].append(mean_r[i])
-                scale = self.optimizer.all_reduce_grads()
+                scale = self.optimizer.all_reduce_grads(average=False)
                 self.optimizer.step(grad_scale=scale, max_norm=5.0)       # clip_grad_norm_(…, 5.0) dsn.py:145, post all-reduce
 
             epoch_avg_reward = float(np.mean([reward_writers[k][-1] for k in my_keys if reward_writers[k]])) if my_keys else float("nan")
             epoch_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")
+            kernels.health_check()               # the epoch's host sync: did any persistent recurrence kernel time out?
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Reward: {epoch_avg_reward:.05f}  Loss: {epoch_avg_loss:.05f}")
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Reward", epoch_avg_reward, epoch)
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", epoch_avg_loss, epoch)

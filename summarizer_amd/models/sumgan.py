@@ -260,9 +260,9 @@ class SumGANTrainer(Trainer):
         self.s_e_optimizer = mk(list(summ.s_lstm.parameters()) + list(summ.vae.e_lstm.parameters()))
         self.d_optimizer = mk(summ.vae.d_lstm.parameters())
         self.c_optimizer = mk(gan.c_lstm.parameters())
+        # the buckets inherit whatever gradients the parameters carry: after VAE pre-training the decoder's last (clipped)
+        # gradient is still there and enters the first global clip norm, exactly as in the reference (sumgan.py:435)
         self._buckets = [self.s_e_optimizer, self.d_optimizer, self.c_optimizer]
-        for b in self._buckets:
-            b.zero_grad()                                  # fresh buckets start empty, like the reference's grad=None
 
     def _update(self, opt, loss):
         opt.zero_grad()
@@ -385,6 +385,7 @@ class SumGANTrainer(Trainer):
                     log[t].append(v)
                 dist_scores[key] = scores
             means = {t: float(torch.stack(v).mean()) for t, v in log.items()}
+            kernels.health_check()               # the epoch's host sync: did any persistent recurrence kernel time out?
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   " + "  ".join(
                 f"{n}: {means[t]:.05f}" for n, t in (("Lse", "Lse"), ("Ld", "Ld"), ("Lc", "Lc"), ("D(x)", "D_x"),
                                                      ("D(x_hat)", "D_x_hat"), ("D(x_hat_p)", "D_x_hat_p"))))

@@ -17,7 +17,7 @@ import torch.nn.init as init
 from .. import kernels
 from . import Trainer
 from .vasnet import _sinusoid_table
-from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
+from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
 class Transformer(nn.Module):
@@ -138,17 +138,12 @@ class TransformerTrainer(Trainer):
         self.draw_gtscores(fold, train_keys)
         dev = self._device()
         rank, world = dist_info()
-        broadcast_parameters(self.model)
         bv = int(self.hps.extra_params.get("batch_videos", 1))
         used = set(kernels.transformer_param_names(self.model.encoder_layers)) | {"pos_embed.weight"}
         self.optimizer = FlatAdam([p for n, p in self.model.named_parameters() if n in used and p.requires_grad],
                                   lr=self.hps.lr, weight_decay=self.hps.weight_decay)
-        if world > 1:
-            lens = [self.dataset[k]["features"].shape[0] for k in train_keys]
-            my_keys = shard_keys(train_keys, lens, rank, world)
-            steps_per_epoch = max(1, math.ceil(max(len(shard_keys(train_keys, lens, r, world)) for r in range(world)) / bv))
-        else:
-            my_keys, steps_per_epoch = train_keys, math.ceil(len(train_keys) / bv)
+        self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
+        my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
         best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
         packed = self.model.max_length is None
         for epoch in range(self.hps.epochs):
@@ -164,18 +159,19 @@ class TransformerTrainer(Trainer):
                         x = vids[0][0] if len(vids) == 1 else torch.cat([v[0] for v in vids])
                         target = vids[0][1] if len(vids) == 1 else torch.cat([v[1] for v in vids])
                         scores = self.model.score_packed(x, lens_b)
-                        loss = kernels.SeqBatch.get(lens_b, dev).segment_mean((scores - target) ** 2).mean()   # MSE per video (transformer.py:161)
+                        per_video = kernels.SeqBatch.get(lens_b, dev).segment_mean((scores - target) ** 2)   # MSE per video (transformer.py:161)
+                        loss = per_video.mean() if world == 1 else per_video.sum() / step_video_total(sizes, bv, step)
                         for k, piece in zip(keys, torch.split(scores.detach(), lens_b)):
                             dist_scores[k] = piece.view(-1, 1, 1)
                     else:
                         loss = 0
                         for k, (seq, target) in zip(keys, vids):
                             sc = self.model(seq.unsqueeze(1).clone())
-                            loss = loss + torch.mean((sc.view(-1) - target) ** 2) / len(vids)
+                            loss = loss + torch.mean((sc.view(-1) - target) ** 2) / (len(vids) if world == 1 else step_video_total(sizes, bv, step))
                             dist_scores[k] = sc.detach()
                     loss.backward()
                     losses.append(loss.detach())
-                self.optimizer.step(grad_scale=self.optimizer.all_reduce_grads())
+                self.optimizer.step(grad_scale=self.optimizer.all_reduce_grads(average=False))
             train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Loss: {train_avg_loss:.05f}")
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", train_avg_loss, epoch)

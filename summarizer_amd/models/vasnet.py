@@ -18,7 +18,7 @@ import torch.nn.init as init
 
 from .. import kernels
 from . import Trainer
-from ..training import FlatAdam, dist_info, shard_keys, broadcast_parameters
+from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
 class VASNet(nn.Module):
@@ -74,6 +74,8 @@ class VASNet(nn.Module):
         if training:
             self._seed_counter += 1
             o.update(dropout_p=float(self.dropout.p), seed=(torch.initial_seed() * 1000003 + self._seed_counter) & (2**63 - 1))
+        if getattr(self, "tail_grads_ready_event", None) is not None:
+            o["tail_grads_ready_event"] = self.tail_grads_ready_event     # data-parallel trainers: see VASNetTrainer.train
         return o
 
     def _pos(self, T, B, device):
@@ -177,17 +179,15 @@ class VASNetTrainer(Trainer):
         self.draw_gtscores(fold, train_keys)
         dev = self._device()
         rank, world = dist_info()
-        broadcast_parameters(self.model)
         bv = int(self.hps.extra_params.get("batch_videos", 1))
         self.optimizer = FlatAdam(filter(lambda p: p.requires_grad, self.model.parameters()), lr=self.hps.lr,
                                   weight_decay=self.hps.weight_decay)
-        if world > 1:
-            lens = [self.dataset[k]["features"].shape[0] for k in train_keys]
-            my_keys = shard_keys(train_keys, lens, rank, world)
-            steps_per_epoch = max(1, math.ceil(max(len(shard_keys(train_keys, lens, r, world)) for r in range(world)) / bv))
-        else:
-            my_keys = train_keys
-            steps_per_epoch = math.ceil(len(my_keys) / bv)
+        self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
+        my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
+        # data-parallel overlap: the HIP backward records this event once the gradients of Wo / k1 / k2 (the tail of the
+        # bucket) are final; their all-reduce then runs on a side stream under the attention backward + QKV weight gradients
+        tail_from = self.optimizer.tail_offset(self.model.attention_head_projection.weight) if world > 1 else None
+        self.model.tail_grads_ready_event = torch.cuda.Event() if world > 1 else None
 
         best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
         use_packed = self.model.max_length is None
@@ -205,19 +205,25 @@ class VASNetTrainer(Trainer):
                         off = np.concatenate([[0], np.cumsum(lens_b)])
                         # mean over videos of the per-video MSE (== nn.MSELoss per video, vasnet.py:209, when bv == 1)
                         target = torch.cat([v[1] for v in vids]) if len(vids) > 1 else vids[0][1]
-                        sbb = kernels.SeqBatch.get(lens_b, dev)
-                        loss = sbb.segment_mean((scores - target) ** 2).mean()
+                        per_video = kernels.SeqBatch.get(lens_b, dev).segment_mean((scores - target) ** 2)
+                        # world == 1: plain mean; data-parallel: every video of the GLOBAL step weighs 1/n_total (ranks whose
+                        # shard has run out contribute nothing and the divisor shrinks with them)
+                        loss = per_video.mean() if world == 1 else per_video.sum() / step_video_total(sizes, bv, step)
                         for i, k in enumerate(keys):
                             dist_scores[k] = scores[off[i]:off[i + 1]].detach().view(-1, 1, 1)
                     else:
                         loss = 0
                         for k, (seq, target) in zip(keys, vids):
                             sc = self.model(seq.unsqueeze(1).clone())   # clone: the positional add is in place, seq is the HBM-cached copy
-                            loss = loss + torch.mean((sc.view(-1) - target) ** 2) / len(vids)
+                            loss = loss + torch.mean((sc.view(-1) - target) ** 2) / (len(vids) if world == 1 else step_video_total(sizes, bv, step))
                             dist_scores[k] = sc.detach()
                     loss.backward()
                     losses.append(loss.detach())
-                scale = self.optimizer.all_reduce_grads()
+                if tail_from is not None and use_packed:          # every rank issues the same two collectives, videos or not
+                    if not keys:
+                        self.model.tail_grads_ready_event.record()
+                    self.optimizer.reduce_tail_async(tail_from, self.model.tail_grads_ready_event)
+                scale = self.optimizer.all_reduce_grads(average=False)
                 self.optimizer.step(grad_scale=scale)
 
             train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")   # one D2H sync per epoch

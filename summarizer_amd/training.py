@@ -31,15 +31,43 @@ def shard_keys(keys, lens, rank, world):
     return [k for i, k in enumerate(keys) if owner[i] == rank]
 
 
-def all_reduce_flat(bucket):
+def all_reduce_flat(bucket, average=True):
     """SUM all-reduce of one flat bucket over the default process group (RCCL on GPUs, gloo in CPU tests).
-    Returns 1/world_size -- the averaging factor is applied later inside the fused Adam kernel, not as an extra pass."""
+    Returns the factor the optimiser step still has to apply: 1/world_size when `average` (folded into the fused Adam
+    kernel, not an extra pass over the bucket), 1.0 when the caller already normalised its loss by the GLOBAL number of
+    videos of the step (`step_video_total`)."""
     import torch.distributed as dist
     rank, world = dist_info()
     if world > 1:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
-        return 1.0 / world
+        return 1.0 / world if average else 1.0
     return 1.0
+
+
+def shard_sizes(keys, lens, world):
+    """Number of videos every rank owns under `shard_keys` (each rank computes the same list, no communication)."""
+    return [len(shard_keys(keys, lens, r, world)) for r in range(world)]
+
+
+def plan_shards(train_keys, lens_fn, bv):
+    """(my_keys, sizes, steps_per_epoch) of this rank for a fold: the static video -> rank assignment (DSN's per-video
+    baselines therefore stay rank-local), every rank's shard size, and the number of optimiser steps per epoch -- padded to
+    the largest shard so that all ranks enter the same number of collectives.  lens_fn() -> frames per key (read only when
+    world > 1)."""
+    import math
+    rank, world = dist_info()
+    if world == 1:
+        return list(train_keys), [len(train_keys)], math.ceil(len(train_keys) / bv)
+    lens = lens_fn()
+    sizes = shard_sizes(train_keys, lens, world)
+    return shard_keys(train_keys, lens, rank, world), sizes, max(1, math.ceil(max(sizes) / bv))
+
+
+def step_video_total(sizes, bv, step):
+    """Videos ALL ranks contribute at optimiser step `step` of an epoch when rank r walks its shard of sizes[r] videos in
+    slices of `bv`.  Ranks whose shard has run out contribute none: dividing the summed gradient by this count (not by
+    world * bv) keeps the ragged tail steps of an epoch correctly averaged and every video equally weighted."""
+    return sum(max(0, min(bv, n - step * bv)) for n in sizes)
 
 
 class FlatAdam:
@@ -68,12 +96,15 @@ class FlatAdam:
                 k = p.numel()
                 self.flat_param[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_param[off:off + k].view_as(p)
+                if p.grad is not None:             # like torch.optim: constructing an optimiser does not touch gradients
+                    self.flat_grad[off:off + k].copy_(p.grad.reshape(-1))
                 p.grad = self.flat_grad[off:off + k].view_as(p)
                 off += k
         self.n = n
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._side, self._tail_from = None, None      # side stream / split point of an in-flight early all-reduce
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -84,10 +115,52 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + k].view_as(p)
             off += k
 
-    def all_reduce_grads(self):
-        """Average the gradient bucket over the data-parallel group: ONE collective per optimiser step.  Returns the
-        scale (1/world) the optimiser step folds into the gradient."""
-        return all_reduce_flat(self.flat_grad)
+    def all_reduce_grads(self, average=True):
+        """Sum the gradient bucket over the data-parallel group: ONE collective per optimiser step (plus the early one of
+        `reduce_tail_async` when that was used).  Returns the scale the optimiser step folds into the gradient
+        (1/world if `average`, else 1.0: the trainers normalise their loss by the global video count instead)."""
+        import torch.distributed as dist
+        rank, world = dist_info()
+        if world == 1:
+            return 1.0
+        if self._tail_from is None:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+        else:                                      # the tail is already in flight on the side stream: reduce the head, then join
+            dist.all_reduce(self.flat_grad[:self._tail_from], op=dist.ReduceOp.SUM)
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+            self._tail_from = None
+        return 1.0 / world if average else 1.0
+
+    def tail_offset(self, first_param):
+        """Element offset in the flat bucket of `first_param` (a Parameter of this optimiser)."""
+        off = 0
+        for p in self.params:
+            if p is first_param:
+                return off
+            off += p.numel()
+        raise KeyError("parameter is not in this optimiser")
+
+    def reduce_tail_async(self, tail_from, ready_event):
+        """Overlap: all-reduce flat_grad[tail_from:] on a side stream as soon as `ready_event` (recorded by the HIP backward
+        once those gradients are final) has fired, while the rest of the backward still runs on the compute stream.
+        No-op outside torch.distributed.  `all_reduce_grads` later reduces the head and joins the side stream."""
+        import torch.distributed as dist
+        rank, world = dist_info()
+        if world == 1 or not self.flat_grad.is_cuda:
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.flat_grad.device)
+        tail_from = (tail_from // 4) * 4                    # keep both pieces 16-byte aligned
+        self._side.wait_event(ready_event)
+        with torch.cuda.stream(self._side):
+            dist.all_reduce(self.flat_grad[tail_from:], op=dist.ReduceOp.SUM)
+        self._tail_from = tail_from
+
+    def broadcast(self, src=0):
+        """Identical weights on every rank: ONE broadcast of the flat parameter bucket."""
+        import torch.distributed as dist
+        if dist_info()[1] > 1:
+            dist.broadcast(self.flat_param, src=src)
 
     def grad_norm(self, grad_scale=1.0):
         """L2 norm of (grad_scale * gradient bucket) -- one HIP reduction + one scalar D2H."""
@@ -108,9 +181,15 @@ class FlatAdam:
 
 
 def broadcast_parameters(model, src=0):
-    """Identical initial weights on every rank."""
+    """Identical initial weights on every rank for a model that has no FlatAdam yet: the parameters travel as
+    ONE flat buffer (one collective), not one broadcast per tensor.  The trainers use `FlatAdam.broadcast()` instead."""
     import torch.distributed as dist
     rank, world = dist_info()
     if world > 1:
-        for p in model.parameters():
-            dist.broadcast(p.data, src=src)
+        params = [p for p in model.parameters()]
+        flat = torch.cat([p.data.reshape(-1) for p in params])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for p in params:
+            p.data.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()

@@ -174,3 +174,9 @@ class DetRandom:
             finally:
                 torch.randn_like, torch.rand = old
         return cm()
+
+
+def sample_idx(name, numel, n=256):
+    """Flat indices at which a large tensor is digested (train_full.npz): seeded by the parameter name, sorted, unique."""
+    seed = int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little")
+    return np.sort(np.random.default_rng(seed).choice(numel, size=min(n, numel), replace=False))

@@ -1,0 +1,252 @@
+"""GPU parity of the TRAINING path at the BASELINE shapes (D = 1024): loss, every parameter gradient,
+dX and one Adam step of VASNet (one T = 300 video, a 3-video and the 50-video S-TVSum packed batch), DSN (H = 256) and
+sLSTM (H = 1024, 2 layers) against
+  (a) digests of the REAL reference's gradients / updated parameters (tests/golden/train_full.npz, produced by
+      make_golden_train_full.py: norms, maxima and 256 sampled entries per tensor; weights by seeded recipe), and
+  (b) autograd through the stock-PyTorch port of the oracle on the CPU, element for element, dropout masks included.
+Plus the learnable positional embedding under the flat-bucket optimiser (its gradient must land in the bucket).
+Tolerances: 3e-4 of the tensor's largest magnitude for gradients (fp32 and bf16x6), 2e-6 absolute after an Adam step."""
+import numpy as np
+import pytest
+import torch
+
+import recipes as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+GTOL = 3e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _video(T, D, seed):            # same recipe as make_golden_train_full.video
+    return R.features(T, 1, D, seed) - 0.1, np.random.default_rng(seed + 5).random((T, 1, 1)).astype(np.float32)
+
+
+def _check_digest(g, tag, named, tol, atol=0.0):
+    for k, v in named:
+        a = v.detach().cpu().numpy().reshape(-1).astype(np.float64)
+        absmax = float(g[f"{tag}/{k}/absmax"])
+        np.testing.assert_allclose(np.sqrt((a * a).sum()), float(g[f"{tag}/{k}/norm"]), rtol=tol, atol=atol, err_msg=f"{tag} {k} norm")
+        err = np.abs(a[R.sample_idx(k, a.size)] - g[f"{tag}/{k}/sample"]).max()
+        assert err <= tol * absmax + atol, (tag, k, err, absmax)
+
+
+def _packed_step(m, vids, dev, opt):
+    """One optimiser step on a packed batch with the trainers' loss (mean over videos of the per-video MSE)."""
+    from summarizer_amd import kernels
+    lens = [x.shape[0] for x, _ in vids]
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x, _ in vids])).to(dev)
+    tgt = torch.from_numpy(np.concatenate([t.reshape(-1) for _, t in vids])).to(dev)
+    opt.zero_grad()
+    s = m.score_packed(xp, lens)
+    per_video = kernels.SeqBatch.get(lens, dev).segment_mean((s - tgt) ** 2)
+    per_video.mean().backward()
+    return s.detach(), per_video.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("tag,lens", [("vasnet_T300", [300]), ("vasnet_batch3", [300, 163, 320])])
+def test_vasnet_full_size_training_step_vs_reference(dev, tag, lens, precision):
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.training import FlatAdam
+    g = load_golden("train_full")
+    D = 1024
+    m = VASNet(input_size=D, precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in R.vasnet_weights(D, 31).items()})
+    m = m.to(dev).eval()                                   # dropout off, as the golden was generated
+    opt = FlatAdam(m.parameters(), lr=5e-5, weight_decay=1e-5)
+    vids = [_video(T, D, 4000 + i) for i, T in enumerate(lens)]
+    s, losses = _packed_step(m, vids, dev, opt)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, T in enumerate(lens):
+        np.testing.assert_allclose(s.cpu().numpy()[off[i]:off[i + 1]], g[f"{tag}/scores/T{T}"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(losses, g[f"{tag}/losses"], rtol=2e-5)
+    _check_digest(g, f"{tag}/grad", [(k, p.grad) for k, p in m.named_parameters()], GTOL)
+    opt.step()
+    _check_digest(g, f"{tag}/param1", list(m.named_parameters()), 0.0, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind,tag,H,L,T", [("dsn", "dsn_T300", 256, 1, 300), ("slstm", "slstm_T60", 1024, 2, 60)])
+def test_bilstm_full_size_training_step_vs_reference(dev, kind, tag, H, L, T):
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.sumgan import sLSTM
+    from summarizer_amd.training import FlatAdam
+    g = load_golden("train_full")
+    D = 1024
+    if kind == "dsn":
+        m, w = DSN(D, H, L), R.lstm_weights("rnn.", D, H, L, 32, "out.0.")
+    else:
+        m, w = sLSTM(D, H, L), R.lstm_weights("lstm.", D, H, L, 33, "out.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m = m.to(dev).eval()
+    opt = FlatAdam(m.parameters(), lr=5e-5, weight_decay=1e-5)
+    s, losses = _packed_step(m, [_video(T, D, 4100 if kind == "dsn" else 4200)], dev, opt)
+    np.testing.assert_allclose(s.cpu().numpy(), g[f"{tag}/scores/T{T}"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(losses, g[f"{tag}/losses"], rtol=2e-5)
+    _check_digest(g, f"{tag}/grad", [(k, p.grad) for k, p in m.named_parameters()], GTOL)
+    opt.step()
+    _check_digest(g, f"{tag}/param1", list(m.named_parameters()), 0.0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ 50-video S-TVSum batch vs the port
+def _tvsum_lens(n=50):
+    return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n)]
+
+
+@pytest.fixture(scope="module")
+def vasnet_port_50():
+    """CPU reference of the bench batch (50 videos, 12 003 frames, D = 1024) in TRAINING mode: per-video autograd through
+    the torch port with the deterministic dropout masks; shared by the precision variants."""
+    from oracle import torch_port
+    torch.set_num_threads(8)
+    D, lens, p, seed = 1024, _tvsum_lens(), 0.5, 777
+    w = R.vasnet_weights(D, 41)
+    xs = [R.features(T, 1, D, 5000 + i) - 0.1 for i, T in enumerate(lens)]
+    cw = np.random.default_rng(6).standard_normal(sum(lens)).astype(np.float32)
+    pt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    off = np.concatenate([[0], np.cumsum(lens)])
+    scores, gx, row0 = [], [], 0
+    for i, x in enumerate(xs):
+        T = lens[i]                                   # masks are indexed by the PACKED row (recipes.vasnet_drop_masks, one video at a time)
+        rows = np.arange(T, dtype=np.uint64) + np.uint64(off[i])
+        sc = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+        ia = (rows[:, None] << np.uint64(20)) | np.arange(T, dtype=np.uint64)[None, :]
+        iy = rows[:, None] * np.uint64(D) + np.arange(D, dtype=np.uint64)[None, :]
+        dm = tuple(torch.from_numpy(R.dropout_keep(seed, site, ix, p).astype(np.float32) * sc).unsqueeze(0)
+                   for site, ix in ((0, ia), (1, iy), (2, iy)))
+        xt = torch.from_numpy(x).clone().requires_grad_(True)
+        y = torch_port.vasnet_scores(xt, pt, drop_masks=dm)[:, 0, 0]
+        (y * torch.from_numpy(cw[off[i]:off[i + 1]])).sum().backward()
+        scores.append(y.detach().numpy()); gx.append(xt.grad.numpy()[:, 0, :])
+    return dict(D=D, lens=lens, p=p, seed=seed, w=w, xs=xs, cw=cw, scores=np.concatenate(scores), gx=np.concatenate(gx),
+                grads={k: v.grad.numpy() for k, v in pt.items()})
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+def test_vasnet_bench_batch_grads_vs_torch_port_with_dropout(dev, vasnet_port_50, precision):
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import VasnetFunction
+    from summarizer_amd.models.vasnet import VASNet
+    c = vasnet_port_50
+    m = VASNet(input_size=c["D"], precision=precision)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["w"].items()}); m = m.to(dev)
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in c["xs"]])).to(dev).requires_grad_(True)
+    sb = kernels.SeqBatch.get(c["lens"], dev)
+    opts = dict(scale=float(m.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=c["p"], seed=c["seed"], precision=precision)
+    names = [k for _, k in kernels.VASNET_FIELDS]
+    params = dict(m.named_parameters())
+    s = VasnetFunction.apply(xp, sb, opts, None, None, names, *[params[n] for n in names])
+    (s * torch.from_numpy(c["cw"]).to(dev)).sum().backward()
+    np.testing.assert_allclose(s.detach().cpu().numpy(), c["scores"], atol=1e-4, rtol=0)
+    for k in names:
+        r = _rel(params[k].grad.cpu().numpy(), c["grads"][k])
+        assert r < GTOL, (k, r)
+    assert _rel(xp.grad.cpu().numpy(), c["gx"]) < GTOL
+
+
+def test_dsn_bench_batch_grads_vs_torch_port(dev):
+    """DSN (1024 -> 2 x 256) on the 50-video S-TVSum batch: persistent forward + BPTT kernels vs torch's nn.LSTM autograd."""
+    from oracle import torch_port
+    from summarizer_amd.models.dsn import DSN
+    torch.set_num_threads(8)
+    D, H, lens = 1024, 256, _tvsum_lens()
+    w = R.lstm_weights("rnn.", D, H, 1, 51, "out.0.")
+    m = DSN(D, H, 1); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    xs = [R.features(T, 1, D, 6000 + i) - 0.1 for i, T in enumerate(lens)]
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev).requires_grad_(True)
+    cw = np.random.default_rng(8).standard_normal(sum(lens)).astype(np.float32)
+    s = m.score_packed(xp, lens)
+    (s * torch.from_numpy(cw).to(dev)).sum().backward()
+    pt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    lstm = torch_port.make_lstm({k: v.detach() for k, v in pt.items()}, "rnn.", D, H, 1)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    gx = []
+    for i, x in enumerate(xs):
+        xt = torch.from_numpy(x).clone().requires_grad_(True)
+        y = torch_port.bilstm_scores(xt, pt, "rnn.", "out.0.weight", "out.0.bias", D, H, 1, lstm=lstm)[:, 0, 0]
+        np.testing.assert_allclose(s.detach().cpu().numpy()[off[i]:off[i + 1]], y.detach().numpy(), atol=1e-4, rtol=0)
+        (y * torch.from_numpy(cw[off[i]:off[i + 1]])).sum().backward()
+        gx.append(xt.grad.numpy()[:, 0, :])
+    ref = {f"rnn.{k}": v.grad.numpy() for k, v in lstm.named_parameters()}
+    ref["out.0.weight"], ref["out.0.bias"] = pt["out.0.weight"].grad.numpy(), pt["out.0.bias"].grad.numpy()
+    for k, p in m.named_parameters():
+        assert _rel(p.grad.cpu().numpy(), ref[k]) < GTOL, (k, _rel(p.grad.cpu().numpy(), ref[k]))
+    assert _rel(xp.grad.cpu().numpy(), np.concatenate(gx)) < GTOL
+
+
+# ------------------------------------------------------------------------------------------------ learnable positional embedding
+def test_vasnet_pos_embed_trains_under_flat_adam(dev):
+    """`max_pos` + pos_embed='simple' (vasnet.py:42,108-109): the table's gradient must reach FlatAdam's bucket and the
+    table must follow torch.optim.Adam on the port for two steps (the second step catches a stale / rebound .grad)."""
+    from oracle import torch_port
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.training import FlatAdam
+    D, ML, T = 128, 80, 37
+    w = R.vasnet_weights(D, 61, max_length=ML)
+    m = VASNet(input_size=D, max_length=ML, pos_embed="simple")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev).eval()
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    pt = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in w.items()}
+    ropt = torch.optim.Adam(list(pt.values()), lr=1e-3, weight_decay=1e-5)
+    x = R.features(T, 1, D, 62) - 0.1
+    tgt = np.random.default_rng(63).random((T, 1, 1)).astype(np.float32)
+    for step in range(2):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(m(torch.from_numpy(x.copy()).to(dev)), torch.from_numpy(tgt).to(dev))
+        loss.backward()
+        ropt.zero_grad()
+        rl = torch.nn.functional.mse_loss(torch_port.vasnet_scores(torch.from_numpy(x), pt, pos_table=pt["pos_embed.weight"]),
+                                          torch.from_numpy(tgt))
+        rl.backward()
+        np.testing.assert_allclose(loss.item(), rl.item(), rtol=2e-5)
+        got = m.pos_embed.weight.grad
+        assert got.data_ptr() >= opt.flat_grad.data_ptr() and got.data_ptr() < opt.flat_grad.data_ptr() + 4 * opt.flat_grad.numel(), \
+            "pos_embed.weight.grad is no longer a view of the flat gradient bucket"
+        assert float(got.abs().max()) > 0
+        assert _rel(got.cpu().numpy(), pt["pos_embed.weight"].grad.numpy()) < GTOL
+        assert float(got[T:].abs().max()) == 0.0                       # rows past the video get no gradient
+        opt.step(); ropt.step()
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.detach().cpu().numpy(), pt[k].detach().numpy(), atol=3e-5, err_msg=f"{k} step {step}")
+
+
+def test_transformer_pos_embed_trains_under_flat_adam(dev):
+    from oracle import torch_port
+    from summarizer_amd import kernels
+    from summarizer_amd.models.transformer import Transformer
+    from summarizer_amd.training import FlatAdam
+    D, L, Hh, ML, T = 64, 2, 4, 50, 29
+    w = R.transformer_weights(D, L, 71, max_length=ML)
+    m = Transformer(input_size=D, encoder_layers=L, attention_heads=Hh, max_length=ML, pos_embed="simple")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=False)
+    m = m.to(dev).eval()
+    used = set(kernels.transformer_param_names(L)) | {"pos_embed.weight"}
+    opt = FlatAdam([p for n, p in m.named_parameters() if n in used], lr=1e-3, weight_decay=1e-5)
+    port = torch_port.TransformerPort(D, L, Hh, max_length=ML)
+    missing = port.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()}, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    ropt = torch.optim.Adam(port.parameters(), lr=1e-3, weight_decay=1e-5)
+    x = R.features(T, 1, D, 72) - 0.1
+    tgt = np.random.default_rng(73).random((T, 1, 1)).astype(np.float32)
+    for step in range(2):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(m(torch.from_numpy(x.copy()).to(dev)), torch.from_numpy(tgt).to(dev))
+        loss.backward()
+        ropt.zero_grad()
+        rl = torch.nn.functional.mse_loss(port(torch.from_numpy(x)), torch.from_numpy(tgt))
+        rl.backward()
+        np.testing.assert_allclose(loss.item(), rl.item(), rtol=5e-5)
+        got = m.pos_embed.weight.grad
+        assert float(got.abs().max()) > 0
+        assert _rel(got.cpu().numpy(), port.pos_embed.weight.grad.numpy()) < GTOL
+        opt.step(); ropt.step()
+        np.testing.assert_allclose(m.pos_embed.weight.detach().cpu().numpy(), port.pos_embed.weight.detach().numpy(), atol=3e-5)

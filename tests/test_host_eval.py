@@ -126,3 +126,90 @@ def test_pack_rows_native_threads():
     assert lib.sumk_pack_rows(None, None, None, 0, D, 0) == 0
     bad = (C.c_void_p * 1)(None)
     assert lib.sumk_pack_rows(C.c_void_p(dst.ctypes.data), bad, _lib.host_i32(np.asarray([3], np.int32)), 1, D, 1) != 0
+
+
+# ------------------------------------------------------------------------------------------------ knapsack: the tie-free surface is pinned
+def _all_optimal_subsets(v, w, cap):
+    n = len(v)
+    sv = np.zeros(1, dtype=np.int64); sw = np.zeros(1, dtype=np.int64)
+    for i in range(n):
+        sv = np.concatenate([sv, sv + v[i]]); sw = np.concatenate([sw, sw + w[i]])
+    feas = sw <= cap
+    best = sv[feas].max()
+    return [[i for i in range(n) if (m >> i) & 1] for m in np.flatnonzero(feas & (sv == best))]
+
+
+def test_knapsack_selected_set_equals_the_unique_optimum():
+    """Wherever the optimal subset is UNIQUE every exact solver (OR-tools' DP included) returns the same set: on such
+    instances the native DP and the CPU restatement must return exactly that set, not merely its value (S <= 18, exhaustive)."""
+    rng = np.random.default_rng(23)
+    unique = tied = 0
+    for trial in range(400):
+        n = int(rng.integers(1, 19))
+        style = trial % 4
+        vals = rng.random(n)
+        if style == 1:
+            vals = np.round(vals, 2)                                  # coarse values: many ties (those instances are skipped)
+        elif style == 2:
+            vals = 0.5 + 0.01 * vals
+        wts = rng.integers(1, 400, n)
+        cap = int(rng.integers(0, max(2, int(wts.sum() * rng.uniform(0.1, 0.9)))))
+        v, w = knapsack_np.to_int_problem(vals.tolist(), wts.tolist())
+        opt = _all_optimal_subsets(v, w, cap)
+        if len(opt) != 1:
+            tied += 1
+            continue
+        unique += 1
+        assert knapsack_ortools(vals.tolist(), wts.tolist(), n, cap) == opt[0], (trial, vals, wts, cap)
+        assert knapsack_np.knapsack_dp(vals.tolist(), wts.tolist(), n, cap) == opt[0]
+    assert unique >= 200 and tied >= 20, (unique, tied)
+
+
+def test_knapsack_e2e_vs_reference_goldens():
+    """tests/golden/knapsack_e2e.npz: the REAL reference's generate_summary(method="knapsack") + evaluate_summary with only
+    OR-tools' solver swapped for an exhaustive one, unique-optimum videos only (make_golden_knapsack.py).  The numpy mirror,
+    the native threaded tail and the oracle must reproduce every machine summary bit for bit and both F-scores."""
+    from summarizer_amd.utils import eval_native
+    g = load_golden("knapsack_e2e")
+    n = int(g["n_cases"])
+    assert n >= 20
+    vids, scores = [], []
+    for ci in range(n):
+        T, U, seed = (int(x) for x in g[f"c{ci}/meta"])
+        v = R.synthetic_video(T, seed, n_users=U)
+        sc = g[f"c{ci}/scores"]
+        args = (sc, v["change_points"], v["n_frames"], v["n_frame_per_seg"].tolist(), v["picks"], 0.15, "knapsack")
+        summ = E.generate_summary(*args)
+        np.testing.assert_array_equal(summ, g[f"c{ci}/summary"].astype(np.float32), err_msg=f"case {ci}")
+        np.testing.assert_array_equal(eval_np.generate_summary(*args), summ)
+        np.testing.assert_array_equal(np.array(E.evaluate_summary(summ, v["user_summary"])), g[f"c{ci}/fscore"])
+        vids.append(eval_native.prepare_video(v["n_frames"], v["picks"], v["change_points"], v["n_frame_per_seg"], v["user_summary"],
+                                              E.rank_users(v["user_scores"])))
+        scores.append(sc)
+    _, f_avg, f_max, summ = eval_native.evaluate_batch(vids, scores, 0.15, "knapsack", want_summaries=True, n_threads=4)
+    for ci in range(n):
+        np.testing.assert_array_equal(summ[ci], g[f"c{ci}/summary"].astype(np.float32))
+        assert (f_avg[ci], f_max[ci]) == tuple(g[f"c{ci}/fscore"]), ci
+
+
+def test_trainer_evaluation_with_knapsack_selection_vs_reference_goldens():
+    """`Trainer.test`'s evaluation tail with hps.selection_algorithm="knapsack" (the reference default, config.py:36) on the
+    golden videos: fold-level mean F-scores equal the means of the reference's per-video values."""
+    from summarizer_amd.models import Trainer
+    from summarizer_amd.utils.datasets import DictDataset
+    from summarizer_amd.utils.hps import make_hps
+    g = load_golden("knapsack_e2e")
+    n = int(g["n_cases"])
+    videos, acts = {}, {}
+    for ci in range(n):
+        T, U, seed = (int(x) for x in g[f"c{ci}/meta"])
+        v = R.synthetic_video(T, seed, n_users=U)
+        videos[f"video_{ci+1}"] = v
+        acts[f"video_{ci+1}"] = g[f"c{ci}/scores"]
+    keys = list(videos)
+    hps = make_hps(DictDataset(videos), [{"train_keys": [], "test_keys": keys}], selection_algorithm="knapsack")
+    tr = Trainer(hps, hps.splits_files[0])
+    _, f_avg, f_max, _ = tr._evaluate_native(acts, keys)
+    ref = np.array([g[f"c{ci}/fscore"] for ci in range(n)])
+    assert np.mean(f_avg) == np.mean(ref[:, 0]) and np.mean(f_max) == np.mean(ref[:, 1])
+    np.testing.assert_allclose(tr._eval_summary(acts, keys), (np.mean(ref[:, 0]), np.mean(ref[:, 1])), rtol=1e-6)   # per-video numpy path (float32 means)
