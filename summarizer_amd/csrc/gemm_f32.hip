@@ -50,6 +50,21 @@ struct GemmKArgs {
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Scalar reads of the problem table (CONSTANT address space + wave-uniform index -> s_load, lgkmcnt).
+typedef const __attribute__((address_space(4))) int64_t* cptr64;
+typedef const __attribute__((address_space(4))) int32_t* cptr32;
+__device__ __forceinline__ int prob_tile_start(const GemmProb* p, int i) { return ((cptr32)(uintptr_t)(p + i))[15]; }
+__device__ __forceinline__ GemmProb load_prob(const GemmProb* p, int i) {
+  const cptr64 q = (cptr64)(uintptr_t)(p + i);
+  const cptr32 r = (cptr32)(uintptr_t)(p + i);
+  GemmProb P;
+  P.a_off = q[0]; P.b_off = q[1]; P.c_off = q[2]; P.r_off = q[3];
+  P.M = r[8]; P.N = r[9]; P.K = r[10]; P.lda = r[11]; P.ldb = r[12]; P.ldc = r[13]; P.ldr = r[14];
+  P.tile_start = r[15]; P.tiles_n = r[16];
+  return P;
+}
+static_assert(offsetof(GemmProb, M) == 32 && offsetof(GemmProb, tile_start) == 60 && offsetof(GemmProb, tiles_n) == 64, "GemmProb layout");
+
 // Per-tile scalars (wave-uniform, live in SGPRs).
 struct TileCtx {
   int64_t c_off, r_off;
@@ -118,13 +133,17 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   const float* pb[NLDB];
 
   // ---- tile decode: which sub-problem / tile (wave-uniform scalar work) + this thread's row pointers
+  // The problem table is read through the CONSTANT address space: with a wave-uniform index these become scalar loads
+  // (s_load, lgkmcnt).  As vector loads they left VM events pending on registers the k-loop reuses, and the compiler's
+  // waitcnt pass then put an s_waitcnt vmcnt(0) at the join in front of the fragment reads -- i.e. every k-tile waited for
+  // the NEXT k-tile's global loads before its own MFMAs (22 % idle matrix pipe in the round-1 profile).
   auto setup = [&](int tile, TileCtx& c) -> bool {
     int lo = 0, hi = ka.nprob - 1;
     while (lo < hi) {
       int mid = (lo + hi + 1) >> 1;
-      if (ka.probs[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+      if (prob_tile_start(ka.probs, mid) <= tile) lo = mid; else hi = mid - 1;
     }
-    const GemmProb P = ka.probs[lo];
+    const GemmProb P = load_prob(ka.probs, lo);
     int mt, nt;
     if (ka.xcd_tiles_m > 0) {
       // XCD-aware map (speed only; correctness never depends on placement).  Blocks b and b+8 share an XCD and its 4 MB
