@@ -1,0 +1,136 @@
+// Device-side pieces shared by the GEMM kernels of libsumk.so (gemm_f32.hip: register-staged, all precisions;
+// gemm_dma.hip: LDS-DMA staged exact-fp32): kernel argument block, scalar reads of the problem table, tile decode and the
+// fused epilogues.
+#pragma once
+#include "sumk_internal.h"
+
+namespace sumk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmKArgs {
+  const float* A;
+  const float* B[4];
+  float* C;
+  const float* R;
+  const float* bias0[4];
+  const float* bias1[4];
+  const GemmProb* probs;
+  int32_t nprob;
+  int32_t n_group;
+  int32_t total_tiles;   // loop bound of the persistent tile walk (virtual tiles when xcd_tiles_m > 0)
+  Drop drop; uint32_t drop_site;   // epilogue dropout (drop.thr == 0: none); mask index = row * N + col
+  int32_t xcd_tiles_m;   // > 0: single-problem launch with the XCD-aware tile map below; value = tiles along M
+  float alpha;
+  int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores
+};
+
+// Scalar reads of the problem table (CONSTANT address space + wave-uniform index -> s_load, lgkmcnt).  As vector loads they
+// left VM events pending on registers the k-loop reuses, and the compiler's waitcnt pass then put an s_waitcnt vmcnt(0) at
+// the join in front of the fragment reads -- every k-tile waited for the NEXT k-tile's global loads before its own MFMAs.
+typedef const __attribute__((address_space(4))) int64_t* cptr64;
+typedef const __attribute__((address_space(4))) int32_t* cptr32;
+__device__ __forceinline__ int prob_tile_start(const GemmProb* p, int i) { return ((cptr32)(uintptr_t)(p + i))[15]; }
+__device__ __forceinline__ GemmProb load_prob(const GemmProb* p, int i) {
+  const cptr64 q = (cptr64)(uintptr_t)(p + i);
+  const cptr32 r = (cptr32)(uintptr_t)(p + i);
+  GemmProb P;
+  P.a_off = q[0]; P.b_off = q[1]; P.c_off = q[2]; P.r_off = q[3];
+  P.M = r[8]; P.N = r[9]; P.K = r[10]; P.lda = r[11]; P.ldb = r[12]; P.ldc = r[13]; P.ldr = r[14];
+  P.tile_start = r[15]; P.tiles_n = r[16];
+  return P;
+}
+static_assert(offsetof(GemmProb, M) == 32 && offsetof(GemmProb, tile_start) == 60 && offsetof(GemmProb, tiles_n) == 64, "GemmProb layout");
+
+// Per-tile scalars (wave-uniform, live in SGPRs).
+struct TileCtx {
+  int64_t c_off, r_off;
+  int32_t M, N, K, lda, ldb, ldc, ldr, m0, n0, klast;
+};
+
+// Which sub-problem / tile does persistent tile id `tile` name?  Wave-uniform scalar work.  Returns false when a remapped
+// (XCD-aware) walk has run past its rectangle.
+template <int BM, int BN>
+__device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileCtx& c, GemmProb& P) {
+  int lo = 0, hi = ka.nprob - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (prob_tile_start(ka.probs, mid) <= tile) lo = mid; else hi = mid - 1;
+  }
+  P = load_prob(ka.probs, lo);
+  int mt, nt;
+  if (ka.xcd_tiles_m > 0) {
+    // XCD-aware map (speed only; correctness never depends on placement).  Blocks b and b+8 share an XCD and its 4 MB
+    // L2 (round-robin dispatch), and the persistent stride is a multiple of 8, so tile%8 labels the XCD for the whole
+    // walk.  The tile grid is cut into 2 (M) x 4 (N) rectangles, one per XCD: a weight quarter (3 MB at D=1024) stays
+    // L2-resident and each A panel is fetched by 4 XCDs instead of 8 -- HBM/Infinity-Cache reads drop ~2.4x vs the
+    // plain round-robin order (PMC FETCH_SIZE, profiles/).
+    const int x = tile & 7, j = tile >> 3;
+    const int sm = (ka.xcd_tiles_m + 1) >> 1, sn = P.tiles_n >> 2;
+    mt = (x >> 2) * sm + j / sn;
+    nt = (x & 3) * sn + j % sn;
+    if (mt >= ka.xcd_tiles_m) return false;
+  } else {
+    const int local = tile - P.tile_start;
+    mt = local / P.tiles_n; nt = local % P.tiles_n;
+  }
+  c.m0 = mt * BM; c.n0 = nt * BN;
+  c.M = P.M; c.N = P.N; c.K = P.K; c.lda = P.lda; c.ldb = P.ldb; c.ldc = P.ldc; c.ldr = P.ldr;
+  c.c_off = P.c_off; c.r_off = P.r_off;
+  c.klast = P.K > 4 ? ((P.K + 3) & ~3) - 4 : 0;   // last legal float4 start along a K-contiguous row
+  return true;
+}
+
+// Epilogue of one wave's (TM x TN) 32x32 accumulator tiles.  C/D map of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  (row0, col0) = the wave's origin inside the matrix.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
+                                               int col0, int li, int lh) {
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = col0 + tn * 32 + li;
+    if (col >= cur.N) continue;
+    float bsum = 0.f;
+    if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2 || EPI == EPI_BIAS_RESIDUAL) {
+      int g = 0, nl = col;
+      if (ka.n_group > 0) { g = col / ka.n_group; nl = col - g * ka.n_group; }
+      const float* b0 = g == 0 ? ka.bias0[0] : g == 1 ? ka.bias0[1] : g == 2 ? ka.bias0[2] : ka.bias0[3];
+      bsum = b0[nl];
+      if constexpr (EPI == EPI_BIAS2) {
+        const float* b1 = g == 0 ? ka.bias1[0] : g == 1 ? ka.bias1[1] : g == 2 ? ka.bias1[2] : ka.bias1[3];
+        if (b1 != nullptr) bsum += b1[nl];   // single-bias projections pass bias1 = nullptr
+      }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= cur.M) continue;
+        float v = acc[tm][tn][r];
+        float* cp = ka.C + cur.c_off + (int64_t)row * cur.ldc + col;
+        if constexpr (EPI == EPI_NONE) v *= ka.alpha;
+        if constexpr (EPI == EPI_RESIDUAL) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+        if constexpr (EPI == EPI_BIAS_RELU) {
+          v += bsum; v = (v < 0.f) ? 0.f : v;   // NaN-propagating, like torch.relu
+          if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
+        }
+        if constexpr (EPI == EPI_BIAS2) v += bsum;
+        if constexpr (EPI == EPI_BIAS_RESIDUAL) {
+          v += bsum;
+          if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
+          v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+        }
+        if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
+        *cp = v;
+      }
+    }
+  }
+}
+
+// gemm_dma.hip: exact-fp32 kernels staged by LDS-DMA.  cfg: tile configuration of GemmLaunch::small_tile.
+int launch_gemm_dma(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);
+bool gemm_dma_enabled();
+
+}  // namespace sumk

@@ -18,58 +18,18 @@
 // K ORDER: the 32x32x2 MFMA takes k from the lane half h (A[i][k=h], B[k=h][j]).  Within an 8-wide k chunk we
 //   feed step j (0..3) with k = 4h + j for BOTH operands, so a KC lane's float4 supplies four MFMA steps.
 //   The sum over k is therefore re-associated relative to a sequential loop (fp32, ~1e-7 relative).
-#include "sumk_internal.h"
+#include "gemm_device.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace sumk {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-
-struct GemmKArgs {
-  const float* A;
-  const float* B[4];
-  float* C;
-  const float* R;
-  const float* bias0[4];
-  const float* bias1[4];
-  const GemmProb* probs;
-  int32_t nprob;
-  int32_t n_group;
-  int32_t total_tiles;   // loop bound of the persistent tile walk (virtual tiles when xcd_tiles_m > 0)
-  Drop drop; uint32_t drop_site;   // epilogue dropout (drop.thr == 0: none); mask index = row * N + col
-  int32_t xcd_tiles_m;   // > 0: single-problem launch with the XCD-aware tile map below; value = tiles along M
-  float alpha;
-};
-
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// Scalar reads of the problem table (CONSTANT address space + wave-uniform index -> s_load, lgkmcnt).
-typedef const __attribute__((address_space(4))) int64_t* cptr64;
-typedef const __attribute__((address_space(4))) int32_t* cptr32;
-__device__ __forceinline__ int prob_tile_start(const GemmProb* p, int i) { return ((cptr32)(uintptr_t)(p + i))[15]; }
-__device__ __forceinline__ GemmProb load_prob(const GemmProb* p, int i) {
-  const cptr64 q = (cptr64)(uintptr_t)(p + i);
-  const cptr32 r = (cptr32)(uintptr_t)(p + i);
-  GemmProb P;
-  P.a_off = q[0]; P.b_off = q[1]; P.c_off = q[2]; P.r_off = q[3];
-  P.M = r[8]; P.N = r[9]; P.K = r[10]; P.lda = r[11]; P.ldb = r[12]; P.ldc = r[13]; P.ldr = r[14];
-  P.tile_start = r[15]; P.tiles_n = r[16];
-  return P;
-}
-static_assert(offsetof(GemmProb, M) == 32 && offsetof(GemmProb, tile_start) == 60 && offsetof(GemmProb, tiles_n) == 64, "GemmProb layout");
-
-// Per-tile scalars (wave-uniform, live in SGPRs).
-struct TileCtx {
-  int64_t c_off, r_off;
-  int32_t M, N, K, lda, ldb, ldc, ldr, m0, n0, klast;
-};
 
 // one plane's fragment (8 consecutive k of this lane's row) of a [k][row] bf16 image: 2 transposing reads
 __device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
@@ -132,38 +92,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   const float* pa[NLDA];
   const float* pb[NLDB];
 
-  // ---- tile decode: which sub-problem / tile (wave-uniform scalar work) + this thread's row pointers
-  // The problem table is read through the CONSTANT address space: with a wave-uniform index these become scalar loads
-  // (s_load, lgkmcnt).  As vector loads they left VM events pending on registers the k-loop reuses, and the compiler's
-  // waitcnt pass then put an s_waitcnt vmcnt(0) at the join in front of the fragment reads -- i.e. every k-tile waited for
-  // the NEXT k-tile's global loads before its own MFMAs (22 % idle matrix pipe in the round-1 profile).
+  // ---- tile decode (wave-uniform scalar work, gemm_device.h) + this thread's row pointers
   auto setup = [&](int tile, TileCtx& c) -> bool {
-    int lo = 0, hi = ka.nprob - 1;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) >> 1;
-      if (prob_tile_start(ka.probs, mid) <= tile) lo = mid; else hi = mid - 1;
-    }
-    const GemmProb P = load_prob(ka.probs, lo);
-    int mt, nt;
-    if (ka.xcd_tiles_m > 0) {
-      // XCD-aware map (speed only; correctness never depends on placement).  Blocks b and b+8 share an XCD and its 4 MB
-      // L2 (round-robin dispatch), and the persistent stride is a multiple of 8, so tile%8 labels the XCD for the whole
-      // walk.  The tile grid is cut into 2 (M) x 4 (N) rectangles, one per XCD: a weight quarter (3 MB at D=1024) stays
-      // L2-resident and each A panel is fetched by 4 XCDs instead of 8 -- HBM/Infinity-Cache reads drop ~2.4x vs the
-      // plain round-robin order (PMC FETCH_SIZE, profiles/).
-      const int x = tile & 7, j = tile >> 3;
-      const int sm = (ka.xcd_tiles_m + 1) >> 1, sn = P.tiles_n >> 2;
-      mt = (x >> 2) * sm + j / sn;
-      nt = (x & 3) * sn + j % sn;
-      if (mt >= ka.xcd_tiles_m) return false;
-    } else {
-      const int local = tile - P.tile_start;
-      mt = local / P.tiles_n; nt = local % P.tiles_n;
-    }
-    c.m0 = mt * BM; c.n0 = nt * BN;
-    c.M = P.M; c.N = P.N; c.K = P.K; c.lda = P.lda; c.ldb = P.ldb; c.ldc = P.ldc; c.ldr = P.ldr;
-    c.c_off = P.c_off; c.r_off = P.r_off;
-    c.klast = P.K > 4 ? ((P.K + 3) & ~3) - 4 : 0;   // last legal float4 start along a K-contiguous row
+    GemmProb P;
+    if (!decode_tile<BM, BN>(ka, tile, c, P)) return false;
     if constexpr (A_KC) {
 #pragma unroll
       for (int p = 0; p < NLDA; ++p) {
@@ -394,47 +326,9 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       }
     }
 
-    // ---- epilogue of `cur`.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = cur.n0 + wn * WTN + tn * 32 + li;
-      if (col >= cur.N) continue;
-      float bsum = 0.f;
-      if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS2 || EPI == EPI_BIAS_RESIDUAL) {
-        int g = 0, nl = col;
-        if (ka.n_group > 0) { g = col / ka.n_group; nl = col - g * ka.n_group; }
-        const float* b0 = g == 0 ? ka.bias0[0] : g == 1 ? ka.bias0[1] : g == 2 ? ka.bias0[2] : ka.bias0[3];
-        bsum = b0[nl];
-        if constexpr (EPI == EPI_BIAS2) {
-          const float* b1 = g == 0 ? ka.bias1[0] : g == 1 ? ka.bias1[1] : g == 2 ? ka.bias1[2] : ka.bias1[3];
-          if (b1 != nullptr) bsum += b1[nl];   // single-bias projections pass bias1 = nullptr
-        }
-      }
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = cur.m0 + wm * WTM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row >= cur.M) continue;
-          float v = acc[tm][tn][r];
-          float* cp = ka.C + cur.c_off + (int64_t)row * cur.ldc + col;
-          if constexpr (EPI == EPI_NONE) v *= ka.alpha;
-          if constexpr (EPI == EPI_RESIDUAL) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
-          if constexpr (EPI == EPI_BIAS_RELU) {
-            v += bsum; v = (v < 0.f) ? 0.f : v;   // NaN-propagating, like torch.relu
-            if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
-          }
-          if constexpr (EPI == EPI_BIAS2) v += bsum;
-          if constexpr (EPI == EPI_BIAS_RESIDUAL) {
-            v += bsum;
-            if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
-            v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
-          }
-          if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
-          *cp = v;
-        }
-      }
-    }
+    // ---- epilogue of `cur` (gemm_device.h)
+    if (!(ka.dbg & 1) || acc[0][0][0] == 12345.f)
+    epilogue_store<EPI, TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
     if (!has_next) break;
     tile = next_tile;
     cur = nxt;
@@ -475,6 +369,8 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = g.nprob; ka.n_group = g.n_group; ka.alpha = g.alpha;
   ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0;
+  static const int dbg = getenv("SUMK_GEMM_DBG") ? atoi(getenv("SUMK_GEMM_DBG")) : 0;
+  ka.dbg = dbg;
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
@@ -485,6 +381,14 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
+  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && gemm_dma_enabled()) {   // default exact-fp32 path: LDS-DMA staging (gemm_dma.hip)
+    rc = launch_gemm_dma(layout, epi, ka, ka.total_tiles, g.small_tile, stream);
+    prof_end(SUMK_PROF_GEMM_ALL, stream);
+    if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
+    if (rc != SUMK_OK) return rc;
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
   if (g.precision == SUMK_PRECISION_BF16X3) {   // bf16x3 arithmetic (same tiles, same k order per tile shape)
@@ -650,10 +554,14 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
   hipStream_t s = (hipStream_t)stream;
   int small = (M <= 64 || N <= 64) ? 1 : 0;
   if (const char* env = getenv("SUMK_ROW_CFG")) if (env[0] >= '0' && env[0] <= '2') small = env[0] - '0';
+  if (getenv("SUMK_FAKE_LD")) { lda = 0; ldb = 0; }   // diagnostic: every row aliases row 0 (tiny footprint, all cache hits)
   SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, small, s));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = small;
   g.total_tiles = gemm_tiles(M, N, small); g.xcd_M = M; g.xcd_N = N; g.precision = precision;
+  // a K-contiguous operand is fetched in 16-byte chunks: with K % 4 != 0 the last chunk of a row runs into the next row, which
+  // only the register-staged kernel masks element by element (internal callers pad such rows with zeros instead)
+  g.no_dma = (layout != GEMM_TN && K % 4 != 0) ? 1 : 0;
   return launch_gemm(layout, EPI_NONE, g, s);
 }
 }  // namespace

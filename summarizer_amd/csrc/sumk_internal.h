@@ -62,6 +62,7 @@ struct GemmLaunch {
   int32_t prof_tag = -1;
   int32_t precision = 0;   // 0: exact fp32 MFMA; 1: bf16x3 split on bf16 MFMA (NT layout only; other layouts stay fp32)
   int32_t xcd_M = 0, xcd_N = 0;  // single-problem launches: (M,N) so the kernel may use the XCD-aware tile map
+  int32_t no_dma = 0;            // 1: keep the register-staged kernel (a K-contiguous operand whose K tail is not zero-padded)
   // training-mode dropout fused in the epilogue (EPI_BIAS_RELU: after the ReLU; EPI_BIAS_RESIDUAL: on acc+bias, before +R);
   // drop_thr == 0 disables it.  Element index of the mask = row * N + col.
   uint64_t drop_seed = 0; uint32_t drop_thr = 0, drop_site = 0; float drop_scale = 1.f;
