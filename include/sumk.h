@@ -307,6 +307,9 @@ int sumk_pack_rows(float* dst, const float* const* srcs, const int32_t* n_rows, 
 #define SUMK_PROF_NTAGS 8
 int sumk_prof_enable(int32_t on);
 int sumk_prof_read(int32_t tag, double* total_ms, int64_t* launches, int32_t reset);
+/* Diagnostic (process started with SUMK_GEMM_DBG=2): the last GEMM launch's in-kernel shader-cycle stamps, 4 values per block
+ * {whole block, k-loops, epilogues, tiles}; synchronises the device.  Returns SUMK_ERR_ARG when stamping is off. */
+int sumk_prof_gemm_stamps(uint64_t* out, int32_t n_blocks);
 
 #ifdef __cplusplus
 }

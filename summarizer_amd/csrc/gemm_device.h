@@ -23,7 +23,8 @@ struct GemmKArgs {
   Drop drop; uint32_t drop_site;   // epilogue dropout (drop.thr == 0: none); mask index = row * N + col
   int32_t xcd_tiles_m;   // > 0: single-problem launch with the XCD-aware tile map below; value = tiles along M
   float alpha;
-  int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores
+  int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores, 2 = in-kernel cycle stamps
+  unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
 };
 
 // Scalar reads of the problem table (CONSTANT address space + wave-uniform index -> s_load, lgkmcnt).  As vector loads they

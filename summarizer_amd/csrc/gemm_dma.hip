@@ -1,14 +1,17 @@
-// Exact-fp32 MFMA GEMM staged by LDS-DMA (gfx950 `global_load_lds_dwordx4`): the default kernel of every fp32 contraction.
+// Exact-fp32 MFMA GEMM staged by LDS-DMA (gfx950 `global_load_lds_dwordx4`): the alternative to gemm_f32.hip's register staging
+// (opt-in: SUMK_GEMM_DMA=1).
 //
-// Why a second staging scheme.  The register-staged kernel (gemm_f32.hip) moves every operand byte global -> VGPR -> LDS:
-// per k-tile each CU's three co-resident blocks push 96 KB through `ds_write_b128` (~79 B/clk/CU, ~1250 cycles) between two
-// barriers, and because co-resident blocks run in lockstep (they are released together and convoy on the shared matrix
-// pipe) nothing covers that pass: the round-1 counters show the matrix pipe idle 22 % of the launch.  Here the operand
-// tiles go global -> LDS directly, asynchronously, into a DOUBLE-BUFFERED LDS ring:
-//   * no VGPR staging (32 fewer registers), no ds_write pass, ONE workgroup barrier per k-tile instead of two;
-//   * the DMA of k-tile t+1 (or of the NEXT output tile's first k-tile: the tile walk is persistent) is in flight while
-//     the 64 MFMAs of k-tile t run; the only thing between two MFMA phases is `s_waitcnt vmcnt(0)` + `s_barrier` + the
-//     issue of the next DMAs.
+// Operand tiles go global -> LDS directly, asynchronously, into a DOUBLE-BUFFERED LDS ring: no VGPR staging, no ds_write pass,
+// ONE workgroup barrier per k-tile; the DMA of k-tile t+1 (or of the NEXT output tile's first k-tile: the tile walk is
+// persistent) is in flight while the MFMAs of k-tile t run, its eight 1-KiB pieces issued one per MFMA group.
+// What was measured (MI355X, scripts/probes/mfma_f32_ceiling.hip, scripts/gemm_stamp_probe.py; DESIGN.md has the table):
+//   * the bare loop (fragment reads + 64 MFMAs + one barrier) sustains 152-155 TFLOP/s; every 1-KiB DMA piece costs the SIMD one
+//     MFMA slot (~62 cycles), so 8 pieces per 64 MFMAs cap this tiling at 136 TFLOP/s;
+//   * __builtin_amdgcn_global_load_lds is an LDS store to hipcc, which then waits `vmcnt(0)` before the next ds_read: the DMA
+//     latency lands in front of the SAME k-tile's fragment reads (88 TFLOP/s in the probe) -- hence the inline-asm form below;
+//   * in the full GEMM this kernel's k-loop runs at 93 % of the matrix-pipe floor (2 blocks / CU), the register-staged one at
+//     97 % (3 blocks / CU); both end at 120-130 TFLOP/s because what is left is outside the loop: lock-stepped epilogue store
+//     bursts (5-8 % of a block's cycles), the tail of the tile walk, and a ~2.25 GHz clock under this load.
 // LDS images (an LDS-DMA instruction writes 64 lanes x 16 B = 1 KiB LINEARLY at a wave-uniform base, so padding is not
 // available; bank conflicts are avoided by permuting what each lane FETCHES):
 //   K-contiguous operand ("KC": A of NT/NN, B of NT): [row][BK] floats, 128-B rows, the 16-B chunk c of row r holds global
@@ -18,7 +21,7 @@
 //     (consecutive lanes, consecutive columns).
 // Rows / columns past M or N are clamped (they only feed outputs that are never stored); k past K must read zeros: those
 // lanes fetch from a 16-byte zero page in the code object instead.
-// Arithmetic, k order, epilogues and therefore RESULTS are identical to gemm_f32.hip's exact-fp32 path
+// Arithmetic, k order, epilogues and therefore RESULTS are bit-identical to gemm_f32.hip's exact-fp32 path
 // (tests/test_gpu_vasnet.py::test_gemm_dma_equals_register_staged_kernel).
 #include "gemm_device.h"
 #include <algorithm>
@@ -149,8 +152,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * WM * WN / 4) void gemm_dma_kern
   if (!setup(tile, cur)) return;
   int st = 0;
   issue(cur, 0, st);          // prologue: the first k-tile of the first tile
+  unsigned long long t_begin = 0, t_k = 0, t_e = 0, n_t = 0;
+  if (ka.dbg & 2) t_begin = __builtin_amdgcn_s_memtime();
 
   while (true) {
+    unsigned long long ta = 0;
+    if (ka.dbg & 2) ta = __builtin_amdgcn_s_memtime();
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -225,16 +232,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * WM * WN / 4) void gemm_dma_kern
       st ^= 1;
     }
 
+    unsigned long long tb = 0;
+    if (ka.dbg & 2) tb = __builtin_amdgcn_s_memtime();
     if (!(ka.dbg & 1) || acc[0][0][0] == 12345.f)
     epilogue_store<EPI, TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+    if (ka.dbg & 2) { const unsigned long long tc = __builtin_amdgcn_s_memtime(); t_k += tb - ta; t_e += tc - tb; n_t += 1; }
     if (!has_next) break;
     tile = next_tile;
     cur = nxt;
   }
+  if ((ka.dbg & 2) && ka.dbg_buf && tid == 0 && blockIdx.x < 2048) {
+    unsigned long long* o = ka.dbg_buf + (size_t)blockIdx.x * 4;
+    o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_k; o[2] = t_e; o[3] = n_t;
+  }
 }
 
+// Opt-in (SUMK_GEMM_DMA=1): measured equal to the register-staged kernel on the bench shapes (DESIGN.md "GEMM: where the
+// cycles go"), so the default stays the kernel with the longer track record.
 bool gemm_dma_enabled() {
-  static const bool on = !(getenv("SUMK_GEMM_DMA") && getenv("SUMK_GEMM_DMA")[0] == '0');
+  static const bool on = getenv("SUMK_GEMM_DMA") && getenv("SUMK_GEMM_DMA")[0] == '1';
   return on;
 }
 

@@ -222,8 +222,12 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   TileCtx cur, nxt;
   if (!setup(tile, cur)) return;   // (remapped walk: a rectangle's tiles are exhausted in increasing order)
   gload(cur, 0);
+  unsigned long long t_begin = 0, t_k = 0, t_e = 0, n_t = 0;
+  if (ka.dbg & 2) t_begin = __builtin_amdgcn_s_memtime();
 
   while (true) {
+    unsigned long long ta = 0;
+    if (ka.dbg & 2) ta = __builtin_amdgcn_s_memtime();
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -327,11 +331,18 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     }
 
     // ---- epilogue of `cur` (gemm_device.h)
+    unsigned long long tb = 0;
+    if (ka.dbg & 2) tb = __builtin_amdgcn_s_memtime();
     if (!(ka.dbg & 1) || acc[0][0][0] == 12345.f)
     epilogue_store<EPI, TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+    if (ka.dbg & 2) { const unsigned long long tc = __builtin_amdgcn_s_memtime(); t_k += tb - ta; t_e += tc - tb; n_t += 1; }
     if (!has_next) break;
     tile = next_tile;
     cur = nxt;
+  }
+  if ((ka.dbg & 2) && ka.dbg_buf && tid == 0 && blockIdx.x < 2048) {
+    unsigned long long* o = ka.dbg_buf + (size_t)blockIdx.x * 4;
+    o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_k; o[2] = t_e; o[3] = n_t;
   }
 }
 
@@ -361,6 +372,13 @@ static int launch_layout(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, in
   return launch_epi<BM, BN, BK, false, false, X3>(epi, ka, tiles, s);
 }
 
+// one 64 KB stamp buffer per process, allocated on first use under SUMK_GEMM_DBG=2
+static unsigned long long* gemm_stamp_buffer() {
+  static unsigned long long* buf = nullptr;
+  if (!buf && hipMalloc(&buf, 2048 * 4 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+  return buf;
+}
+
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream) {
   SUMK_ARG(g.A && g.B[0] && g.C && g.probs, "gemm: null operand");
   if (g.total_tiles <= 0) return SUMK_OK;
@@ -370,7 +388,8 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = g.nprob; ka.n_group = g.n_group; ka.alpha = g.alpha;
   ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0;
   static const int dbg = getenv("SUMK_GEMM_DBG") ? atoi(getenv("SUMK_GEMM_DBG")) : 0;
-  ka.dbg = dbg;
+  ka.dbg = dbg; ka.dbg_buf = nullptr;
+  if (dbg & 2) ka.dbg_buf = gemm_stamp_buffer();   // diagnostic only (never on a product path)
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
@@ -381,7 +400,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
-  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && gemm_dma_enabled()) {   // default exact-fp32 path: LDS-DMA staging (gemm_dma.hip)
+  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && gemm_dma_enabled()) {   // opt-in (SUMK_GEMM_DMA=1): LDS-DMA staging (gemm_dma.hip)
     rc = launch_gemm_dma(layout, epi, ka, ka.total_tiles, g.small_tile, stream);
     prof_end(SUMK_PROF_GEMM_ALL, stream);
     if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
@@ -565,6 +584,15 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
   return launch_gemm(layout, EPI_NONE, g, s);
 }
 }  // namespace
+
+extern "C" int sumk_prof_gemm_stamps(uint64_t* out, int32_t n_blocks) {
+  using namespace sumk;
+  static const bool on = getenv("SUMK_GEMM_DBG") && (atoi(getenv("SUMK_GEMM_DBG")) & 2);
+  SUMK_ARG(on && out && n_blocks > 0 && n_blocks <= 2048, "gemm stamps: start the process with SUMK_GEMM_DBG=2 (n_blocks <= 2048)");
+  SUMK_HIP(hipDeviceSynchronize());
+  SUMK_HIP(hipMemcpy(out, gemm_stamp_buffer(), (size_t)n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return SUMK_OK;
+}
 
 extern "C" int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
   return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream);

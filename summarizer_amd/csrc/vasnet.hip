@@ -124,13 +124,23 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
     }
     return;
   }
+  // Every thread needs the prefix sums over the videos before its own: O(n_seq^2) reads of the offset array in total, served
+  // from LDS (the array is staged once per block; read straight from global memory the dependent loads made this tiny kernel
+  // take 11 us per call).
+  constexpr int STAGE_MAX = 4096;
+  __shared__ int32_t soff[STAGE_MAX + 1];
+  const bool staged = a.n_seq <= STAGE_MAX;
+  if (staged) {
+    for (int i = threadIdx.x; i <= a.n_seq; i += blockDim.x) soff[i] = a.off[i];
+    __syncthreads();
+  }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.n_seq) return;
   const int D = a.D, tn = (D + a.pv_tn - 1) / a.pv_tn;
   int64_t eoff = 0;
   int ts = 0, tpv = 0;
   for (int q = 0; q < s; ++q) {
-    int T = a.off[q + 1] - a.off[q];
+    int T = staged ? soff[q + 1] - soff[q] : a.off[q + 1] - a.off[q];
     eoff += (int64_t)T * ((T + 3) & ~3);
     ts += ((T + a.s_tm - 1) / a.s_tm) * ((T + a.s_tn - 1) / a.s_tn);
     tpv += ((T + a.pv_tm - 1) / a.pv_tm) * tn;

@@ -282,8 +282,8 @@ np.savez(out, **res)
 
 
 def test_gemm_dma_equals_register_staged_kernel(dev, tmp_path):
-    """The LDS-DMA staged fp32 GEMM (csrc/gemm_dma.hip, default) and the register-staged one (csrc/gemm_f32.hip,
-    SUMK_GEMM_DMA=0) issue the same MFMAs in the same k order: every result must be BIT-identical -- plain GEMMs in the three
+    """The LDS-DMA staged fp32 GEMM (csrc/gemm_dma.hip, SUMK_GEMM_DMA=1) and the register-staged one (csrc/gemm_f32.hip,
+    the default) issue the same MFMAs in the same k order: every result must be BIT-identical -- plain GEMMs in the three
     layouts (ragged M / N / K tails included) and a whole VASNet forward + backward on a ragged packed batch."""
     import os, subprocess, sys
     from conftest import ROOT
