@@ -165,9 +165,10 @@ def main():
                          "memory and scores end there (summarizer_amd/ingest.py) -- never the headline value")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16x6"], default="fp32",
-                    help="GEMM arithmetic: fp32 = exact fp32 MFMA (headline); bf16x3 = fp32 operands split into bf16 hi+lo, "
-                         "3 bf16 MFMAs per product, fp32 accumulate (scores within ~1e-5 of fp32; DESIGN.md)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16x6", "bf16"], default="fp32",
+                    help="GEMM arithmetic: fp32 = exact fp32 MFMA (headline); bf16x6 / bf16x3 = fp32 operands split into 3 / 2 bf16 "
+                         "planes, 6 / 3 bf16 MFMAs per product, fp32 accumulate (fp32-grade / ~1e-5 on scores); bf16 = plain bf16 "
+                         "operands, 1 MFMA per product: the mixed-precision TRAINING mode of BASELINE config 2 (use with --mode train)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -223,7 +224,7 @@ def main():
         # one optimiser step per packed batch: forward + MSE to a random target + backward + flat-bucket Adam
         # (+ one gradient all-reduce under torch.distributed)
         from summarizer_amd.training import FlatAdam
-        opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
+        opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5, comm_dtype=torch.bfloat16 if args.precision == "bf16" else None)
         target = torch.rand(frames, device=dev)
         def run_step():
             opt.zero_grad()
@@ -325,7 +326,7 @@ def main():
             pmc = json.load(open(tp))                                              # PMC passes of this exact launch shape
             traffic = pmc.get("gemm_qkv_hbm_bytes_per_launch")
         # bf16x3 issues 3 dense-bf16 MFMA flops per algorithmic flop: its ceiling is the bf16 peak / 3
-        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else round(BF16_MFMA_PEAK_TFLOPS / (3.0 if args.precision == "bf16x3" else 6.0), 1)
+        peak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else round(BF16_MFMA_PEAK_TFLOPS / {"bf16": 1.0, "bf16x3": 3.0, "bf16x6": 6.0}[args.precision], 1)
         roof = dict(bound="mfma", kernel="gemm_f32_kernel<128,NT> (QKV projection)" + ("" if args.precision == "fp32" else f" [{args.precision}]"),
                     achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                     traffic=traffic, avg_launch_us=round(avg_s * 1e6, 2), launches=int(n.value),
@@ -348,7 +349,7 @@ def main():
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32" if args.precision == "fp32" else f"f32 storage/accumulate, {args.precision} split products",
+                   vs_baseline=None, dtype="f32" if args.precision == "fp32" else ("bf16 products, f32 accumulate/storage/master weights" if args.precision == "bf16" else f"f32 storage/accumulate, {args.precision} split products"),
                    data="synthetic",
                    config=dict(workload=(f"{args.model} {args.mode}, S-TVSum: {args.videos} videos/GPU, T~U(150,320) (sum {frames}), D=1024, packed batch"
                                          if args.workload == "tvsum" else

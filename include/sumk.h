@@ -38,6 +38,9 @@ int sumk_device_count(void);
 #define SUMK_PRECISION_FP32 0
 #define SUMK_PRECISION_BF16X3 1
 #define SUMK_PRECISION_BF16X6 2   /* x = x1+x2+x3 exactly, 6 bf16 MFMAs per product: fp32-grade results */
+#define SUMK_PRECISION_BF16 3     /* plain bf16 operands (one plane), ONE bf16 MFMA per product, fp32 accumulate: the mixed-precision
+                                     TRAINING arithmetic of BASELINE config 2 (storage, master weights and optimiser stay fp32) */
+#define SUMK_PRECISION_MAX 3
 
 /* ------------------------------------------------------------------------------------------------ VASNet
  * Weights of summarizer/models/vasnet.py:56-66, each as stored by nn.Linear ([out][in]).
@@ -254,6 +257,11 @@ int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * workspace: sumk_sumsq_workspace_bytes() bytes of device scratch. */
 size_t sumk_sumsq_workspace_bytes(void);
 int sumk_sumsq(const float* v, int64_t n, float* out, void* workspace, void* stream);
+/* Flat fp32 <-> bf16 casts (round to nearest even): in the mixed-precision training mode (SUMK_PRECISION_BF16) the gradient
+ * bucket crosses the data-parallel all-reduce as bf16 -- 10.5 MB instead of 21 MB for VASNet -- and comes back into the fp32
+ * bucket the optimiser reads.  No reference counterpart (the reference has no distributed code). */
+int sumk_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+int sumk_cast_bf16_f32(const void* src_bf16, float* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ generic
  * fp32 MFMA GEMM (the dominant kernel), exposed for tests and for bench.py's roofline probe:

@@ -133,5 +133,8 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
 // gemm_dma.hip: exact-fp32 kernels staged by LDS-DMA.  cfg: tile configuration of GemmLaunch::small_tile.
 int launch_gemm_dma(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);
 bool gemm_dma_enabled();
+// gemm_split.hip: the register-staged kernel with fp32 operands split into bf16 planes on their way into LDS
+// (SUMK_PRECISION_BF16 / BF16X3 / BF16X6).
+int launch_gemm_split(int precision, GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);
 
 }  // namespace sumk

@@ -1233,7 +1233,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
                                          size_t workspace_bytes, int32_t training, int32_t precision, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && seq_off_dev && w && h_out && workspace, "bilstm_forward: null pointer");
-  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "bilstm_forward: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "bilstm_forward: unknown precision %d", precision);
   for (int d = 0; d < 2; ++d)
     SUMK_ARG(w->w_ih[d] && w->w_hh[d] && w->b_ih[d] && w->b_hh[d], "bilstm_forward: null weight (dir %d)", d);
   LstmWs L;
@@ -1351,7 +1351,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
                                           int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
                                           const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* gr, float* dx,
                                           void* workspace, size_t workspace_bytes, int32_t precision, void* stream_) {
-  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "bilstm_backward: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "bilstm_backward: unknown precision %d", precision);
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && h_out && dh_out && seq_off_dev && w && gr && workspace, "bilstm_backward: null pointer");
   for (int d = 0; d < 2; ++d)
@@ -1523,7 +1523,7 @@ extern "C" int sumk_lstm_layer_forward(const float* x, int32_t In, int32_t H, in
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && seq_off_dev && w && h_out && workspace, "lstm_forward: null pointer");
   SUMK_ARG(w->w_ih && w->w_hh && w->b_ih && w->b_hh, "lstm_forward: null weight");
-  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "lstm_forward: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "lstm_forward: unknown precision %d", precision);
   Lstm1Ws L;
   SUMK_TRY(lstm1_carve(In, H, n_seq, seq_off_host, training, &L));
   if (workspace_bytes < L.total) {
@@ -1592,7 +1592,7 @@ extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, cons
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && h_out && seq_off_dev && w && gr && workspace, "lstm_backward: null pointer");
   SUMK_ARG(w->w_ih && w->w_hh && gr->w_ih && gr->w_hh && gr->b_ih && gr->b_hh, "lstm_backward: null weight/grad");
-  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "lstm_backward: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "lstm_backward: unknown precision %d", precision);
   Lstm1Ws L;
   SUMK_TRY(lstm1_carve(In, H, n_seq, seq_off_host, 1, &L));
   if (workspace_bytes < L.total) {
@@ -2029,7 +2029,7 @@ extern "C" int sumk_linear_forward(const float* x, const float* w, const float* 
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && w && y && workspace, "linear_forward: null pointer");
   SUMK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0, "linear_forward: bad shape M=%d N=%d K=%d (K must be a multiple of 4)", M, N, K);
-  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "linear_forward: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "linear_forward: unknown precision %d", precision);
   LinWs L; linear_carve(N, K, &L);
   if (workspace_bytes < L.total) { set_error("linear_forward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
   GemmProb* prob = (GemmProb*)((char*)workspace + L.prob);
@@ -2046,7 +2046,7 @@ extern "C" int sumk_linear_backward(const float* x, const float* w, const float*
   hipStream_t stream = (hipStream_t)stream_;
   SUMK_ARG(x && w && dy && workspace, "linear_backward: null pointer");
   SUMK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0 && N % 4 == 0, "linear_backward: bad shape M=%d N=%d K=%d (N, K multiples of 4)", M, N, K);
-  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_BF16X6, "linear_backward: unknown precision %d", precision);
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "linear_backward: unknown precision %d", precision);
   LinWs L; linear_carve(N, K, &L);
   if (workspace_bytes < L.total) { set_error("linear_backward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
   char* ws = (char*)workspace;

@@ -56,9 +56,43 @@ __global__ void sumsq_final_kernel(const float* __restrict__ partial, int n, flo
   if (threadIdx.x == 0) out[0] += s;
 }
 
+// fp32 <-> bf16 of a flat buffer (round to nearest even; hipcc emits v_cvt_pk_bf16_f32, NaN stays NaN): the gradient bucket
+// travels through the data-parallel all-reduce as bf16 in the mixed-precision training mode (half the bytes over xGMI).
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    reinterpret_cast<bf16x4_t*>(dst)[i] = __builtin_convertvector(reinterpret_cast<const f32x4_t*>(src)[i], bf16x4_t);
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (__bf16)src[i];
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    reinterpret_cast<f32x4_t*>(dst)[i] = __builtin_convertvector(reinterpret_cast<const bf16x4_t*>(src)[i], f32x4_t);
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (float)src[i];
+}
+
 }  // namespace sumk
 
 using namespace sumk;
+
+extern "C" int sumk_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, void* stream) {
+  SUMK_ARG(src && dst_bf16 && n > 0, "cast_f32_bf16: bad argument");
+  SUMK_ARG(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst_bf16 & 7) == 0, "cast_f32_bf16: buffers must be 16- / 8-byte aligned");
+  int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst_bf16, n);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+extern "C" int sumk_cast_bf16_f32(const void* src_bf16, float* dst, int64_t n, void* stream) {
+  SUMK_ARG(src_bf16 && dst && n > 0, "cast_bf16_f32: bad argument");
+  SUMK_ARG(((uintptr_t)dst & 15) == 0 && ((uintptr_t)src_bf16 & 7) == 0, "cast_bf16_f32: buffers must be 16- / 8-byte aligned");
+  int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src_bf16, dst, n);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
 
 extern "C" int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,

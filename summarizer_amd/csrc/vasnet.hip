@@ -533,7 +533,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   SUMK_ARG((pos_table == nullptr) == (pos_rows == nullptr), "vasnet_forward: pos_table and pos_rows go together");
   SUMK_ARG(opts->dropout_p >= 0.f && opts->dropout_p < 1.f, "vasnet_forward: dropout_p=%f out of [0,1)", opts->dropout_p);
   SUMK_ARG(opts->dropout_p == 0.f || training, "vasnet_forward: dropout needs training mode");
-  SUMK_ARG(opts->precision >= SUMK_PRECISION_FP32 && opts->precision <= SUMK_PRECISION_BF16X6, "vasnet_forward: unknown precision %d", opts->precision);
+  SUMK_ARG(opts->precision >= SUMK_PRECISION_FP32 && opts->precision <= SUMK_PRECISION_MAX, "vasnet_forward: unknown precision %d", opts->precision);
   Geometry G;
   SUMK_TRY(geometry(D, n_seq, seq_off_host, training, &G));
   const VasnetWs& L = G.L;

@@ -92,11 +92,12 @@ VASNET_FIELDS = [("Wk", "K.weight"), ("Wq", "Q.weight"), ("Wv", "V.weight"), ("W
                  ("ln_w", "layer_norm.weight"), ("ln_b", "layer_norm.bias")]
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2}      # SUMK_PRECISION_* of include/sumk.h
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x6": 2, "bf16": 3}      # SUMK_PRECISION_* of include/sumk.h
 
 
 def precision_code(p):
-    """"fp32" (default: exact fp32 MFMA) or "bf16x3" (hi+lo bf16 split, 3 bf16 MFMAs per product, fp32 accumulate)."""
+    """"fp32" (default: exact fp32 MFMA), "bf16x6" (fp32-grade, 6 bf16 MFMAs per product), "bf16x3" (hi+lo bf16 split, 3 MFMAs)
+    or "bf16" (plain bf16 operands, 1 MFMA, fp32 accumulate: mixed-precision TRAINING arithmetic, ~2^-9 per product)."""
     if p is None:
         return 0
     if p not in PRECISIONS:
@@ -228,6 +229,22 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
     rc = lib.sumk_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
                             weight_decay, int(step), float(grad_scale), _stream())
     _lib.check(rc, "sumk_adam_step")
+
+
+def cast_f32_bf16(src, dst):
+    """dst (bf16, same numel) <- src (fp32), round to nearest even (HIP)."""
+    _require_gpu(src, "cast_f32_bf16")
+    if dst.dtype != torch.bfloat16 or dst.numel() != src.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise SumkError("cast_f32_bf16: dst must be a contiguous bfloat16 buffer of the same size")
+    _lib.check(_lib.load().sumk_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "sumk_cast_f32_bf16")
+
+
+def cast_bf16_f32(src, dst):
+    """dst (fp32) <- src (bf16) (HIP)."""
+    _require_gpu(dst, "cast_bf16_f32")
+    if src.dtype != torch.bfloat16 or dst.numel() != src.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise SumkError("cast_bf16_f32: src must be a contiguous bfloat16 buffer of the same size")
+    _lib.check(_lib.load().sumk_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "sumk_cast_bf16_f32")
 
 
 _sumsq_ws = {}

@@ -92,7 +92,8 @@ class DSNTrainer(Trainer):
         dev = self._device()
         rank, world = dist_info()
         bv = int(self.hps.extra_params.get("batch_videos", 1))
-        self.optimizer = FlatAdam(self.model.parameters(), lr=self.hps.lr, weight_decay=self.hps.weight_decay)
+        self.optimizer = FlatAdam(self.model.parameters(), lr=self.hps.lr, weight_decay=self.hps.weight_decay,
+                                  comm_dtype=torch.bfloat16 if getattr(self.model, "precision", "fp32") == "bf16" else None)
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
         my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
 

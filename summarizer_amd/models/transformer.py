@@ -141,7 +141,8 @@ class TransformerTrainer(Trainer):
         bv = int(self.hps.extra_params.get("batch_videos", 1))
         used = set(kernels.transformer_param_names(self.model.encoder_layers)) | {"pos_embed.weight"}
         self.optimizer = FlatAdam([p for n, p in self.model.named_parameters() if n in used and p.requires_grad],
-                                  lr=self.hps.lr, weight_decay=self.hps.weight_decay)
+                                  lr=self.hps.lr, weight_decay=self.hps.weight_decay,
+                                  comm_dtype=torch.bfloat16 if getattr(self.model, "precision", "fp32") == "bf16" else None)
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
         my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
         best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0

@@ -180,8 +180,11 @@ class VASNetTrainer(Trainer):
         dev = self._device()
         rank, world = dist_info()
         bv = int(self.hps.extra_params.get("batch_videos", 1))
+        # precision "bf16" = mixed-precision training (BASELINE config 2): bf16 matrix arithmetic with fp32 accumulation, fp32
+        # master weights / moments in the flat bucket, and the gradient bucket crossing the all-reduce as bf16
         self.optimizer = FlatAdam(filter(lambda p: p.requires_grad, self.model.parameters()), lr=self.hps.lr,
-                                  weight_decay=self.hps.weight_decay)
+                                  weight_decay=self.hps.weight_decay,
+                                  comm_dtype=torch.bfloat16 if self.model.precision == "bf16" else None)
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
         my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
         # data-parallel overlap: the HIP backward records this event once the gradients of Wo / k1 / k2 (the tail of the

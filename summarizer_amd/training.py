@@ -78,7 +78,7 @@ class FlatAdam:
       * step() is one HIP kernel (sumk_adam_step) -- optionally with the clip_grad_norm_ scale folded in (dsn.py:145).
     The gradient tensors autograd produces are accumulated into the views in place."""
 
-    def __init__(self, params, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, comm_dtype=None):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
@@ -105,6 +105,12 @@ class FlatAdam:
         self.step_count = 0
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._side, self._tail_from = None, None      # side stream / split point of an in-flight early all-reduce
+        # mixed-precision mode: the gradient bucket crosses the all-reduce as bf16 (half the bytes over xGMI); the fp32 bucket,
+        # the moments and the master weights stay fp32.  The bf16 staging buffer exists only under torch.distributed.
+        if comm_dtype not in (None, torch.float32, torch.bfloat16):
+            raise kernels.SumkError(f"FlatAdam: comm_dtype must be None, float32 or bfloat16, got {comm_dtype}")
+        self.comm_dtype = torch.bfloat16 if comm_dtype == torch.bfloat16 else torch.float32
+        self._comm = None
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -124,12 +130,26 @@ class FlatAdam:
         if world == 1:
             return 1.0
         if self._tail_from is None:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self._reduce(self.flat_grad)
         else:                                      # the tail is already in flight on the side stream: reduce the head, then join
-            dist.all_reduce(self.flat_grad[:self._tail_from], op=dist.ReduceOp.SUM)
+            self._reduce(self.flat_grad[:self._tail_from])
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
             self._tail_from = None
         return 1.0 / world if average else 1.0
+
+    def _reduce(self, piece):
+        """SUM all-reduce of a slice of the gradient bucket, through a bf16 staging buffer when comm_dtype is bfloat16."""
+        import torch.distributed as dist
+        if self.comm_dtype == torch.float32:
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+            return
+        if self._comm is None:
+            self._comm = torch.empty(self.flat_grad.numel(), dtype=torch.bfloat16, device=self.flat_grad.device)
+        off = (piece.data_ptr() - self.flat_grad.data_ptr()) // 4
+        stage = self._comm[off:off + piece.numel()]
+        kernels.cast_f32_bf16(piece, stage)
+        dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+        kernels.cast_bf16_f32(stage, piece)
 
     def tail_offset(self, first_param):
         """Element offset in the flat bucket of `first_param` (a Parameter of this optimiser)."""
@@ -153,7 +173,7 @@ class FlatAdam:
         tail_from = (tail_from // 4) * 4                    # keep both pieces 16-byte aligned
         self._side.wait_event(ready_event)
         with torch.cuda.stream(self._side):
-            dist.all_reduce(self.flat_grad[tail_from:], op=dist.ReduceOp.SUM)
+            self._reduce(self.flat_grad[tail_from:])
         self._tail_from = tail_from
 
     def broadcast(self, src=0):

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, q, bv):
+def _run(rank, world, port, q, bv, precision="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import random
     import torch.distributed as dist
@@ -25,7 +25,7 @@ def _run(rank, world, port, q, bv):
         ds = synthetic_dataset(3, seed=9, D=128, t_range=(40, 90), n_users=4)
         keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
         hps = make_hps(ds, [{"train_keys": keys[:2], "test_keys": keys[2:]}], epochs=2, test_every_epochs=5, lr=1e-3,
-                       selection_algorithm="rank", extra_params={"input_size": "128", "batch_videos": str(bv)})
+                       selection_algorithm="rank", extra_params={"input_size": "128", "batch_videos": str(bv), "precision": precision})
         torch.manual_seed(100 + rank)          # DIFFERENT init per rank: broadcast_parameters must make them agree
         random.seed(5)
         tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
@@ -39,11 +39,11 @@ def _run(rank, world, port, q, bv):
             dist.destroy_process_group()
 
 
-def _spawn(world, bv):
+def _spawn(world, bv, precision="fp32"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q, bv)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, bv, precision)) for r in range(world)]
     for p in procs: p.start()
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs: p.join(timeout=120)
@@ -56,6 +56,17 @@ def test_dp_two_ranks_equal_single_process_batch_of_two():
     for k in dp[0]:
         np.testing.assert_array_equal(dp[0][k], dp[1][k], err_msg=f"ranks disagree on {k}")
         np.testing.assert_allclose(dp[0][k], single[k], atol=2e-6, err_msg=f"DP != single-process batch for {k}")
+
+
+def test_dp_mixed_precision_bf16_gradient_bucket():
+    """precision "bf16": the gradient bucket crosses the all-reduce as bf16 (cast kernels + one bf16 collective, and the early
+    tail piece on the side stream).  Both ranks must end bit-identical; against the single-process batch of two the weights agree
+    to bf16-rounding of the gradients (Adam steps of lr = 1e-3 => a few 1e-4 after 4 steps)."""
+    dp = _spawn(2, 1, "bf16")
+    single = _spawn(1, 2, "bf16")[0]
+    for k in dp[0]:
+        np.testing.assert_array_equal(dp[0][k], dp[1][k], err_msg=f"ranks disagree on {k}")
+        np.testing.assert_allclose(dp[0][k], single[k], atol=2e-3, err_msg=f"DP(bf16 comm) far from single-process batch for {k}")
 
 
 def test_bench_multi_rank_control_flow_on_one_gpu():

@@ -223,3 +223,36 @@ def test_dsn_trainer_reproduces_the_reference_trainer_end_to_end():
     f_avg = [v for _, v in sc["synthetic/Fold_1/Test/F-score_avg"]]; f_max = [v for _, v in sc["synthetic/Fold_1/Test/F-score_max"]]
     np.testing.assert_allclose(f_avg, g["f_avg"], atol=2e-2); np.testing.assert_allclose(f_max, g["f_max"], atol=2e-2)
     np.testing.assert_allclose(best[0], g["best"][0], atol=5e-3)
+
+
+def test_vasnet_trainer_mixed_precision_bf16_tracks_the_reference_trainer():
+    """BASELINE config 2 ("VASNet train on TVSum ... bf16"): the G7 run again with `--precision bf16` (bf16 matrix arithmetic,
+    fp32 accumulation, fp32 master weights / moments).  Gate = north_star's training bar, not 1e-4: the loss trajectory stays
+    within 5 % of the REAL reference trainer's, correlation within 0.05, F-scores within +-0.1 (measured far inside)."""
+    from conftest import load_golden
+    from summarizer_amd.models.vasnet import VASNetTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    g = load_golden("e2e_vasnet")
+    D, SEED, n, dseed, t0, t1, nu = [int(v) for v in g["meta"]]
+    ds = synthetic_dataset(n, seed=dseed, D=D, t_range=(t0, t1), n_users=nu)
+    keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
+    hps = make_hps(ds, [{"train_keys": keys[3:], "test_keys": keys[:3]}], epochs=3, test_every_epochs=1, lr=1e-3,
+                   selection_algorithm="rank", extra_params={"local": "12", "input_size": str(D), "precision": "bf16"})
+    torch.manual_seed(SEED); random.seed(SEED)
+    tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+    assert tr.model.precision == "bf16"
+    tr.model.dropout.p = 0.0
+    tr.train(0)
+    assert tr.optimizer.comm_dtype == torch.bfloat16
+    for p in tr.model.parameters():
+        assert p.dtype == torch.float32                       # master weights stay fp32
+    losses = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Train/Loss"]]
+    np.testing.assert_allclose(losses, g["losses"], rtol=5e-2)
+    assert not np.allclose(losses, g["losses"], rtol=1e-6)    # ... and it really is a different arithmetic
+    corr = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/Correlation"]]
+    np.testing.assert_allclose(corr, g["corr"], atol=5e-2)
+    f_avg = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/F-score_avg"]]
+    f_max = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/F-score_max"]]
+    assert np.abs(np.array(f_avg) - g["f_avg"]).max() < 0.1 and np.abs(np.array(f_max) - g["f_max"]).max() < 0.1
+    print("bf16 training: losses", losses, "reference", g["losses"].tolist(), "| max dF_avg", float(np.abs(np.array(f_avg) - g["f_avg"]).max()))

@@ -299,3 +299,51 @@ def test_gemm_dma_equals_register_staged_kernel(dev, tmp_path):
     for k in a.files:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
         assert np.isfinite(a[k]).all(), k
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 4, 4), (132, 192, 100), (300, 3072, 1024), (200, 1024, 260)])
+def test_gemm_plain_bf16_vs_float64(dev, M, N, K):
+    """precision "bf16" (SUMK_PRECISION_BF16: one bf16 plane, ONE MFMA per product, fp32 accumulate -- the mixed-precision
+    training arithmetic): each operand is rounded to 8 significant bits, so a product carries <= 2^-8 + 2^-8 relative error:
+    bound 2^-7 * |A|.|B|^T; bf16-representable data must come out exact (fragment / plane mapping) in all three layouts."""
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bt = rng.standard_normal((N, K)).astype(np.float32)
+    Ai = (np.arange(M * K).reshape(M, K) % 7 - 3).astype(np.float32)
+    Bi = ((np.arange(N * K).reshape(N, K) % 5 - 2) + (np.arange(N)[:, None] % 3)).astype(np.float32)
+    for a_np, b_np, exact in ((A, Bt, False), (Ai, Bi, True)):
+        ref = a_np.astype(np.float64) @ b_np.astype(np.float64).T
+        bound = 2.0 ** -7 * (np.abs(a_np).astype(np.float64) @ np.abs(b_np).astype(np.float64).T) + 1e-6
+        for layout, name in ((0, "NT"), (1, "NN"), (2, "TN")):
+            a_host = a_np if layout < 2 else np.ascontiguousarray(a_np.T)
+            b_host = b_np if layout == 0 else np.ascontiguousarray(b_np.T)
+            a = torch.from_numpy(a_host).to(dev); b = torch.from_numpy(b_host).to(dev)
+            c = torch.full((M, N), float("nan"), device=dev)
+            _lib.check(lib.sumk_gemm_prec(layout, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 3, st), "gemm")
+            torch.cuda.synchronize()
+            got = c.cpu().numpy()
+            if exact:
+                np.testing.assert_array_equal(got, ref, err_msg=name)
+            else:
+                err = np.abs(got - ref)
+                assert (err <= bound).all(), f"{name} bf16 max err {err.max()}"
+                assert err.max() > 1e-5 * np.abs(ref).max(), "suspiciously exact: is the bf16 path really taken?"
+
+
+def test_vasnet_plain_bf16_scores_are_close_but_not_fp32_grade(dev):
+    """Plain bf16 arithmetic is a TRAINING mode: scores stay within 3e-2 of the reference goldens but miss the 1e-4 scoring gate
+    the fp32-grade paths hold -- it is never the default."""
+    g = load_golden("vasnet_full")
+    worst = 0.0
+    for ci in (0, 1, 2):
+        cfg = js(g[f"c{ci}/cfg"])
+        w = R.vasnet_weights(cfg["D"], cfg["wseed"]); x = R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"])
+        model = _model(dev, cfg["D"], w, precision="bf16", **cfg["kw"])
+        with torch.no_grad():
+            y = model(torch.from_numpy(x).to(dev)).cpu().numpy()
+        worst = max(worst, float(np.abs(y - g[f"c{ci}/y"]).max()))
+    print("plain bf16: max |d score| vs reference goldens:", worst)
+    assert 1e-4 < worst < 3e-2, worst

@@ -10,9 +10,9 @@ def test_precision_selector():
     from summarizer_amd import kernels
     from summarizer_amd._lib import SumkError
     assert kernels.precision_code(None) == 0 and kernels.precision_code("fp32") == 0 and kernels.precision_code("bf16x3") == 1
-    assert kernels.precision_code("bf16x6") == 2
+    assert kernels.precision_code("bf16x6") == 2 and kernels.precision_code("bf16") == 3      # plain bf16: the training mode
     with pytest.raises(SumkError):
-        kernels.precision_code("bf16")
+        kernels.precision_code("fp16")
 
 
 def test_models_refuse_cpu_tensors():
