@@ -307,13 +307,17 @@ int sumk_eval_videos(sumk_eval_video* videos, int32_t n_videos, double proportio
  * (summarizer/models/__init__.py:47-51, vasnet.py:194-205, dsn.py:98-110).  n_threads <= 0: min(16, hardware threads). */
 int sumk_pack_rows(float* dst, const float* const* srcs, const int32_t* n_rows, int32_t n_videos, int32_t D, int32_t n_threads);
 
-/* Per-kernel timing for bench.py's roofline object: when enabled, launches of the tagged kernel are
- * bracketed with hipEvents ON THE LAUNCH STREAM.  sumk_prof_read synchronises and returns the sums. */
+/* Per-kernel timing for bench.py's roofline object: launches tagged t are bracketed with hipEvents ON THE LAUNCH STREAM while
+ * bit t of the mask passed to sumk_prof_enable is set (0 = off).  sumk_prof_read synchronises and returns the sums. */
 #define SUMK_PROF_GEMM_QKV 0
 #define SUMK_PROF_GEMM_ALL 1
 #define SUMK_PROF_LSTM_REC 2
+#define SUMK_PROF_GEMM_QKT 3     /* per-video Q.K^T launches of sumk_vasnet_forward                     */
+#define SUMK_PROF_GEMM_PV 4      /* per-video alpha.V launches                                          */
+#define SUMK_PROF_GEMM_OPROJ 5   /* output projection (+ residual)                                      */
+#define SUMK_PROF_GEMM_K1 6      /* k1 (+ bias, ReLU)                                                   */
 #define SUMK_PROF_NTAGS 8
-int sumk_prof_enable(int32_t on);
+int sumk_prof_enable(int32_t tag_mask);
 int sumk_prof_read(int32_t tag, double* total_ms, int64_t* launches, int32_t reset);
 /* Diagnostic (process started with SUMK_GEMM_DBG=2): the last GEMM launch's in-kernel shader-cycle stamps, 4 values per block
  * {whole block, k-loops, epilogues, tiles}; synchronises the device.  Returns SUMK_ERR_ARG when stamping is off. */

@@ -138,7 +138,7 @@ _SIGS = {
     "sumk_prof_gemm_stamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
 }
 
-PROF_GEMM_QKV, PROF_GEMM_ALL, PROF_LSTM_REC = 0, 1, 2
+PROF_GEMM_QKV, PROF_GEMM_ALL, PROF_LSTM_REC, PROF_GEMM_QKT, PROF_GEMM_PV, PROF_GEMM_OPROJ, PROF_GEMM_K1 = 0, 1, 2, 3, 4, 5, 6
 
 _lib = None
 

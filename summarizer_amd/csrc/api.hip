@@ -29,11 +29,11 @@ struct ProfTag {
   int64_t launches = 0;
 };
 static ProfTag g_tags[SUMK_PROF_NTAGS];
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0u;   // bit t set: launches tagged t are bracketed with events
 static std::mutex g_prof_mu;
 
 void prof_begin(int tag, hipStream_t s) {
-  if (!g_prof_on || tag < 0 || tag >= SUMK_PROF_NTAGS) return;
+  if (tag < 0 || tag >= SUMK_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfTag& t = g_tags[tag];
   if (t.used == t.start.size()) {
@@ -45,7 +45,7 @@ void prof_begin(int tag, hipStream_t s) {
 }
 
 void prof_end(int tag, hipStream_t s) {
-  if (!g_prof_on || tag < 0 || tag >= SUMK_PROF_NTAGS) return;
+  if (tag < 0 || tag >= SUMK_PROF_NTAGS || !(g_prof_mask & (1u << tag))) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfTag& t = g_tags[tag];
   if (t.used >= t.stop.size()) return;
@@ -75,7 +75,7 @@ extern "C" int sumk_device_count(void) {
 }
 extern "C" int sumk_prof_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(sumk::g_prof_mu);
-  sumk::g_prof_on = on != 0;
+  sumk::g_prof_mask = (unsigned)on;
   return SUMK_OK;
 }
 extern "C" int sumk_prof_read(int32_t tag, double* total_ms, int64_t* launches, int32_t reset) {

@@ -573,7 +573,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   {  // 2: logits per video
     GemmLaunch g; g.precision = opts->precision;
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
-    g.total_tiles = G.tiles_s;
+    g.total_tiles = G.tiles_s; g.prof_tag = SUMK_PROF_GEMM_QKT;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
@@ -582,13 +582,13 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   {  // 4: context
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
-    g.total_tiles = G.tiles_pv;
+    g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {  // 5: output projection + residual
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
-    g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
+    g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
   }
   // 6: dropout + LayerNorm
@@ -597,7 +597,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   {  // 7: k1 + bias + ReLU
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
-    g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
+    g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid

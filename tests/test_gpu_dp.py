@@ -69,6 +69,88 @@ def test_dp_mixed_precision_bf16_gradient_bucket():
         np.testing.assert_allclose(dp[0][k], single[k], atol=2e-3, err_msg=f"DP(bf16 comm) far from single-process batch for {k}")
 
 
+def _run_dsn(rank, world, port, q, bv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import random
+    import zlib
+    import torch.distributed as dist
+    from summarizer_amd.models.dsn import DSNTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ds = synthetic_dataset(3, seed=11, D=128, t_range=(40, 90), n_users=4)
+        keys = sorted(ds.keys(), key=lambda k: int(k.split("_")[1]))
+
+        class ReplayDSNTrainer(DSNTrainer):
+            """Bernoulli draws as a pure function of (video key, how often that video has been drawn): the same episodes
+            whichever rank / batch composition processes the video (the device generators of two processes cannot be matched)."""
+            def _sample_actions(self, dist_, n_episodes, keys_):
+                self._draws = getattr(self, "_draws", {})
+                out, off = [], 0
+                for k in keys_:
+                    T = self.dataset[k]["features"].shape[0]
+                    c = self._draws[k] = self._draws.get(k, 0) + 1
+                    u = np.random.default_rng([zlib.crc32(k.encode()), c]).random((n_episodes, T)).astype(np.float32)
+                    out.append((torch.from_numpy(u).to(dist_.probs.device) < dist_.probs[off:off + T]).float())
+                    off += T
+                return torch.cat(out, dim=1)
+
+        hps = make_hps(ds, [{"train_keys": keys[:2], "test_keys": keys[2:]}], epochs=3, test_every_epochs=5, lr=1e-3,
+                       selection_algorithm="rank",
+                       extra_params={"input_size": "128", "hidden_size": "24", "num_episodes": "3", "sup": True, "batch_videos": str(bv)})
+        torch.manual_seed(200 + rank); random.seed(5)      # DIFFERENT init per rank: the flat broadcast must make them agree
+        tr = ReplayDSNTrainer(hps, hps.splits_files[0]).reset()
+        if world == 1:
+            torch.manual_seed(200); tr = ReplayDSNTrainer(hps, hps.splits_files[0]).reset()
+        tr.train(0)
+        rewards = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Train/Reward"]]
+        q.put((rank, {k: v.detach().cpu().numpy() for k, v in tr.model.state_dict().items()}, rewards))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_dsn_reinforce_dp_two_ranks_equal_single_process_batch_of_two():
+    """DSNTrainer under data parallelism (BASELINE config 4 in miniature): per-video baselines stay on the rank that owns the
+    video, the flat bucket is all-reduced once per step and clip_grad_norm_(5.0) is applied AFTER the reduction, on the
+    globally averaged gradient -- so two ranks with one video each must follow a single process stepping on both videos."""
+    def spawn(world, bv):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_run_dsn, args=(r, world, port, q, bv)) for r in range(world)]
+        for p in procs: p.start()
+        res = {r: (w, rew) for r, w, rew in (q.get(timeout=300) for _ in procs)}
+        for p in procs: p.join(timeout=120)
+        return res
+    dp = spawn(2, 1)
+    single = spawn(1, 2)[0]
+    for k in dp[0][0]:
+        np.testing.assert_array_equal(dp[0][0][k], dp[1][0][k], err_msg=f"ranks disagree on {k}")
+        np.testing.assert_allclose(dp[0][0][k], single[0][k], atol=5e-6, err_msg=f"DP != single-process batch for {k}")
+    # each rank logs the reward of ITS video; the single process logs the mean over both
+    np.testing.assert_allclose(np.mean([dp[0][1], dp[1][1]], axis=0), single[1], atol=1e-5)
+
+
+def test_bench_train_mode_two_ranks_on_one_gpu():
+    """`bench.py --mode train --gpus 2` as the driver would launch it (gloo, both ranks on the test box's one GPU): every step
+    ends in the flat-bucket gradient all-reduce; one JSON line whose value counts both ranks' frames."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SUMK_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--videos", "6",
+           "--mode", "train"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and "train" in out["config"]["workload"]
+    assert abs(out["value"] - 2 * out["config"]["frames_per_step_per_gpu"] * 4 / (out["ms_per_step"] * 4 / 1e3)) / out["value"] < 1e-3
+
+
 def test_bench_multi_rank_control_flow_on_one_gpu():
     """`bench.py` as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) -- here with both ranks on the
     one GPU of the test box over gloo (SUMK_BENCH_ONE_GPU=1): barriers, max-over-ranks timing, ONE JSON line from rank 0 whose
@@ -88,3 +170,6 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     per_rank = out["config"]["frames_per_step_per_gpu"]
     assert abs(out["value"] - 2 * per_rank * 5 / (out["ms_per_step"] * 5 / 1e3)) / out["value"] < 1e-3
     assert out["roofline"]["frac"] > 0 and out["bf16x3_mode"]["max_abs_score_diff_vs_fp32"] < 1e-4
+    # the scaling line also carries a data-parallel TRAINING leg, so that a multi-GPU run measures the gradient all-reduce
+    tl = out["train_step_mode"]
+    assert tl["frames_per_s"] > 0 and tl["allreduce_bytes_per_step"] > 20e6 and tl["collectives_per_step"] == 1
