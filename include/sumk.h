@@ -301,6 +301,18 @@ typedef struct sumk_eval_video {
 /* method: 0 = knapsack (sumk_knapsack_dp), 1 = rank.  n_threads <= 0: min(16, hardware threads). */
 int sumk_eval_videos(sumk_eval_video* videos, int32_t n_videos, double proportion, int32_t method, int32_t n_threads);
 
+/* ------------------------------------------------------------------------------------------------ data-parallel exchange (RCCL)
+ * The gradient all-reduce of data-parallel training as a library call: SUM, in place, over one flat bucket, on the caller's
+ * HIP stream (one collective per optimiser step; the reference has no distributed code).  Bootstrap:
+ * rank 0 obtains a 128-byte id (sumk_comm_unique_id) and ships it to every rank by any channel it has; every rank then calls
+ * sumk_comm_init with its rank -- the communicator binds the CURRENT HIP device.  dtype: 0 = fp32, 1 = bf16 (the
+ * mixed-precision mode's gradient bucket).  RCCL is dlopen'ed on first use (never linked): single-GPU users never load it.
+ * summarizer_amd/training.py uses torch.distributed by default and this path under SUMK_RCCL_DIRECT=1. */
+int sumk_comm_unique_id(uint8_t* id128);
+int sumk_comm_init(const uint8_t* id128, int32_t rank, int32_t world, void** comm_out);
+int sumk_allreduce_flat(void* comm, void* buf, int64_t n, int32_t dtype, void* stream);
+int sumk_comm_destroy(void* comm);
+
 /* ------------------------------------------------------------------------------------------------ feature ingest (host)
  * Packs the (n_rows[i], D) fp32 feature matrices srcs[i] back to back into dst (normally a pinned staging buffer that ONE
  * H2D copy then ships) with a pool of memcpy threads; replaces the per-video host->device uploads of the reference's loops

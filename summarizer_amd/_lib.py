@@ -125,6 +125,10 @@ _SIGS = {
     "sumk_sumsq": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_void_p]),
     "sumk_cast_f32_bf16": (C.c_int, [c_f32p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sumk_cast_bf16_f32": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_void_p]),
+    "sumk_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "sumk_comm_init": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "sumk_allreduce_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "sumk_comm_destroy": (C.c_int, [C.c_void_p]),
     "sumk_gemm_nt": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_pack_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), HOST_I32P, C.c_int32, C.c_int32, C.c_int32]),
     "sumk_gemm_prec": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

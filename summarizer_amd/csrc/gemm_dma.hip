@@ -51,7 +51,7 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int EPI, int OCC>
 __global__ __launch_bounds__(64 * WM * WN, OCC * WM * WN / 4) void gemm_dma_kernel(GemmKArgs ka) {
   constexpr int BK = 32;
-  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;          // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;          // 32x32 MFMA tiles per wave
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA tile");

@@ -70,6 +70,61 @@ def step_video_total(sizes, bv, step):
     return sum(max(0, min(bv, n - step * bv)) for n in sizes)
 
 
+class RcclDirect:
+    """The flat-bucket all-reduce through libsumk's own RCCL entry point (`sumk_allreduce_flat`) instead of torch.distributed:
+    the collective is enqueued on the CURRENT HIP stream like any other kernel of the step (no process-group stream hop).
+    The 128-byte RCCL id travels over the torch.distributed group that already exists (broadcast_object_list); one
+    communicator per process.  Opt-in: SUMK_RCCL_DIRECT=1 (FlatAdam picks it up); torch.distributed stays the default."""
+    _instance = None
+
+    def __init__(self):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self._lib, self._C = _lib.load(), C
+        rank, world = dist_info()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(self._lib.sumk_comm_unique_id(ident), "sumk_comm_unique_id")
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        _lib.check(self._lib.sumk_comm_init(ident, rank, world, C.byref(comm)), "sumk_comm_init")
+        self.comm, self.world = comm, world
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None:
+            cls._instance = RcclDirect()
+        return cls._instance
+
+    def all_reduce(self, buf):
+        """SUM all-reduce of a contiguous fp32 / bf16 device tensor, in place, on the current stream."""
+        from . import _lib
+        dtype = {torch.float32: 0, torch.bfloat16: 1}[buf.dtype]
+        _lib.check(self._lib.sumk_allreduce_flat(self.comm, self._C.c_void_p(buf.data_ptr()), buf.numel(), dtype,
+                                                 self._C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "sumk_allreduce_flat")
+
+    def close(self):
+        from . import _lib
+        if self.comm:
+            _lib.check(self._lib.sumk_comm_destroy(self.comm), "sumk_comm_destroy")
+            self.comm = None
+        RcclDirect._instance = None
+
+
+def _collective_sum(t):
+    """One SUM all-reduce of tensor `t`: torch.distributed, or libsumk's RCCL entry point under SUMK_RCCL_DIRECT=1 (GPU tensors)."""
+    import os
+    import torch.distributed as dist
+    if t.is_cuda and os.environ.get("SUMK_RCCL_DIRECT") == "1":
+        RcclDirect.get().all_reduce(t)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class FlatAdam:
     """torch.optim.Adam(params, lr, weight_decay) semantics (vasnet.py:181, dsn.py:70-73) over ONE flat fp32 bucket:
     parameters and their .grad become views of two contiguous buffers, so
@@ -141,14 +196,14 @@ class FlatAdam:
         """SUM all-reduce of a slice of the gradient bucket, through a bf16 staging buffer when comm_dtype is bfloat16."""
         import torch.distributed as dist
         if self.comm_dtype == torch.float32:
-            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+            _collective_sum(piece)
             return
         if self._comm is None:
             self._comm = torch.empty(self.flat_grad.numel(), dtype=torch.bfloat16, device=self.flat_grad.device)
         off = (piece.data_ptr() - self.flat_grad.data_ptr()) // 4
         stage = self._comm[off:off + piece.numel()]
         kernels.cast_f32_bf16(piece, stage)
-        dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+        _collective_sum(stage)
         kernels.cast_bf16_f32(stage, piece)
 
     def tail_offset(self, first_param):

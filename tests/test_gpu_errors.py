@@ -96,3 +96,67 @@ def test_integration_md_binding_stub_runs():
         assert torch.equal(torch.cat(list(got)), want)
     finally:
         os.chdir(cwd)
+
+
+def test_rccl_entry_point_single_rank():
+    """`sumk_allreduce_flat` (the data-parallel exchange behind the C ABI): bootstrap a one-rank communicator on the
+    test box's single GPU and reduce an fp32 and a bf16 bucket in place on the current stream -- a one-rank SUM is the identity,
+    which checks the dlopen of RCCL, the by-value unique id, the dtype / op codes and the stream argument.  (Two ranks need two
+    GPUs: RCCL refuses duplicate devices.)"""
+    import ctypes as C
+    import torch
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    ident = (C.c_uint8 * 128)()
+    _lib.check(lib.sumk_comm_unique_id(ident), "unique id")
+    assert any(ident)
+    comm = C.c_void_p()
+    _lib.check(lib.sumk_comm_init(ident, 0, 1, C.byref(comm)), "init")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.randn(1 << 20, device="cuda"); a0 = a.clone()
+    _lib.check(lib.sumk_allreduce_flat(comm, C.c_void_p(a.data_ptr()), a.numel(), 0, st), "allreduce f32")
+    b = torch.randn(4099, device="cuda").to(torch.bfloat16); b0 = b.clone()
+    _lib.check(lib.sumk_allreduce_flat(comm, C.c_void_p(b.data_ptr()), b.numel(), 1, st), "allreduce bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    assert lib.sumk_allreduce_flat(comm, C.c_void_p(a.data_ptr()), a.numel(), 7, st) != 0 and b"dtype" in lib.sumk_last_error()
+    _lib.check(lib.sumk_comm_destroy(comm), "destroy")
+
+
+def test_flat_adam_through_the_rccl_entry_point(monkeypatch):
+    """SUMK_RCCL_DIRECT=1: FlatAdam's gradient exchange goes through RcclDirect (here a one-rank group over gloo for the
+    bootstrap): the step must equal the plain single-process step."""
+    import os, socket
+    import torch
+    import torch.distributed as dist
+    from summarizer_amd import training
+    from summarizer_amd.training import FlatAdam
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    monkeypatch.setenv("SUMK_RCCL_DIRECT", "1")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(training, "dist_info", lambda: (0, 2))        # pretend a 2-rank job so the collective path is taken
+        torch.manual_seed(0)
+        p = torch.nn.Parameter(torch.randn(1000, device="cuda")); q = torch.nn.Parameter(p.detach().clone())
+        g = torch.randn(1000, device="cuda")
+        a = FlatAdam([p], lr=1e-2); b = FlatAdam([q], lr=1e-2)
+        a.flat_grad[:1000] = g; b.flat_grad[:1000] = g
+        monkeypatch.setattr(training.RcclDirect, "__init__", _one_rank_init)
+        scale = a.all_reduce_grads()                    # one-rank RCCL sum == identity; scale = 1/2 of the pretended world
+        assert scale == 0.5
+        a.step(grad_scale=1.0); b.step(grad_scale=1.0)
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=0, atol=0)
+        training.RcclDirect.get().close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _one_rank_init(self):
+    import ctypes as C
+    from summarizer_amd import _lib
+    self._lib, self._C = _lib.load(), C
+    ident = (C.c_uint8 * 128)()
+    _lib.check(self._lib.sumk_comm_unique_id(ident), "sumk_comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(self._lib.sumk_comm_init(ident, 0, 1, C.byref(comm)), "sumk_comm_init")
+    self.comm, self.world = comm, 1
