@@ -83,6 +83,15 @@ int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int32_t* seq_o
                         float* scores, void* workspace, size_t workspace_bytes, int32_t training,
                         void* stream);
 
+/* Inference with the value and output projections folded: Wvo (D,D) = Wo . Wv, computed once per weight change by the caller
+ * (sumk_gemm_nn(Wo, Wv, Wvo, D, D, D)).  (alpha V) Wo^T = alpha (X Wvo^T): the out-projection GEMM of vasnet.py:132 disappears
+ * (18 % of the step's FLOPs); results equal sumk_vasnet_forward's up to fp32 re-association (~1e-6 on scores).  Opt-in
+ * (VASNet(fold_vo=True)): the default path keeps the reference's operation order. */
+int sumk_vasnet_forward_folded(float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                               const int32_t* seq_off_dev, const sumk_vasnet_weights* w, const float* Wvo,
+                               const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
+                               float* scores, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ BiLSTM
  * One bidirectional LSTM layer (torch.nn.LSTM semantics: gates i,f,g,o; h0=c0=0), as used by DSN
  * (summarizer/models/dsn.py:23-27,45) and sLSTM (summarizer/models/sumgan.py:27-32,43).

@@ -75,6 +75,8 @@ _SIGS = {
     "sumk_vasnet_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
                                       C.POINTER(VasnetOpts), c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
                                       C.c_int32, C.c_void_p]),
+    "sumk_vasnet_forward_folded": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights), c_f32p,
+                                             C.POINTER(VasnetOpts), c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_vasnet_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
                                        C.POINTER(VasnetOpts), c_f32p, C.POINTER(VasnetGrads), c_f32p, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_void_p]),

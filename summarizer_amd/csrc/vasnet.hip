@@ -154,6 +154,7 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   // forward
   put_prob(a.tabs + TB_S * n + s, q0, q0 + D, eoff, T, T, D, 3 * D, 3 * D, ldE, ts, tm);            // E = Q K^T        (NT)
   put_prob(a.tabs + TB_PV * n + s, eoff, q0 + 2 * D, c0, T, D, T, ldE, 3 * D, D, tpv, tn);           // C = alpha V      (NN)
+  a.tabs[TB_PV * n + s].r_off = c0; a.tabs[TB_PV * n + s].ldr = D;   // folded inference path: + X in the epilogue (same rows as C)
   // backward
   put_prob(a.tabs + TB_DV * n + s, eoff, c0, q0 + 2 * D, T, D, T, ldE, D, 3 * D, tpv, tn);           // dV = alpha^T dC  (TN)
   put_prob(a.tabs + TB_DP * n + s, c0, q0 + 2 * D, eoff, T, T, D, D, 3 * D, ldE, ts, tm);            // dAlpha = dC V^T  (NT)
@@ -521,12 +522,17 @@ extern "C" size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const in
   return w.total;
 }
 
-extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
-                                   const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
-                                   const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
-                                   float* scores, void* workspace, size_t workspace_bytes, int32_t training,
-                                   void* stream_) {
+// Wvo != nullptr: inference with the value and output projections FOLDED (Wvo = Wo . Wv, computed once per weight change by the
+// caller): (alpha V) Wo^T = alpha (X Wv^T Wo^T) = alpha (X Wvo^T), so the third slice of the packed projection is U = X Wvo^T,
+// the per-video product alpha U lands directly in Y0 with the residual added in its epilogue, and the R x D x D output
+// projection (18 % of the step's FLOPs) disappears.  Same mathematics, a different association of the fp32 products.
+static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                               const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
+                               const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
+                               float* scores, void* workspace, size_t workspace_bytes, int32_t training,
+                               void* stream_, const float* Wvo) {
   hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(Wvo == nullptr || !training, "vasnet_forward: the folded projection is an inference-only path");
   SUMK_ARG(x && seq_off_dev && w && opts && scores && workspace, "vasnet_forward: null pointer");
   SUMK_ARG(w->Wk && w->Wq && w->Wv && w->Wo && w->W1 && w->b1 && w->w2 && w->b2 && w->ln_w && w->ln_b,
            "vasnet_forward: null weight");
@@ -565,7 +571,7 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
 
   {  // 1: QKV projection
     GemmLaunch g; g.precision = opts->precision;
-    g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
+    g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = Wvo ? Wvo : w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
@@ -581,11 +587,11 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
                      seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop);
   {  // 4: context
     GemmLaunch g; g.precision = opts->precision;
-    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
+    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
-    SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+    SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? EPI_RESIDUAL : EPI_NONE, g, stream));
   }
-  {  // 5: output projection + residual
+  if (!Wvo) {  // 5: output projection + residual
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
@@ -606,6 +612,24 @@ extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int
   SUMK_HIP(hipGetLastError());
   if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
   return SUMK_OK;
+}
+
+extern "C" int sumk_vasnet_forward(float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                                   const int32_t* seq_off_dev, const sumk_vasnet_weights* w,
+                                   const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
+                                   float* scores, void* workspace, size_t workspace_bytes, int32_t training,
+                                   void* stream) {
+  return vasnet_forward_impl(x, D, n_seq, seq_off_host, seq_off_dev, w, opts, pos_table, pos_rows, scores, workspace,
+                             workspace_bytes, training, stream, nullptr);
+}
+
+extern "C" int sumk_vasnet_forward_folded(float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
+                                          const int32_t* seq_off_dev, const sumk_vasnet_weights* w, const float* Wvo,
+                                          const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
+                                          float* scores, void* workspace, size_t workspace_bytes, void* stream) {
+  SUMK_ARG(Wvo != nullptr, "vasnet_forward_folded: null folded weight");
+  return vasnet_forward_impl(x, D, n_seq, seq_off_host, seq_off_dev, w, opts, pos_table, pos_rows, scores, workspace,
+                             workspace_bytes, 0, stream, Wvo);
 }
 
 template <bool HEAD>

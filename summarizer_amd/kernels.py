@@ -119,8 +119,20 @@ def _vasnet_structs(params, opts):
     return w, o
 
 
-def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, training=False):
-    """x: (n_rows, D) packed, contiguous, on GPU.  Returns (scores (n_rows,), workspace or None)."""
+def fold_vo(w_o, w_v, out=None):
+    """Wvo = Wo . Wv (D, D) for the folded inference path (sumk_vasnet_forward_folded); one fp32 MFMA GEMM."""
+    lib = _lib.load()
+    _require_gpu(w_o, "fold_vo"); _require_gpu(w_v, "fold_vo")
+    D = w_o.shape[0]
+    if out is None:
+        out = torch.empty(D, D, dtype=torch.float32, device=w_o.device)
+    _lib.check(lib.sumk_gemm_nn(_p(w_o.contiguous()), _p(w_v.contiguous()), _p(out), D, D, D, _stream()), "sumk_gemm_nn (fold_vo)")
+    return out
+
+
+def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, training=False, wvo=None):
+    """x: (n_rows, D) packed, contiguous, on GPU.  Returns (scores (n_rows,), workspace or None).
+    wvo: folded Wo.Wv (inference only) -> the output projection is absorbed into the packed projection (fold_vo)."""
     lib = _lib.load()
     _require_gpu(x, "vasnet input")
     if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
@@ -132,8 +144,14 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
         _lib.check(-1, "sumk_vasnet_workspace_bytes")
     ws = workspace(nbytes, x.device, persistent=training)
     scores = torch.empty(sb.n_rows, dtype=torch.float32, device=x.device)
-    rc = lib.sumk_vasnet_forward(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o),
-                                 _p(pos_table), _p(pos_rows), _p(scores), _p(ws), ws.numel(), int(training), _stream())
+    if wvo is not None:
+        if training:
+            raise SumkError("vasnet: the folded projection is inference-only")
+        rc = lib.sumk_vasnet_forward_folded(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), _p(wvo), C.byref(o),
+                                            _p(pos_table), _p(pos_rows), _p(scores), _p(ws), ws.numel(), _stream())
+    else:
+        rc = lib.sumk_vasnet_forward(_p(x), D, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.byref(w), C.byref(o),
+                                     _p(pos_table), _p(pos_rows), _p(scores), _p(ws), ws.numel(), int(training), _stream())
     _lib.check(rc, "sumk_vasnet_forward")
     return scores, (ws if training else None)
 

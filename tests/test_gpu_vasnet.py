@@ -347,3 +347,60 @@ def test_vasnet_plain_bf16_scores_are_close_but_not_fp32_grade(dev):
         worst = max(worst, float(np.abs(y - g[f"c{ci}/y"]).max()))
     print("plain bf16: max |d score| vs reference goldens:", worst)
     assert 1e-4 < worst < 3e-2, worst
+
+
+def test_vasnet_folded_vo_inference_matches_reference_goldens(dev):
+    """fold_vo=True (opt-in): Wvo = Wo.Wv is folded once and the out-projection GEMM disappears.  Same gate as the default
+    path: every golden from the REAL reference within 1e-4 -- small-D variants (masks, batch > 1, pos-embed), the full-size
+    cases -- and the ragged packed batch within 1e-5 of the unfolded HIP path."""
+    g = load_golden("vasnet_small")
+    for vname, kw in js(g["meta"]).items():
+        w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{vname}/w/")}
+        m = _model(dev, 64, w, fold_vo=True, **kw)
+        if kw.get("pos_embed") == "attention":
+            m.pos_embed = torch.from_numpy(g[f"{vname}/pos_table"])
+        for c in sorted(k.split("/")[-1] for k in g.files if k.startswith(f"{vname}/x/")):
+            with torch.no_grad():
+                y = m(torch.from_numpy(g[f"{vname}/x/{c}"].copy()).to(dev)).cpu().numpy()
+            np.testing.assert_allclose(y, g[f"{vname}/y/{c}"], atol=TOL, rtol=0, equal_nan=True, err_msg=f"{vname} {c}")
+    g = load_golden("vasnet_full")
+    for ci in range(len([k for k in g.files if k.endswith("/cfg")])):
+        cfg = js(g[f"c{ci}/cfg"])
+        w = R.vasnet_weights(cfg["D"], cfg["wseed"]); x = R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"])
+        with torch.no_grad():
+            y = _model(dev, cfg["D"], w, fold_vo=True, **cfg["kw"])(torch.from_numpy(x).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(y, g[f"c{ci}/y"], atol=TOL, rtol=0, err_msg=str(cfg))
+    D, lens = 1024, [70, 1, 33, 129, 300, 5]
+    w = R.vasnet_weights(D, 9)
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 60 + i)[:, 0, :] - 0.15 for i, T in enumerate(lens)])).to(dev)
+    a, b = _model(dev, D, w), _model(dev, D, w, fold_vo=True)
+    with torch.no_grad():
+        sa, sb_ = a.score_packed(x, lens), b.score_packed(x, lens)
+    assert float((sa - sb_).abs().max()) < 1e-5 and not torch.equal(sa, sb_)      # equal up to re-association, and really another path
+
+
+def test_vasnet_folded_vo_follows_weight_updates(dev):
+    """The folded matrix is a cache of two weights: a training step through the HIP optimiser (invisible to torch's version
+    counters), load_state_dict and a plain in-place torch edit must all be picked up by the next scoring call."""
+    from summarizer_amd.training import FlatAdam
+    D, lens = 128, [40, 17]
+    w = R.vasnet_weights(D, 5)
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 90 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    m, ref = _model(dev, D, w, fold_vo=True), _model(dev, D, w)
+    def same():
+        with torch.no_grad():
+            return float((m.score_packed(x, lens) - ref.score_packed(x, lens)).abs().max()) < 1e-5
+    assert same()
+    for mm in (m, ref):                                        # one identical optimiser step on both models
+        mm.train(); mm.dropout.p = 0.0
+        opt = FlatAdam(mm.parameters(), lr=1e-2)
+        opt.zero_grad(); (mm.score_packed(x, lens) ** 2).mean().backward(); opt.step()
+        mm.eval()
+    assert same()
+    with torch.no_grad():
+        for mm in (m, ref):
+            mm.V.weight.mul_(1.5)                              # in-place edit in eval mode: caught by the version counter
+    assert same()
+    sd = {k: torch.from_numpy(v) for k, v in R.vasnet_weights(D, 6).items()}
+    m.load_state_dict(sd); ref.load_state_dict(sd)
+    assert same()
