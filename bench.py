@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the side legs (split-bf16 / folded modes, per-kernel pass, training leg): what profiling runs use")
     ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer", "sumgan"], default="vasnet",
                     help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024; "
                          "sumgan (--mode train only) = one SumGANTrainer video step: selector+encoder, decoder and "
@@ -370,7 +372,7 @@ def main():
 
     # the other GEMMs of the step, each against the same peak (a separate short pass: their event pairs stay out of the timed region)
     kern = None
-    if args.model == "vasnet" and args.mode == "score" and run_step is not None:
+    if args.model == "vasnet" and args.mode == "score" and run_step is not None and not args.headline_only:
         tags = {"qkt": _lib.PROF_GEMM_QKT, "alpha_v": _lib.PROF_GEMM_PV, "out_proj": _lib.PROF_GEMM_OPROJ, "k1": _lib.PROF_GEMM_K1}
         for t in tags.values():
             lib.sumk_prof_read(t, None, None, 1)
@@ -391,7 +393,7 @@ def main():
                 kern[name] = dict(avg_launch_us=round(us, 2), tflops=round(fl[name] / us / 1e6, 2), frac_of_peak=round(fl[name] / us / 1e6 / pk, 4))
 
     alt = alt6 = folded = None
-    if args.model == "vasnet" and args.mode == "score" and args.precision == "fp32":
+    if args.model == "vasnet" and args.mode == "score" and args.precision == "fp32" and not args.headline_only:
         alt = alt_precision_leg(model, x, lens, s, args.steps, frames)     # every rank runs it, so ranks stay in step
         alt6 = alt_precision_leg(model, x, lens, s, args.steps, frames, "bf16x6")
         folded = folded_leg(model, x, lens, s, args.steps, frames)
@@ -399,7 +401,7 @@ def main():
     # data-parallel TRAINING leg on the same batch (every rank): forward + MSE + backward + the flat-bucket gradient all-reduce +
     # fused Adam.  Scoring has no data-path collective, so this is what makes a multi-GPU run of this script exercise RCCL.
     train_leg = None
-    if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum":
+    if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         from summarizer_amd.training import FlatAdam
         model.train()
         opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)

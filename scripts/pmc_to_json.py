@@ -18,7 +18,7 @@ M, N, K = 12003, 3072, 1024
 fetch_kb, write_kb = mean["FETCH_SIZE"], mean["WRITE_SIZE"]
 doc = {
     "source": "rocprofv3 --kernel-trace --pmc <group> (one group per pass, scripts/pmc_pass.sh + scripts/pmc_to_json.py) on "
-              "`python bench.py --steps 3 --warmup 2`, MI355X, round 1",
+              "`python bench.py --steps 3 --warmup 2`, MI355X, round 2 (scalar problem-table loads, per-tag event mask)",
     "kernel": f"sumk::{KERNEL} (QKV projection, M={M} N={N} K={K})",
     "launches_averaged": len(vals["FETCH_SIZE"]),
     "counters_mean_per_launch": mean,
