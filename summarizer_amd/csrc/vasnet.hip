@@ -124,26 +124,38 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
     }
     return;
   }
-  // Every thread needs the prefix sums over the videos before its own: O(n_seq^2) reads of the offset array in total, served
-  // from LDS (the array is staged once per block; read straight from global memory the dependent loads made this tiny kernel
-  // take 11 us per call).
-  constexpr int STAGE_MAX = 4096;
-  __shared__ int32_t soff[STAGE_MAX + 1];
+  // Every thread needs three prefix sums over the videos before its own (logit elements, tiles of the two per-video products).
+  // The per-video terms -- with their integer divisions -- are computed ONCE per block into LDS, one video per thread and
+  // pass; each thread then just adds up the terms before its own video.  (Recomputing the terms inside an O(n_seq) loop per
+  // thread, from global memory, made this tiny kernel take 12 us per call.)
+  constexpr int STAGE_MAX = 2048;
+  __shared__ int32_t sT[STAGE_MAX];      // frames of video q
+  __shared__ int32_t sTs[STAGE_MAX];     // tiles of its (T x T) product
+  __shared__ int32_t sTpv[STAGE_MAX];    // tiles of its (T x D) product
+  const int D = a.D, tn = (D + a.pv_tn - 1) / a.pv_tn;
   const bool staged = a.n_seq <= STAGE_MAX;
   if (staged) {
-    for (int i = threadIdx.x; i <= a.n_seq; i += blockDim.x) soff[i] = a.off[i];
+    for (int q = threadIdx.x; q < a.n_seq; q += blockDim.x) {
+      const int T = a.off[q + 1] - a.off[q];
+      sT[q] = T;
+      sTs[q] = ((T + a.s_tm - 1) / a.s_tm) * ((T + a.s_tn - 1) / a.s_tn);
+      sTpv[q] = ((T + a.pv_tm - 1) / a.pv_tm) * tn;
+    }
     __syncthreads();
   }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.n_seq) return;
-  const int D = a.D, tn = (D + a.pv_tn - 1) / a.pv_tn;
   int64_t eoff = 0;
   int ts = 0, tpv = 0;
-  for (int q = 0; q < s; ++q) {
-    int T = staged ? soff[q + 1] - soff[q] : a.off[q + 1] - a.off[q];
-    eoff += (int64_t)T * ((T + 3) & ~3);
-    ts += ((T + a.s_tm - 1) / a.s_tm) * ((T + a.s_tn - 1) / a.s_tn);
-    tpv += ((T + a.pv_tm - 1) / a.pv_tm) * tn;
+  if (staged) {
+    for (int q = 0; q < s; ++q) { const int T = sT[q]; eoff += (int64_t)T * ((T + 3) & ~3); ts += sTs[q]; tpv += sTpv[q]; }
+  } else {
+    for (int q = 0; q < s; ++q) {
+      const int T = a.off[q + 1] - a.off[q];
+      eoff += (int64_t)T * ((T + 3) & ~3);
+      ts += ((T + a.s_tm - 1) / a.s_tm) * ((T + a.s_tn - 1) / a.s_tn);
+      tpv += ((T + a.pv_tm - 1) / a.pv_tm) * tn;
+    }
   }
   const int row0 = a.off[s], T = a.off[s + 1] - a.off[s], ldE = (T + 3) & ~3;
   const int tm = (T + a.s_tn - 1) / a.s_tn;   // tiles along N of the (T x T) products
@@ -199,6 +211,9 @@ __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int
 // ------------------------------------------------------------------------------------------- softmax rows
 // One wave per query row.  Reads raw Q.K^T, writes alpha in place and zeroes the [T, ldE) pad so the alpha.V product
 // can stream K in float4 units.  Training with dropout (vasnet.py:130) also writes dropout(alpha) to E2.
+// NR > 0: the row (T <= 64 * NR keys) is held in registers -- one read of the logits, one exp per element, one write.  NR == 0:
+// any length, three passes over the (L2-resident) row.  Same operations per element either way, so the results are identical.
+template <int NR>
 __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2, const SeqInfo* seq, const int32_t* off,
                                                              int n_seq, int n_rows, float scale, int ignore_self,
                                                              int aperture, Drop drop) {
@@ -209,13 +224,42 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   const SeqInfo si = seq[s];
   const int i = row - si.row0, T = si.T;
   float* e = E + si.eoff + (int64_t)i * si.ldE;
+  float* e2 = E2 ? E2 + si.eoff + (int64_t)i * si.ldE : nullptr;
+  if constexpr (NR > 0) {
+    float v[NR];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = lane + 64 * r;
+      v[r] = j < T ? masked_logit(e[j], scale, i, j, ignore_self, aperture) : -INFINITY;
+      m = fmaxf(m, v[r]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = lane + 64 * r;
+      v[r] = j < T ? expf(v[r] - m) : 0.f;
+      sum += v[r];
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = lane + 64 * r;
+      if (j < si.ldE) {
+        const float a = j < T ? v[r] / sum : 0.f;
+        e[j] = a;
+        if (e2) e2[j] = drop.thr ? drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, a) : a;
+      }
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int j = lane; j < T; j += 64) m = fmaxf(m, masked_logit(e[j], scale, i, j, ignore_self, aperture));
   m = wave_max(m);
   float sum = 0.f;
   for (int j = lane; j < T; j += 64) sum += expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m);
   sum = wave_sum(sum);
-  float* e2 = E2 ? E2 + si.eoff + (int64_t)i * si.ldE : nullptr;
   for (int j = lane; j < si.ldE; j += 64) {
     float v = 0.f;
     if (j < T) v = expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m) / sum;
@@ -258,7 +302,9 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
 // y = (x - mean) * rstd * g + b over D, biased variance, one wave per row (torch.nn.LayerNorm, vasnet.py:54).
 // `site` dropout (vasnet.py:136 / :142) is applied to x on load.  HEAD: no y is written; instead
 // scores[r] = sigmoid(y . w2 + b2)  (vasnet.py:144-145).
-template <bool HEAD>
+// NQ > 0: the row (D <= 256 * NQ) is held in registers (NQ float4 per lane): ONE read of x instead of three.  NQ == 0: any D,
+// three passes.  The per-lane accumulation order is the same, so both forms give identical results.
+template <bool HEAD, int NQ>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, float* __restrict__ Y,
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
@@ -278,38 +324,78 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     return v;
   };
-  float s = 0.f;
-  for (int c = lane; c < D4; c += 64) { float4 v = ld(c); s += (v.x + v.y) + (v.z + v.w); }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-  for (int c = lane; c < D4; c += 64) {
-    float4 v = ld(c);
-    float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, d = v.w - mean;
-    q += (a * a + bb * bb) + (cc * cc + d * d);
+  constexpr int NR = NQ > 0 ? NQ : 1;
+  float4 xr[NR];
+  if constexpr (NQ > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; xr[q] = c < D4 ? ld(c) : make_float4(0.f, 0.f, 0.f, 0.f); }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  auto get = [&](int q, int c) { if constexpr (NQ > 0) return xr[q]; else return ld(c); };
+  float s = 0.f;
+  if constexpr (NQ > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) { float4 v = xr[q]; s += (v.x + v.y) + (v.z + v.w); } }
+  } else {
+    for (int c = lane; c < D4; c += 64) { float4 v = ld(c); s += (v.x + v.y) + (v.z + v.w); }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q2 = 0.f;
+  auto sq = [&](float4 v) {
+    float a = v.x - mean, bb = v.y - mean, cc = v.z - mean, d = v.w - mean;
+    q2 += (a * a + bb * bb) + (cc * cc + d * d);
+  };
+  if constexpr (NQ > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) sq(xr[q]); }
+  } else {
+    for (int c = lane; c < D4; c += 64) sq(ld(c));
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + eps);
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* b4 = reinterpret_cast<const float4*>(b);
   if constexpr (!HEAD) {
     float4* y4 = reinterpret_cast<float4*>(Y + (int64_t)row * D);
-    for (int c = lane; c < D4; c += 64) {
-      float4 v = ld(c), gg = g4[c], bv = b4[c], o;
+    auto emit = [&](int c, float4 v) {
+      float4 gg = g4[c], bv = b4[c], o;
       o.x = (v.x - mean) * rstd * gg.x + bv.x; o.y = (v.y - mean) * rstd * gg.y + bv.y;
       o.z = (v.z - mean) * rstd * gg.z + bv.z; o.w = (v.w - mean) * rstd * gg.w + bv.w;
       y4[c] = o;
+    };
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) emit(c, xr[q]); }
+    } else {
+      for (int c = lane; c < D4; c += 64) emit(c, ld(c));
     }
   } else {
     const float4* w4 = reinterpret_cast<const float4*>(w2);
     float dot = 0.f;
-    for (int c = lane; c < D4; c += 64) {
-      float4 v = ld(c), gg = g4[c], bv = b4[c], ww = w4[c];
+    auto acc = [&](int c, float4 v) {
+      float4 gg = g4[c], bv = b4[c], ww = w4[c];
       dot += ((v.x - mean) * rstd * gg.x + bv.x) * ww.x + ((v.y - mean) * rstd * gg.y + bv.y) * ww.y +
              ((v.z - mean) * rstd * gg.z + bv.z) * ww.z + ((v.w - mean) * rstd * gg.w + bv.w) * ww.w;
+    };
+    if constexpr (NQ > 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) acc(c, xr[q]); }
+    } else {
+      for (int c = lane; c < D4; c += 64) acc(c, ld(c));
     }
     dot = wave_sum(dot);
     if (lane == 0) scores[row] = 1.0f / (1.0f + expf(-(dot + b2[0])));
   }
   if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
+template <bool HEAD>
+static void launch_ln_rows(const float* X, float* Y, const float* g, const float* b, const float* w2, const float* b2, float* scores,
+                           int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream) {
+  const dim3 grid((n_rows + 3) / 4), block(256);
+  const int D4 = D >> 2;
+#define SUMK_LN(NQ) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site)
+  if (D4 <= 64) SUMK_LN(1); else if (D4 <= 128) SUMK_LN(2); else if (D4 <= 256) SUMK_LN(4); else if (D4 <= 512) SUMK_LN(8); else SUMK_LN(0);
+#undef SUMK_LN
 }
 
 // Backward of  y = LN(drop(x)) * g + b  for a strided set of rows per wave.
@@ -478,30 +564,26 @@ static Drop make_drop(const sumk_vasnet_opts* o) { return make_drop(o->dropout_p
 int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
                      hipStream_t stream) {
   Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
-  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, X, Y, g, b, nullptr, nullptr,
-                     nullptr, n_rows, D, eps, stats, none, 0u);
+  launch_ln_rows<false>(X, Y, g, b, nullptr, nullptr, nullptr, n_rows, D, eps, stats, none, 0u, stream);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 int launch_ln_head(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
                    int n_rows, int D, float eps, hipStream_t stream) {
   Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
-  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, Z, nullptr, g, b, w2, b2, scores,
-                     n_rows, D, eps, nullptr, none, 0u);
+  launch_ln_rows<true>(Z, nullptr, g, b, w2, b2, scores, n_rows, D, eps, nullptr, none, 0u, stream);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 int launch_layernorm_drop(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
                           Drop drop, uint32_t site, hipStream_t stream) {
-  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, X, Y, g, b, nullptr, nullptr,
-                     nullptr, n_rows, D, eps, stats, drop, site);
+  launch_ln_rows<false>(X, Y, g, b, nullptr, nullptr, nullptr, n_rows, D, eps, stats, drop, site, stream);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 int launch_ln_head_drop(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
                         int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream) {
-  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((n_rows + 3) / 4), dim3(256), 0, stream, Z, nullptr, g, b, w2, b2, scores,
-                     n_rows, D, eps, stats, drop, site);
+  launch_ln_rows<true>(Z, nullptr, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site, stream);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -583,8 +665,15 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
-  hipLaunchKernelGGL(vasnet_softmax_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, use_e2 ? E2 : nullptr, seq,
-                     seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop);
+  {
+    int t_max = 0;
+    for (int q = 0; q < n_seq; ++q) t_max = std::max(t_max, seq_off_host[q + 1] - seq_off_host[q]);
+    const dim3 sg((R + 3) / 4), sb(256);
+    float* e2p = use_e2 ? E2 : nullptr;
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop)
+    if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
+#undef SUMK_SOFTMAX
+  }
   {  // 4: context
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
@@ -598,8 +687,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
   }
   // 6: dropout + LayerNorm
-  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, stream, Y0, Y1, w->ln_w, w->ln_b, nullptr,
-                     nullptr, nullptr, R, D, opts->eps, stats, drop, 1u);
+  launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
   {  // 7: k1 + bias + ReLU
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
@@ -607,8 +695,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
-  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((R + 3) / 4), dim3(256), 0, stream, Z, nullptr, w->ln_w, w->ln_b, w->w2,
-                     w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u);
+  launch_ln_rows<true>(Z, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
   SUMK_HIP(hipGetLastError());
   if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
   return SUMK_OK;
