@@ -12,7 +12,7 @@
 //   8 s  = sigmoid(LayerNorm(Z) . w2 + b2)  SAME LayerNorm, fused with the head   vasnet.py:143-145
 // Logits are materialised: with a single head of width D the products have D/6 >= 170 FLOP per byte of E
 // traffic, far above the fp32 ridge (~20 FLOP/B), so a flash-style kernel would buy nothing.
-#include "sumk_internal.h"
+#include "gemm_device.h"
 #include <math.h>
 #include <algorithm>
 #include <cstdlib>
@@ -33,6 +33,7 @@ constexpr int COLSUM_CHUNKS = 128;
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
   size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, total;
+  size_t pl_x, pl_a, pl_w;   // inference only: bf16 planes of x, of the current activation (CTX, then Y1) and of the five weights
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
   size_t slab_elems;
@@ -70,6 +71,12 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->scores = take(R * 4);
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
+  w->pl_x = w->pl_a = w->pl_w = 0;
+  if (!training && gemm_planes_enabled()) {   // room for up to three bf16 planes (opt-in split-bf16 inference path, gemm_planes.hip)
+    w->pl_x = take(R * D * 2 * 3);
+    w->pl_a = take(R * D * 2 * 3);
+    w->pl_w = take((size_t)5 * D * D * 2 * 3);
+  }
   if (training) {
     w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
     w->dz = take(R * D * 4);
@@ -651,12 +658,30 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   }
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
 
+  // Split-bf16 inference: the three row-wise projections run on PRE-SPLIT bf16 planes (gemm_planes.hip) -- weights split once
+  // per call (12 us), x / CTX / Y1 by a streaming kernel -- instead of splitting both operands inside every k-loop.
+  const int np = planes_of_precision(opts->precision);
+  const bool planes = !training && np > 0 && gemm_planes_enabled() && D % 32 == 0 && D >= 128 && G.st_qkv == 0 && G.st_d == 0;
+  char* PLX = ws + L.pl_x; char* PLA = ws + L.pl_a; char* PLW = ws + L.pl_w;
+  const int64_t DD = (int64_t)D * D, RD = (int64_t)R * D;
+  auto wplanes = [&](int i) { return (const float*)(PLW + (size_t)i * np * DD * 2); };
+  if (planes) {
+    const float* Ws[5] = {w->Wq, w->Wk, Wvo ? Wvo : w->Wv, w->Wo, w->W1};
+    for (int i = 0; i < 5; ++i)
+      if (!(i == 3 && Wvo)) SUMK_TRY(launch_split_planes(Ws[i], (void*)wplanes(i), DD, DD, opts->precision, stream));
+    SUMK_TRY(launch_split_planes(x, PLX, RD, RD, opts->precision, stream));
+  }
   {  // 1: QKV projection
     GemmLaunch g; g.precision = opts->precision;
     g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = Wvo ? Wvo : w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
-    SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
+    if (planes) {
+      g.A = (const float*)PLX; g.B[0] = wplanes(0); g.B[1] = wplanes(1); g.B[2] = wplanes(2);
+      SUMK_TRY(launch_gemm_planes(EPI_NONE, g, RD, DD, stream));
+    } else {
+      SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
+    }
   }
   {  // 2: logits per video
     GemmLaunch g; g.precision = opts->precision;
@@ -684,7 +709,13 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
-    SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
+    if (planes) {
+      SUMK_TRY(launch_split_planes(CTX, PLA, RD, RD, opts->precision, stream));
+      g.A = (const float*)PLA; g.B[0] = wplanes(3);
+      SUMK_TRY(launch_gemm_planes(EPI_RESIDUAL, g, RD, DD, stream));
+    } else {
+      SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
+    }
   }
   // 6: dropout + LayerNorm
   launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
@@ -692,7 +723,13 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
-    SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
+    if (planes) {
+      SUMK_TRY(launch_split_planes(Y1, PLA, RD, RD, opts->precision, stream));
+      g.A = (const float*)PLA; g.B[0] = wplanes(4);
+      SUMK_TRY(launch_gemm_planes(EPI_BIAS_RELU, g, RD, DD, stream));
+    } else {
+      SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
+    }
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
   launch_ln_rows<true>(Z, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
