@@ -71,6 +71,11 @@ class DSNTrainer(Trainer):
     def compute_reward(self, seq, actions, far_sim=False, temp_dist_thre=20):
         """Reference signature (dsn.py:185): seq (seq_len,1,input_size), actions (seq_len,1,1) -> 0-d reward tensor."""
         T = seq.shape[0]
+        if int(actions.detach().sum().item()) == 1:
+            # exactly one picked frame: the reference indexes its (T, T) distance matrix with a 0-dim tensor and `.min(1, ...)` then
+            # fails (dsn.py:229-230) -- the same exception type here.  (The batched trainer path below does not go through this
+            # helper: there the kernel defines the one-pick reward as (0 + exp(-mean d^2)) / 2 instead of ending the run.)
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
         sb = kernels.SeqBatch.get([T], seq.device)
         r = kernels.dsn_reward(seq.detach().reshape(T, -1).contiguous(), sb, actions.detach().reshape(1, T).contiguous(),
                                far_sim=far_sim, temp_dist_thre=temp_dist_thre)

@@ -132,6 +132,10 @@ def test_dsn_trainer_reinforce_runs(data):
         act = (torch.rand(seq.shape[0], 1, 1, device="cuda") < 0.5).float()
         r = tr.compute_reward(seq, act)
         assert r.dim() == 0 and 0 < float(r) < 1
+        one = torch.zeros_like(act); one[7] = 1.0                  # exactly one pick: the reference raises IndexError (dsn.py:229-230)
+        with pytest.raises(IndexError):
+            tr.compute_reward(seq, one)
+        assert float(tr.compute_reward(seq, torch.zeros_like(act))) == 0.0      # no pick: zero reward (dsn.py:199-203)
 
 
 def test_vasnet_trainer_reproduces_the_reference_trainer_end_to_end():
