@@ -491,6 +491,14 @@ struct PersistArgs {
   int32_t n_seq, H, gsize, n_groups, upm, n_active, hout_bytes, n_teams;
 };
 
+// The hand-off counters of a persistent launch are zeroed by a KERNEL, not hipMemsetAsync: as a graph memset node the fill can
+// bypass the L2 lines the previous replay's atomics left behind, and the next launch's first poll then reads the OLD counts (seen
+// as replay-to-replay drift of the scores under hipGraphLaunch; scripts/probes/graph_capture_debug.py).  A kernel's stores are
+// ordered with the following kernel's loads at the launch boundary.
+__global__ void zero_words_kernel(unsigned* p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
 // Sticky per-device health word: every persistent kernel ORs 1 into it when a bounded hand-off wait times out, in addition to
 // the per-call word in the workspace (which the next call on a shared inference workspace clears).  sumk_health_check reads
 // and resets it; the Python host calls that at the synchronisation points it already has (score D2H, per-epoch loss).
@@ -1259,7 +1267,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
-  SUMK_HIP(hipMemsetAsync(ws + L.pstate, 0, (size_t)PSTATE_WORDS * 4, stream));
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)(ws + L.pstate), (int)PSTATE_WORDS);
   static const bool persist_ok = persistent_kernels_usable();
   // H <= 256: 8 XCD teams with an LDS panel; 256 < H <= 1024: the two-team register-resident kernel; otherwise the launch chain
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
@@ -1373,7 +1381,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
 
   static const bool persist_ok = persistent_kernels_usable();
-  SUMK_HIP(hipMemsetAsync(ws + L.pstate_b, 0, (size_t)PSTATE_WORDS * 4, stream));
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)(ws + L.pstate_b), (int)PSTATE_WORDS);
   bool done = false;
   if (persist_ok && H <= 256 && L.xchg_bytes > 0) {
     PersistBwdArgs pa;

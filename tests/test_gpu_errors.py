@@ -160,3 +160,35 @@ def _one_rank_init(self):
     comm = C.c_void_p()
     _lib.check(self._lib.sumk_comm_init(ident, 0, 1, C.byref(comm)), "sumk_comm_init")
     self.comm, self.world = comm, 1
+
+
+def test_scoring_call_is_hip_graph_capturable(monkeypatch):
+    """INTEGRATION.md states that every entry point only enqueues on the caller's stream (no hidden allocation, no host sync):
+    a packed scoring call is captured into a HIP graph (torch.cuda.CUDAGraph: the ABI receives the capturing stream) and the
+    replays reproduce the eager scores bit for bit, also after the input buffer was refilled in place."""
+    from summarizer_amd import kernels
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.models.dsn import DSN
+    monkeypatch.setattr(kernels, "CHECK_LSTM", False)    # the test-suite's per-layer health check synchronises: not inside a capture
+    dev = torch.device("cuda:0")
+    D, lens = 256, [70, 1, 33, 129, 64]
+    for make in (lambda: VASNet(input_size=D), lambda: DSN(input_size=D, hidden_size=32)):
+        torch.manual_seed(3)
+        m = make().to(dev).eval()
+        xs = [torch.from_numpy(np.concatenate([R.features(T, 1, D, 10 * k + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev) for k in range(2)]
+        with torch.no_grad():
+            eager = [m.score_packed(x, lens).clone() for x in xs]
+            static_x = xs[0].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                m.score_packed(static_x, lens)                     # warm-up on the side stream (workspace cache, table build)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = m.score_packed(static_x, lens)
+            for k in (0, 1, 0):
+                static_x.copy_(xs[k])
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(static_out, eager[k]), (type(m).__name__, k)
