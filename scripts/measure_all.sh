@@ -24,7 +24,7 @@ run dsn_stream --no-cpu-baseline --mode stream --model dsn --steps 100 --warmup 
 run sumgan_train --model sumgan --mode train --steps 5 --warmup 1
 for m in "vasnet_score" "dsn_score --model dsn" "slstm_score --model slstm --steps 10 --warmup 3"; do
   set -- $m; name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o p -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 10 "$@" > $OUT/prof_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o p -- python3 bench.py --no-cpu-baseline --headline-only --steps 50 --warmup 10 "$@" > $OUT/prof_$name.log 2>&1
   rm -f $OUT/prof_$name/*kernel_trace.csv $OUT/prof_$name/*.db
 done
 for f in $OUT/*.json; do echo "$(basename $f .json): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('frac'))")"; done
