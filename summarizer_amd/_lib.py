@@ -3,6 +3,11 @@ or a call fails, this module raises -- there is no CPU or eager-PyTorch fallback
 import ctypes as C
 import os
 
+# torch FIRST: PyTorch-ROCm ships its own libamdhip64 and libsumk.so links the system one (same soname).  Whichever is loaded
+# first serves the whole process; if libsumk.so came first, torch would later sit on a second HIP runtime and every call that
+# mixes the two (our kernels on torch's streams and buffers) fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsumk.so")
 

@@ -57,3 +57,17 @@ def test_det_random_is_device_independent_and_counter_based():
     assert not torch.equal(x1, a.randn_like(t))                       # the counter advances
     assert torch.randn_like(t).shape == t.shape and not torch.equal(torch.randn_like(t), x1)   # patch removed afterwards
     assert float(u1.min()) >= 0.0 and float(u1.max()) < 1.0
+
+
+def test_library_binding_imports_torch_first():
+    """libsumk.so links the system libamdhip64, PyTorch-ROCm bundles its own: the binding must pull torch in before it dlopens the
+    library (loading them the other way round leaves two HIP runtimes in the process -- seen as 'no ROCm-capable device is
+    detected' from the first kernel launch on a GPU box when build() ran before smoke() in one process)."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from summarizer_amd import _lib\n"
+            "assert 'torch' in sys.modules, 'summarizer_amd._lib must import torch before loading libsumk.so'\n"
+            "_lib.load(); print('OK')") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip().endswith("OK"), r.stdout + r.stderr
