@@ -151,6 +151,17 @@ int sumk_bilstm_layer_backward(const float* x, const float* h_out, const float* 
                                const sumk_lstm_layer_weights* w, const sumk_lstm_layer_grads* grads, float* dx,
                                void* workspace, size_t workspace_bytes, int32_t precision, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ GRU cell
+ * The reference's optional `DSN(cell="gru")` (dsn.py:28-33, nn.GRU).  One fused element-wise step for B sequences, gate order
+ * r, z, n (torch): gx = x_t W_ih^T + b_ih and gh = h_prev W_hh^T + b_hh are (B, 3H) (the host computes them with
+ * sumk_linear_forward); mask (B) or NULL: 0 = the sequence has ended (h passes through, no gradient).  rzn (B, 3H) keeps the
+ * gate values for sumk_gru_cell_backward, which returns d(gx), d(gh) and the DIRECT part of d(h_prev) (the caller adds dgh . W_hh).
+ * Functional path, not a tuned one: DSNTrainer never builds the GRU cell. */
+int sumk_gru_cell_forward(const float* gx, const float* gh, const float* h_prev, const float* mask, float* h_out, float* rzn,
+                          int32_t B, int32_t H, void* stream);
+int sumk_gru_cell_backward(const float* dh, const float* rzn, const float* gh, const float* h_prev, const float* mask,
+                           float* dgx, float* dgh, float* dh_prev, int32_t B, int32_t H, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ unidirectional LSTM layer
  * One forward-running nn.LSTM(bidirectional=False) layer with an optional initial state and the final state as an output:
  * the layers of SumGAN's eLSTM / dLSTM / cLSTM (summarizer/models/sumgan.py:48-115,185-210).  Packed batch as above;

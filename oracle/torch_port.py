@@ -85,3 +85,15 @@ class TransformerPort(torch.nn.Module):
         if self.more_residuals:
             e = e + x
         return torch.sigmoid(self.k2(self.layer_norm(torch.relu(self.k1(e)))))
+
+
+def make_gru(p, prefix, input_size, hidden_size, num_layers):
+    """Stock nn.GRU carrying the given weights (the reference's optional DSN(cell="gru"), dsn.py:28-33)."""
+    m = torch.nn.GRU(input_size, hidden_size, num_layers=num_layers, bidirectional=True)
+    m.load_state_dict({k[len(prefix):]: torch.as_tensor(v) for k, v in p.items() if k.startswith(prefix)})
+    return m
+
+
+def bigru_scores(x, p, prefix, head_w, head_b, gru):
+    h, _ = gru(x)
+    return torch.sigmoid(F.linear(h, p[head_w], p[head_b]))

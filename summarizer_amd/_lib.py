@@ -107,6 +107,8 @@ _SIGS = {
     "sumk_lstm_decoder_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(LstmDirWeights), c_f32p,
                                              c_f32p, c_f32p, C.POINTER(LstmDirGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                              C.c_void_p]),
+    "sumk_gru_cell_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_gru_cell_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_linear_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sumk_linear_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                       C.c_int32, C.c_void_p]),

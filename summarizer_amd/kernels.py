@@ -551,3 +551,25 @@ def lstm_decoder_backward(sb, layers, H, c0, out, dout, grads, ws, want_d0):
     _lib.check(lib.sumk_lstm_decoder_backward(H, L, sb.n_seq, sb.off_host_p, sb.off_dev_p, w, _p(c0), _p(out), _p(dout.contiguous()), g,
                                               _p(dh0), _p(dc0), _p(ws), ws.numel(), _stream()), "sumk_lstm_decoder_backward")
     return dh0, dc0
+
+
+# ------------------------------------------------------------------------------------------------ GRU cell (DSN(cell="gru"))
+def gru_cell_forward(gx, gh, h_prev, mask, save=True):
+    """One fused GRU step for B sequences: gx, gh (B, 3H), h_prev (B, H), mask (B,) or None -> (h (B, H), rzn (B, 3H) or None)."""
+    lib = _lib.load()
+    _require_gpu(gx, "gru_cell gx")
+    B, H = h_prev.shape
+    h = torch.empty_like(h_prev)
+    rzn = torch.empty_like(gx) if save else None
+    _lib.check(lib.sumk_gru_cell_forward(_p(gx), _p(gh), _p(h_prev), _p(mask), _p(h), _p(rzn), B, H, _stream()), "sumk_gru_cell_forward")
+    return h, rzn
+
+
+def gru_cell_backward(dh, rzn, gh, h_prev, mask):
+    """-> (dgx (B, 3H), dgh (B, 3H), direct part of dh_prev (B, H))."""
+    lib = _lib.load()
+    B, H = h_prev.shape
+    dgx, dgh, dhp = torch.empty_like(gh), torch.empty_like(gh), torch.empty_like(h_prev)
+    _lib.check(lib.sumk_gru_cell_backward(_p(dh.contiguous()), _p(rzn), _p(gh), _p(h_prev), _p(mask), _p(dgx), _p(dgh), _p(dhp), B, H,
+                                          _stream()), "sumk_gru_cell_backward")
+    return dgx, dgh, dhp

@@ -13,7 +13,7 @@ from torch.distributions import Bernoulli
 from .. import kernels
 from .._lib import SumkError
 from . import Trainer
-from ._bilstm import pack_time_major, bilstm_scores
+from ._bilstm import pack_time_major, bilstm_scores, bigru_scores
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
@@ -22,12 +22,14 @@ class DSN(nn.Module):
     def __init__(self, input_size=1024, hidden_size=256, num_layers=1, cell="lstm"):
         super().__init__()
         assert cell in ["lstm", "gru"], "cell must be either 'lstm' or 'gru'"          # dsn.py:21
-        if cell != "lstm":
-            raise SumkError("summarizer_amd.DSN: only cell='lstm' has a HIP kernel (the reference's optional GRU "
-                            "cell, dsn.py:28-33, is not on the scored path: DSNTrainer always builds DSN())")
+        self.cell = cell
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
         self.precision = "fp32"          # GEMM arithmetic: "fp32" (exact) | "bf16x3" (kernels.precision_code); not in the reference
-        self.rnn = nn.LSTM(input_size, hidden_size, num_layers=num_layers, bidirectional=True)
+        # parameter containers only (same names / shapes / init as the reference); never called.  The optional GRU cell
+        # (dsn.py:28-33) runs on a functional step-by-step path (models/_bilstm.py: GruLayerFunction, csrc/gru.hip) -- the
+        # reference's own DSNTrainer always builds DSN(), i.e. the LSTM, which has the persistent kernels.
+        rnn = nn.LSTM if cell == "lstm" else nn.GRU
+        self.rnn = rnn(input_size, hidden_size, num_layers=num_layers, bidirectional=True)
         self.out = nn.Sequential(nn.Linear(hidden_size * 2, 1), nn.Sigmoid())
 
     def forward(self, x):
@@ -41,6 +43,9 @@ class DSN(nn.Module):
     def score_packed(self, x_packed, lens):
         """Batched extension: frames of several videos back to back (sum(lens), D) -> (sum(lens),) probabilities."""
         sb = kernels.SeqBatch.get(lens, x_packed.device)
+        if self.cell == "gru":
+            kernels._require_gpu(x_packed, "DSN.score_packed")
+            return bigru_scores(self, x_packed, sb, self.num_layers, self.hidden_size, "out.0.weight", "out.0.bias")
         return bilstm_scores(self, x_packed, sb, "rnn.", self.num_layers, self.hidden_size, "out.0.weight", "out.0.bias")
 
 

@@ -47,8 +47,7 @@ def test_status_codes_and_messages():
     with pytest.raises(SumkError):
         kernels.SeqBatch([3, 0], dev)
     from summarizer_amd.models.dsn import DSN
-    with pytest.raises(SumkError):
-        DSN(cell="gru")
+    assert isinstance(DSN(cell="gru").rnn, torch.nn.GRU)         # the optional cell exists (tests/test_gpu_gru.py)
     with pytest.raises(AssertionError):
         DSN(cell="rnn")                     # dsn.py:21
 
