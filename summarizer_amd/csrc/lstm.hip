@@ -90,6 +90,8 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
       int gsize = std::min(32, std::max(1, (2 * n_seq + 7) / 8));
       int items = 2 * ((n_seq + gsize - 1) / gsize);
       w->xchg_bytes = H <= 256 ? (size_t)2 * items * 32 * 32 * H * 4 : 0;
+      // wide persistent BPTT (256 < H <= 1024, H % 128 == 0): [dir 2][group parity 2][step parity 2][KG = H/32][64 videos][H]
+      if (H > 256 && H <= 1024 && H % 128 == 0) w->xchg_bytes = (size_t)8 * (H / 32) * 64 * H * 4;
       w->xchg = take(w->xchg_bytes);
     }
     w->partial = take(n_seq <= GV_MAXB ? tgemv_partial_bytes(H, n_seq, 2) : 0);   // small-batch transposed mat-vec (H > 256 at a few videos)
@@ -1186,6 +1188,203 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
   }
 }
 
+// ------------------------------------------------------------------------------------------- wide persistent BPTT
+// One launch runs the whole backward recurrence for 256 < H <= 1024 (sLSTM: H = 1024; the launch chain above re-reads the
+// 16 MB W_hh per direction from the Infinity Cache every step: 74 us per step measured, 60 % of an sLSTM training step).
+// Two teams of up to 128 CUs, team = direction (as lstm_wide_kernel).  The contraction of step t,
+//     dh_rec[i][j] = sum_k dG_t[i][k] W_hh[k][j]        (i < 64 videos, k < 4H, j < H),
+// is tiled K x N over the team: member (kg, ng) keeps W_hh[4 gates x units 32kg..32kg+31][columns 256ng..256ng+255] -- a
+// 128 x 256 slice, 128 KB -- as MFMA B fragments in REGISTERS for the whole launch (64 VGPRs per lane; wave w owns the 32
+// columns 256ng + 32w..), so W_hh never moves again.  Per step a member
+//   1. sums, in a FIXED order, the KG partial products of step t+1 for ITS 32 units (sc1 16-B loads: 256 KB per member and
+//      step, the same bytes as the forward kernel's h panel), adds dHout and runs the cell backward for 64 videos x 32 units
+//      (dc stays in registers) -- the NG members that share kg do this redundantly and bit-identically, only ng = 0 stores dG;
+//   2. puts dG_t[64][its 128 gate columns] in LDS as the MFMA A operand (34 KB), multiplies by its register-resident slice
+//      (2 x 64 fp32 MFMAs per wave, no split-K inside the CU) and publishes partial_kg(t)[64][256 columns] with sc1 stores
+//      into the exchange buffer of parity t & 1, then bumps the item's step counter.
+// Hand-off protocol, bounded spins and the error word are those of lstm_persist_kernel (Guideline 16 R1); exchange buffers
+// are double-buffered by step parity AND by group parity (a member may start group g+1 while a slow one still reads group g).
+struct WideBwdArgs {
+  const float* whh[2]; const float* dHout; const float* gates; const float* c_all;
+  float* dG; float* xchg; const int32_t* off; unsigned* state;
+  int32_t n_seq, H, n_groups, KG, NG, n_active, xchg_dir_bytes;
+};
+constexpr int WB_P = 136;   // LDS row pitch of the A tile (floats): 8 lanes x 16 B cover the 32 banks
+
+__global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, H4 = 4 * H;
+  float* sA = smem;                                          // [64 videos][WB_P]  dG_t, this member's 128 gate columns
+  int* sR0 = reinterpret_cast<int*>(sA + 64 * WB_P);         // [64]
+  int* sT = sR0 + 64;                                        // [64]
+  int* sTg = sT + 64;                                        // [1]
+
+  const int d = (blockIdx.x & 7) >> 2;                       // team = direction
+  const int slot = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
+  if (slot >= a.n_active) return;
+  // (kg, ng): the NG members that share kg read the same partials -- kept on one XCD (speed only)
+  const int rest = slot >> 2, ng = rest % a.NG, kg = (rest / a.NG) * 4 + (slot & 3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  float* xbase = a.xchg + (size_t)d * (a.xchg_dir_bytes >> 2);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(xbase, (short)0, a.xchg_dir_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x7ffffff0u;
+  bool dead = false;
+
+  // this lane's W_hh fragments: chunk c = local k 8c..8c+7 (gate c>>2, units 8(c&3)..), lane half lh holds k = 8c+4lh .. +3
+  const int ncol = ng * 256 + wave * 32 + li;
+  float4 wreg[16];
+  {
+    const float* wp = a.whh[d] + min(ncol, H - 1);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int64_t krow = (int64_t)(c >> 2) * H + 32 * kg + 8 * (c & 3) + 4 * lh;
+      float4 w4;
+      w4.x = wp[(krow + 0) * H]; w4.y = wp[(krow + 1) * H]; w4.z = wp[(krow + 2) * H]; w4.w = wp[(krow + 3) * H];
+      wreg[c] = ncol < H ? w4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const size_t slab = (size_t)a.KG * 64 * H;                 // floats per (group parity, step parity) exchange buffer
+
+  for (int g = 0; g < a.n_groups; ++g) {
+    const int item = 2 * g + d;
+    const int v0 = g * WK_GROUP, nv = min(WK_GROUP, a.n_seq - v0);
+    unsigned* bar = a.state + 16 + item;
+    __syncthreads();
+    if (tid == 0) *sTg = 0;
+    __syncthreads();
+    if (tid < 64) {
+      int r0 = 0, T = 0;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; atomicMax(sTg, T); }
+      sR0[tid] = r0; sT[tid] = T;
+    }
+    __syncthreads();
+    const int Tg = *sTg;
+
+    // cell role: thread = (video ei, unit quad uq): units j..j+3 of this member's 32
+    const int ei = tid >> 3, uq = tid & 7;
+    const bool erole = ei < nv;
+    const int er0 = erole ? sR0[ei] : 0, eT = erole ? sT[ei] : 0;
+    const int j = 32 * kg + 4 * uq;
+    float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 sv_i, sv_f, sv_g, sv_o, sv_c, sv_cp, sv_dh;
+    sv_i = sv_f = sv_g = sv_o = sv_c = sv_cp = sv_dh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int t) {
+      const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+      const float* gs = a.gates + row * (8 * H) + d * H4 + j;
+      sv_i = *reinterpret_cast<const float4*>(gs); sv_f = *reinterpret_cast<const float4*>(gs + H);
+      sv_g = *reinterpret_cast<const float4*>(gs + 2 * H); sv_o = *reinterpret_cast<const float4*>(gs + 3 * H);
+      sv_c = *reinterpret_cast<const float4*>(a.c_all + row * (2 * H) + d * H + j);
+      sv_cp = t > 0 ? *reinterpret_cast<const float4*>(a.c_all + (d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      sv_dh = *reinterpret_cast<const float4*>(a.dHout + row * (2 * H) + d * H + j);
+    };
+    if (erole && eT == Tg) fetch(Tg - 1);
+    const size_t gbase = (size_t)(g & 1) * 2 * slab;
+
+    for (int t = Tg - 1; t >= 0; --t) {
+      if (t < Tg - 1) {
+        if (tid == 0 && !dead) {   // wait until every member published step t+1
+          const unsigned want = (unsigned)(Tg - 1 - t) * (unsigned)a.n_active;
+          unsigned spins = 0;
+          while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
+                 __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); dead = true; break;
+            }
+          }
+        }
+      }
+      __syncthreads();   // hand-off seen by every wave; previous step's MFMA reads of sA are over
+      float4 o_i, o_f, o_g, o_o;
+      o_i = o_f = o_g = o_o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (erole && t < eT) {
+        float dh[4] = {sv_dh.x, sv_dh.y, sv_dh.z, sv_dh.w};
+        if (t + 1 < eT) {   // recurrent part: fixed-order sum over kg' of partial_{kg'}(t+1)[ei][j..j+3]   (sc1 loads ONLY)
+          const unsigned b0 = (unsigned)((gbase + (size_t)((t + 1) & 1) * slab + (size_t)ei * H + j) * 4);
+#pragma unroll 1
+          for (int mb = 0; mb < 32; mb += 16) {   // 16 loads in flight per lane (32 would spill next to the 64 weight VGPRs)
+            u32x4 pv[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+              pv[m] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, mb + m < a.KG ? b0 + (unsigned)(mb + m) * (unsigned)(64 * H * 4) : OOB,
+                                                            0, 16 /* sc1 */);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+              const f32x4 p = __builtin_bit_cast(f32x4, pv[m]);
+              dh[0] += p[0]; dh[1] += p[1]; dh[2] += p[2]; dh[3] += p[3];
+            }
+          }
+        }
+        const float si[4] = {sv_i.x, sv_i.y, sv_i.z, sv_i.w}, sf[4] = {sv_f.x, sv_f.y, sv_f.z, sv_f.w};
+        const float sg[4] = {sv_g.x, sv_g.y, sv_g.z, sv_g.w}, so[4] = {sv_o.x, sv_o.y, sv_o.z, sv_o.w};
+        const float sc[4] = {sv_c.x, sv_c.y, sv_c.z, sv_c.w}, scp[4] = {sv_cp.x, sv_cp.y, sv_cp.z, sv_cp.w};
+        float di[4], df[4], dg_[4], do_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float tc = tanhf(sc[e]);
+          const float dc = dcarry[e] + dh[e] * so[e] * (1.f - tc * tc);
+          di[e] = dc * sg[e] * si[e] * (1.f - si[e]);
+          df[e] = dc * scp[e] * sf[e] * (1.f - sf[e]);
+          dg_[e] = dc * si[e] * (1.f - sg[e] * sg[e]);
+          do_[e] = dh[e] * tc * so[e] * (1.f - so[e]);
+          dcarry[e] = dc * sf[e];
+        }
+        o_i = make_float4(di[0], di[1], di[2], di[3]); o_f = make_float4(df[0], df[1], df[2], df[3]);
+        o_g = make_float4(dg_[0], dg_[1], dg_[2], dg_[3]); o_o = make_float4(do_[0], do_[1], do_[2], do_[3]);
+        if (ng == 0) {
+          const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+          float* dg = a.dG + row * (8 * H) + d * H4 + j;
+          *reinterpret_cast<float4*>(dg) = o_i; *reinterpret_cast<float4*>(dg + H) = o_f;
+          *reinterpret_cast<float4*>(dg + 2 * H) = o_g; *reinterpret_cast<float4*>(dg + 3 * H) = o_o;
+        }
+      }
+      {   // every thread owns its 16 entries of the A tile: finished / absent videos contribute zeros
+        float* ap = sA + ei * WB_P + 4 * uq;
+        *reinterpret_cast<float4*>(ap) = o_i; *reinterpret_cast<float4*>(ap + 32) = o_f;
+        *reinterpret_cast<float4*>(ap + 64) = o_g; *reinterpret_cast<float4*>(ap + 96) = o_o;
+      }
+      if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, in flight during the MFMAs
+      __syncthreads();
+      if (t > 0) {   // partial_kg(t) is only ever read by step t-1
+        float* xo = xbase + gbase + (size_t)(t & 1) * slab + (size_t)kg * 64 * H;
+        const int ntile = nv > 32 ? 2 : 1;
+        for (int tile = 0; tile < ntile; ++tile) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const float* ap = sA + (tile * 32 + li) * WB_P + 4 * lh;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            const float4 av = *reinterpret_cast<const float4*>(ap + 8 * c);
+            const float4 bv = wreg[c];
+            // operands swapped (W as the MFMA "A", dG as "B"): the tile comes out transposed, lane = video, and each lane holds
+            // 4 x 4 CONSECUTIVE columns -> 16-byte sc1 stores (dword sc1 stores cost ~6x per byte: MI355X_MICROARCH.md)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc, 0, 0, 0);
+          }
+          const int i = tile * 32 + li;
+          if (t < sT[i]) {
+            const unsigned rowoff = (unsigned)((xo - xbase + (size_t)i * H + ng * 256 + wave * 32 + 4 * lh) * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const u32x4 v = __builtin_bit_cast(u32x4, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+              if (ng * 256 + wave * 32 + 8 * q + 4 * lh < H)
+                __builtin_amdgcn_raw_buffer_store_b128(v, xrsrc, rowoff + 32u * q, 0, 16 /* sc1 */);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Frame head backward: du = ds*s*(1-s); dh[r,:] = du*w; per-wave partial sums of du*h[r,:] and du (deterministic reduce).
 __global__ __launch_bounds__(256) void frame_head_bwd_kernel(const float* __restrict__ h, const float* __restrict__ scores,
                                                              const float* __restrict__ dscores, const float* __restrict__ w,
@@ -1404,6 +1603,26 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
                                           (unsigned)shmem, stream));
       done = true;
     }
+  }
+  static const bool wide_bwd = !(getenv("SUMK_LSTM_WIDE_BWD") && getenv("SUMK_LSTM_WIDE_BWD")[0] == '0');
+  if (!done && persist_ok && wide_bwd && n_seq > GV_MAXB && H > 256 && H <= 1024 && H % 128 == 0 && L.xchg_bytes > 0 &&
+      2 * ((n_seq + WK_GROUP - 1) / WK_GROUP) <= PSTATE_WORDS - 16) {
+    WideBwdArgs wa;
+    wa.whh[0] = w->w_hh[0]; wa.whh[1] = w->w_hh[1]; wa.dHout = dh_out; wa.gates = (const float*)(ws + L.gates);
+    wa.c_all = (const float*)(ws + L.call); wa.dG = dG; wa.xchg = (float*)(ws + L.xchg);
+    wa.off = seq_off_dev; wa.state = (unsigned*)(ws + L.pstate_b);
+    wa.n_seq = n_seq; wa.H = H; wa.n_groups = (n_seq + WK_GROUP - 1) / WK_GROUP;
+    wa.KG = H / 32; wa.NG = (H + 255) / 256; wa.n_active = wa.KG * wa.NG;
+    wa.xchg_dir_bytes = (int32_t)(L.xchg_bytes / 2);
+    static bool wb_attr_set = false;
+    if (!wb_attr_set) {
+      SUMK_HIP(hipFuncSetAttribute((const void*)lstm_wide_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      wb_attr_set = true;
+    }
+    void* kargs[] = {&wa};
+    SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_wide_bwd_kernel, dim3(256), dim3(PK_THREADS), kargs,
+                                        (unsigned)(96 * 1024), stream));   // 35 KB used; > 80 KB keeps one block per CU
+    done = true;
   }
   if (!done && n_seq <= GV_MAXB) {   // a few videos and no persistent BPTT (H > 256): bandwidth-shaped transposed mat-vec per step
     const TGemvGeom tg = tgemv_geom(H);
