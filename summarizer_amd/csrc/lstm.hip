@@ -36,13 +36,13 @@ struct LstmWs {
 };
 
 constexpr int GV_MAXB = 8;      // "a few sequences": the small-batch mat-vec step kernels below take over up to this many
-// geometry of the transposed mat-vec: strips of 256 columns x k splits sized for ~512 blocks
+// geometry of the transposed mat-vec: strips of 256 columns x k splits sized for ~2048 blocks
 struct TGemvGeom { int strips, n_ksplit, rows_per_split; };
 static TGemvGeom tgemv_geom(int H) {
   TGemvGeom g;
   g.strips = (H + 255) / 256;
   const int H4 = 4 * H;
-  int want = std::max(1, 512 / g.strips);
+  int want = std::max(1, 2048 / g.strips);                // ~8 blocks = 32 waves per CU: the weight stream needs the loads in flight
   want = std::min(want, std::max(1, H4 / 32));            // at least 32 rows per split (8 per wave)
   want = std::min(want, 128);
   g.rows_per_split = ((H4 + want - 1) / want + 3) / 4 * 4;
@@ -158,16 +158,28 @@ __global__ __launch_bounds__(256) void lstm_gemv_step_kernel(GemvStepArgs a) {
 #pragma unroll
     for (int b = 0; b < GV_MAXB; ++b) any |= src[b] != nullptr;
     if (!any) continue;                  // uniform: e.g. layer 0 of the decoder at t = 0, or no initial state
-    for (int k = 4 * lane; k < H; k += 256) {
-      float4 wq[4];
+    // 4 k-chunks = 16 weight loads (256 B) in flight per lane before the first FMA.  (Measured neutral: 20.6 us per step on
+    // the SumGAN mix either way, as was one block per unit with K split over its waves, and rotating the start column per
+    // unit -- the 64-128 MB weight stream of an H = 2048 step already runs at 3-4 TB/s.)
+    for (int k0 = 4 * lane; k0 < H; k0 += 1024) {
+      float4 wq[4][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const float4*>(w + (int64_t)(q * H + j) * H + k);
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 256 * u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          wq[u][q] = k < H ? *reinterpret_cast<const float4*>(w + (int64_t)(q * H + j) * H + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
       for (int b = 0; b < GV_MAXB; ++b) {
         if (b < nb && src[b] != nullptr) {
-          const float4 x = *reinterpret_cast<const float4*>(src[b] + k);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q][b] += (wq[q].x * x.x + wq[q].y * x.y) + (wq[q].z * x.z + wq[q].w * x.w);
+          for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 256 * u;
+            const float4 x = k < H ? *reinterpret_cast<const float4*>(src[b] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][b] += (wq[u][q].x * x.x + wq[u][q].y * x.y) + (wq[u][q].z * x.z + wq[u][q].w * x.w);
+          }
         }
       }
     }
@@ -243,13 +255,22 @@ __global__ __launch_bounds__(256) void lstm_tgemv_partial_kernel(TGemvArgs a) {
       }
     }
     if (!any) continue;
-    for (int k = kbeg + wave; k < kend; k += 4) {
-      const float4 w4 = jok ? *reinterpret_cast<const float4*>(w + (int64_t)k * H + jq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = kbeg + wave; k0 < kend; k0 += 16) {   // 4 rows in flight per lane before the first FMA
+      float4 w4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 4 * u;
+        w4[u] = (jok && k < kend) ? *reinterpret_cast<const float4*>(w + (int64_t)k * H + jq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
       for (int b = 0; b < GV_MAXB; ++b) {
         if (b < nb && g[b] != nullptr) {
-          const float gv = g[b][k];
-          acc[b].x += gv * w4.x; acc[b].y += gv * w4.y; acc[b].z += gv * w4.z; acc[b].w += gv * w4.w;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 4 * u;
+            const float gv = k < kend ? g[b][k] : 0.f;
+            acc[b].x += gv * w4[u].x; acc[b].y += gv * w4[u].y; acc[b].z += gv * w4[u].z; acc[b].w += gv * w4[u].w;
+          }
         }
       }
     }
@@ -840,6 +861,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wlo[sidx], acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, whi[sidx], acc0, 0, 0, 0);
           }
+          if (nv > 32)      // second MFMA tile only when the group has more than 32 videos (uniform)
 #pragma unroll
           for (int sidx = 0; sidx < NS; ++sidx) {
             bf16x8 bh, bl;
@@ -870,6 +892,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc0, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc0, 0, 0, 0);
           }
+          if (nv > 32)      // second MFMA tile only when the group has more than 32 videos (uniform)
 #pragma unroll
           for (int cc = 0; cc < WK_CPW; ++cc) {
             const float4 bv = wreg[cc];
