@@ -85,7 +85,8 @@ __device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileC
 
 // Epilogue of one wave's (TM x TN) 32x32 accumulator tiles.  C/D map of the 32x32 MFMA: col = lane&31,
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  (row0, col0) = the wave's origin inside the matrix.
-template <int EPI, int TM, int TN>
+// RES_DONE: the residual of EPI_RESIDUAL is already in the accumulators (residual_init below).
+template <int EPI, int TM, int TN, bool RES_DONE = false>
 __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
                                                int col0, int li, int lh) {
 #pragma unroll
@@ -112,7 +113,7 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
         float v = acc[tm][tn][r];
         float* cp = ka.C + cur.c_off + (int64_t)row * cur.ldc + col;
         if constexpr (EPI == EPI_NONE) v *= ka.alpha;
-        if constexpr (EPI == EPI_RESIDUAL) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+        if constexpr (EPI == EPI_RESIDUAL && !RES_DONE) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
         if constexpr (EPI == EPI_BIAS_RELU) {
           v += bsum; v = (v < 0.f) ? 0.f : v;   // NaN-propagating, like torch.relu
           if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
@@ -125,6 +126,27 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
         }
         if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
         *cp = v;
+      }
+    }
+  }
+}
+
+// EPI_RESIDUAL with the residual read at the START of a tile: the accumulators begin at R instead of zero, so the 64 KB read of
+// a 128 x 128 tile overlaps the first operand loads instead of joining the store burst at the end (where every co-resident
+// block of a single-round launch reads and writes at once).  Same C/D map as epilogue_store; rows / columns outside the problem
+// start at zero.
+template <int TM, int TN>
+__device__ __forceinline__ void residual_init(const GemmKArgs& ka, const TileCtx& cur, f32x16 (&acc)[TM][TN], int row0, int col0,
+                                              int li, int lh) {
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = col0 + tn * 32 + li;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        acc[tm][tn][r] = (col < cur.N && row < cur.M) ? ka.R[cur.r_off + (int64_t)row * cur.ldr + col] : 0.f;
       }
     }
   }

@@ -159,12 +159,16 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * WM * WN / 4) void gemm_dma_kern
     unsigned long long ta = 0;
     if (ka.dbg & 2) ta = __builtin_amdgcn_s_memtime();
     f32x16 acc[TM][TN];
+    if constexpr (EPI == EPI_RESIDUAL) {   // as the register-staged kernel: the accumulators start at R (bit-identical results)
+      residual_init<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+    } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     const int next_tile = tile + gridDim.x;
     bool has_next = next_tile < ka.total_tiles;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * WM * WN / 4) void gemm_dma_kern
     unsigned long long tb = 0;
     if (ka.dbg & 2) tb = __builtin_amdgcn_s_memtime();
     if (!(ka.dbg & 1) || acc[0][0][0] == 12345.f)
-    epilogue_store<EPI, TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+    epilogue_store<EPI, TM, TN, true>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
     if (ka.dbg & 2) { const unsigned long long tc = __builtin_amdgcn_s_memtime(); t_k += tb - ta; t_e += tc - tb; n_t += 1; }
     if (!has_next) break;
     tile = next_tile;

@@ -337,7 +337,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; xr[q] = c < D4 ? ld(c) : make_float4(0.f, 0.f, 0.f, 0.f); }
   }
-  auto get = [&](int q, int c) { if constexpr (NQ > 0) return xr[q]; else return ld(c); };
   float s = 0.f;
   if constexpr (NQ > 0) {
 #pragma unroll
