@@ -189,6 +189,6 @@ def test_lstm_launch_chain_path_still_matches(dev):
     from conftest import ROOT
     env = dict(os.environ, SUMK_LSTM_PERSIST="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
-                        os.path.join(ROOT, "tests", "test_gpu_train.py"), "-k", "dsn_train_step or bilstm_grads",
+                        os.path.join(ROOT, "tests", "test_gpu_train.py"), "-k", "(dsn_train_step or bilstm_grads) and not 1024",   # (the H = 1024 case costs 2 min of CPU reference per process)
                         os.path.join(ROOT, "tests", "test_gpu_lstm.py")], env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
