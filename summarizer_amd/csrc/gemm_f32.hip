@@ -120,6 +120,33 @@ __global__ void slab_reduce_kernel(SlabReduceArgs a) {
   float* o = g == 0 ? a.out[0] : g == 1 ? a.out[1] : g == 2 ? a.out[2] : a.out[3];
   o[(int64_t)rl * a.ldo + col] += a.alpha * v;
 }
+// N % 4 == 0 and ldo % 4 == 0 (every weight gradient of the models): four columns per thread, the S slab loads of a thread in
+// flight together -- the scalar form moved 24 MB in 19.5 us.  Same summation order per element (slab 0, 1, ...): same bits.
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(SlabReduceArgs a) {
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t mn = (int64_t)a.M * a.N;
+  const int64_t idx = 4 * i4;
+  if (idx >= mn) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 4 <= a.S; s += 4) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(a.slab + (int64_t)(s + u) * mn + idx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+  }
+  for (; s < a.S; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(a.slab + (int64_t)s * mn + idx);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const int row = (int)(idx / a.N), col = (int)(idx % a.N);
+  const int g = row / a.rows_per_out, rl = row - g * a.rows_per_out;
+  float* o = (g == 0 ? a.out[0] : g == 1 ? a.out[1] : g == 2 ? a.out[2] : a.out[3]) + (int64_t)rl * a.ldo + col;
+  float4 c = *reinterpret_cast<float4*>(o);
+  c.x += a.alpha * v.x; c.y += a.alpha * v.y; c.z += a.alpha * v.z; c.w += a.alpha * v.w;
+  *reinterpret_cast<float4*>(o) = c;
+}
 
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
@@ -144,7 +171,10 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   r.slab = slab; for (int i = 0; i < 4; ++i) r.out[i] = out[i];
   r.S = S; r.M = M; r.N = N; r.rows_per_out = rows_per_out; r.ldo = ldo; r.alpha = alpha;
   int64_t mn = (int64_t)M * N;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, r);
+  bool vec4 = (N % 4 == 0) && (ldo % 4 == 0);
+  for (int i = 0; i < 4; ++i) vec4 = vec4 && (out[i] == nullptr || ((uintptr_t)out[i] & 15) == 0);
+  if (vec4) hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, stream, r);
+  else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, r);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -186,6 +216,61 @@ int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_c
   chunks = (R + rpc - 1) / rpc;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, stream, X, ld, R, N, rpc, partial);
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, partial, chunks, N, N, out);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+// block = 64 slot columns (16 lanes x float4: 256 contiguous bytes per partial row) x 16 partial groups; every thread has its
+// n_part / 16 loads in flight at once, then a fixed-order LDS combine (deterministic).
+struct ReduceMultiArgs { const float* partial; int32_t n_part, stride, nseg; int32_t off[6], n[6]; float* out[6]; };
+__global__ __launch_bounds__(256) void partial_reduce_multi_kernel(ReduceMultiArgs a) {
+  __shared__ float4 red[16][17];
+  const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  // column blocks are laid over the segments one after the other (each segment padded to 64 columns)
+  int blk = blockIdx.x, seg = 0;
+  for (; seg < a.nseg; ++seg) { const int nb = (a.n[seg] + 63) >> 6; if (blk < nb) break; blk -= nb; }
+  if (seg >= a.nseg) return;
+  const int c = blk * 64 + 4 * cl;                     // column inside the segment
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < a.n[seg]) {
+    const float* base = a.partial + a.off[seg] + c;
+    for (int p0 = pg; p0 < a.n_part; p0 += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + 16 * u;
+        v[u] = p < a.n_part ? *reinterpret_cast<const float4*>(base + (int64_t)p * a.stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+  }
+  red[pg][cl] = s;
+  __syncthreads();
+  if (pg == 0 && c < a.n[seg]) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const float4 o = red[q][cl]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    float* o = a.out[seg] + c;
+    const int left = a.n[seg] - c;
+    o[0] += t.x;
+    if (left > 1) o[1] += t.y;
+    if (left > 2) o[2] += t.z;
+    if (left > 3) o[3] += t.w;
+  }
+}
+int partial_reduce_multi(const float* partial, int n_part, int stride, const ReduceSeg* segs, int nseg, hipStream_t stream) {
+  SUMK_ARG(nseg >= 0 && nseg <= 6 && stride % 4 == 0, "partial_reduce_multi: bad segment list");
+  ReduceMultiArgs a;
+  a.partial = partial; a.n_part = n_part; a.stride = stride; a.nseg = 0;
+  int blocks = 0;
+  for (int k = 0; k < nseg; ++k) {
+    if (segs[k].out == nullptr || segs[k].n <= 0) continue;
+    SUMK_ARG(segs[k].off % 4 == 0, "partial_reduce_multi: segment offset %d is not a multiple of 4", segs[k].off);
+    a.off[a.nseg] = segs[k].off; a.n[a.nseg] = segs[k].n; a.out[a.nseg] = segs[k].out; ++a.nseg;
+    blocks += (segs[k].n + 63) >> 6;
+  }
+  if (blocks == 0) return SUMK_OK;
+  hipLaunchKernelGGL(partial_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

@@ -90,6 +90,10 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream);
 // out[c] += sum_p partial[p*stride + c]
 int partial_reduce_accum(const float* partial, int n_part, int stride, int N, float* out, hipStream_t stream);
+// ONE launch for several column ranges of the same slots: segs[k].out[c] += sum_p partial[p*stride + segs[k].off + c], c < segs[k].n.
+// Every off must be a multiple of 4 (float4 columns); nseg <= 6; null outputs are skipped.
+struct ReduceSeg { int32_t off, n; float* out; };
+int partial_reduce_multi(const float* partial, int n_part, int stride, const ReduceSeg* segs, int nseg, hipStream_t stream);
 
 // Dropout keep-mask: a pure function of (seed, site, element index) so backward regenerates it and the numpy oracle
 // can reproduce it bit for bit (tests/golden/recipes.py: dropout_keep).  splitmix64 finaliser.
@@ -128,13 +132,19 @@ int launch_layernorm_drop(const float* X, float* Y, const float* g, const float*
                           Drop drop, uint32_t site, hipStream_t stream);
 int launch_ln_head_drop(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
                         int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream);
-// Backward of Y = LN(drop(X)) * g + b: dX from dY; per-wave partial sums of (dgamma, dbeta) go to `part`
-// ([n_waves][3*D + 4] floats, n_waves <= LNB_MAX_WAVES returned in *n_waves) for partial_reduce_accum.
+// Backward of Y = LN(drop(X)) * g + b: dX from dY; per-BLOCK partial sums (the block's 4 waves are combined through LDS in a
+// fixed order) go to `part`: [n_slots][ln_slot_floats(D)] floats = [dgamma D][dbeta D][dw2 D][column sums of dX D][db2, pad x3],
+// n_slots <= LNB_MAX_WAVES / 4 returned in *n_waves; ln_bwd_reduce adds the slots into the gradients in ONE launch.
 constexpr int LNB_MAX_WAVES = 1024;
+inline int ln_slot_floats(int D) { return 4 * D + 4; }
+// dgamma / dbeta always; dw2, db2, dcol (= column sums of the dX the kernel wrote: the bias gradient of the layer below) when
+// non-null (head variant only).
+int ln_bwd_reduce(const float* part, int n_slots, int D, float* dgamma, float* dbeta, float* dw2, float* db2, float* dcol,
+                  hipStream_t stream);
 int launch_ln_bwd_rows(int D, int R, const float* X, const float* stats, const float* g, const float* b, const float* dY,
                        float* dX, float* part, Drop drop, uint32_t site, int* n_waves, hipStream_t stream);
 // Backward of scores = sigmoid(LN(drop(Z)) . w2 + b2) with Z = post-ReLU activations: dZ (ReLU + dropout masks applied),
-// partials of (dgamma, dbeta, dw2) and db2 in slot [3*D].
+// partials of (dgamma, dbeta, dw2), the column sums of dZ and db2 (slot layout above).
 int launch_ln_head_bwd(int D, int R, const float* Z, const float* stats, const float* g, const float* b, const float* w2,
                        const float* scores, const float* dscores, float* dZ, float* part, Drop drop, uint32_t site,
                        int* n_waves, hipStream_t stream);

@@ -59,7 +59,7 @@ static int tf_carve(int D, int F, int heads, int n_layers, int n_seq, const int3
     w->hfin = take(R * D * 4); w->z = take(R * D * 4); w->stats_fin = take(R * 4 * 4); w->scores = take(R * 4);
     w->g0 = take(R * D * 4); w->g1 = take(R * D * 4); w->g2 = take(R * D * 4);
     w->dqkv = take(R * 3 * D * 4); w->dff = take(R * (size_t)F * 4);
-    w->lnpart = take((size_t)LNB_MAX_WAVES * (3 * (size_t)D + 4) * 4);
+    w->lnpart = take((size_t)(LNB_MAX_WAVES / 4) * ln_slot_floats(D) * 4);
     w->colpart = take((size_t)TF_COLSUM_CHUNKS * 3 * D * 4 + (size_t)TF_COLSUM_CHUNKS * F * 4);
     w->slab_elems = (size_t)24 * D * std::max(D, F);
     w->slab = take(w->slab_elems * 4);
@@ -346,7 +346,7 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
   const TfWs& L = G.L;
   if (workspace_bytes < L.total) { set_error("transformer_backward: workspace %zu < required %zu (needs the training-mode forward's workspace)", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
   char* ws = (char*)workspace;
-  const int R = G.R, dh = G.dh, np = n_seq * n_heads, pstride = 3 * D + 4;
+  const int R = G.R, dh = G.dh, np = n_seq * n_heads;
   const int64_t nRD = (int64_t)R * D, nRF = (int64_t)R * F;
   TfSeq* seq = (TfSeq*)(ws + L.seq);
   GemmProb* prow = (GemmProb*)(ws + L.prob_row);
@@ -377,19 +377,14 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
   // ---- scoring head: dZ (ReLU + head dropout masks applied), dk2, db2, shared-LN grads
   SUMK_TRY(launch_ln_head_bwd(D, R, Z, sfin + 2 * (size_t)R, head->ln_w, head->ln_b, head->k2_w, scores, dscores, g0, lnpart, dhd,
                               1000u, &nw, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, hgr->ln_w, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, hgr->ln_b, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + 2 * D, nw, pstride, D, hgr->k2_w, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + 3 * D, nw, pstride, 1, hgr->k2_b, stream));
-  SUMK_TRY(colsum_accum(g0, D, R, D, colpart, TF_COLSUM_CHUNKS, hgr->k1_b, stream));
+  SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, hgr->ln_w, hgr->ln_b, hgr->k2_w, hgr->k2_b, hgr->k1_b, stream));   // dk1_b = column sums of g0
   SUMK_TRY(wgrad(g0, D, D, hfin, D, D, hgr->k1_w, nullptr, nullptr, D));
   SUMK_TRY(nn(g0, head->k1_w, g1, P_DD, EPI_NONE, D));                       // dHfin' -> g1
   if (opts->more_residuals && dx) SUMK_HIP(hipMemcpyAsync(dx, g1, (size_t)nRD * 4, hipMemcpyDeviceToDevice, stream));
   // encoder's final (shared) LayerNorm
   const float* hlast = (const float*)(ws + L.lay0 + (size_t)(n_layers - 1) * L.lay_stride + L.l_hout);
   SUMK_TRY(launch_ln_bwd_rows(D, R, hlast, sfin, head->ln_w, head->ln_b, g1, g2, lnpart, none, 0u, &nw, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, hgr->ln_w, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, hgr->ln_b, stream));
+  SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, hgr->ln_w, hgr->ln_b, nullptr, nullptr, nullptr, stream));
   float* dH = g2;            // gradient w.r.t. the current layer's output
   float* fa = g0; float* fb = g1;   // the two free (R,D) buffers
 
@@ -406,8 +401,7 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
     const uint32_t site = 10u * (uint32_t)l;
     // norm2
     SUMK_TRY(launch_ln_bwd_rows(D, R, T1b, stats + 2 * (size_t)R, W.norm2_w, W.norm2_b, dH, fa, lnpart, none, 0u, &nw, stream));
-    SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, Gd.norm2_w, stream));
-    SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, Gd.norm2_b, stream));
+    SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, Gd.norm2_w, Gd.norm2_b, nullptr, nullptr, nullptr, stream));
     // fa = dT1b (also the residual gradient into hmid).  dropout2 mask -> fb = d(linear2 output)
     const float* dL2 = fa;
     if (dl.thr) { hipLaunchKernelGGL(mask_scale_kernel, blocks(nRD), dim3(256), 0, stream, fb, fa, nRD, dl, site + 3); dL2 = fb; }
@@ -420,8 +414,7 @@ extern "C" int sumk_transformer_backward(const float* x, int32_t D, int32_t F, i
     SUMK_TRY(nn(dFF, W.lin1_w, fa, P_NN_FD, EPI_ACCUM, D));                     // fa = dT1b + dFF . W1 = dHmid   (W1 stored (F,D) = (K,N))
     // norm1
     SUMK_TRY(launch_ln_bwd_rows(D, R, T1a, stats, W.norm1_w, W.norm1_b, fa, dH, lnpart, none, 0u, &nw, stream));   // dH buffer reused: dT1a
-    SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, Gd.norm1_w, stream));
-    SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, Gd.norm1_b, stream));
+    SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, Gd.norm1_w, Gd.norm1_b, nullptr, nullptr, nullptr, stream));
     float* dT1a = dH;
     const float* dAO = dT1a;
     if (dl.thr) { hipLaunchKernelGGL(mask_scale_kernel, blocks(nRD), dim3(256), 0, stream, fb, dT1a, nRD, dl, site + 1); dAO = fb; }

@@ -84,7 +84,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->dy0 = take(R * D * 4);
     w->dctx = take(R * D * 4);
     w->dqkv = take(R * 3 * D * 4);
-    w->lnpart = take((size_t)LNB_MAX_WAVES * (3 * (size_t)D + 4) * 4);
+    w->lnpart = take((size_t)(LNB_MAX_WAVES / 4) * ln_slot_floats(D) * 4);
     w->colpart = take((size_t)COLSUM_CHUNKS * D * 4);
     w->slab_elems = (size_t)32 * D * D;
     w->slab = take(w->slab_elems * 4);
@@ -407,8 +407,11 @@ static void launch_ln_rows(const float* X, float* Y, const float* g, const float
 // Backward of  y = LN(drop(x)) * g + b  for a strided set of rows per wave.
 //   HEAD : upstream is the scalar du = dscore * s(1-s) through y . w2 + b2; x = Z (post-ReLU): dX also takes the ReLU mask.
 //   !HEAD: upstream is the matrix dY.
-// Each wave keeps per-column partial sums (dgamma, dbeta [, dw2]) in registers over its rows and writes them to its own
-// slot of `part` ([n_waves][3*D + 4]); a fixed-order reduction kernel adds the slots into the gradients (deterministic).
+// Each wave keeps per-column partial sums (dgamma, dbeta [, dw2, column sums of the dX it writes = the bias gradient of the layer
+// below]) in registers over its rows; the block's 4 waves are added through LDS in a fixed order and the block writes ONE slot
+// of `part` ([n_blocks][4*D + 4], sumk_internal.h: ln_slot_floats); ln_bwd_reduce adds the slots into the gradients in one
+// launch (deterministic).  Round 1 wrote one slot per wave and reduced each vector with its own launch over ~1000 slots, and the
+// bias gradient took a separate pass over dX: 7 launches x 18 us + 45 us per training step.
 template <int NQ, bool HEAD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ X, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const float* __restrict__ b,
@@ -421,9 +424,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * 4;
   const int D4 = D >> 2;
-  float4 ag[NQ], ab[NQ], aw[NQ];
+  __shared__ float4 red[3][NQ * 64];
+  float4 ag[NQ], ab[NQ], aw[NQ], ax[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) ag[q] = ab[q] = aw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < NQ; ++q) ag[q] = ab[q] = aw[q] = ax[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   float ab2 = 0.f;
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* b4 = reinterpret_cast<const float4*>(b);
@@ -489,20 +493,43 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.z = rstd * (dxh[q].z - s1 - xh[q].z * s2) * keep[q].z;
         o.w = rstd * (dxh[q].w - s1 - xh[q].w * s2) * keep[q].w;
         reinterpret_cast<float4*>(dX + (int64_t)row * D)[c] = o;
+        if constexpr (HEAD) { ax[q].x += o.x; ax[q].y += o.y; ax[q].z += o.z; ax[q].w += o.w; }
       }
     }
   }
-  float* slot = part + (int64_t)wave_id * (3 * D + 4);
+  // block combine, one vector at a time: waves 1..3 park their registers in LDS, wave 0 adds them in wave order and stores
+  const int wv = threadIdx.x >> 6;
+  float* slot = part + (int64_t)blockIdx.x * (4 * D + 4);
+  auto combine = [&](float4 (&acc)[NQ], float* dst) {
+    __syncthreads();
+    if (wv > 0) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int c = lane + 64 * q;
-    if (c < D4) {
-      reinterpret_cast<float4*>(slot)[c] = ag[q];
-      reinterpret_cast<float4*>(slot + D)[c] = ab[q];
-      reinterpret_cast<float4*>(slot + 2 * D)[c] = aw[q];
+      for (int q = 0; q < NQ; ++q) red[wv - 1][lane + 64 * q] = acc[q];
     }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c = lane + 64 * q;
+        if (c < D4) {
+          float4 t = acc[q];
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) { const float4 o = red[w3][c]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+          reinterpret_cast<float4*>(dst)[c] = t;
+        }
+      }
+    }
+  };
+  combine(ag, slot);
+  combine(ab, slot + D);
+  if constexpr (HEAD) {
+    combine(aw, slot + 2 * D);
+    combine(ax, slot + 3 * D);
+    __shared__ float red_b2[4];
+    if (lane == 0) red_b2[wv] = ab2;
+    __syncthreads();
+    if (threadIdx.x == 0) slot[4 * D] = (red_b2[0] + red_b2[1]) + (red_b2[2] + red_b2[3]);
   }
-  if (lane == 0) slot[3 * D] = ab2;
 }
 
 // x[r,:] += table[pos_rows[r],:]   (in place, like vasnet.py:109/111)
@@ -763,7 +790,7 @@ static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const
   const int nq = (D4 + 63) / 64;
   int blocks = std::min((R + 3) / 4, LNB_MAX_WAVES / 4);
   blocks = std::max(blocks, 1);
-  *n_waves_out = blocks * 4;
+  *n_waves_out = blocks;              // slots written: one per block
   dim3 grid(blocks), block(256);
 #define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site)
   if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
@@ -774,6 +801,11 @@ static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const
 }
 
 namespace sumk {
+int ln_bwd_reduce(const float* part, int n_slots, int D, float* dgamma, float* dbeta, float* dw2, float* db2, float* dcol,
+                  hipStream_t stream) {
+  const ReduceSeg segs[5] = {{0, D, dgamma}, {D, D, dbeta}, {2 * D, D, dw2}, {3 * D, D, dcol}, {4 * D, 1, db2}};
+  return partial_reduce_multi(part, n_slots, ln_slot_floats(D), segs, 5, stream);
+}
 int launch_ln_bwd_rows(int D, int R, const float* X, const float* stats, const float* g, const float* b, const float* dY,
                        float* dX, float* part, Drop drop, uint32_t site, int* n_waves, hipStream_t stream) {
   return launch_ln_bwd<false>(D, R, X, stats, g, b, dY, nullptr, nullptr, nullptr, dX, part, drop, site, n_waves, stream);
@@ -816,7 +848,6 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   float* dCTX = (float*)(ws + L.dctx);
   float* dQKV = (float*)(ws + L.dqkv);
   float* lnpart = (float*)(ws + L.lnpart);
-  float* colpart = (float*)(ws + L.colpart);
   float* slab = (float*)(ws + L.slab);
   float* stats = (float*)(ws + L.stats);
   const float* scores = (const float*)(ws + L.scores);
@@ -826,18 +857,13 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
   const Drop drop = make_drop(opts);
   const bool use_e2 = drop.thr != 0;
-  const int pstride = 3 * D + 4;
   int nw = 0;
 
   // 8': head + second LayerNorm + dropout + ReLU  ->  dZ (w.r.t. the k1 pre-activation), dw2, db2, dgamma, dbeta
   SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, dZ, lnpart,
                                drop, 2u, &nw, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, gr->ln_w, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, gr->ln_b, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + 2 * D, nw, pstride, D, gr->w2, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + 3 * D, nw, pstride, 1, gr->b2, stream));
+  SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, gr->w2, gr->b2, gr->b1, stream));   // db1 = column sums of dZ, from the same slots
   // 7': k1
-  SUMK_TRY(colsum_accum(dZ, D, R, D, colpart, COLSUM_CHUNKS, gr->b1, stream));
   {
     float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
@@ -847,8 +873,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   }
   // 6': first LayerNorm + dropout -> dY0 (gradient of the residual sum)
   SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, dY1, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart, nw, pstride, D, gr->ln_w, stream));
-  SUMK_TRY(partial_reduce_accum(lnpart + D, nw, pstride, D, gr->ln_b, stream));
+  SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
   // 5': output projection (+ residual branch into dx)
   {
     float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
