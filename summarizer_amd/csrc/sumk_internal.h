@@ -135,7 +135,7 @@ int launch_ln_head_drop(const float* Z, const float* g, const float* b, const fl
 // Backward of Y = LN(drop(X)) * g + b: dX from dY; per-BLOCK partial sums (the block's 4 waves are combined through LDS in a
 // fixed order) go to `part`: [n_slots][ln_slot_floats(D)] floats = [dgamma D][dbeta D][dw2 D][column sums of dX D][db2, pad x3],
 // n_slots <= LNB_MAX_WAVES / 4 returned in *n_waves; ln_bwd_reduce adds the slots into the gradients in ONE launch.
-constexpr int LNB_MAX_WAVES = 1024;
+constexpr int LNB_MAX_WAVES = 3072;   // 768 blocks = 3 per CU (the kernels hold 124-164 VGPRs: 3-4 waves per SIMD fit)
 inline int ln_slot_floats(int D) { return 4 * D + 4; }
 // dgamma / dbeta always; dw2, db2, dcol (= column sums of the dX the kernel wrote: the bias gradient of the layer below) when
 // non-null (head variant only).
