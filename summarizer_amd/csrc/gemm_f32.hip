@@ -210,6 +210,41 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
     out[c] += t;
   }
 }
+// four columns per thread, four rows in flight per thread (N % 4 == 0, ld % 4 == 0, X 16-byte aligned)
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ X, int ld, int R, int N, int rows_per_chunk,
+                                                              float* __restrict__ partial) {
+  const int c = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (c >= N) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(X + (int64_t)(r + u) * ld + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; r < r1; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)r * ld + c);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * N + c) = s;
+}
+// segs[k].out[c] += sum_r X[r*ld + segs[k].off + c]: ONE pass over X for every output (an LSTM layer's b_ih and b_hh receive the
+// same column sums of dG, both directions side by side: one pass instead of four) and one fixed-order reduce launch.
+int colsum_multi(const float* X, int ld, int R, int N, float* partial, int max_chunks, const ReduceSeg* segs, int nseg,
+                 hipStream_t stream) {
+  int chunks = std::max(1, std::min(max_chunks, (R + 31) / 32));
+  int rpc = (R + chunks - 1) / chunks;
+  chunks = (R + rpc - 1) / rpc;
+  if (N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3((N / 4 + 255) / 256, chunks), dim3(256), 0, stream, X, ld, R, N, rpc, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, stream, X, ld, R, N, rpc, partial);
+  SUMK_HIP(hipGetLastError());
+  return partial_reduce_multi(partial, chunks, N, segs, nseg, stream);
+}
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream) {
   int chunks = std::max(1, std::min(max_chunks, (R + 63) / 64));
   int rpc = (R + chunks - 1) / chunks;

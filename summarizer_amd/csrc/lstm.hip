@@ -1687,8 +1687,10 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     float* out[4] = {gr->w_hh[d], nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dG + (size_t)d * 4 * H, 8 * H, hprev + (size_t)d * H, 2 * H, 4 * H, H, R, slab, L.slab_elems,
                                   psk, 64, out, 4 * H, H, 1.f, stream, precision));
-    SUMK_TRY(colsum_accum(dG + (size_t)d * 4 * H, 8 * H, R, 4 * H, colpart, 128, gr->b_ih[d], stream));
-    SUMK_TRY(colsum_accum(dG + (size_t)d * 4 * H, 8 * H, R, 4 * H, colpart, 128, gr->b_hh[d], stream));
+  }
+  {   // b_ih and b_hh of a direction both receive the column sums of its half of dG: one pass over dG for all four
+    const ReduceSeg segs[4] = {{0, 4 * H, gr->b_ih[0]}, {0, 4 * H, gr->b_hh[0]}, {4 * H, 4 * H, gr->b_ih[1]}, {4 * H, 4 * H, gr->b_hh[1]}};
+    SUMK_TRY(colsum_multi(dG, 8 * H, R, 8 * H, colpart, 128, segs, 4, stream));
   }
   if (dx) {  // dX = dG_fwd W_ih_fwd + dG_rev W_ih_rev
     const int small = gemm_tiles(R, In, 0) >= 512 ? 0 : 1;
@@ -1893,8 +1895,8 @@ extern "C" int sumk_lstm_layer_backward(const float* x, const float* h_out, cons
   {
     float* out[4] = {gr->w_hh, nullptr, nullptr, nullptr};
     SUMK_TRY(gemm_tn_splitk_accum(dG, 4 * H, hprev, H, 4 * H, H, R, slab, L.slab_elems, psk, 64, out, 4 * H, H, 1.f, stream, precision));
-    SUMK_TRY(colsum_accum(dG, 4 * H, R, 4 * H, colpart, 128, gr->b_ih, stream));
-    SUMK_TRY(colsum_accum(dG, 4 * H, R, 4 * H, colpart, 128, gr->b_hh, stream));
+    const ReduceSeg segs[2] = {{0, 4 * H, gr->b_ih}, {0, 4 * H, gr->b_hh}};
+    SUMK_TRY(colsum_multi(dG, 4 * H, R, 4 * H, colpart, 128, segs, 2, stream));
   }
   if (dx) {
     const int small = gemm_tiles(R, In, 0) >= 512 ? 0 : 1;
@@ -2250,8 +2252,8 @@ extern "C" int sumk_lstm_decoder_backward(int32_t H, int32_t n_layers, int32_t n
     { float* o[4] = {gr[l].w_hh, nullptr, nullptr, nullptr};
       SUMK_TRY(gemm_tn_splitk_accum(dG(l), 4 * H, (const float*)(ws + L.hprev + L.s_hseq * l), H, 4 * H, H, R, slab, L.slab_elems, psk, 64, o,
                                     4 * H, H, 1.f, stream)); }
-    SUMK_TRY(colsum_accum(dG(l), 4 * H, R, 4 * H, colpart, 128, gr[l].b_ih, stream));
-    SUMK_TRY(colsum_accum(dG(l), 4 * H, R, 4 * H, colpart, 128, gr[l].b_hh, stream));
+    const ReduceSeg segs[2] = {{0, 4 * H, gr[l].b_ih}, {0, 4 * H, gr[l].b_hh}};
+    SUMK_TRY(colsum_multi(dG(l), 4 * H, R, 4 * H, colpart, 128, segs, 2, stream));
   }
   return SUMK_OK;
 }

@@ -94,6 +94,10 @@ int partial_reduce_accum(const float* partial, int n_part, int stride, int N, fl
 // Every off must be a multiple of 4 (float4 columns); nseg <= 6; null outputs are skipped.
 struct ReduceSeg { int32_t off, n; float* out; };
 int partial_reduce_multi(const float* partial, int n_part, int stride, const ReduceSeg* segs, int nseg, hipStream_t stream);
+// segs[k].out[c] += sum_r X[r*ld + segs[k].off + c] for c < segs[k].n: one pass over X(R, N), any number of (overlapping) column
+// ranges; partial must hold max_chunks*N floats.  N % 4 == 0 is required (partial_reduce_multi's stride).
+int colsum_multi(const float* X, int ld, int R, int N, float* partial, int max_chunks, const ReduceSeg* segs, int nseg,
+                 hipStream_t stream);
 
 // Dropout keep-mask: a pure function of (seed, site, element index) so backward regenerates it and the numpy oracle
 // can reproduce it bit for bit (tests/golden/recipes.py: dropout_keep).  splitmix64 finaliser.
