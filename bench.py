@@ -185,6 +185,8 @@ def main():
                     help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024; "
                          "sumgan (--mode train only) = one SumGANTrainer video step: selector+encoder, decoder and "
                          "discriminator updates at the reference's default sizes (350 M parameters)")
+    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph after warm-up and time the replays "
+                    "(single process; roofline events are not recorded inside a captured step)")
     ap.add_argument("--mode", choices=["score", "train", "reinforce", "stream"], default="score",
                     help="headline = score (frames scored/sec, features resident in HBM); train = MSE step; reinforce = DSN "
                          "REINFORCE step (BASELINE config 4); stream = PCIe-inclusive scoring: features start in pageable host "
@@ -269,16 +271,15 @@ def main():
         sb = kernels.SeqBatch.get(lens, dev)
         base = torch.zeros(len(lens), device=dev)
         def run_step():
-            nonlocal base
             opt.zero_grad()
             probs = model.score_packed(x, lens)
-            dist_ = Bernoulli(probs)
+            dist_ = Bernoulli(probs, validate_args=False)          # (validation is a D2H sync per step)
             actions = dist_.sample((5,))
             rewards = kernels.dsn_reward(x, sb, actions.contiguous())
             loss = (-(sb.segment_mean(dist_.log_prob(actions)) * (rewards - base)).sum(dim=0) / 5.0).mean()
             loss.backward()
             opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
-            base = 0.9 * base + 0.1 * rewards.mean(dim=0)
+            base.mul_(0.9).add_(rewards.mean(dim=0), alpha=0.1)        # in place: also valid under --graph replays
             return loss.detach()
     elif args.mode == "stream":
         # host -> host: every step ships the batch again (packed pinned staging, one H2D, packed scoring, one D2H), two slots deep
@@ -305,6 +306,27 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    graph = None
+    if args.graph:
+        # --graph: the whole step (forward, loss, autograd backward, optimiser; Bernoulli draws through torch's graph-safe Philox
+        # state) is captured once into a HIP graph and REPLAYED: the launch-bound phases (the ~80 small kernels of a REINFORCE step)
+        # no longer wait for the host.  Every libsumk entry point only enqueues on the caller's stream, so it captures as is.
+        assert run_step is not None and dist is None, "--graph: single-process step modes only"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                run_step()                      # allocator pools, workspace cache, one-time function attributes
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = run_step()
+        eager_step = run_step
+        def run_step():
+            graph.replay()
+            return graph_out
 
     if run_step is None:
         s = run_steps(args.warmup)
@@ -445,6 +467,8 @@ def main():
                                frames_per_step_per_gpu=frames, parallelism=f"video-sharded x{world}"),
                    whole_path_tflops=round(frames * world * args.steps / elapsed * flops_frame / 1e12, 2),
                    roofline=roof)
+        if graph is not None:
+            out["config"]["hip_graph"] = "step captured once, timed region = graph replays"
         if step_ms is not None:
             out["step_ms_device_events"] = step_ms
         if kern:

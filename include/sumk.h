@@ -273,6 +273,14 @@ int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq
 int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
+/* The same step with NOTHING on the host: `state` is a 16-byte device block the caller zeroes once -- state[0] (int32) counts
+ * the optimiser steps and is incremented by the call, state[1..3] are scratch -- so the bias correction follows a counter that
+ * lives on the device, and when `sumsq` (device scalar from sumk_sumsq: the squared L2 norm of the UNscaled gradient) is
+ * given, torch.nn.utils.clip_grad_norm_(params, max_norm) (dsn.py:145) is folded in without reading the norm back.  No host
+ * synchronisation, captures into a HIP graph and replays with the right step count.  Same arithmetic as sumk_adam_step. */
+int sumk_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t* state,
+                       float grad_scale, const float* sumsq, float max_norm, void* stream);
 /* out[0] += sum of squares of a flat buffer (for clip_grad_norm_), deterministic two-stage reduction.
  * workspace: sumk_sumsq_workspace_bytes() bytes of device scratch. */
 size_t sumk_sumsq_workspace_bytes(void);

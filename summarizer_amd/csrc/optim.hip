@@ -9,9 +9,13 @@ namespace sumk {
 
 // torch (non-amsgrad, maximize=False):  g = grad*grad_scale + wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// dyn != nullptr: step size, bias correction and gradient scale come from the device block adam_prep_kernel wrote (the
+// sync-free / graph-capturable form: the step counter and the clip coefficient never visit the host).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float step_size, float inv_sqrt_bc2, float grad_scale) {
+                                                   float wd, float step_size, float inv_sqrt_bc2, float grad_scale,
+                                                   const float* __restrict__ dyn) {
+  if (dyn != nullptr) { step_size = dyn[1]; inv_sqrt_bc2 = dyn[2]; grad_scale = dyn[3]; }
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -34,6 +38,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mi; v[i] = vi;
     p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
   }
+}
+
+// state[0] (int32): optimiser steps taken so far, incremented here; state[1..3] (float): lr / (1 - b1^t), 1 / sqrt(1 - b2^t) and
+// the effective gradient scale = grad_scale * min(1, max_norm / (sqrt(sumsq) * grad_scale + 1e-6)) -- torch's clip_grad_norm_ --
+// all in double like the host path of sumk_adam_step.
+__global__ void adam_prep_kernel(int32_t* state, float lr, float b1, float b2, float grad_scale, const float* sumsq, float max_norm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int step = state[0] + 1;
+  state[0] = step;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  float* f = reinterpret_cast<float*>(state);
+  f[1] = (float)((double)lr / bc1);
+  f[2] = (float)(1.0 / sqrt(bc2));
+  double gs = (double)grad_scale;
+  if (sumsq != nullptr) {
+    const double norm = sqrt((double)sumsq[0]) * (double)grad_scale;
+    const double coef = fmin(1.0, (double)max_norm / (norm + 1e-6));
+    gs = (double)grad_scale * coef;
+  }
+  f[3] = (float)gs;
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
@@ -105,7 +130,21 @@ extern "C" int sumk_adam_step(float* param, const float* grad, float* exp_avg, f
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                     beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
+                     beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale, (const float*)nullptr);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+extern "C" int sumk_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int32_t* state, float grad_scale,
+                                  const float* sumsq, float max_norm, void* stream) {
+  SUMK_ARG(param && grad && exp_avg && exp_avg_sq && state, "adam_dev: null pointer");
+  SUMK_ARG(n > 0, "adam_dev: n=%lld", (long long)n);
+  SUMK_ARG(sumsq == nullptr || max_norm > 0.f, "adam_dev: max_norm=%g with a norm given", (double)max_norm);
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2, grad_scale, sumsq, max_norm);
+  int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, weight_decay, 0.f, 0.f, 0.f, (const float*)state);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

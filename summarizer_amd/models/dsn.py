@@ -107,14 +107,19 @@ class DSNTrainer(Trainer):
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
         my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
 
-        baselines = {key: 0. for key in my_keys}                         # dsn.py:81
-        reward_writers = {key: [] for key in my_keys}                    # dsn.py:84
+        # dsn.py:81,84: per-video moving-average baselines and the last reward of every video -- kept ON THE DEVICE (float64 like the
+        # reference's Python floats) so that a training step never synchronises with the host: the reference reads E rewards
+        # back per video, round 1 of this mirror read one vector per step
+        key_index = {key: i for i, key in enumerate(my_keys)}
+        baselines = torch.zeros(max(len(my_keys), 1), dtype=torch.float64, device=dev)
+        last_reward = torch.full((max(len(my_keys), 1),), float("nan"), dtype=torch.float64, device=dev)
         best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
         E = self.num_episodes
 
         for epoch in range(self.hps.epochs):
             losses, dist_scores = [], {}
             random.shuffle(my_keys)
+            order = torch.tensor([key_index[k] for k in my_keys], dtype=torch.int64).to(dev) if my_keys else None   # one H2D per epoch
             for step in range(steps_per_epoch):
                 keys = my_keys[step * bv:(step + 1) * bv]
                 self.optimizer.zero_grad()
@@ -124,13 +129,14 @@ class DSNTrainer(Trainer):
                     x = torch.cat([v[0] for v in vids]) if len(vids) > 1 else vids[0][0]
                     sb = kernels.SeqBatch.get(lens_b, dev)
                     probs = self.model.score_packed(x, lens_b)            # (sum T,)
-                    dist = Bernoulli(probs)
+                    dist = Bernoulli(probs, validate_args=False)          # (argument validation is a D2H sync; probs come from the sigmoid kernel)
                     actions = self._sample_actions(dist, E, keys)         # (E, sum T)   dsn.py:125
                     log_probs = dist.log_prob(actions)                    # dsn.py:126
                     rewards = kernels.dsn_reward(x, sb, actions.contiguous(), far_sim=self.far_sim,
                                                  temp_dist_thre=self.temp_dist_thre)       # (E, n_videos)  dsn.py:129-131
                     off = np.concatenate([[0], np.cumsum(lens_b)])
-                    base = torch.tensor([baselines[k] for k in keys], dtype=torch.float32, device=dev)
+                    idx = order[step * bv:step * bv + len(keys)]
+                    base = baselines[idx].float()
                     # all videos of the step at once (per-video means via SeqBatch.segment_mean); for one video this is
                     # exactly dsn.py:115-140
                     l_v = self.beta * (sb.segment_mean(probs) - self.eps) ** 2                      # dsn.py:115   (n_videos,)
@@ -146,14 +152,13 @@ class DSNTrainer(Trainer):
                         dist_scores[k] = probs[off[i]:off[i + 1]].detach().view(-1, 1, 1)
                     loss.backward()
                     losses.append(loss.detach())
-                    mean_r = rewards.mean(dim=0).tolist()                 # one D2H per step (the reference does E per video)
-                    for i, k in enumerate(keys):
-                        baselines[k] = 0.9 * baselines[k] + 0.1 * mean_r[i]                 # dsn.py:149
-                        reward_writers[k].append(mean_r[i])
+                    mean_r = rewards.detach().mean(dim=0).double()
+                    baselines.index_copy_(0, idx, 0.9 * baselines[idx] + 0.1 * mean_r)     # dsn.py:149
+                    last_reward.index_copy_(0, idx, mean_r)
                 scale = self.optimizer.all_reduce_grads(average=False)
                 self.optimizer.step(grad_scale=scale, max_norm=5.0)       # clip_grad_norm_(…, 5.0) dsn.py:145, post all-reduce
 
-            epoch_avg_reward = float(np.mean([reward_writers[k][-1] for k in my_keys if reward_writers[k]])) if my_keys else float("nan")
+            epoch_avg_reward = float(torch.nanmean(last_reward)) if my_keys else float("nan")      # the epoch's host sync
             epoch_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")
             kernels.health_check()               # the epoch's host sync: did any persistent recurrence kernel time out?
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Reward: {epoch_avg_reward:.05f}  Loss: {epoch_avg_loss:.05f}")

@@ -159,6 +159,7 @@ class FlatAdam:
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._state = torch.zeros(4, dtype=torch.int32, device=dev)     # [0]: steps taken, kept on the device (sumk_adam_step_dev)
         self._side, self._tail_from = None, None      # side stream / split point of an in-flight early all-reduce
         # mixed-precision mode: the gradient bucket crosses the all-reduce as bf16 (half the bytes over xGMI); the fp32 bucket,
         # the moments and the master weights stay fp32.  The bf16 staging buffer exists only under torch.distributed.
@@ -245,14 +246,17 @@ class FlatAdam:
 
     def step(self, grad_scale=1.0, max_norm=None):
         """grad_scale: multiplies the gradient first (1/world_size of a DP average).  max_norm: clip_grad_norm_
-        semantics applied AFTER the all-reduce, on the averaged gradient (torch: coef = max_norm/(norm+1e-6), clamped to 1)."""
+        semantics applied AFTER the all-reduce, on the averaged gradient (torch: coef = max_norm/(norm+1e-6), clamped to 1).
+        The step counter and the clip coefficient stay on the device (sumk_adam_step_dev): no host synchronisation, so a whole
+        training step enqueues without waiting and can be captured into a HIP graph (the replays advance the counter)."""
+        sumsq = None
         if max_norm is not None:
-            norm = self.grad_norm(grad_scale)
-            coef = min(1.0, max_norm / (norm + 1e-6))
-            grad_scale = grad_scale * coef
-        self.step_count += 1
-        kernels.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                          self.betas, self.eps, self.weight_decay, grad_scale)
+            self._norm.zero_()
+            kernels.sumsq(self.flat_grad, out=self._norm)
+            sumsq = self._norm
+        self.step_count += 1          # host mirror (not advanced by graph replays; the device counter in _state[0] is authoritative)
+        kernels.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._state, self.lr, self.betas,
+                              self.eps, self.weight_decay, grad_scale, sumsq, 0.0 if max_norm is None else max_norm)
 
 
 def broadcast_parameters(model, src=0):

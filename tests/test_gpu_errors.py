@@ -191,3 +191,51 @@ def test_scoring_call_is_hip_graph_capturable(monkeypatch):
                 graph.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(static_out, eager[k]), (type(m).__name__, k)
+
+
+def test_training_step_is_hip_graph_capturable_and_replays_advance_adam(monkeypatch):
+    """A whole training step -- forward, loss, autograd backward through the libsumk Functions, grad-norm clip and Adam -- has no
+    host synchronisation (the optimiser's step counter and clip coefficient live on the device: sumk_adam_step_dev), so it can be
+    captured into a HIP graph: one eager step + three replays must leave exactly the weights of four eager steps."""
+    from summarizer_amd import kernels
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.training import FlatAdam
+    monkeypatch.setattr(kernels, "CHECK_LSTM", False)
+    dev = torch.device("cuda:0")
+    D, lens = 128, [40, 3, 77, 18]
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 70 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    target = torch.rand(sum(lens), generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def make():
+        torch.manual_seed(11)
+        m = DSN(input_size=D, hidden_size=48).to(dev)
+        return m, FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+
+    def step(m, opt):
+        opt.zero_grad()
+        loss = torch.mean((m.score_packed(x, lens) - target) ** 2) * 50.0      # large enough for the 0.05 clip to bite
+        loss.backward()
+        opt.step(max_norm=0.05)
+        return loss.detach()
+
+    ma, oa = make()
+    eager = [float(step(ma, oa)) for _ in range(4)]
+    mb, ob = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        first = step(mb, ob)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step(mb, ob)
+    got = [float(first)]
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        got.append(float(out))
+    assert got == eager, (got, eager)
+    assert int(ob._state[0]) == 4                                             # the device-side step counter followed the replays
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), k
