@@ -396,12 +396,12 @@ def main():
     kern = None
     if args.model == "vasnet" and args.mode == "score" and run_step is not None and not args.headline_only:
         tags = {"qkt": _lib.PROF_GEMM_QKT, "alpha_v": _lib.PROF_GEMM_PV, "out_proj": _lib.PROF_GEMM_OPROJ, "k1": _lib.PROF_GEMM_K1}
-        for t in tags.values():
+        for t in tags.values():                      # one tag per pass: every extra event pair in a step costs the others ~10 us
             lib.sumk_prof_read(t, None, None, 1)
-        lib.sumk_prof_enable(sum(1 << t for t in tags.values()))
-        for _ in range(10):
-            run_step()
-        torch.cuda.synchronize()
+            lib.sumk_prof_enable(1 << t)
+            for _ in range(10):
+                run_step()
+            torch.cuda.synchronize()
         lib.sumk_prof_enable(0)
         sq = float(sum(t * t for t in lens))
         fl = {"qkt": 2.0 * sq * D, "alpha_v": 2.0 * sq * D, "out_proj": 2.0 * frames * D * D, "k1": 2.0 * frames * D * D}
