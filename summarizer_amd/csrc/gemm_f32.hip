@@ -246,6 +246,10 @@ int colsum_multi(const float* X, int ld, int R, int N, float* partial, int max_c
   return partial_reduce_multi(partial, chunks, N, segs, nseg, stream);
 }
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream) {
+  if (N % 4 == 0) {     // the float4 pass + the one-launch reduce
+    const ReduceSeg seg = {0, N, out};
+    return colsum_multi(X, ld, R, N, partial, max_chunks, &seg, 1, stream);
+  }
   int chunks = std::max(1, std::min(max_chunks, (R + 63) / 64));
   int rpc = (R + chunks - 1) / chunks;
   chunks = (R + rpc - 1) / rpc;
