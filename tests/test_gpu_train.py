@@ -148,6 +148,7 @@ def test_dsn_bce_grads_golden(dev):
                                               ("slstm", 64, 264, 2, [21, 40, 2, 1] + [3] * 64),   # H > 256: wide persistent forward, > 64 videos
                                               ("slstm", 64, 264, 2, [21, 40, 2, 1, 9]),            # H > 256, few videos: small-batch mat-vec BPTT
                                               ("slstm", 64, 384, 2, [21, 40, 2, 1] + [3] * 64 + [17] * 63),   # wide persistent BPTT: KG 12 x NG 2, 3 groups (ragged, last partial)
+                                              ("slstm", 64, 512, 1, [9, 30, 1, 14, 22, 5, 17, 3, 30, 11, 8, 2]),      # wide persistent BPTT, one MFMA tile (9 < videos <= 32), KG 16 x NG 2
                                               ("slstm", 128, 1024, 2, [int(v) for v in np.random.default_rng(9).integers(1, 70, 50)])])   # wide persistent BPTT at sLSTM's H: 32 x 4 members per direction
 def test_bilstm_grads_vs_torch_port_ragged_batch(dev, kind, D, H, L, lens, precision, gtol):
     from oracle import torch_port
