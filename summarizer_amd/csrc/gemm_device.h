@@ -131,6 +131,56 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
   }
 }
 
+// Sum over the 16 lanes of a DPP row, left in every lane of the row: four VALU adds with DPP operands (quad xor 1, quad xor 2,
+// mirror within 8, mirror within 16) -- no LDS crossbar traffic (a __shfl_xor butterfly is five ds_bpermute round trips).
+__device__ __forceinline__ float dpp_row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// EPI_BIAS_RELU_HEAD: the wave's 64-column slice of relu(acc + bias) is reduced per row to the three moments of the fused
+// LayerNorm + head tail and written as ONE float4 per (row, 16-column slot) -- slot = (32-column MFMA tile, 16-lane DPP row): the
+// activations themselves never leave registers.  (First version: xor-shuffle butterflies over the 32-lane half, 480 ds_bpermute
+// per wave and tile -- the epilogue cost more than storing the tile did.)
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_head_moments(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
+                                                      int col0, int li, int lh) {
+  static_assert(TN == 2, "head epilogue: a wave covers one 64-column slot");
+  float bias[TN], gw[TN];
+  bool colok[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = col0 + tn * 32 + li;
+    colok[tn] = col < cur.N;
+    const int cc = colok[tn] ? col : 0;
+    bias[tn] = ka.bias0[0][cc];
+    gw[tn] = ka.bias1[0][cc] * ka.bias1[1][cc];
+  }
+  // slots per row: N / 32 (the wave's two 32-column tiles are added in-lane first) x 2 DPP rows of 16 lanes
+  const int slots = cur.N >> 5, slot = (col0 >> 5) + (li >> 4);
+  float4* part = reinterpret_cast<float4*>(ka.C);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        float v = acc[tm][tn][r] + bias[tn];
+        v = (v < 0.f) ? 0.f : v;          // NaN-propagating like torch.relu
+        if (!colok[tn]) v = 0.f;
+        s1 += v; s2 += v * v; s3 += v * gw[tn];
+      }
+      s1 = dpp_row_sum16(s1); s2 = dpp_row_sum16(s2); s3 = dpp_row_sum16(s3);
+      const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if ((li & 15) == 0 && row < cur.M) part[(int64_t)row * slots + slot] = make_float4(s1, s2, s3, 0.f);
+    }
+  }
+}
+
 // EPI_RESIDUAL with the residual read at the START of a tile: the accumulators begin at R instead of zero, so the 64 KB read of
 // a 128 x 128 tile overlaps the first operand loads instead of joining the store burst at the end (where every co-resident
 // block of a single-round launch reads and writes at once).  Same C/D map as epilogue_store; rows / columns outside the problem

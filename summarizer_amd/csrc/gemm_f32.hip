@@ -50,7 +50,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
-  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && gemm_dma_enabled()) {   // opt-in (SUMK_GEMM_DMA=1): LDS-DMA staging (gemm_dma.hip)
+  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && epi != EPI_BIAS_RELU_HEAD && gemm_dma_enabled()) {   // opt-in (SUMK_GEMM_DMA=1): LDS-DMA staging (gemm_dma.hip)
     rc = launch_gemm_dma(layout, epi, ka, ka.total_tiles, g.small_tile, stream);
     prof_end(SUMK_PROF_GEMM_ALL, stream);
     if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);

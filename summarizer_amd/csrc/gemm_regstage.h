@@ -321,6 +321,9 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     // ---- epilogue of `cur` (gemm_device.h)
     unsigned long long tb = 0;
     if (ka.dbg & 2) tb = __builtin_amdgcn_s_memtime();
+    if constexpr (EPI == EPI_BIAS_RELU_HEAD) {
+      epilogue_head_moments<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+    } else
     if (!(ka.dbg & 1) || acc[0][0][0] == 12345.f)
     epilogue_store<EPI, TM, TN, true>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
     if (ka.dbg & 2) { const unsigned long long tc = __builtin_amdgcn_s_memtime(); t_k += tb - ta; t_e += tc - tb; n_t += 1; }
@@ -348,6 +351,10 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
     case EPI_BIAS2: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS2, X3>), grid, block, 0, s, ka); break;
     case EPI_ACCUM: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_ACCUM, X3>), grid, block, 0, s, ka); break;
     case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RESIDUAL, X3>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RELU_HEAD:
+      if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC) {
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RELU_HEAD, X3>), grid, block, 0, s, ka); break;
+      } else { set_error("gemm: the head epilogue exists for 128x128 NT tiles only"); return SUMK_ERR_ARG; }
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;

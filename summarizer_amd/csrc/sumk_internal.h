@@ -44,6 +44,10 @@ enum GemmEpi {
   EPI_BIAS2 = 3,      // C = acc + bias0[col] + bias1[col]
   EPI_ACCUM = 4,      // C += alpha*acc   (gradient accumulation)
   EPI_BIAS_RESIDUAL = 5,  // C = acc + bias0[col] + R
+  // v = relu(acc + bias0[col]) is NOT stored: per row and slot (N / 32 slots) the kernel writes {sum v, sum v^2, sum v * bias1[0][col] *
+  // bias1[1][col], 0} to C viewed as float4[M][N / 32] -- the moments a LayerNorm + dot-product head over the row needs (VASNet
+  // inference tail: k1 + ReLU + LayerNorm + k2 in one pass, vasnet.hip head_finalize_kernel).  128x128 NT tiles, N % 64 == 0.
+  EPI_BIAS_RELU_HEAD = 6,
 };
 
 struct GemmLaunch {

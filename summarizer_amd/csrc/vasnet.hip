@@ -393,6 +393,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
+// Tail of the fused inference path (k1 GEMM with EPI_BIAS_RELU_HEAD): per row the N / 32 slot moments {sum z, sum z^2, sum z g w2}
+// are added (double) and  score = sigmoid( rstd (S3 - mean GW) + BW + b2 ),  mean = S1 / D, rstd = 1 / sqrt(S2 / D - mean^2 + eps),
+// GW = sum g w2, BW = sum b w2  -- algebraically the LayerNorm + k2 of layernorm_kernel<true>, without ever storing z.
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float4* __restrict__ part, int slots, int n_rows, int D,
+                                                            const float* __restrict__ g, const float* __restrict__ b,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2, float eps,
+                                                            float* __restrict__ scores) {
+  __shared__ double red[2][4];
+  double gw = 0.0, bw = 0.0;
+  for (int c = threadIdx.x; c < D; c += 256) { const double w = (double)w2[c]; gw += (double)g[c] * w; bw += (double)b[c] * w; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { gw += __shfl_xor(gw, m, 64); bw += __shfl_xor(bw, m, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = gw; red[1][threadIdx.x >> 6] = bw; }
+  __syncthreads();
+  gw = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  bw = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  // 8 lanes per row (32 rows per block): each adds every 8th slot, then a 3-step butterfly inside the 8-lane group
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (row < n_rows)
+    for (int k = sub; k < slots; k += 8) { const float4 p = part[(int64_t)row * slots + k]; s1 += p.x; s2 += p.y; s3 += p.z; }
+#pragma unroll
+  for (int m = 1; m <= 4; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); s3 += __shfl_xor(s3, m, 64); }
+  if (row >= n_rows || sub != 0) return;
+  const double mean = s1 / D, var = s2 / D - mean * mean;
+  const double rstd = 1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps);
+  const double pre = rstd * (s3 - mean * gw) + bw + (double)b2[0];
+  scores[row] = (float)(1.0 / (1.0 + exp(-pre)));
+}
+
 // one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
 template <bool HEAD>
 static void launch_ln_rows(const float* X, float* Y, const float* g, const float* b, const float* w2, const float* b2, float* scores,
@@ -745,6 +775,22 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   }
   // 6: dropout + LayerNorm
   launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
+  // 7 + 8 fused (inference, 128x128 tiles): k1 + bias + ReLU with the LayerNorm + k2 moments taken in the GEMM epilogue -- the
+  // (R, D) activation matrix is neither written (49 MB in the lock-stepped store burst of this single-round launch) nor read
+  // back by a LayerNorm kernel.  SUMK_FUSED_HEAD=0 keeps the two-kernel form (A/B switch; training always uses it).
+  static const bool fused_head_on = !(getenv("SUMK_FUSED_HEAD") && getenv("SUMK_FUSED_HEAD")[0] == '0');
+  if (fused_head_on && !training && !planes && drop.thr == 0 && G.st_d == 0 && D % 64 == 0) {
+    GemmLaunch g; g.precision = opts->precision;
+    g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.bias1[0] = w->ln_w; g.bias1[1] = w->w2;
+    g.C = Z;                       // reused as float4[R][D / 32] moments (R * D / 8 floats of the R * D region)
+    g.probs = prow + RP_DD; g.small_tile = 0;
+    g.total_tiles = gemm_tiles(R, D, 0); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
+    SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU_HEAD, g, stream));
+    hipLaunchKernelGGL(head_finalize_kernel, dim3((R + 31) / 32), dim3(256), 0, stream, (const float4*)Z, D / 32, R, D, w->ln_w,
+                       w->ln_b, w->w2, w->b2, opts->eps, scores);
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   {  // 7: k1 + bias + ReLU
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
