@@ -155,7 +155,11 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   SUMK_ARG(slab_elems >= (size_t)M * N, "splitk: slab too small");
   const int small = gemm_tiles(M, N, 0) >= 64 ? 0 : 1;
   const int tiles = gemm_tiles(M, N, small);
-  int S = (1024 + tiles - 1) / tiles;
+  // K slices so that S x tiles fills the resident slots of the persistent grid ONCE (768 blocks of the 128x128 kernel, 2048 of the
+  // 64x64 one): every block then walks exactly one (long) tile.  The first version aimed at >= 1024 tiles: 1152 for the QKV
+  // weight gradient = one and a half rounds, the second half-empty (744 -> 6xx us), 1024 for the D x D ones.
+  const int slots = small ? 2048 : 768;
+  int S = std::max(1, slots / tiles);
   S = std::min(S, (K + 63) / 64);
   S = std::min(S, (int)std::min<size_t>(slab_elems / ((size_t)M * N), (size_t)probs_cap));
   S = std::max(S, 1);
