@@ -267,6 +267,7 @@ def main():
         from torch.distributions import Bernoulli
         from summarizer_amd import kernels
         from summarizer_amd.training import FlatAdam
+        from summarizer_amd.autograd import PolicyLossFunction
         opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
         sb = kernels.SeqBatch.get(lens, dev)
         base = torch.zeros(len(lens), device=dev)
@@ -276,7 +277,7 @@ def main():
             dist_ = Bernoulli(probs, validate_args=False)          # (validation is a D2H sync per step)
             actions = dist_.sample((5,))
             rewards = kernels.dsn_reward(x, sb, actions.contiguous())
-            loss = (-(sb.segment_mean(dist_.log_prob(actions)) * (rewards - base)).sum(dim=0) / 5.0).mean()
+            loss = PolicyLossFunction.apply(probs, sb, actions, rewards, base, 0.01, 0.5).mean()    # dsn.py:113-140 in two HIP kernels
             loss.backward()
             opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
             base.mul_(0.9).add_(rewards.mean(dim=0), alpha=0.1)        # in place: also valid under --graph replays

@@ -264,6 +264,18 @@ size_t sumk_dsn_reward_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* 
 int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host,
                     const int32_t* seq_off_dev, const float* actions, int32_t n_episodes, int32_t far_sim,
                     int32_t temp_dist_thre, float* reward, void* workspace, size_t workspace_bytes, void* stream);
+/* The loss glue of DSNTrainer.train for a packed batch (dsn.py:113-140), per video v:
+ *   loss_per_video[v] = [ beta (mean_t p_t - eps_target)^2 - sum_e (rewards[e,v] - base[v]) mean_t log P(actions[e,t] | p_t) ] / E
+ * with torch.distributions.Bernoulli's log_prob (probabilities clamped to [eps, 1 - eps], eps = float32 epsilon), and its
+ * gradient w.r.t. the probabilities given dloss_per_video.  actions (E, n_rows), rewards (E, n_seq), base (n_seq); mean_probs
+ * (n_seq) is written by the forward and read by the backward.  E <= 16.  The supervised BCE term of `sup=True` stays outside. */
+int sumk_dsn_policy_loss_forward(const float* probs, const float* actions, const float* rewards, const float* base,
+                                 int32_t n_seq, int32_t n_rows, const int32_t* seq_off_dev, int32_t n_episodes,
+                                 float beta, float eps_target, float* loss_per_video, float* mean_probs, void* stream);
+int sumk_dsn_policy_loss_backward(const float* probs, const float* actions, const float* rewards, const float* base,
+                                  const float* mean_probs, const float* dloss_per_video, int32_t n_seq, int32_t n_rows,
+                                  const int32_t* seq_off_dev, int32_t n_episodes, float beta, float eps_target,
+                                  float* dprobs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ optimiser
  * torch.optim.Adam(lr, betas, eps, weight_decay) exactly as the trainers construct it (vasnet.py:181,

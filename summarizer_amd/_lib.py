@@ -128,6 +128,10 @@ _SIGS = {
     "sumk_dsn_reward_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_dsn_reward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, c_f32p, C.c_int32, C.c_int32,
                                   C.c_int32, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sumk_dsn_policy_loss_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_float,
+                                               C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    "sumk_dsn_policy_loss_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p,
+                                                C.c_int32, C.c_float, C.c_float, c_f32p, C.c_void_p]),
     "sumk_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     "sumk_adam_step_dev": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,

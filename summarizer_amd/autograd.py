@@ -238,3 +238,25 @@ class LstmDecoderFunction(torch.autograd.Function):
         ctx.ws = ctx.params = None
         return (None, None, dh0 if (has_h0 and ctx.needs_input_grad[2]) else None,
                 dc0 if (has_c0 and ctx.needs_input_grad[3]) else None) + tuple(ret)
+
+
+class PolicyLossFunction(torch.autograd.Function):
+    """DSNTrainer's REINFORCE loss glue for a packed batch in two HIP kernels (sumk_dsn_policy_loss_*, dsn.py:113-140):
+    (probs (n_rows,), actions (E, n_rows), rewards (E, n_seq), base (n_seq,)) -> loss per video (n_seq,), already divided by E.
+    Only `probs` receives a gradient (rewards and baselines are constants of the step, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, probs, sb, actions, rewards, base, beta, eps_target):
+        probs_c, actions_c = probs.contiguous(), actions.contiguous()
+        rewards_c, base_c = rewards.detach().contiguous(), base.detach().contiguous().float()
+        lv, mp = kernels.dsn_policy_loss_forward(probs_c, sb, actions_c, rewards_c, base_c, beta, eps_target)
+        ctx.save_for_backward(probs_c, actions_c, rewards_c, base_c, mp)
+        ctx.meta = (sb, beta, eps_target)
+        return lv
+
+    @staticmethod
+    def backward(ctx, dlv):
+        probs, actions, rewards, base, mp = ctx.saved_tensors
+        sb, beta, eps_target = ctx.meta
+        dprobs = kernels.dsn_policy_loss_backward(probs, sb, actions, rewards, base, mp, dlv, beta, eps_target)
+        return dprobs, None, None, None, None, None, None

@@ -152,3 +152,108 @@ extern "C" int sumk_dsn_reward(const float* x, int32_t D, int32_t n_seq, const i
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
+
+// ------------------------------------------------------------------------------------------- REINFORCE policy loss
+// The loss glue of DSNTrainer.train (dsn.py:113-140) for a packed batch, one block per video:
+//   l_v = [ beta * (mean_t p_t - eps_t)^2  -  sum_e (r[e,v] - b[v]) * mean_t log P(a[e,t] | p_t) ] / E
+// with log P = a log(pc) + (1 - a) log1p(-pc), pc = clamp(p, 2^-23 .., 1 - ..) -- torch.distributions.Bernoulli.log_prob
+// (probs_to_logits + binary_cross_entropy_with_logits) written out -- and its gradient w.r.t. p
+//   dl_v/dp_t = [ 2 beta (mean p - eps_t) - sum_e (r - b)[e,v] (a[e,t] - pc) / (pc (1 - pc)) * [p inside the clamp] ] / (E T_v).
+// As ~35 torch element-wise / reduction launches and their autograd twins this was 0.33 ms of a 4.5 ms REINFORCE step.
+namespace sumk {
+constexpr int PL_MAX_E = 16;
+constexpr float PL_EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps: clamp_probs
+
+__global__ __launch_bounds__(256) void policy_loss_fwd_kernel(const float* __restrict__ probs, const float* __restrict__ actions,
+                                                              const float* __restrict__ rewards, const float* __restrict__ base,
+                                                              const int32_t* __restrict__ off, int n_seq, int n_rows, int E,
+                                                              float beta, float eps_t, float* __restrict__ lv,
+                                                              float* __restrict__ meanp) {
+  __shared__ float red[4][PL_MAX_E + 1];
+  const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
+  float s[PL_MAX_E + 1];
+#pragma unroll
+  for (int e = 0; e <= PL_MAX_E; ++e) s[e] = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float p = probs[r0 + t];
+    const float pc = fminf(fmaxf(p, PL_EPS), 1.f - PL_EPS);
+    const float lp = logf(pc), lq = log1pf(-pc);
+    s[PL_MAX_E] += p;
+#pragma unroll
+    for (int e = 0; e < PL_MAX_E; ++e)
+      if (e < E) { const float a = actions[(int64_t)e * n_rows + r0 + t]; s[e] += a * lp + (1.f - a) * lq; }
+  }
+#pragma unroll
+  for (int e = 0; e <= PL_MAX_E; ++e) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s[e] += __shfl_xor(s[e], m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = s[e];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float invT = 1.f / (float)T;
+    const float mp = ((red[0][PL_MAX_E] + red[1][PL_MAX_E]) + (red[2][PL_MAX_E] + red[3][PL_MAX_E])) * invT;
+    float l = beta * (mp - eps_t) * (mp - eps_t);
+    for (int e = 0; e < E; ++e) {
+      const float lpm = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * invT;
+      l -= lpm * (rewards[(int64_t)e * n_seq + v] - base[v]);
+    }
+    lv[v] = l / (float)E;
+    meanp[v] = mp;
+  }
+}
+
+__global__ __launch_bounds__(256) void policy_loss_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ actions,
+                                                              const float* __restrict__ rewards, const float* __restrict__ base,
+                                                              const float* __restrict__ meanp, const float* __restrict__ dlv,
+                                                              const int32_t* __restrict__ off, int n_seq, int n_rows, int E,
+                                                              float beta, float eps_t, float* __restrict__ dprobs) {
+  __shared__ float adv[PL_MAX_E];
+  const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
+  if (threadIdx.x < E) adv[threadIdx.x] = rewards[(int64_t)threadIdx.x * n_seq + v] - base[v];
+  __syncthreads();
+  const float scale = dlv[v] / ((float)E * (float)T);
+  const float g0 = 2.f * beta * (meanp[v] - eps_t);
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float p = probs[r0 + t];
+    const float pc = fminf(fmaxf(p, PL_EPS), 1.f - PL_EPS);
+    const bool inside = p >= PL_EPS && p <= 1.f - PL_EPS;     // torch.clamp passes the gradient on its closed range
+    float g = g0;
+    if (inside) {
+      const float inv = 1.f / (pc * (1.f - pc));
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e) acc += adv[e] * (actions[(int64_t)e * n_rows + r0 + t] - pc);
+      g -= acc * inv;
+    }
+    dprobs[r0 + t] = g * scale;
+  }
+}
+}  // namespace sumk
+
+extern "C" int sumk_dsn_policy_loss_forward(const float* probs, const float* actions, const float* rewards, const float* base,
+                                            int32_t n_seq, int32_t n_rows, const int32_t* seq_off_dev, int32_t n_episodes,
+                                            float beta, float eps_target, float* loss_per_video, float* mean_probs,
+                                            void* stream) {
+  using namespace sumk;
+  SUMK_ARG(probs && actions && rewards && base && seq_off_dev && loss_per_video && mean_probs, "policy_loss_forward: null pointer");
+  SUMK_ARG(n_seq > 0 && n_rows > 0 && n_episodes > 0 && n_episodes <= PL_MAX_E, "policy_loss_forward: n_seq=%d n_rows=%d episodes=%d (max %d)",
+           n_seq, n_rows, n_episodes, PL_MAX_E);
+  hipLaunchKernelGGL(policy_loss_fwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, probs, actions, rewards, base, seq_off_dev,
+                     n_seq, n_rows, n_episodes, beta, eps_target, loss_per_video, mean_probs);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+extern "C" int sumk_dsn_policy_loss_backward(const float* probs, const float* actions, const float* rewards, const float* base,
+                                             const float* mean_probs, const float* dloss_per_video, int32_t n_seq, int32_t n_rows,
+                                             const int32_t* seq_off_dev, int32_t n_episodes, float beta, float eps_target,
+                                             float* dprobs, void* stream) {
+  using namespace sumk;
+  SUMK_ARG(probs && actions && rewards && base && mean_probs && dloss_per_video && seq_off_dev && dprobs, "policy_loss_backward: null pointer");
+  SUMK_ARG(n_seq > 0 && n_rows > 0 && n_episodes > 0 && n_episodes <= PL_MAX_E, "policy_loss_backward: n_seq=%d n_rows=%d episodes=%d (max %d)",
+           n_seq, n_rows, n_episodes, PL_MAX_E);
+  hipLaunchKernelGGL(policy_loss_bwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, probs, actions, rewards, base, mean_probs,
+                     dloss_per_video, seq_off_dev, n_seq, n_rows, n_episodes, beta, eps_target, dprobs);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}

@@ -353,6 +353,35 @@ def dsn_reward(x, sb, actions, far_sim=False, temp_dist_thre=20):
     return out
 
 
+def dsn_policy_loss_forward(probs, sb, actions, rewards, base, beta, eps_target):
+    """(loss_per_video (n_seq,), mean_probs (n_seq,)) of sumk_dsn_policy_loss_forward (include/sumk.h)."""
+    lib = _lib.load()
+    for t, what in ((probs, "probs"), (actions, "actions"), (rewards, "rewards"), (base, "base")):
+        _require_gpu(t, "dsn_policy_loss " + what)
+        if not t.is_contiguous():
+            raise SumkError(f"dsn_policy_loss: {what} must be contiguous")
+    E = actions.shape[0]
+    if probs.shape != (sb.n_rows,) or actions.shape != (E, sb.n_rows) or rewards.shape != (E, sb.n_seq) or base.shape != (sb.n_seq,):
+        raise SumkError(f"dsn_policy_loss: shapes probs {tuple(probs.shape)} actions {tuple(actions.shape)} rewards "
+                        f"{tuple(rewards.shape)} base {tuple(base.shape)} do not fit {sb.n_rows} rows / {sb.n_seq} videos")
+    lv = torch.empty(sb.n_seq, dtype=torch.float32, device=probs.device)
+    mp = torch.empty(sb.n_seq, dtype=torch.float32, device=probs.device)
+    rc = lib.sumk_dsn_policy_loss_forward(_p(probs), _p(actions), _p(rewards), _p(base), sb.n_seq, sb.n_rows, sb.off_dev_p, E,
+                                          float(beta), float(eps_target), _p(lv), _p(mp), _stream())
+    _lib.check(rc, "sumk_dsn_policy_loss_forward")
+    return lv, mp
+
+
+def dsn_policy_loss_backward(probs, sb, actions, rewards, base, mean_probs, dlv, beta, eps_target):
+    lib = _lib.load()
+    dlv = dlv.contiguous()
+    dprobs = torch.empty_like(probs)
+    rc = lib.sumk_dsn_policy_loss_backward(_p(probs), _p(actions), _p(rewards), _p(base), _p(mean_probs), _p(dlv), sb.n_seq, sb.n_rows,
+                                           sb.off_dev_p, actions.shape[0], float(beta), float(eps_target), _p(dprobs), _stream())
+    _lib.check(rc, "sumk_dsn_policy_loss_backward")
+    return dprobs
+
+
 # ------------------------------------------------------------------------------------------------ Transformer scorer
 TF_LAYER_FIELDS = (("in_proj_w", "self_attn.in_proj_weight"), ("in_proj_b", "self_attn.in_proj_bias"),
                    ("out_proj_w", "self_attn.out_proj.weight"), ("out_proj_b", "self_attn.out_proj.bias"),

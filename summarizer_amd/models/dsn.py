@@ -11,6 +11,7 @@ import torch.nn as nn
 from torch.distributions import Bernoulli
 
 from .. import kernels
+from ..autograd import PolicyLossFunction
 from .._lib import SumkError
 from . import Trainer
 from ._bilstm import pack_time_major, bilstm_scores, bigru_scores
@@ -131,21 +132,19 @@ class DSNTrainer(Trainer):
                     probs = self.model.score_packed(x, lens_b)            # (sum T,)
                     dist = Bernoulli(probs, validate_args=False)          # (argument validation is a D2H sync; probs come from the sigmoid kernel)
                     actions = self._sample_actions(dist, E, keys)         # (E, sum T)   dsn.py:125
-                    log_probs = dist.log_prob(actions)                    # dsn.py:126
                     rewards = kernels.dsn_reward(x, sb, actions.contiguous(), far_sim=self.far_sim,
                                                  temp_dist_thre=self.temp_dist_thre)       # (E, n_videos)  dsn.py:129-131
                     off = np.concatenate([[0], np.cumsum(lens_b)])
                     idx = order[step * bv:step * bv + len(keys)]
                     base = baselines[idx].float()
-                    # all videos of the step at once (per-video means via SeqBatch.segment_mean); for one video this is
-                    # exactly dsn.py:115-140
-                    l_v = self.beta * (sb.segment_mean(probs) - self.eps) ** 2                      # dsn.py:115   (n_videos,)
+                    # all videos of the step at once; for one video this is exactly dsn.py:115-140:
+                    #   l_v = [beta (mean p - eps)^2 (+ BCE) - sum_e mean_t log_prob(a_e) (r_e - b)] / E
+                    # the length penalty, Bernoulli.log_prob (dsn.py:126), the per-video means and the advantage product are two HIP
+                    # kernels (forward / backward: sumk_dsn_policy_loss_*) instead of ~35 element-wise launches and their autograd twins
+                    l_v = PolicyLossFunction.apply(probs, sb, actions, rewards, base, self.beta, self.eps)      # (n_videos,)
                     if self.sup:
                         target = torch.cat([v[1] for v in vids]) if len(vids) > 1 else vids[0][1]
-                        l_v = l_v + sb.segment_mean(torch.nn.functional.binary_cross_entropy(probs, target, reduction="none"))  # dsn.py:117-119
-                    lp = sb.segment_mean(log_probs)                                                  # (E, n_videos)
-                    l_v = l_v - (lp * (rewards - base)).sum(dim=0)                                   # dsn.py:134
-                    l_v = l_v / float(E)                                                             # dsn.py:140
+                        l_v = l_v + sb.segment_mean(torch.nn.functional.binary_cross_entropy(probs, target, reduction="none")) / float(E)  # dsn.py:117-119,140
                     # data-parallel: every video of the GLOBAL step weighs 1/n_total (see training.step_video_total)
                     loss = l_v.mean() if world == 1 else l_v.sum() / step_video_total(sizes, bv, step)
                     for i, k in enumerate(keys):

@@ -40,3 +40,39 @@ def test_reward_goldens_and_batch():
         for s, x in enumerate(xs):
             ref = reward_np.compute_reward(x, acts[e, off[s]:off[s + 1]])
             np.testing.assert_allclose(got[e, s], ref, atol=3e-5, rtol=1e-5, err_msg=f"ep {e} video {s}")
+
+
+def test_policy_loss_kernels_match_the_torch_ops_they_replace():
+    """sumk_dsn_policy_loss_forward/backward (through PolicyLossFunction) against the element-wise torch formulation of
+    dsn.py:113-140 -- Bernoulli.log_prob, per-video means, advantage product, length penalty, / E -- values and the gradient
+    w.r.t. the probabilities, on a ragged batch that includes probabilities exactly at 0 and 1 (clamped: zero log-prob gradient)."""
+    import torch
+    from torch.distributions import Bernoulli
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import PolicyLossFunction
+    dev = torch.device("cuda:0")
+    lens, E, beta, eps = [70, 1, 33, 129, 5], 5, 0.01, 0.5
+    sb = kernels.SeqBatch.get(lens, dev)
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.rand(sum(lens), generator=g) * 0.98 + 0.01
+    p0[3] = 0.0; p0[40] = 1.0; p0[75] = 1e-9
+    actions = (torch.rand(E, sum(lens), generator=g) < 0.4).float().to(dev)
+    rewards = torch.rand(E, len(lens), generator=g).to(dev)
+    base = torch.rand(len(lens), generator=g).to(dev)
+    w = torch.rand(len(lens), generator=g).to(dev)                       # a non-trivial upstream gradient per video
+
+    pa = p0.clone().to(dev).requires_grad_(True)
+    lv = PolicyLossFunction.apply(pa, sb, actions, rewards, base, beta, eps)
+    (lv * w).sum().backward()
+
+    pb = p0.clone().to(dev).requires_grad_(True)
+    dist = Bernoulli(pb, validate_args=False)
+    ref = beta * (sb.segment_mean(pb) - eps) ** 2 - (sb.segment_mean(dist.log_prob(actions)) * (rewards - base)).sum(dim=0)
+    ref = ref / float(E)
+    (ref * w).sum().backward()
+    torch.testing.assert_close(lv.detach(), ref.detach(), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(pa.grad, pb.grad, rtol=2e-4, atol=1e-6)
+    # at p = 0 and p = 1 (clamped) only the length-penalty term is left: w_v * 2 beta (mean p - eps) / (E T_v)
+    mp = sb.segment_mean(pb.detach())
+    want = (w * 2 * beta * (mp - eps) / (E * torch.tensor(lens, dtype=torch.float32, device=dev)))[0]
+    torch.testing.assert_close(pa.grad[[3, 40]], want.expand(2), rtol=1e-5, atol=0)
