@@ -254,9 +254,12 @@ def main():
         from summarizer_amd.training import FlatAdam
         opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5, comm_dtype=torch.bfloat16 if args.precision == "bf16" else None)
         target = torch.rand(frames, device=dev)
+        from summarizer_amd import kernels as _k
+        from summarizer_amd.autograd import SegmentMseFunction
+        sb_t = _k.SeqBatch.get(lens, dev)
         def run_step():
             opt.zero_grad()
-            loss = torch.mean((model.score_packed(x, lens) - target) ** 2)
+            loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()   # the trainers' loss: mean over videos of nn.MSELoss per video
             loss.backward()
             opt.step(grad_scale=opt.all_reduce_grads())
             return loss.detach()
@@ -430,9 +433,12 @@ def main():
         opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
         opt.broadcast()
         target = torch.rand(frames, device=dev)
+        from summarizer_amd import kernels as _k
+        from summarizer_amd.autograd import SegmentMseFunction
+        sb_t = _k.SeqBatch.get(lens, dev)
         def train_step():
             opt.zero_grad()
-            loss = torch.mean((model.score_packed(x, lens) - target) ** 2)
+            loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()
             loss.backward()
             opt.step(grad_scale=opt.all_reduce_grads())
             return loss.detach()

@@ -276,6 +276,12 @@ int sumk_dsn_policy_loss_backward(const float* probs, const float* actions, cons
                                   const float* mean_probs, const float* dloss_per_video, int32_t n_seq, int32_t n_rows,
                                   const int32_t* seq_off_dev, int32_t n_episodes, float beta, float eps_target,
                                   float* dprobs, void* stream);
+/* nn.MSELoss per video of a packed batch (vasnet.py:209, transformer.py:161): mse_per_video[v] = mean_t (scores_t - target_t)^2,
+ * and dscores_t = 2 (scores_t - target_t) / T_v * dmse_per_video[v]. */
+int sumk_segment_mse_forward(const float* scores, const float* target, int32_t n_seq, const int32_t* seq_off_dev,
+                             float* mse_per_video, void* stream);
+int sumk_segment_mse_backward(const float* scores, const float* target, const float* dmse_per_video, int32_t n_seq,
+                              const int32_t* seq_off_dev, float* dscores, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ optimiser
  * torch.optim.Adam(lr, betas, eps, weight_decay) exactly as the trainers construct it (vasnet.py:181,

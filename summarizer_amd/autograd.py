@@ -260,3 +260,32 @@ class PolicyLossFunction(torch.autograd.Function):
         sb, beta, eps_target = ctx.meta
         dprobs = kernels.dsn_policy_loss_backward(probs, sb, actions, rewards, base, mp, dlv, beta, eps_target)
         return dprobs, None, None, None, None, None, None
+
+
+class SegmentMseFunction(torch.autograd.Function):
+    """Per-video nn.MSELoss of a packed batch in two HIP kernels (sumk_segment_mse_*): (scores (n_rows,), target (n_rows,)) ->
+    (n_seq,).  Only `scores` receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, scores, target, sb):
+        from . import _lib
+        lib = _lib.load()
+        s, y = scores.contiguous(), target.detach().contiguous().float()
+        kernels._require_gpu(s, "segment_mse scores"); kernels._require_gpu(y, "segment_mse target")
+        if s.shape != (sb.n_rows,) or y.shape != (sb.n_rows,):
+            raise kernels.SumkError(f"segment_mse: scores {tuple(s.shape)} / target {tuple(y.shape)} do not fit {sb.n_rows} rows")
+        out = torch.empty(sb.n_seq, dtype=torch.float32, device=s.device)
+        _lib.check(lib.sumk_segment_mse_forward(kernels._p(s), kernels._p(y), sb.n_seq, sb.off_dev_p, kernels._p(out), kernels._stream()),
+                   "sumk_segment_mse_forward")
+        ctx.save_for_backward(s, y)
+        ctx.sb = sb
+        return out
+
+    @staticmethod
+    def backward(ctx, dmse):
+        from . import _lib
+        s, y = ctx.saved_tensors
+        ds = torch.empty_like(s)
+        _lib.check(_lib.load().sumk_segment_mse_backward(kernels._p(s), kernels._p(y), kernels._p(dmse.contiguous()), ctx.sb.n_seq,
+                                                         ctx.sb.off_dev_p, kernels._p(ds), kernels._stream()), "sumk_segment_mse_backward")
+        return ds, None, None

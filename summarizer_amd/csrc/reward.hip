@@ -257,3 +257,44 @@ extern "C" int sumk_dsn_policy_loss_backward(const float* probs, const float* ac
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
+
+// ------------------------------------------------------------------------------------------- per-video MSE
+// nn.MSELoss of every video of a packed batch (vasnet.py:209, transformer.py:161): mse[v] = mean_t (s_t - y_t)^2 and
+// ds_t = 2 (s_t - y_t) / T_v * dmse[v].  One block per video; replaces sub / pow / index_add / div and their autograd twins.
+namespace sumk {
+__global__ __launch_bounds__(256) void segment_mse_fwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
+                                                              const int32_t* __restrict__ off, float* __restrict__ mse) {
+  __shared__ float red[4];
+  const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
+  float acc = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) { const float d = s[r0 + t] - y[r0 + t]; acc += d * d; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) mse[v] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)T;
+}
+__global__ __launch_bounds__(256) void segment_mse_bwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
+                                                              const float* __restrict__ dmse, const int32_t* __restrict__ off,
+                                                              float* __restrict__ ds) {
+  const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
+  const float c = 2.f * dmse[v] / (float)T;
+  for (int t = threadIdx.x; t < T; t += 256) ds[r0 + t] = c * (s[r0 + t] - y[r0 + t]);
+}
+}  // namespace sumk
+
+extern "C" int sumk_segment_mse_forward(const float* scores, const float* target, int32_t n_seq, const int32_t* seq_off_dev,
+                                        float* mse_per_video, void* stream) {
+  SUMK_ARG(scores && target && seq_off_dev && mse_per_video && n_seq > 0, "segment_mse_forward: bad argument");
+  hipLaunchKernelGGL(sumk::segment_mse_fwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, scores, target, seq_off_dev, mse_per_video);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+extern "C" int sumk_segment_mse_backward(const float* scores, const float* target, const float* dmse_per_video, int32_t n_seq,
+                                         const int32_t* seq_off_dev, float* dscores, void* stream) {
+  SUMK_ARG(scores && target && dmse_per_video && seq_off_dev && dscores && n_seq > 0, "segment_mse_backward: bad argument");
+  hipLaunchKernelGGL(sumk::segment_mse_bwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, scores, target, dmse_per_video,
+                     seq_off_dev, dscores);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from .. import kernels
+from ..autograd import SegmentMseFunction
 from . import Trainer
 from .vasnet import _sinusoid_table
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
@@ -160,7 +161,7 @@ class TransformerTrainer(Trainer):
                         x = vids[0][0] if len(vids) == 1 else torch.cat([v[0] for v in vids])
                         target = vids[0][1] if len(vids) == 1 else torch.cat([v[1] for v in vids])
                         scores = self.model.score_packed(x, lens_b)
-                        per_video = kernels.SeqBatch.get(lens_b, dev).segment_mean((scores - target) ** 2)   # MSE per video (transformer.py:161)
+                        per_video = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev))   # MSE per video (transformer.py:161)
                         loss = per_video.mean() if world == 1 else per_video.sum() / step_video_total(sizes, bv, step)
                         for k, piece in zip(keys, torch.split(scores.detach(), lens_b)):
                             dist_scores[k] = piece.view(-1, 1, 1)

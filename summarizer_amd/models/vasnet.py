@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from .. import kernels
+from ..autograd import SegmentMseFunction
 from . import Trainer
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
@@ -237,7 +238,7 @@ class VASNetTrainer(Trainer):
                         off = np.concatenate([[0], np.cumsum(lens_b)])
                         # mean over videos of the per-video MSE (== nn.MSELoss per video, vasnet.py:209, when bv == 1)
                         target = torch.cat([v[1] for v in vids]) if len(vids) > 1 else vids[0][1]
-                        per_video = kernels.SeqBatch.get(lens_b, dev).segment_mean((scores - target) ** 2)
+                        per_video = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev))
                         # world == 1: plain mean; data-parallel: every video of the GLOBAL step weighs 1/n_total (ranks whose
                         # shard has run out contribute nothing and the divisor shrinks with them)
                         loss = per_video.mean() if world == 1 else per_video.sum() / step_video_total(sizes, bv, step)

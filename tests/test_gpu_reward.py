@@ -76,3 +76,19 @@ def test_policy_loss_kernels_match_the_torch_ops_they_replace():
     mp = sb.segment_mean(pb.detach())
     want = (w * 2 * beta * (mp - eps) / (E * torch.tensor(lens, dtype=torch.float32, device=dev)))[0]
     torch.testing.assert_close(pa.grad[[3, 40]], want.expand(2), rtol=1e-5, atol=0)
+
+
+def test_segment_mse_kernels_match_torch():
+    import torch
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import SegmentMseFunction
+    dev = torch.device("cuda:0")
+    lens = [70, 1, 300, 33, 129]
+    sb = kernels.SeqBatch.get(lens, dev)
+    g = torch.Generator().manual_seed(8)
+    s0 = torch.rand(sum(lens), generator=g); y = torch.rand(sum(lens), generator=g).to(dev); w = torch.rand(len(lens), generator=g).to(dev)
+    a = s0.clone().to(dev).requires_grad_(True); b = s0.clone().to(dev).requires_grad_(True)
+    got = SegmentMseFunction.apply(a, y, sb); (got * w).sum().backward()
+    ref = sb.segment_mean((b - y) ** 2); (ref * w).sum().backward()
+    torch.testing.assert_close(got.detach(), ref.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-8)
