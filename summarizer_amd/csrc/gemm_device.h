@@ -25,6 +25,8 @@ struct GemmKArgs {
   float alpha;
   int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores, 2 = in-kernel cycle stamps
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
+  float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
+  const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
 };
 
 // Scalar reads of the problem table (CONSTANT address space + wave-uniform index -> s_load, lgkmcnt).  As vector loads they
@@ -113,7 +115,7 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
         float v = acc[tm][tn][r];
         float* cp = ka.C + cur.c_off + (int64_t)row * cur.ldc + col;
         if constexpr (EPI == EPI_NONE) v *= ka.alpha;
-        if constexpr (EPI == EPI_RESIDUAL && !RES_DONE) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
+        if constexpr ((EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_MOMENTS) && !RES_DONE) v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
         if constexpr (EPI == EPI_BIAS_RELU) {
           v += bsum; v = (v < 0.f) ? 0.f : v;   // NaN-propagating, like torch.relu
           if (ka.drop.thr) v = drop_apply(ka.drop, ka.drop_site, (uint64_t)row * (uint64_t)cur.N + (uint64_t)col, v);
@@ -145,12 +147,19 @@ __device__ __forceinline__ float dpp_row_sum16(float v) {
 // LayerNorm + head tail and written as ONE float4 per (row, 16-column slot) -- slot = (32-column MFMA tile, 16-lane DPP row): the
 // activations themselves never leave registers.  (First version: xor-shuffle butterflies over the 32-lane half, 480 ds_bpermute
 // per wave and tile -- the epilogue cost more than storing the tile did.)
+// lds_stats: block-shared scratch of >= 128 float2 (the operand staging area, free between two k-loops); m0: the tile's first row.
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_head_moments(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
-                                                      int col0, int li, int lh) {
+                                                      int col0, int li, int lh, float2* lds_stats, int m0, int tid) {
   static_assert(TN == 2, "head epilogue: a wave covers one 64-column slot");
-  float bias[TN], gw[TN];
+  float bias[TN], gw[TN], c1[TN];
   bool colok[TN];
+  const bool ln = ka.ln_stats != nullptr;      // kernel-uniform
+  if (ln) {   // {mean, rstd} of the tile's 128 rows: one coalesced load into LDS instead of 32 dependent broadcast loads per lane
+    __syncthreads();                           // every wave is done with the last k-tile's operands
+    if (tid < 128) lds_stats[tid] = reinterpret_cast<const float2*>(ka.ln_stats)[min(m0 + tid, cur.M - 1)];
+    __syncthreads();
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + tn * 32 + li;
@@ -158,6 +167,8 @@ __device__ __forceinline__ void epilogue_head_moments(const GemmKArgs& ka, const
     const int cc = colok[tn] ? col : 0;
     bias[tn] = ka.bias0[0][cc];
     gw[tn] = ka.bias1[0][cc] * ka.bias1[1][cc];
+    c1[tn] = 0.f;
+    if (ln) { c1[tn] = ka.ln_c1[cc]; bias[tn] += ka.ln_c2[cc]; }
   }
   // slots per row: N / 32 (the wave's two 32-column tiles are added in-lane first) x 2 DPP rows of 16 lanes
   const int slots = cur.N >> 5, slot = (col0 >> 5) + (li >> 4);
@@ -167,9 +178,14 @@ __device__ __forceinline__ void epilogue_head_moments(const GemmKArgs& ka, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      float mean = 0.f, rstd = 1.f;
+      if (ln) {
+        const float2 st = lds_stats[row0 - m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        mean = st.x; rstd = st.y;
+      }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        float v = acc[tm][tn][r] + bias[tn];
+        float v = rstd * (acc[tm][tn][r] - mean * c1[tn]) + bias[tn];
         v = (v < 0.f) ? 0.f : v;          // NaN-propagating like torch.relu
         if (!colok[tn]) v = 0.f;
         s1 += v; s2 += v * v; s3 += v * gw[tn];
@@ -177,6 +193,34 @@ __device__ __forceinline__ void epilogue_head_moments(const GemmKArgs& ka, const
       s1 = dpp_row_sum16(s1); s2 = dpp_row_sum16(s2); s3 = dpp_row_sum16(s3);
       const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if ((li & 15) == 0 && row < cur.M) part[(int64_t)row * slots + slot] = make_float4(s1, s2, s3, 0.f);
+    }
+  }
+}
+
+// EPI_RESIDUAL_MOMENTS: per row {sum v, sum v^2} of the wave's 64 columns, one float2 per (row, 16-lane DPP row), next to the
+// ordinary store of the tile (acc already holds acc + R: residual_init).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_row_moments(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
+                                                     int col0, int li, int lh) {
+  static_assert(TN == 2, "moments epilogue: a wave covers 64 columns");
+  bool colok[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) colok[tn] = col0 + tn * 32 + li < cur.N;
+  const int slots = cur.N >> 5, slot = (col0 >> 5) + (li >> 4);
+  float2* part = reinterpret_cast<float2*>(ka.moments);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const float v = colok[tn] ? acc[tm][tn][r] : 0.f;
+        s1 += v; s2 += v * v;
+      }
+      s1 = dpp_row_sum16(s1); s2 = dpp_row_sum16(s2);
+      const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if ((li & 15) == 0 && row < cur.M) part[(int64_t)row * slots + slot] = make_float2(s1, s2);
     }
   }
 }

@@ -41,6 +41,9 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   ka.dbg = dbg; ka.dbg_buf = nullptr;
   if (dbg & 2) ka.dbg_buf = gemm_stamp_buffer();   // diagnostic only (never on a product path)
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
+  ka.moments = g.moments; ka.ln_stats = g.ln_stats; ka.ln_c1 = g.ln_c1; ka.ln_c2 = g.ln_c2;
+  SUMK_ARG(epi != EPI_RESIDUAL_MOMENTS || g.moments, "gemm: the moments epilogue needs an output buffer");
+  SUMK_ARG(!g.ln_stats || (epi == EPI_BIAS_RELU_HEAD && g.ln_c1 && g.ln_c2), "gemm: ln_stats goes with the head epilogue and c1 / c2");
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
   static const bool xcd_map = !(getenv("SUMK_XCD_MAP") && getenv("SUMK_XCD_MAP")[0] == '0');
@@ -50,7 +53,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
-  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && epi != EPI_BIAS_RELU_HEAD && gemm_dma_enabled()) {   // opt-in (SUMK_GEMM_DMA=1): LDS-DMA staging (gemm_dma.hip)
+  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && epi != EPI_BIAS_RELU_HEAD && epi != EPI_RESIDUAL_MOMENTS && gemm_dma_enabled()) {   // opt-in (SUMK_GEMM_DMA=1): LDS-DMA staging (gemm_dma.hip)
     rc = launch_gemm_dma(layout, epi, ka, ka.total_tiles, g.small_tile, stream);
     prof_end(SUMK_PROF_GEMM_ALL, stream);
     if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     unsigned long long ta = 0;
     if (ka.dbg & 2) ta = __builtin_amdgcn_s_memtime();
     f32x16 acc[TM][TN];
-    if constexpr (EPI == EPI_RESIDUAL) {
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_MOMENTS) {
       residual_init<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
     } else {
 #pragma unroll
@@ -322,7 +322,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     unsigned long long tb = 0;
     if (ka.dbg & 2) tb = __builtin_amdgcn_s_memtime();
     if constexpr (EPI == EPI_BIAS_RELU_HEAD) {
-      epilogue_head_moments<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+      epilogue_head_moments<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh, reinterpret_cast<float2*>(lds), cur.m0, tid);
+    } else if constexpr (EPI == EPI_RESIDUAL_MOMENTS) {
+      epilogue_row_moments<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+      epilogue_store<EPI, TM, TN, true>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
     } else
     if (!(ka.dbg & 1) || acc[0][0][0] == 12345.f)
     epilogue_store<EPI, TM, TN, true>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
@@ -355,6 +358,10 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
       if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC) {
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RELU_HEAD, X3>), grid, block, 0, s, ka); break;
       } else { set_error("gemm: the head epilogue exists for 128x128 NT tiles only"); return SUMK_ERR_ARG; }
+    case EPI_RESIDUAL_MOMENTS:
+      if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC) {
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL_MOMENTS, X3>), grid, block, 0, s, ka); break;
+      } else { set_error("gemm: the moments epilogue exists for 128x128 NT tiles only"); return SUMK_ERR_ARG; }
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;

@@ -48,6 +48,9 @@ enum GemmEpi {
   // bias1[1][col], 0} to C viewed as float4[M][N / 32] -- the moments a LayerNorm + dot-product head over the row needs (VASNet
   // inference tail: k1 + ReLU + LayerNorm + k2 in one pass, vasnet.hip head_finalize_kernel).  128x128 NT tiles, N % 64 == 0.
   EPI_BIAS_RELU_HEAD = 6,
+  // C = acc + R as EPI_RESIDUAL, AND per row and slot (N / 32 slots) {sum C, sum C^2} to `moments` viewed as float2[M][N / 32]: what
+  // a LayerNorm over the rows of C needs, taken while the tile is still in registers.  128x128 NT tiles.
+  EPI_RESIDUAL_MOMENTS = 7,
 };
 
 struct GemmLaunch {
@@ -70,6 +73,11 @@ struct GemmLaunch {
   // training-mode dropout fused in the epilogue (EPI_BIAS_RELU: after the ReLU; EPI_BIAS_RESIDUAL: on acc+bias, before +R);
   // drop_thr == 0 disables it.  Element index of the mask = row * N + col.
   uint64_t drop_seed = 0; uint32_t drop_thr = 0, drop_site = 0; float drop_scale = 1.f;
+  float* moments = nullptr;            // EPI_RESIDUAL_MOMENTS output
+  // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
+  // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],
+  // c2[n] = sum_k beta_k B[n][k] -- the LayerNorm is applied to the PRODUCT, the normalised matrix never exists.
+  const float* ln_stats = nullptr; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
 };
 
 // number of tiles an (M,N) problem takes with the chosen tile size

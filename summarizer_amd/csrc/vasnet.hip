@@ -423,6 +423,49 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float4* __rest
   scores[row] = (float)(1.0 / (1.0 + exp(-pre)));
 }
 
+// Prep launch of the fused inference tail: blocks [0, D) fold the first LayerNorm's gain into the k1 weights,
+//   W1g[n][k] = W1[n][k] gamma[k],  c1[n] = sum_k gamma[k] W1[n][k],  c2[n] = sum_k beta[k] W1[n][k]     (one block per output row n),
+// so that  LN(y) . W1[n]  =  rstd (y . W1g[n] - mean c1[n]) + c2[n]  and the k1 GEMM can read the raw Y0; the remaining blocks turn
+// the out-projection's per-row slot moments into {mean, rstd} (8 lanes per row, double).  (The fold depends on weights only; it is
+// redone per call -- 8 MB of traffic inside a launch that is needed anyway -- rather than cached across calls.)
+__global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restrict__ W1, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int D, float* __restrict__ W1g,
+                                                            float* __restrict__ c1, float* __restrict__ c2,
+                                                            const float2* __restrict__ moments, int slots, int n_rows, float eps,
+                                                            float2* __restrict__ stats) {
+  if ((int)blockIdx.x < D) {
+    __shared__ double red[2][4];
+    const int n = blockIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 4 * threadIdx.x; k < D; k += 1024) {
+      const float4 w = *reinterpret_cast<const float4*>(W1 + (int64_t)n * D + k);
+      const float4 g = *reinterpret_cast<const float4*>(gamma + k), b = *reinterpret_cast<const float4*>(beta + k);
+      float4 o; o.x = w.x * g.x; o.y = w.y * g.y; o.z = w.z * g.z; o.w = w.w * g.w;
+      *reinterpret_cast<float4*>(W1g + (int64_t)n * D + k) = o;
+      a1 += ((double)o.x + (double)o.y) + ((double)o.z + (double)o.w);
+      a2 += ((double)w.x * b.x + (double)w.y * b.y) + ((double)w.z * b.z + (double)w.w * b.w);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m, 64); a2 += __shfl_xor(a2, m, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      c1[n] = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+      c2[n] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+    return;
+  }
+  const int row = ((int)blockIdx.x - D) * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double s1 = 0.0, s2 = 0.0;
+  if (row < n_rows)
+    for (int k = sub; k < slots; k += 8) { const float2 p = moments[(int64_t)row * slots + k]; s1 += p.x; s2 += p.y; }
+#pragma unroll
+  for (int m = 1; m <= 4; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (row >= n_rows || sub != 0) return;
+  const double mean = s1 / D, var = s2 / D - mean * mean;
+  stats[row] = make_float2((float)mean, (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps)));
+}
+
 // one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
 template <bool HEAD>
 static void launch_ln_rows(const float* X, float* Y, const float* g, const float* b, const float* w2, const float* b2, float* scores,
@@ -761,10 +804,33 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? EPI_RESIDUAL : EPI_NONE, g, stream));
   }
+  // Fused inference tail (128x128 tiles, no dropout; SUMK_FUSED_HEAD=0 / SUMK_FUSED_LN=0 are the A/B switches, training always
+  // runs the separate kernels):
+  //  (b) fused_tail: the k1 epilogue reduces relu(.) to the LayerNorm + k2 moments -- Z never exists;
+  //  (a) fused_ln:   the output projection's epilogue also emits the per-row moments of Y0, one prep launch folds the first
+  //      LayerNorm's gain into W1 and turns the moments into {mean, rstd}, and the k1 GEMM reads the RAW Y0: the LayerNorm is
+  //      applied to the product in the k1 epilogue -- no LayerNorm kernel, Y1 never exists.  Its scratch (moments, folded
+  //      weights, c1 / c2, stats) lives in the unused Y1 region, which must be large enough (R >~ 1.1 D).
+  static const bool fused_head_on = !(getenv("SUMK_FUSED_HEAD") && getenv("SUMK_FUSED_HEAD")[0] == '0');
+  static const bool fused_ln_on = !(getenv("SUMK_FUSED_LN") && getenv("SUMK_FUSED_LN")[0] == '0');
+  const bool fused_tail = fused_head_on && !training && !planes && drop.thr == 0 && G.st_d == 0 && D % 64 == 0;
+  const size_t ln_mom_f = align_up((size_t)R * D / 16, 64), ln_w_f = (size_t)D * D, ln_c_f = align_up((size_t)2 * D, 64);
+  const bool fused_ln = fused_tail && fused_ln_on && !Wvo && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D;
+  float* ln_moments = Y1;
+  float* ln_W1g = Y1 + ln_mom_f;
+  float* ln_c1 = ln_W1g + ln_w_f;
+  float* ln_stats = ln_c1 + ln_c_f;
   if (!Wvo) {  // 5: output projection + residual
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
+    if (fused_ln) {
+      g.moments = ln_moments;
+      SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL_MOMENTS, g, stream));
+      hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
+                         ln_c1 + D, (const float2*)ln_moments, D / 32, R, opts->eps, (float2*)ln_stats);
+      SUMK_HIP(hipGetLastError());
+    } else
     if (planes) {
       SUMK_TRY(launch_split_planes(CTX, PLA, RD, RD, opts->precision, stream));
       g.A = (const float*)PLA; g.B[0] = wplanes(3);
@@ -774,14 +840,14 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     }
   }
   // 6: dropout + LayerNorm
-  launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
+  if (!fused_ln) launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
   // 7 + 8 fused (inference, 128x128 tiles): k1 + bias + ReLU with the LayerNorm + k2 moments taken in the GEMM epilogue -- the
   // (R, D) activation matrix is neither written (49 MB in the lock-stepped store burst of this single-round launch) nor read
-  // back by a LayerNorm kernel.  SUMK_FUSED_HEAD=0 keeps the two-kernel form (A/B switch; training always uses it).
-  static const bool fused_head_on = !(getenv("SUMK_FUSED_HEAD") && getenv("SUMK_FUSED_HEAD")[0] == '0');
-  if (fused_head_on && !training && !planes && drop.thr == 0 && G.st_d == 0 && D % 64 == 0) {
+  // back by a LayerNorm kernel.
+  if (fused_tail) {
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.bias1[0] = w->ln_w; g.bias1[1] = w->w2;
+    if (fused_ln) { g.A = Y0; g.B[0] = ln_W1g; g.ln_stats = ln_stats; g.ln_c1 = ln_c1; g.ln_c2 = ln_c1 + D; }
     g.C = Z;                       // reused as float4[R][D / 32] moments (R * D / 8 floats of the R * D region)
     g.probs = prow + RP_DD; g.small_tile = 0;
     g.total_tiles = gemm_tiles(R, D, 0); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
