@@ -170,3 +170,15 @@ def test_bilstm_time_reversal_symmetry_full_size(dev, kind, T):
         a = m.score_packed(x, [T])
         b = m2.score_packed(torch.flip(x, (0,)).contiguous(), [T])
     np.testing.assert_allclose(torch.flip(b, (0,)).cpu().numpy(), a.cpu().numpy(), atol=1e-6, rtol=0)
+
+
+def test_persistent_recurrences_are_bitwise_repeatable_under_foreign_traffic():
+    """The hand-off protocol of the persistent recurrence kernels (forward and BPTT, H = 256 and H = 1024) under repetition: the
+    same training step from identical inputs must give bit-identical scores and gradients every time, also while another buffer
+    is being streamed through the caches between repetitions -- a stale or torn read in a hand-off would show as a difference
+    (scripts/probes/wide_bptt_soak.py, 2 x 6 repetitions per model here; 2 x 40 were run for DESIGN.md)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probes", "wide_bptt_soak.py"), "6"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 differed" in r.stdout
