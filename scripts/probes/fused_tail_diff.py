@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests/golden")
+_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _root); sys.path.insert(0, os.path.join(_root, "tests", "golden"))
 import numpy as np, torch, recipes as R
 from summarizer_amd.models.vasnet import VASNet
 torch.manual_seed(0)

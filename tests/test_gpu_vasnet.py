@@ -450,3 +450,21 @@ def test_planes_gemm_path_matches_inloop_split_path(dev, tmp_path):
             d_path = float(np.abs(a[k] - b[k]).max()); d_fp32 = float(np.abs(a[k] - a["fp32_0"]).max())
             print(k, "planes vs in-loop", d_path, "| planes vs exact fp32", d_fp32)
             assert d_path < tol_path and d_fp32 < tol_fp32, (k, d_path, d_fp32)
+
+
+def test_fused_inference_tail_equals_separate_kernels(tmp_path):
+    """The fused inference tail (LayerNorm 1 applied to the k1 product, LayerNorm 2 + k2 taken from the k1 epilogue: neither
+    activation matrix is stored) against the separate LayerNorm kernels on the S-TVSum batch (50 videos, D = 1024): the
+    re-association moves scores by a few 1e-6 at most.  The switches are read once per process, hence the subprocesses."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    probe = os.path.join(ROOT, "scripts", "probes", "fused_tail_diff.py")
+    outs = {}
+    for tag, env in (("fused", {}), ("head_only", {"SUMK_FUSED_LN": "0"}), ("separate", {"SUMK_FUSED_LN": "0", "SUMK_FUSED_HEAD": "0"})):
+        f = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, probe, f], env=dict(os.environ, **env), capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[tag] = np.load(f)
+    assert np.isfinite(outs["fused"]).all() and outs["fused"].shape == (12003,)
+    assert np.abs(outs["head_only"] - outs["separate"]).max() < 2e-6
+    assert np.abs(outs["fused"] - outs["separate"]).max() < 1e-5
