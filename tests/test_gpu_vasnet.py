@@ -349,14 +349,17 @@ def test_vasnet_plain_bf16_scores_are_close_but_not_fp32_grade(dev):
     assert 1e-4 < worst < 3e-2, worst
 
 
-def test_vasnet_folded_vo_inference_matches_reference_goldens(dev):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+def test_vasnet_folded_vo_inference_matches_reference_goldens(dev, precision):
     """fold_vo=True (opt-in): Wvo = Wo.Wv is folded once and the out-projection GEMM disappears.  Same gate as the default
     path: every golden from the REAL reference within 1e-4 -- small-D variants (masks, batch > 1, pos-embed), the full-size
-    cases -- and the ragged packed batch within 1e-5 of the unfolded HIP path."""
+    cases -- and the ragged packed batch within 1e-5 of the unfolded HIP path.  Also in the fp32-grade bf16x6 arithmetic: that
+    combination is the fastest mode that still holds the fp32 tolerances (0.74 ms per S-TVSum batch)."""
     g = load_golden("vasnet_small")
     for vname, kw in js(g["meta"]).items():
         w = {k.split("/w/")[1]: g[k] for k in g.files if k.startswith(f"{vname}/w/")}
         m = _model(dev, 64, w, fold_vo=True, **kw)
+        m.precision = precision
         if kw.get("pos_embed") == "attention":
             m.pos_embed = torch.from_numpy(g[f"{vname}/pos_table"])
         for c in sorted(k.split("/")[-1] for k in g.files if k.startswith(f"{vname}/x/")):
@@ -367,13 +370,15 @@ def test_vasnet_folded_vo_inference_matches_reference_goldens(dev):
     for ci in range(len([k for k in g.files if k.endswith("/cfg")])):
         cfg = js(g[f"c{ci}/cfg"])
         w = R.vasnet_weights(cfg["D"], cfg["wseed"]); x = R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"])
+        mf = _model(dev, cfg["D"], w, fold_vo=True, **cfg["kw"]); mf.precision = precision
         with torch.no_grad():
-            y = _model(dev, cfg["D"], w, fold_vo=True, **cfg["kw"])(torch.from_numpy(x).to(dev)).cpu().numpy()
+            y = mf(torch.from_numpy(x).to(dev)).cpu().numpy()
         np.testing.assert_allclose(y, g[f"c{ci}/y"], atol=TOL, rtol=0, err_msg=str(cfg))
     D, lens = 1024, [70, 1, 33, 129, 300, 5]
     w = R.vasnet_weights(D, 9)
     x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 60 + i)[:, 0, :] - 0.15 for i, T in enumerate(lens)])).to(dev)
     a, b = _model(dev, D, w), _model(dev, D, w, fold_vo=True)
+    b.precision = precision
     with torch.no_grad():
         sa, sb_ = a.score_packed(x, lens), b.score_packed(x, lens)
     assert float((sa - sb_).abs().max()) < 1e-5 and not torch.equal(sa, sb_)      # equal up to re-association, and really another path
