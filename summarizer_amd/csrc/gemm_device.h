@@ -202,12 +202,14 @@ __device__ __forceinline__ void epilogue_head_moments(const GemmKArgs& ka, const
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_row_moments(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
                                                      int col0, int li, int lh) {
-  static_assert(TN == 2, "moments epilogue: a wave covers 64 columns");
+  static_assert(TN == 1 || TN == 2, "moments epilogue: a wave covers 32 or 64 columns");
   bool colok[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) colok[tn] = col0 + tn * 32 + li < cur.N;
-  const int slots = cur.N >> 5, slot = (col0 >> 5) + (li >> 4);
-  float2* part = reinterpret_cast<float2*>(ka.moments);
+  // TN = 2 (128x128 tiles): the two 32-column tiles are added in-lane, N / 32 slots per row; TN = 1 (64x64 tiles): N / 16 slots.
+  // Grouped (per-video) launches: `row` is relative to the sub-problem, the moments are indexed by the row of the packed matrix.
+  const int slots = TN == 2 ? cur.N >> 5 : cur.N >> 4, slot = (TN == 2 ? col0 >> 5 : col0 >> 4) + (li >> 4);
+  float2* part = reinterpret_cast<float2*>(ka.moments) + (cur.c_off / cur.ldc) * slots;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll

@@ -359,9 +359,9 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_BIAS_RELU_HEAD, X3>), grid, block, 0, s, ka); break;
       } else { set_error("gemm: the head epilogue exists for 128x128 NT tiles only"); return SUMK_ERR_ARG; }
     case EPI_RESIDUAL_MOMENTS:
-      if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC) {
+      if constexpr ((BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC) || (BM == 64 && BN == 64 && BK == 32 && A_KC && !B_KC)) {
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL_MOMENTS, X3>), grid, block, 0, s, ka); break;
-      } else { set_error("gemm: the moments epilogue exists for 128x128 NT tiles only"); return SUMK_ERR_ARG; }
+      } else { set_error("gemm: the moments epilogue exists for 128x128 NT and 64x64 NN tiles only"); return SUMK_ERR_ARG; }
     default: set_error("gemm: bad epilogue %d", (int)epi); return SUMK_ERR_ARG;
   }
   return SUMK_OK;

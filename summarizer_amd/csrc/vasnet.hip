@@ -798,28 +798,37 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
-  {  // 4: context
-    GemmLaunch g; g.precision = opts->precision;
-    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
-    g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
-    SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? EPI_RESIDUAL : EPI_NONE, g, stream));
-  }
   // Fused inference tail (128x128 tiles, no dropout; SUMK_FUSED_HEAD=0 / SUMK_FUSED_LN=0 are the A/B switches, training always
   // runs the separate kernels):
   //  (b) fused_tail: the k1 epilogue reduces relu(.) to the LayerNorm + k2 moments -- Z never exists;
-  //  (a) fused_ln:   the output projection's epilogue also emits the per-row moments of Y0, one prep launch folds the first
+  //  (a) fused_ln:   the epilogue of the GEMM that produces Y0 also emits its per-row moments, one prep launch folds the first
   //      LayerNorm's gain into W1 and turns the moments into {mean, rstd}, and the k1 GEMM reads the RAW Y0: the LayerNorm is
   //      applied to the product in the k1 epilogue -- no LayerNorm kernel, Y1 never exists.  Its scratch (moments, folded
   //      weights, c1 / c2, stats) lives in the unused Y1 region, which must be large enough (R >~ 1.1 D).
   static const bool fused_head_on = !(getenv("SUMK_FUSED_HEAD") && getenv("SUMK_FUSED_HEAD")[0] == '0');
   static const bool fused_ln_on = !(getenv("SUMK_FUSED_LN") && getenv("SUMK_FUSED_LN")[0] == '0');
   const bool fused_tail = fused_head_on && !training && !planes && drop.thr == 0 && G.st_d == 0 && D % 64 == 0;
-  const size_t ln_mom_f = align_up((size_t)R * D / 16, 64), ln_w_f = (size_t)D * D, ln_c_f = align_up((size_t)2 * D, 64);
-  const bool fused_ln = fused_tail && fused_ln_on && !Wvo && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D;
+  // producer of Y0: the output projection (128x128 tiles, D / 32 moment slots per row) or, on the folded path, the per-video
+  // alpha.(X Wvo) product with the residual (64x64 tiles, D / 16 slots)
+  const int ln_slots = Wvo ? D / 16 : D / 32;
+  const size_t ln_mom_f = align_up((size_t)R * ln_slots * 2, 64), ln_w_f = (size_t)D * D, ln_c_f = align_up((size_t)2 * D, 64);
+  const bool fused_ln = fused_tail && fused_ln_on && (!Wvo || G.cfg_pv == 1) && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D;
   float* ln_moments = Y1;
   float* ln_W1g = Y1 + ln_mom_f;
   float* ln_c1 = ln_W1g + ln_w_f;
   float* ln_stats = ln_c1 + ln_c_f;
+  {  // 4: context
+    GemmLaunch g; g.precision = opts->precision;
+    g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
+    g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
+    if (Wvo && fused_ln) g.moments = ln_moments;
+    SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
+    if (Wvo && fused_ln) {
+      hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
+                         ln_c1 + D, (const float2*)ln_moments, ln_slots, R, opts->eps, (float2*)ln_stats);
+      SUMK_HIP(hipGetLastError());
+    }
+  }
   if (!Wvo) {  // 5: output projection + residual
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
@@ -828,7 +837,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
       g.moments = ln_moments;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL_MOMENTS, g, stream));
       hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
-                         ln_c1 + D, (const float2*)ln_moments, D / 32, R, opts->eps, (float2*)ln_stats);
+                         ln_c1 + D, (const float2*)ln_moments, ln_slots, R, opts->eps, (float2*)ln_stats);
       SUMK_HIP(hipGetLastError());
     } else
     if (planes) {
