@@ -22,6 +22,7 @@ struct GemmKArgs {
   int32_t total_tiles;   // loop bound of the persistent tile walk (virtual tiles when xcd_tiles_m > 0)
   Drop drop; uint32_t drop_site;   // epilogue dropout (drop.thr == 0: none); mask index = row * N + col
   int32_t xcd_tiles_m;   // > 0: single-problem launch with the XCD-aware tile map below; value = tiles along M
+  int32_t group_remap;   // 1: grouped (per-video) launch, tile ids dealt so that one XCD walks a CONTIGUOUS range of tiles (decode_tile)
   float alpha;
   int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores, 2 = in-kernel cycle stamps
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
@@ -56,6 +57,15 @@ struct TileCtx {
 // (XCD-aware) walk has run past its rectangle.
 template <int BM, int BN>
 __device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileCtx& c, GemmProb& P) {
+  if (ka.group_remap) {
+    // Grouped launches number their tiles sub-problem by sub-problem, and block b runs on XCD b % 8 (round-robin dispatch; speed
+    // only): dealt as they are, the tiles of one sub-problem land on all eight XCDs and each of the eight private L2s pulls that
+    // sub-problem's operand rows from the Infinity Cache for itself.  Here XCD x (tile ids 8 j + x) walks the contiguous range
+    // [start_x, start_x + n_x): whole sub-problems per XCD, operand rows fetched into ONE L2 and shared by their tiles.  Used by
+    // the split-K weight-gradient GEMMs (a K slice = a sub-problem).  A bijection on [0, total_tiles).
+    const int total = ka.total_tiles, x = tile & 7, j = tile >> 3, base = total >> 3, r = total & 7;
+    tile = x * base + min(x, r) + j;
+  }
   int lo = 0, hi = ka.nprob - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;

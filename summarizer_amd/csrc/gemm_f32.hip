@@ -37,9 +37,17 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = g.nprob; ka.n_group = g.n_group; ka.alpha = g.alpha;
   ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0;
+  // SUMK_GROUP_REMAP: 0 never; 1 (default) split-K slices in every arithmetic + the per-video products of the bf16-plane modes, which
+  // are bound by operand bytes (bf16 training step 1.35 -> 1.21 ms, bf16x3 / bf16x6 ~1 %); the exact-fp32 per-video products did
+  // not gain (alpha.V 85 -> 89 us) and keep the plain order; 2 every grouped launch
+  static const int group_remap = getenv("SUMK_GROUP_REMAP") ? atoi(getenv("SUMK_GROUP_REMAP")) : 1;
+  ka.group_remap = (g.nprob > 1 && (group_remap == 2 || (group_remap == 1 && (g.group_remap || g.precision != SUMK_PRECISION_FP32)))) ? 1 : 0;
   static const int dbg = getenv("SUMK_GEMM_DBG") ? atoi(getenv("SUMK_GEMM_DBG")) : 0;
   ka.dbg = dbg; ka.dbg_buf = nullptr;
-  if (dbg & 2) ka.dbg_buf = gemm_stamp_buffer();   // diagnostic only (never on a product path)
+  if (dbg & 2) {   // diagnostic only (never on a product path); SUMK_STAMP_TAG=<prof tag>: stamp only that GEMM of a forward pass
+    static const int only_tag = getenv("SUMK_STAMP_TAG") ? atoi(getenv("SUMK_STAMP_TAG")) : -1;
+    if (only_tag < 0 || only_tag == g.prof_tag) ka.dbg_buf = gemm_stamp_buffer(); else ka.dbg &= ~2;
+  }
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
   ka.moments = g.moments; ka.ln_stats = g.ln_stats; ka.ln_c1 = g.ln_c1; ka.ln_c2 = g.ln_c2;
   SUMK_ARG(epi != EPI_RESIDUAL_MOMENTS || g.moments, "gemm: the moments epilogue needs an output buffer");
@@ -173,6 +181,9 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = slab; g.probs = probs_dev; g.nprob = S; g.small_tile = small; g.total_tiles = S * tiles;
   g.precision = precision;
+  // the tiles of one K slice share their operand rows: keep a slice on one XCD (measured: the bf16 training step 1.35 -> 1.21 ms,
+  // fp32 unchanged; the per-video attention products did not gain and are left in plain order)
+  g.group_remap = 1;
   SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   SlabReduceArgs r;
   r.slab = slab; for (int i = 0; i < 4; ++i) r.out[i] = out[i];

@@ -246,7 +246,7 @@ int launch_gemm_planes(GemmEpi epi, const GemmLaunch& g, int64_t a_plane, int64_
   for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = 1; ka.n_group = g.n_group; ka.alpha = g.alpha;
   static const int dbg = getenv("SUMK_GEMM_DBG") ? atoi(getenv("SUMK_GEMM_DBG")) : 0;   // 4: no MFMAs, 8: no DMAs (timing diagnostics)
-  ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0; ka.dbg = dbg; ka.dbg_buf = nullptr;
+  ka.total_tiles = g.total_tiles; ka.xcd_tiles_m = 0; ka.group_remap = 0; ka.dbg = dbg; ka.dbg_buf = nullptr;
   ka.drop.seed = 0; ka.drop.thr = 0; ka.drop.scale = 1.f; ka.drop_site = 0;
   ka.moments = nullptr; ka.ln_stats = ka.ln_c1 = ka.ln_c2 = nullptr;
   pa.a_plane = a_plane; pa.b_plane = b_plane;

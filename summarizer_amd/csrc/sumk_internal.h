@@ -74,6 +74,7 @@ struct GemmLaunch {
   // drop_thr == 0 disables it.  Element index of the mask = row * N + col.
   uint64_t drop_seed = 0; uint32_t drop_thr = 0, drop_site = 0; float drop_scale = 1.f;
   float* moments = nullptr;            // EPI_RESIDUAL_MOMENTS output
+  int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
   // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],
   // c2[n] = sum_k beta_k B[n][k] -- the LayerNorm is applied to the PRODUCT, the normalised matrix never exists.
