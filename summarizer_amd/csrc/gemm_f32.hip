@@ -41,7 +41,10 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   // are bound by operand bytes (bf16 training step 1.35 -> 1.21 ms, bf16x3 / bf16x6 ~1 %); the exact-fp32 per-video products did
   // not gain (alpha.V 85 -> 89 us) and keep the plain order; 2 every grouped launch
   static const int group_remap = getenv("SUMK_GROUP_REMAP") ? atoi(getenv("SUMK_GROUP_REMAP")) : 1;
-  ka.group_remap = (g.nprob > 1 && (group_remap == 2 || (group_remap == 1 && (g.group_remap || g.precision != SUMK_PRECISION_FP32)))) ? 1 : 0;
+  // (per-video products only while a video is a handful of tiles: at T = 10 000 a sub-problem is thousands of tiles, a contiguous
+  //  range is a band of one video and the plain order was 6 % faster)
+  const bool small_groups = (int64_t)g.total_tiles <= (int64_t)256 * g.nprob;
+  ka.group_remap = (g.nprob > 1 && (group_remap == 2 || (group_remap == 1 && (g.group_remap || (g.precision != SUMK_PRECISION_FP32 && small_groups))))) ? 1 : 0;
   static const int dbg = getenv("SUMK_GEMM_DBG") ? atoi(getenv("SUMK_GEMM_DBG")) : 0;
   ka.dbg = dbg; ka.dbg_buf = nullptr;
   if (dbg & 2) {   // diagnostic only (never on a product path); SUMK_STAMP_TAG=<prof tag>: stamp only that GEMM of a forward pass
