@@ -17,4 +17,5 @@ o = out.reshape(nb, 4).astype(np.float64)[(760 if os.environ.get('SUMK_STAMP_TAG
 o = o[o[:, 3] > 0]
 tot, kl, ep, nt = o[:, 0], o[:, 1], o[:, 2], o[:, 3]
 print(f"tag {os.environ.get('SUMK_STAMP_TAG', 'alpha.V (tail of the buffer)')}: blocks {len(o)} tiles/block {nt.min():.0f}-{nt.max():.0f} (mean {nt.mean():.2f}); block total median {np.median(tot):.0f} max {tot.max():.0f} min {tot.min():.0f}; k-loop {np.median(kl/tot)*100:.0f}% epilogue {np.median(ep/tot)*100:.0f}%; per tile: k-loop {np.median(kl/nt):.0f} epilogue {np.median(ep/nt):.0f}")
+print("block total percentiles p1/p10/p50/p90/p99:", [int(np.percentile(tot, q)) for q in (1, 10, 50, 90, 99)])
 print("mean T", np.mean(lens), "k-iters/tile ~", np.mean([ (t+31)//32 for t in lens]))
