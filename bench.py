@@ -436,41 +436,48 @@ def main():
         barrier()
     # data-parallel TRAINING leg on the same batch (every rank): forward + MSE + backward + the flat-bucket gradient all-reduce +
     # fused Adam.  Scoring has no data-path collective, so this is what makes a multi-GPU run of this script exercise RCCL.
-    train_leg = None
+    train_leg = train_leg_bf16 = None
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         from summarizer_amd.training import FlatAdam
-        model.train()
-        opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
-        opt.broadcast()
-        target = torch.rand(frames, device=dev)
         from summarizer_amd import kernels as _k
         from summarizer_amd.autograd import SegmentMseFunction
         sb_t = _k.SeqBatch.get(lens, dev)
-        def train_step():
-            opt.zero_grad()
-            loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()
-            loss.backward()
-            opt.step(grad_scale=opt.all_reduce_grads())
-            return loss.detach()
-        for _ in range(3):
-            l = train_step()
-        barrier()
-        tt0 = time.perf_counter()
-        n_train = 10
-        for _ in range(n_train):
-            l = train_step()
-        barrier()
-        tel = time.perf_counter() - tt0
-        if dist is not None:
-            t = torch.tensor([tel], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tel = float(t.item())
-        assert bool(torch.isfinite(l))
-        model.eval()
-        train_leg = dict(frames_per_s=round(frames * world * n_train / tel, 1), ms_per_step=round(tel / n_train * 1e3, 4), steps=n_train,
-                         allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0,
-                         collectives_per_step=1 if world > 1 else 0,
-                         note="fp32; forward + MSE + backward + one all-reduce of the flat gradient bucket (RCCL when world > 1) + fused Adam")
+        target = torch.rand(frames, device=dev)
+
+        def run_train_leg(precision):
+            """exact fp32, or the mixed-precision mode of BASELINE config 2 (bf16 products, bf16 gradient bucket over the all-reduce)"""
+            model.train(); model.precision = precision
+            opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5, comm_dtype=torch.bfloat16 if precision == "bf16" else None)
+            opt.broadcast()
+            def train_step():
+                opt.zero_grad()
+                loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()
+                loss.backward()
+                opt.step(grad_scale=opt.all_reduce_grads())
+                return loss.detach()
+            for _ in range(3):
+                l = train_step()
+            barrier()
+            tt0 = time.perf_counter()
+            n_train = 10
+            for _ in range(n_train):
+                l = train_step()
+            barrier()
+            tel = time.perf_counter() - tt0
+            if dist is not None:
+                t = torch.tensor([tel], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tel = float(t.item())
+            assert bool(torch.isfinite(l))
+            model.eval(); model.precision = "fp32"
+            bytes_per_elem = 2 if precision == "bf16" else 4
+            return dict(frames_per_s=round(frames * world * n_train / tel, 1), ms_per_step=round(tel / n_train * 1e3, 4), steps=n_train,
+                        allreduce_bytes_per_step=int(opt.flat_grad.numel() * bytes_per_elem) if world > 1 else 0,
+                        collectives_per_step=1 if world > 1 else 0,
+                        note=(f"{precision}; forward + per-video MSE + backward + one all-reduce of the flat gradient bucket "
+                              "(RCCL when world > 1) + fused Adam"))
+        train_leg = run_train_leg("fp32")
+        train_leg_bf16 = run_train_leg("bf16")
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
@@ -492,6 +499,7 @@ def main():
             out["gemm_kernels"] = kern
         if train_leg:
             out["train_step_mode"] = train_leg
+            out["train_step_bf16_mode"] = train_leg_bf16
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
         if args.mode == "stream":

@@ -173,3 +173,5 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     # the scaling line also carries a data-parallel TRAINING leg, so that a multi-GPU run measures the gradient all-reduce
     tl = out["train_step_mode"]
     assert tl["frames_per_s"] > 0 and tl["allreduce_bytes_per_step"] > 20e6 and tl["collectives_per_step"] == 1
+    tb = out["train_step_bf16_mode"]              # BASELINE config 2: bf16 products and a bf16 gradient bucket (half the bytes)
+    assert tb["frames_per_s"] > 0 and 10e6 < tb["allreduce_bytes_per_step"] < 11e6
