@@ -30,7 +30,7 @@ def tvsum_lens(n_videos=50):
     return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
 
 
-def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet"):
+def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None):
     """Reference-equivalent stock-PyTorch CPU path (oracle/torch_port.py), one video per call as in
     Trainer.test (summarizer/models/__init__.py:45-54).  torch's intra-op pool is swept over a few thread
     counts (a 256-thread pool is far slower than 16-32 threads on (T<=320, 1024) matrices); the BEST setting is
@@ -71,7 +71,15 @@ def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet"):
                     break
             res[nt] = (frames / el, n, el)
     best = max(res, key=lambda k: res[k][0])
-    return dict(value=round(res[best][0], 1), unit="frames/s", cores=best, kind="port",
+    parity = None
+    if gpu_scores is not None:
+        # the SAME weights (seed 1234 default constructor) and the SAME inputs as the timed GPU batch: every video of the headline
+        # batch through the port, compared with what the HIP path just produced (north_star gate: 1e-4)
+        torch.set_num_threads(best)
+        with torch.no_grad():
+            ref = torch.cat([score(x).reshape(-1) for x in xs])
+        parity = float((gpu_scores.detach().cpu().reshape(-1) - ref).abs().max())
+    return dict(value=round(res[best][0], 1), unit="frames/s", cores=best, kind="port", parity_max_abs_diff_vs_port=parity,
                 sample=f"single-video {kind} forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops) on a "
                        f"{ncores}-cpu host; frames/s by intra-op threads: " +
                        ", ".join(f"{k}t={v[0]:.0f} ({v[1]} videos/{v[2]:.1f}s)" for k, v in res.items()))
@@ -174,6 +182,47 @@ def bench_sumgan(args, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
+def make_reinforce_step(model, x, lens, dev):
+    """One DSNTrainer step on the packed batch (dsn.py:96-156): probabilities, 5 Bernoulli episodes, reward kernel,
+    policy-gradient loss, backward, [gradient all-reduce under data parallelism,] grad-norm clip folded into the flat Adam
+    (applied AFTER the reduction), moving-average baselines.  BASELINE config 4 per GPU."""
+    from torch.distributions import Bernoulli
+    from summarizer_amd import kernels
+    from summarizer_amd.training import FlatAdam
+    from summarizer_amd.autograd import PolicyLossFunction
+    opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
+    sb = kernels.SeqBatch.get(lens, dev)
+    base = torch.zeros(len(lens), device=dev)
+
+    def run_step():
+        opt.zero_grad()
+        probs = model.score_packed(x, lens)
+        dist_ = Bernoulli(probs, validate_args=False)          # (validation is a D2H sync per step)
+        actions = dist_.sample((5,))
+        rewards = kernels.dsn_reward(x, sb, actions.contiguous())
+        loss = PolicyLossFunction.apply(probs, sb, actions, rewards, base, 0.01, 0.5).mean()    # dsn.py:113-140 in two HIP kernels
+        loss.backward()
+        opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
+        base.mul_(0.9).add_(rewards.mean(dim=0), alpha=0.1)        # in place: also valid under --graph replays
+        return loss.detach()
+    return run_step, opt
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: THIS process has not touched the GPU yet (torch is imported, nothing is
+    initialised), so it starts N fresh rank processes through torch.distributed.run as CHILDREN (never an exec), lets rank 0's JSON
+    line through on the inherited stdout and exits with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,7 +250,13 @@ def main():
                          "operands, 1 MFMA per product: the mixed-precision TRAINING mode of BASELINE config 2 (use with --mode train)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world} "
+              "(or run plain `python bench.py --gpus N`, which starts its own N ranks)", file=sys.stderr, flush=True)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
@@ -218,6 +273,13 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    ranks_seen = 1
+    if dist is not None:
+        # first contact with the collective backend (RCCL over xGMI on a multi-GPU node): a SUM all-reduce of ones must see every rank
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"all-reduce of ones saw {ranks_seen} ranks, expected {world}"
 
     import recipes as R
     from summarizer_amd import _lib
@@ -266,27 +328,8 @@ def main():
             opt.step(grad_scale=opt.all_reduce_grads())
             return loss.detach()
     elif args.mode == "reinforce":
-        # one DSNTrainer step on the packed batch (dsn.py:96-156): probabilities, 5 Bernoulli episodes, reward kernel,
-        # policy-gradient loss, backward, grad-norm clip folded into the flat Adam (+ gradient all-reduce under DP)
         assert args.model == "dsn", "--mode reinforce is the DSN trainer step"
-        from torch.distributions import Bernoulli
-        from summarizer_amd import kernels
-        from summarizer_amd.training import FlatAdam
-        from summarizer_amd.autograd import PolicyLossFunction
-        opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
-        sb = kernels.SeqBatch.get(lens, dev)
-        base = torch.zeros(len(lens), device=dev)
-        def run_step():
-            opt.zero_grad()
-            probs = model.score_packed(x, lens)
-            dist_ = Bernoulli(probs, validate_args=False)          # (validation is a D2H sync per step)
-            actions = dist_.sample((5,))
-            rewards = kernels.dsn_reward(x, sb, actions.contiguous())
-            loss = PolicyLossFunction.apply(probs, sb, actions, rewards, base, 0.01, 0.5).mean()    # dsn.py:113-140 in two HIP kernels
-            loss.backward()
-            opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
-            base.mul_(0.9).add_(rewards.mean(dim=0), alpha=0.1)        # in place: also valid under --graph replays
-            return loss.detach()
+        run_step, opt = make_reinforce_step(model, x, lens, dev)
     elif args.mode == "stream":
         # host -> host: every step ships the batch again (packed pinned staging, one H2D, packed scoring, one D2H), two slots deep
         from summarizer_amd.ingest import StreamingScorer
@@ -436,7 +479,7 @@ def main():
         barrier()
     # data-parallel TRAINING leg on the same batch (every rank): forward + MSE + backward + the flat-bucket gradient all-reduce +
     # fused Adam.  Scoring has no data-path collective, so this is what makes a multi-GPU run of this script exercise RCCL.
-    train_leg = train_leg_bf16 = None
+    train_leg = train_leg_bf16 = reinforce_leg = None
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         from summarizer_amd.training import FlatAdam
         from summarizer_amd import kernels as _k
@@ -478,10 +521,48 @@ def main():
                               "(RCCL when world > 1) + fused Adam"))
         train_leg = run_train_leg("fp32")
         train_leg_bf16 = run_train_leg("bf16")
+
+        def run_reinforce_leg():
+            """BASELINE config 4: the DSN REINFORCE step, data-parallel by video (every rank its own 50 videos, one all-reduce of the
+            10.5 MB flat gradient bucket per step, clip after the reduction, per-video baselines rank-local)."""
+            from summarizer_amd.models.dsn import DSN
+            torch.manual_seed(1234)
+            dsn = DSN(input_size=D).to(dev).train()
+            step, opt = make_reinforce_step(dsn, x, lens, dev)
+            opt.broadcast()
+            for _ in range(3):
+                l = step()
+            barrier()
+            tt0 = time.perf_counter()
+            n_train = 10
+            for _ in range(n_train):
+                l = step()
+            barrier()
+            tel = time.perf_counter() - tt0
+            if dist is not None:
+                t = torch.tensor([tel], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tel = float(t.item())
+            assert bool(torch.isfinite(l))
+            from summarizer_amd import kernels as _kk
+            _kk.health_check()                                            # persistent recurrences: no hand-off timed out
+            return dict(frames_per_s=round(frames * world * n_train / tel, 1), ms_per_step=round(tel / n_train * 1e3, 4), steps=n_train,
+                        allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0,
+                        collectives_per_step=1 if world > 1 else 0,
+                        note="DSN (BiLSTM 1024 -> 2 x 256) REINFORCE step: scores, 5 Bernoulli episodes, reward kernel, policy loss, "
+                             "backward, one all-reduce of the flat gradient bucket (RCCL when world > 1), clip + fused Adam")
+        try:
+            reinforce_leg = run_reinforce_leg()
+        except Exception as e:          # noqa: BLE001
+            if dist is not None:
+                raise                   # a rank that drops out of a collective leg would leave the others waiting: fail the job
+            reinforce_leg = dict(error=f"{type(e).__name__}: {e}"[:300])
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
-                   unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   unit="frames/s", n_gpus=world, rccl_ranks_seen=ranks_seen if (dist is not None and not one_gpu) else None,
+                   ranks_seen=ranks_seen, collective_backend=(None if dist is None else dist.get_backend()),
+                   steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 4), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32" if args.precision == "fp32" else ("bf16 products, f32 accumulate/storage/master weights" if args.precision == "bf16" else f"f32 storage/accumulate, {args.precision} split products"),
                    data="synthetic",
@@ -500,6 +581,7 @@ def main():
         if train_leg:
             out["train_step_mode"] = train_leg
             out["train_step_bf16_mode"] = train_leg_bf16
+            out["dsn_reinforce_step_mode"] = reinforce_leg
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
         if args.mode == "stream":
@@ -512,10 +594,17 @@ def main():
             out["folded_vo_bf16x6_mode"] = folded6
         if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
             try:
-                out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model)
+                out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None)
+                # the headline batch against the oracle port, every video (gate 1e-4): what `value` times is what was checked
+                out["parity_max_abs_diff_vs_port"] = out["cpu_baseline"].pop("parity_max_abs_diff_vs_port")
+                out["parity_gate"] = 1e-4
             except Exception as e:          # noqa: BLE001
                 out["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         print(json.dumps(out), flush=True)
+        pd = out.get("parity_max_abs_diff_vs_port")
+        if pd is not None and not pd < out["parity_gate"]:
+            print(f"bench.py: PARITY FAILURE: max |score - port| = {pd} on the timed batch (gate {out['parity_gate']})", file=sys.stderr, flush=True)
+            sys.exit(3)
     if dist is not None:
         dist.destroy_process_group()
 

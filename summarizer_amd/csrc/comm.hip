@@ -25,15 +25,19 @@ struct Rccl {
   fn_comm_destroy comm_destroy = nullptr;
   fn_all_reduce all_reduce = nullptr;
   fn_get_error_string error_string = nullptr;
+  char load_error[256] = "symbols missing";   // dlerror() text of the failed dlopen, captured ONCE (dlerror clears itself when read)
 };
 
+Rccl g_rccl;
+
 Rccl* rccl() {
-  static Rccl r;
+  Rccl& r = g_rccl;
   static std::once_flag once;
-  std::call_once(once, [] {
+  std::call_once(once, [&r] {
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
       r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (r.handle) break;
+      if (const char* e = dlerror()) snprintf(r.load_error, sizeof(r.load_error), "%s", e);
     }
     if (!r.handle) return;
     r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
@@ -44,6 +48,7 @@ Rccl* rccl() {
   });
   return (r.handle && r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce) ? &r : nullptr;
 }
+const char* rccl_load_error() { rccl(); return g_rccl.load_error; }
 
 int rccl_fail(int rc, const char* what) {
   Rccl* r = rccl();
@@ -60,7 +65,7 @@ extern "C" int sumk_comm_unique_id(uint8_t* id128) {
   using namespace sumk;
   SUMK_ARG(id128 != nullptr, "comm_unique_id: null pointer");
   Rccl* r = rccl();
-  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded (%s)", rccl_load_error());
   UniqueId128 id;
   int rc = r->get_unique_id(&id);
   if (rc != 0) return rccl_fail(rc, "ncclGetUniqueId");
@@ -73,7 +78,7 @@ extern "C" int sumk_comm_init(const uint8_t* id128, int32_t rank, int32_t world,
   SUMK_ARG(id128 && comm_out, "comm_init: null pointer");
   SUMK_ARG(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d of %d", rank, world);
   Rccl* r = rccl();
-  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded");
+  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded (%s)", rccl_load_error());
   UniqueId128 id;
   for (int i = 0; i < 128; ++i) id.internal[i] = (char)id128[i];
   void* comm = nullptr;
@@ -88,7 +93,7 @@ extern "C" int sumk_allreduce_flat(void* comm, void* buf, int64_t n, int32_t dty
   SUMK_ARG(comm && buf && n > 0, "allreduce_flat: bad argument");
   SUMK_ARG(dtype == 0 || dtype == 1, "allreduce_flat: dtype must be 0 (fp32) or 1 (bf16), got %d", dtype);
   Rccl* r = rccl();
-  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded");
+  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded (%s)", rccl_load_error());
   int rc = r->all_reduce(buf, buf, (size_t)n, dtype == 0 ? kNcclFloat32 : kNcclBfloat16, kNcclSum, comm, (hipStream_t)stream);
   if (rc != 0) return rccl_fail(rc, "ncclAllReduce");
   return SUMK_OK;
@@ -98,7 +103,7 @@ extern "C" int sumk_comm_destroy(void* comm) {
   using namespace sumk;
   if (!comm) return SUMK_OK;
   Rccl* r = rccl();
-  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded");
+  SUMK_ARG(r != nullptr, "comm: librccl.so could not be loaded (%s)", rccl_load_error());
   int rc = r->comm_destroy(comm);
   if (rc != 0) return rccl_fail(rc, "ncclCommDestroy");
   return SUMK_OK;

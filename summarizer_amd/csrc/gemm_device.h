@@ -1,5 +1,4 @@
-// Device-side pieces shared by the GEMM kernels of libsumk.so (gemm_f32.hip: register-staged, all precisions;
-// gemm_dma.hip: LDS-DMA staged exact-fp32): kernel argument block, scalar reads of the problem table, tile decode and the
+// Device-side pieces shared by the GEMM kernels of libsumk.so (gemm_f32.hip / gemm_split.hip: register-staged): kernel argument block, scalar reads of the problem table, tile decode and the
 // fused epilogues.
 #pragma once
 #include "sumk_internal.h"
@@ -258,9 +257,6 @@ __device__ __forceinline__ void residual_init(const GemmKArgs& ka, const TileCtx
   }
 }
 
-// gemm_dma.hip: exact-fp32 kernels staged by LDS-DMA.  cfg: tile configuration of GemmLaunch::small_tile.
-int launch_gemm_dma(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);
-bool gemm_dma_enabled();
 // gemm_split.hip: the register-staged kernel with fp32 operands split into bf16 planes on their way into LDS
 // (SUMK_PRECISION_BF16 / BF16X3 / BF16X6).
 int launch_gemm_split(int precision, GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);

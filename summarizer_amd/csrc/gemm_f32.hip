@@ -45,7 +45,11 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   //  range is a band of one video and the plain order was 6 % faster)
   const bool small_groups = (int64_t)g.total_tiles <= (int64_t)256 * g.nprob;
   ka.group_remap = (g.nprob > 1 && (group_remap == 2 || (group_remap == 1 && (g.group_remap || (g.precision != SUMK_PRECISION_FP32 && small_groups))))) ? 1 : 0;
+#ifdef SUMK_DIAG   // `make DIAG=1` only: SUMK_GEMM_DBG=1 skips the epilogue stores (wrong results by design), =2 in-kernel cycle stamps
   static const int dbg = getenv("SUMK_GEMM_DBG") ? atoi(getenv("SUMK_GEMM_DBG")) : 0;
+#else
+  constexpr int dbg = 0;
+#endif
   ka.dbg = dbg; ka.dbg_buf = nullptr;
   if (dbg & 2) {   // diagnostic only (never on a product path); SUMK_STAMP_TAG=<prof tag>: stamp only that GEMM of a forward pass
     static const int only_tag = getenv("SUMK_STAMP_TAG") ? atoi(getenv("SUMK_STAMP_TAG")) : -1;
@@ -64,14 +68,6 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
-  if (g.precision == SUMK_PRECISION_FP32 && !g.no_dma && epi != EPI_BIAS_RELU_HEAD && epi != EPI_RESIDUAL_MOMENTS && gemm_dma_enabled()) {   // opt-in (SUMK_GEMM_DMA=1): LDS-DMA staging (gemm_dma.hip)
-    rc = launch_gemm_dma(layout, epi, ka, ka.total_tiles, g.small_tile, stream);
-    prof_end(SUMK_PROF_GEMM_ALL, stream);
-    if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
-    if (rc != SUMK_OK) return rc;
-    SUMK_HIP(hipGetLastError());
-    return SUMK_OK;
-  }
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
   if (g.precision != SUMK_PRECISION_FP32) {   // bf16-plane arithmetics: instantiated in gemm_split.hip
@@ -362,7 +358,9 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
   hipStream_t s = (hipStream_t)stream;
   int small = (M <= 64 || N <= 64) ? 1 : 0;
   if (const char* env = getenv("SUMK_ROW_CFG")) if (env[0] >= '0' && env[0] <= '2') small = env[0] - '0';
-  if (getenv("SUMK_FAKE_LD")) { lda = 0; ldb = 0; }   // diagnostic: every row aliases row 0 (tiny footprint, all cache hits)
+#ifdef SUMK_DIAG
+  if (getenv("SUMK_FAKE_LD")) { lda = 0; ldb = 0; }   // `make DIAG=1` only: every row aliases row 0 (tiny footprint, all cache hits; wrong results by design)
+#endif
   SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, small, s));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = small;
@@ -376,8 +374,12 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
 
 extern "C" int sumk_prof_gemm_stamps(uint64_t* out, int32_t n_blocks) {
   using namespace sumk;
+#ifdef SUMK_DIAG
   static const bool on = getenv("SUMK_GEMM_DBG") && (atoi(getenv("SUMK_GEMM_DBG")) & 2);
-  SUMK_ARG(on && out && n_blocks > 0 && n_blocks <= 2048, "gemm stamps: start the process with SUMK_GEMM_DBG=2 (n_blocks <= 2048)");
+#else
+  constexpr bool on = false;
+#endif
+  SUMK_ARG(on && out && n_blocks > 0 && n_blocks <= 2048, "gemm stamps: needs a diagnostic build (make -C summarizer_amd/csrc DIAG=1) started with SUMK_GEMM_DBG=2 (n_blocks <= 2048)");
   SUMK_HIP(hipDeviceSynchronize());
   SUMK_HIP(hipMemcpy(out, gemm_stamp_buffer(), (size_t)n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SUMK_OK;

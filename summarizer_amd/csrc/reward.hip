@@ -171,33 +171,43 @@ __global__ __launch_bounds__(256) void policy_loss_fwd_kernel(const float* __res
                                                               float* __restrict__ meanp) {
   __shared__ float red[4][PL_MAX_E + 1];
   const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
-  float s[PL_MAX_E + 1];
+  const float invT = 1.f / (float)T;
+  float l = 0.f, mp = 0.f;                  // thread 0 only
+  // episodes in chunks of PL_MAX_E (the reference takes any num_episodes, dsn.py:53): the per-episode sums of a chunk live in
+  // registers; for E <= PL_MAX_E this is one pass, with the summation order it always had
+  for (int e0 = 0; e0 < E; e0 += PL_MAX_E) {
+    float s[PL_MAX_E + 1];
 #pragma unroll
-  for (int e = 0; e <= PL_MAX_E; ++e) s[e] = 0.f;
-  for (int t = threadIdx.x; t < T; t += 256) {
-    const float p = probs[r0 + t];
-    const float pc = fminf(fmaxf(p, PL_EPS), 1.f - PL_EPS);
-    const float lp = logf(pc), lq = log1pf(-pc);
-    s[PL_MAX_E] += p;
+    for (int e = 0; e <= PL_MAX_E; ++e) s[e] = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float p = probs[r0 + t];
+      const float pc = fminf(fmaxf(p, PL_EPS), 1.f - PL_EPS);
+      const float lp = logf(pc), lq = log1pf(-pc);
+      s[PL_MAX_E] += p;
 #pragma unroll
-    for (int e = 0; e < PL_MAX_E; ++e)
-      if (e < E) { const float a = actions[(int64_t)e * n_rows + r0 + t]; s[e] += a * lp + (1.f - a) * lq; }
-  }
-#pragma unroll
-  for (int e = 0; e <= PL_MAX_E; ++e) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s[e] += __shfl_xor(s[e], m, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = s[e];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float invT = 1.f / (float)T;
-    const float mp = ((red[0][PL_MAX_E] + red[1][PL_MAX_E]) + (red[2][PL_MAX_E] + red[3][PL_MAX_E])) * invT;
-    float l = beta * (mp - eps_t) * (mp - eps_t);
-    for (int e = 0; e < E; ++e) {
-      const float lpm = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * invT;
-      l -= lpm * (rewards[(int64_t)e * n_seq + v] - base[v]);
+      for (int e = 0; e < PL_MAX_E; ++e)
+        if (e0 + e < E) { const float a = actions[(int64_t)(e0 + e) * n_rows + r0 + t]; s[e] += a * lp + (1.f - a) * lq; }
     }
+#pragma unroll
+    for (int e = 0; e <= PL_MAX_E; ++e) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) s[e] += __shfl_xor(s[e], m, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = s[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (e0 == 0) {
+        mp = ((red[0][PL_MAX_E] + red[1][PL_MAX_E]) + (red[2][PL_MAX_E] + red[3][PL_MAX_E])) * invT;
+        l = beta * (mp - eps_t) * (mp - eps_t);
+      }
+      for (int e = 0; e < PL_MAX_E && e0 + e < E; ++e) {
+        const float lpm = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * invT;
+        l -= lpm * (rewards[(int64_t)(e0 + e) * n_seq + v] - base[v]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     lv[v] = l / (float)E;
     meanp[v] = mp;
   }
@@ -208,9 +218,9 @@ __global__ __launch_bounds__(256) void policy_loss_bwd_kernel(const float* __res
                                                               const float* __restrict__ meanp, const float* __restrict__ dlv,
                                                               const int32_t* __restrict__ off, int n_seq, int n_rows, int E,
                                                               float beta, float eps_t, float* __restrict__ dprobs) {
-  __shared__ float adv[PL_MAX_E];
+  extern __shared__ float adv[];            // E advantages (dynamic: any number of episodes)
   const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
-  if (threadIdx.x < E) adv[threadIdx.x] = rewards[(int64_t)threadIdx.x * n_seq + v] - base[v];
+  for (int e = threadIdx.x; e < E; e += 256) adv[e] = rewards[(int64_t)e * n_seq + v] - base[v];
   __syncthreads();
   const float scale = dlv[v] / ((float)E * (float)T);
   const float g0 = 2.f * beta * (meanp[v] - eps_t);
@@ -236,8 +246,7 @@ extern "C" int sumk_dsn_policy_loss_forward(const float* probs, const float* act
                                             void* stream) {
   using namespace sumk;
   SUMK_ARG(probs && actions && rewards && base && seq_off_dev && loss_per_video && mean_probs, "policy_loss_forward: null pointer");
-  SUMK_ARG(n_seq > 0 && n_rows > 0 && n_episodes > 0 && n_episodes <= PL_MAX_E, "policy_loss_forward: n_seq=%d n_rows=%d episodes=%d (max %d)",
-           n_seq, n_rows, n_episodes, PL_MAX_E);
+  SUMK_ARG(n_seq > 0 && n_rows > 0 && n_episodes > 0, "policy_loss_forward: n_seq=%d n_rows=%d episodes=%d", n_seq, n_rows, n_episodes);
   hipLaunchKernelGGL(policy_loss_fwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, probs, actions, rewards, base, seq_off_dev,
                      n_seq, n_rows, n_episodes, beta, eps_target, loss_per_video, mean_probs);
   SUMK_HIP(hipGetLastError());
@@ -250,9 +259,9 @@ extern "C" int sumk_dsn_policy_loss_backward(const float* probs, const float* ac
                                              float* dprobs, void* stream) {
   using namespace sumk;
   SUMK_ARG(probs && actions && rewards && base && mean_probs && dloss_per_video && seq_off_dev && dprobs, "policy_loss_backward: null pointer");
-  SUMK_ARG(n_seq > 0 && n_rows > 0 && n_episodes > 0 && n_episodes <= PL_MAX_E, "policy_loss_backward: n_seq=%d n_rows=%d episodes=%d (max %d)",
-           n_seq, n_rows, n_episodes, PL_MAX_E);
-  hipLaunchKernelGGL(policy_loss_bwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, probs, actions, rewards, base, mean_probs,
+  SUMK_ARG(n_seq > 0 && n_rows > 0 && n_episodes > 0 && n_episodes <= 8192, "policy_loss_backward: n_seq=%d n_rows=%d episodes=%d (max 8192)",
+           n_seq, n_rows, n_episodes);
+  hipLaunchKernelGGL(policy_loss_bwd_kernel, dim3(n_seq), dim3(256), (size_t)n_episodes * sizeof(float), (hipStream_t)stream, probs, actions, rewards, base, mean_probs,
                      dloss_per_video, seq_off_dev, n_seq, n_rows, n_episodes, beta, eps_target, dprobs);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;

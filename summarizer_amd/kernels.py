@@ -237,6 +237,11 @@ def vasnet_backward_packed(x, sb, params, opts, dscores, ws, grads, want_dx=Fals
     return dx
 
 
+# Bumped by every C-ABI call that WRITES model weights (the optimiser kernels): torch cannot see those writes (no ._version bump,
+# same storage), so caches derived from weights -- VASNet's folded Wvo -- carry this counter in their key.
+WEIGHTS_EPOCH = [0]
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     """In-place torch.optim.Adam-equivalent update of one flat fp32 buffer (HIP kernel)."""
     lib = _lib.load()
@@ -247,6 +252,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
     rc = lib.sumk_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
                             weight_decay, int(step), float(grad_scale), _stream())
     _lib.check(rc, "sumk_adam_step")
+    WEIGHTS_EPOCH[0] += 1
 
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
@@ -265,6 +271,7 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999
                                 weight_decay, _p(state), float(grad_scale), None if sumsq is None else _p(sumsq), float(max_norm),
                                 _stream())
     _lib.check(rc, "sumk_adam_step_dev")
+    WEIGHTS_EPOCH[0] += 1
 
 
 def cast_f32_bf16(src, dst):

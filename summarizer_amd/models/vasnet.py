@@ -140,10 +140,13 @@ class VASNet(nn.Module):
         return scores
 
     def _folded(self):
-        """Cached Wvo = Wo.Wv.  The key holds what torch can see (storage addresses and tensor versions); optimiser steps through
-        the C ABI are invisible to it, so every train() / eval() switch and load_state_dict() drops the cache as well."""
+        """Cached Wvo = Wo.Wv.  The key holds what torch can see (storage addresses and tensor versions) plus
+        kernels.WEIGHTS_EPOCH, which every optimiser step through the C ABI bumps (those writes are invisible to torch: a model kept
+        in eval() while FlatAdam steps it would otherwise score with a stale Wvo); train() / eval() switches and load_state_dict()
+        drop the cache as well.  (Replays of a HIP-graph-captured training step bypass the Python wrappers: call
+        invalidate_folded() after them.)"""
         wo, wv = self.attention_head_projection.weight, self.V.weight
-        key = (wo.data_ptr(), wv.data_ptr(), wo._version, wv._version)
+        key = (wo.data_ptr(), wv.data_ptr(), wo._version, wv._version, kernels.WEIGHTS_EPOCH[0])
         if self._wvo is None or self._wvo_key != key:
             with torch.no_grad():
                 self._wvo = kernels.fold_vo(wo.detach(), wv.detach(), out=self._wvo if self._wvo is not None and self._wvo.device == wo.device else None)

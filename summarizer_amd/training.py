@@ -224,9 +224,14 @@ class FlatAdam:
         rank, world = dist_info()
         if world == 1 or not self.flat_grad.is_cuda:
             return
+        import os
+        if os.environ.get("SUMK_RCCL_DIRECT") == "1":
+            return        # ONE communicator: its collectives stay on one stream, in one order (no early piece; all_reduce_grads reduces the whole bucket)
         if self._side is None:
             self._side = torch.cuda.Stream(self.flat_grad.device)
-        tail_from = (tail_from // 4) * 4                    # keep both pieces 16-byte aligned
+        # keep both pieces 16-byte aligned -- rounding UP: the (up to 3) elements in between belong to the parameter BEFORE the tail,
+        # whose gradient is not final yet when ready_event fires; they travel with the head reduce after the whole backward
+        tail_from = -(-tail_from // 4) * 4
         self._side.wait_event(ready_event)
         with torch.cuda.stream(self._side):
             self._reduce(self.flat_grad[tail_from:])

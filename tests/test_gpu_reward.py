@@ -42,7 +42,8 @@ def test_reward_goldens_and_batch():
             np.testing.assert_allclose(got[e, s], ref, atol=3e-5, rtol=1e-5, err_msg=f"ep {e} video {s}")
 
 
-def test_policy_loss_kernels_match_the_torch_ops_they_replace():
+@pytest.mark.parametrize("E", [5, 16, 37])
+def test_policy_loss_kernels_match_the_torch_ops_they_replace(E):
     """sumk_dsn_policy_loss_forward/backward (through PolicyLossFunction) against the element-wise torch formulation of
     dsn.py:113-140 -- Bernoulli.log_prob, per-video means, advantage product, length penalty, / E -- values and the gradient
     w.r.t. the probabilities, on a ragged batch that includes probabilities exactly at 0 and 1 (clamped: zero log-prob gradient)."""
@@ -51,7 +52,7 @@ def test_policy_loss_kernels_match_the_torch_ops_they_replace():
     from summarizer_amd import kernels
     from summarizer_amd.autograd import PolicyLossFunction
     dev = torch.device("cuda:0")
-    lens, E, beta, eps = [70, 1, 33, 129, 5], 5, 0.01, 0.5
+    lens, beta, eps = [70, 1, 33, 129, 5], 0.01, 0.5      # E = 37: more episodes than one register chunk (the reference takes any num_episodes, dsn.py:53)
     sb = kernels.SeqBatch.get(lens, dev)
     g = torch.Generator().manual_seed(3)
     p0 = torch.rand(sum(lens), generator=g) * 0.98 + 0.01

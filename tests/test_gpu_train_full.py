@@ -260,3 +260,75 @@ def test_transformer_pos_embed_trains_under_flat_adam(dev):
         solid = solid_all = solid_all & (np.abs(ref_g) > 1e-3 * np.abs(ref_g).max())
         d = np.abs(m.pos_embed.weight.detach().cpu().numpy() - port.pos_embed.weight.detach().numpy())
         assert d[solid].max() < 3e-5 and d.max() <= 2.2e-3 * (step + 1), (step, d[solid].max(), d.max())
+
+
+# ------------------------------------------------------------------------------------------------ the HEADLINE path vs the port
+@pytest.fixture(scope="module")
+def vasnet_port_50_inference():
+    """CPU reference of exactly what bench.py times: the 50-video S-TVSum batch (12 003 frames, D = 1024) scored in
+    INFERENCE mode, one video per call through the torch port (= Trainer.test, models/__init__.py:45-54)."""
+    from oracle import torch_port
+    torch.set_num_threads(8)
+    D, lens = 1024, _tvsum_lens()
+    w = R.vasnet_weights(D, 41)
+    xs = [R.features(T, 1, D, 1000 + i) for i, T in enumerate(lens)]         # bench.py's inputs
+    p = {k: torch.from_numpy(v) for k, v in w.items()}
+    with torch.no_grad():
+        scores = np.concatenate([torch_port.vasnet_scores(torch.from_numpy(x), p)[:, 0, 0].numpy() for x in xs])
+    return dict(D=D, lens=lens, w=w, xs=xs, scores=scores)
+
+
+@pytest.mark.parametrize("fold_vo", [False, True])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
+def test_vasnet_headline_inference_batch_vs_torch_port(dev, vasnet_port_50_inference, precision, fold_vo):
+    """at R = 12 003 rows the inference path runs the 128 x 128 tiles and the FUSED tail
+    (EPI_RESIDUAL_MOMENTS, ln_fold_stats_kernel, EPI_BIAS_RELU_HEAD, head_finalize_kernel) and the per-video attention kernels
+    of the headline -- none of which a single-video golden reaches.  Every video's scores against the port at north_star's 1e-4."""
+    from summarizer_amd.models.vasnet import VASNet
+    c = vasnet_port_50_inference
+    m = VASNet(input_size=c["D"], precision=precision, fold_vo=fold_vo)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["w"].items()}); m = m.to(dev).eval()
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in c["xs"]])).to(dev)
+    with torch.no_grad():
+        s = m.score_packed(xp, c["lens"]).cpu().numpy()
+    assert s.shape == c["scores"].shape and np.isfinite(s).all()
+    off = np.concatenate([[0], np.cumsum(c["lens"])])
+    worst = max(float(np.abs(s[off[i]:off[i + 1]] - c["scores"][off[i]:off[i + 1]]).max()) for i in range(len(c["lens"])))
+    print(f"headline batch {precision} fold_vo={fold_vo}: max |score - port| over 50 videos = {worst:.3e}")
+    assert worst < 1e-4, worst
+    assert float(np.ptp(c["scores"])) > 1e-2          # the comparison is not vacuous: scores vary over the batch
+
+
+def _cos(a, b):
+    a = a.reshape(-1).astype(np.float64); b = b.reshape(-1).astype(np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def test_vasnet_bench_batch_grads_bf16_vs_torch_port_with_dropout(dev, vasnet_port_50):
+    """BASELINE config 2 AT SIZE: the mixed-precision training step (one bf16 MFMA per product, fp32
+    accumulation, split-K over K = 12 003 in the weight gradients) on the 50-video batch with dropout against fp32 autograd through
+    the port.  Bound: every operand of every product is rounded to bf16 (2^-9 relative, independent signs), a gradient entry is a
+    sum of >= 1024 such products and passes through <= 6 chained products, so the per-tensor error is ~ sqrt(6) 2^-9 |g|_rms-ish:
+    per tensor max |d| <= 2e-2 max |g| and cosine >= 0.999; scores within 2e-2 (they sit 1.3e-2 from fp32 by DESIGN section 3)."""
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import VasnetFunction
+    from summarizer_amd.models.vasnet import VASNet
+    c = vasnet_port_50
+    m = VASNet(input_size=c["D"], precision="bf16")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in c["w"].items()}); m = m.to(dev)
+    xp = torch.from_numpy(np.concatenate([x[:, 0, :] for x in c["xs"]])).to(dev).requires_grad_(True)
+    sb = kernels.SeqBatch.get(c["lens"], dev)
+    opts = dict(scale=float(m.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=c["p"], seed=c["seed"], precision="bf16")
+    names = [k for _, k in kernels.VASNET_FIELDS]
+    params = dict(m.named_parameters())
+    s = VasnetFunction.apply(xp, sb, opts, None, None, names, *[params[n] for n in names])
+    (s * torch.from_numpy(c["cw"]).to(dev)).sum().backward()
+    np.testing.assert_allclose(s.detach().cpu().numpy(), c["scores"], atol=2e-2, rtol=0)
+    for k in names:
+        g, ref = params[k].grad.cpu().numpy(), c["grads"][k]
+        assert np.isfinite(g).all()
+        r, cs = _rel(g, ref), _cos(g, ref)
+        print(f"bf16 grad {k}: rel max err {r:.3e} cosine {cs:.6f}")
+        assert r < 2e-2 and cs > 0.999, (k, r, cs)
+    gx = xp.grad.cpu().numpy()
+    assert _rel(gx, c["gx"]) < 2e-2 and _cos(gx, c["gx"]) > 0.999

@@ -260,3 +260,51 @@ def test_vasnet_trainer_mixed_precision_bf16_tracks_the_reference_trainer():
     f_max = [v for _, v in hps.writer.scalars["synthetic/Fold_1/Test/F-score_max"]]
     assert np.abs(np.array(f_avg) - g["f_avg"]).max() < 0.1 and np.abs(np.array(f_max) - g["f_max"]).max() < 0.1
     print("bf16 training: losses", losses, "reference", g["losses"].tolist(), "| max dF_avg", float(np.abs(np.array(f_avg) - g["f_avg"]).max()))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6"])
+def test_c1_summe_fold0_trainer_test_at_size_vs_the_reference(precision):
+    """BASELINE config 1 AT SIZE (VERDICT r2 missing #2): S-SumMe -- 25 videos video_1..video_25, T ~ U(100, 650), D = 1024 -- and
+    fold 0 of the reference's real splits/summe_splits.json through `Trainer.test` (models/__init__.py:40-58).  Golden =
+    the REAL reference VASNetTrainer (own _init_model, seed-1234 default weights) run by tests/golden/make_golden_c1.py: per-video
+    scores (1e-4), machine summaries under "rank" and "knapsack" (bit-exact; every test video has a UNIQUE optimal subset, so any
+    exact solver -- OR-tools' included -- selects it), per-video F-scores / Spearman, and the three numbers Trainer.test returns."""
+    import hashlib, json
+    from conftest import load_golden
+    from summarizer_amd.models.vasnet import VASNetTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    from summarizer_amd.utils import eval as E
+    g = load_golden("c1_summe_fold0")
+    meta = json.loads(bytes(g["meta"]).decode())
+    ds = synthetic_dataset(meta["n_videos"], seed=meta["dataset_seed"], D=meta["D"], t_range=tuple(meta["t_range"]), n_users=meta["n_users"])
+    keys = meta["fold0"]["test_keys"]
+    assert keys == ["video_11", "video_12", "video_2", "video_24", "video_7"] and len(meta["fold0"]["train_keys"]) == 20
+    for k in keys:                                       # the regenerated dataset is the one the reference saw
+        assert hashlib.sha256(np.ascontiguousarray(ds[k]["features"][...]).tobytes()).digest() == bytes(g[f"digest/{k}"]), k
+    for algo in ("rank", "knapsack"):
+        hps = make_hps(ds, meta["splits"], splits_file="splits/summe_splits.json", dataset_name="summe", selection_algorithm=algo,
+                       extra_params={"precision": precision})
+        torch.manual_seed(meta["weight_seed"]); random.seed(meta["weight_seed"])
+        tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+        for k, v in tr.model.state_dict().items():       # same creation order under the same seed -> the reference's weights
+            assert hashlib.sha256(np.ascontiguousarray(v.cpu().numpy()).tobytes()).digest() == bytes(g[f"wdigest/{k}"]), k
+        corr, (f_avg, f_max) = tr.test(0)
+        ref = g[f"test_{algo}"]
+        np.testing.assert_allclose(corr, ref[0], atol=2e-5)
+        np.testing.assert_allclose([f_avg, f_max], ref[1:], rtol=1e-6)
+        tr.model.eval()
+        with torch.no_grad():
+            acts = tr._score_keys(keys)
+        _, fa, fm, summ = tr._evaluate_native(acts, keys, want_summaries=True)
+        for i, k in enumerate(keys):
+            T, n_frames, _ = (int(x) for x in g[f"shape/{k}"])
+            assert acts[k].shape == (T,)
+            d = float(np.abs(acts[k] - g[f"scores/{k}"]).max())
+            assert d < 1e-4, (k, d)
+            want = np.unpackbits(g[f"summary_{algo}/{k}"])[:n_frames].astype(np.float32)
+            np.testing.assert_array_equal(summ[i], want, err_msg=f"{algo} {k}")
+            np.testing.assert_allclose([fa[i], fm[i]], g[f"fscore_{algo}/{k}"], rtol=1e-6)
+            m = tr._video_meta(k, "scores")
+            c = E.evaluate_scores(E.generate_scores(acts[k], m.n_frames, m.picks), m.user_scores, metric="spearmanr")
+            np.testing.assert_allclose(c, float(g[f"corr/{k}"]), atol=5e-5)

@@ -250,57 +250,6 @@ def test_vasnet_full_stress_size_properties(dev):
     assert float((head[6000 - 64:] - full[6000 - 64:6000]).abs().max()) > 0          # the cut does matter inside the band
 
 
-_DMA_PROBE = r'''
-import sys, ctypes as C, numpy as np, torch
-root, out = sys.argv[1:3]
-sys.path.insert(0, root); sys.path.insert(0, root + "/tests/golden")
-import recipes as R
-from summarizer_amd import _lib
-from summarizer_amd.models.vasnet import VASNet
-lib = _lib.load(); dev = torch.device("cuda:0"); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-res = {}
-for (M, N, K) in [(4, 4, 4), (37, 64, 64), (132, 192, 100), (129, 128, 1024), (300, 3072, 1024), (64, 1000, 36), (260, 260, 8), (2051, 1024, 1024)]:
-    rng = np.random.default_rng(M + N + K)
-    A = rng.standard_normal((M, K)).astype(np.float32); Bt = rng.standard_normal((N, K)).astype(np.float32)
-    for layout in (0, 1, 2):
-        if layout == 2 and M % 4: continue
-        a = torch.from_numpy(A if layout < 2 else np.ascontiguousarray(A.T)).to(dev)
-        b = torch.from_numpy(Bt if layout == 0 else np.ascontiguousarray(Bt.T)).to(dev)
-        c = torch.full((M, N), float("nan"), device=dev)
-        _lib.check(lib.sumk_gemm_prec(layout, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 0, st), "gemm")
-        res[f"g_{M}_{N}_{K}_{layout}"] = c.cpu().numpy()
-D, lens = 256, [70, 1, 33, 129, 300, 5]
-m = VASNet(input_size=D); m.load_state_dict({k: torch.from_numpy(v) for k, v in R.vasnet_weights(D, 9).items()}); m = m.to(dev).eval()
-x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 60 + i)[:, 0, :] - 0.15 for i, T in enumerate(lens)])).to(dev)
-with torch.no_grad():
-    res["scores"] = m.score_packed(x, lens).cpu().numpy()
-xg = x.clone().requires_grad_(True)
-m.score_packed(xg, lens).sum().backward()          # eval mode, grad enabled: training kernels without dropout
-res["dx"] = xg.grad.cpu().numpy(); res["dWq"] = m.Q.weight.grad.cpu().numpy(); res["dW1"] = m.k1.weight.grad.cpu().numpy()
-np.savez(out, **res)
-'''
-
-
-def test_gemm_dma_equals_register_staged_kernel(dev, tmp_path):
-    """The LDS-DMA staged fp32 GEMM (csrc/gemm_dma.hip, SUMK_GEMM_DMA=1) and the register-staged one (csrc/gemm_f32.hip,
-    the default) issue the same MFMAs in the same k order: every result must be BIT-identical -- plain GEMMs in the three
-    layouts (ragged M / N / K tails included) and a whole VASNet forward + backward on a ragged packed batch."""
-    import os, subprocess, sys
-    from conftest import ROOT
-    outs = []
-    for flag in ("1", "0"):
-        out = str(tmp_path / f"dma{flag}.npz")
-        r = subprocess.run([sys.executable, "-c", _DMA_PROBE, ROOT, out], env=dict(os.environ, SUMK_GEMM_DMA=flag),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs.append(np.load(out))
-    a, b = outs
-    assert sorted(a.files) == sorted(b.files) and len(a.files) > 20
-    for k in a.files:
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-        assert np.isfinite(a[k]).all(), k
-
-
 @pytest.mark.parametrize("M,N,K", [(4, 4, 4), (132, 192, 100), (300, 3072, 1024), (200, 1024, 260)])
 def test_gemm_plain_bf16_vs_float64(dev, M, N, K):
     """precision "bf16" (SUMK_PRECISION_BF16: one bf16 plane, ONE MFMA per product, fp32 accumulate -- the mixed-precision
@@ -382,6 +331,26 @@ def test_vasnet_folded_vo_inference_matches_reference_goldens(dev, precision):
     with torch.no_grad():
         sa, sb_ = a.score_packed(x, lens), b.score_packed(x, lens)
     assert float((sa - sb_).abs().max()) < 1e-5 and not torch.equal(sa, sb_)      # equal up to re-association, and really another path
+
+
+def test_vasnet_folded_vo_sees_optimiser_steps_without_a_mode_switch(dev):
+    """a model that STAYS in eval() (fine-tuning with dropout off; StreamingScorer between steps) while FlatAdam steps it
+    through the C ABI -- no train()/eval() switch, no torch-visible version bump -- must not score with a stale Wvo."""
+    from summarizer_amd.training import FlatAdam
+    D, lens = 128, [40, 17]
+    w = R.vasnet_weights(D, 5)
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 90 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    m, ref = _model(dev, D, w, fold_vo=True), _model(dev, D, w)
+    opts = [FlatAdam(mm.parameters(), lr=1e-2) for mm in (m, ref)]
+    for _ in range(2):
+        with torch.no_grad():
+            a, b = m.score_packed(x, lens), ref.score_packed(x, lens)        # folded scoring BETWEEN the steps fills the cache
+        assert float((a - b).abs().max()) < 1e-5
+        for mm, opt in zip((m, ref), opts):                                   # eval mode throughout: gradients still flow
+            opt.zero_grad(); (mm.score_packed(x, lens) ** 2).mean().backward(); opt.step()
+    with torch.no_grad():
+        a, b = m.score_packed(x, lens), ref.score_packed(x, lens)
+    assert float((a - b).abs().max()) < 1e-5
 
 
 def test_vasnet_folded_vo_follows_weight_updates(dev):

@@ -71,3 +71,14 @@ def test_library_binding_imports_torch_first():
             "_lib.load(); print('OK')") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """A launcher that started 2 ranks while --gpus says 1 (or the reverse) must not produce a line that claims the wrong N."""
+    import os, socket, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SUMK_BENCH_ONE_GPU="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -154,3 +154,42 @@ def test_transformer_oracle_vs_reference_goldens():
     assert R.digest(w) == cfg["wdigest"]
     y = transformer_np.transformer_forward(R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"]), w, cfg["layers"], cfg["heads"])
     np.testing.assert_allclose(y, g["c1/y"], atol=TOL, rtol=0)
+
+
+def test_c1_summe_fold0_oracle_vs_the_reference_at_size():
+    """BASELINE config 1 at size: the oracle (torch port scores, numpy evaluation tail, knapsack restatement) against the REAL
+    reference's Trainer.test(fold 0) on S-SumMe (tests/golden/make_golden_c1.py): scores 2e-5, machine summaries bit-exact under both
+    selection algorithms, per-video F-scores and Spearman, and the fold means Trainer.test returned."""
+    import hashlib, json
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    g = load_golden("c1_summe_fold0")
+    meta = json.loads(bytes(g["meta"]).decode())
+    ds = synthetic_dataset(meta["n_videos"], seed=meta["dataset_seed"], D=meta["D"], t_range=tuple(meta["t_range"]), n_users=meta["n_users"])
+    torch.manual_seed(meta["weight_seed"])
+    p = {k: v.detach() for k, v in VASNet(input_size=meta["D"]).named_parameters()}
+    for k, v in p.items():
+        assert hashlib.sha256(np.ascontiguousarray(v.numpy()).tobytes()).digest() == bytes(g[f"wdigest/{k}"]), k
+    keys = meta["fold0"]["test_keys"]
+    corrs, fs = [], {"rank": [], "knapsack": []}
+    torch.set_num_threads(4)
+    for k in keys:
+        d = ds[k]
+        assert hashlib.sha256(np.ascontiguousarray(d["features"][...]).tobytes()).digest() == bytes(g[f"digest/{k}"]), k
+        with torch.no_grad():
+            y = torch_port.vasnet_scores(torch.from_numpy(d["features"][...]).unsqueeze(1), p)[:, 0, 0].numpy()
+        np.testing.assert_allclose(y, g[f"scores/{k}"], atol=TOL, rtol=0)
+        n_frames = int(d["n_frames"][()])
+        for algo in ("rank", "knapsack"):
+            summ = eval_np.generate_summary(y, d["change_points"][...], n_frames, d["n_frame_per_seg"][...].tolist(), d["picks"][...], 0.15, algo)
+            np.testing.assert_array_equal(summ, np.unpackbits(g[f"summary_{algo}/{k}"])[:n_frames].astype(np.float32), err_msg=f"{algo} {k}")
+            f = eval_np.evaluate_summary(summ, d["user_summary"][...])
+            np.testing.assert_allclose(f, g[f"fscore_{algo}/{k}"], rtol=1e-6)
+            fs[algo].append(f)
+        c = eval_np.evaluate_scores(eval_np.upsample(y, n_frames, d["picks"][...]), d["user_scores"][...])
+        np.testing.assert_allclose(c, float(g[f"corr/{k}"]), atol=5e-5)
+        corrs.append(c)
+    for algo in ("rank", "knapsack"):
+        ref = g[f"test_{algo}"]
+        np.testing.assert_allclose(np.mean(corrs), ref[0], atol=2e-5)
+        np.testing.assert_allclose(np.mean(np.array(fs[algo]), axis=0), ref[1:], rtol=1e-6)
