@@ -30,7 +30,7 @@ def tvsum_lens(n_videos=50):
     return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
 
 
-def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None):
+def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None, seed_base=0):
     """Reference-equivalent stock-PyTorch CPU path (oracle/torch_port.py), one video per call as in
     Trainer.test (summarizer/models/__init__.py:45-54).  torch's intra-op pool is swept over a few thread
     counts (a 256-thread pool is far slower than 16-32 threads on (T<=320, 1024) matrices); the BEST setting is
@@ -51,7 +51,7 @@ def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None):
         lstm = torch_port.make_lstm(p, pre, D, m.hidden_size, m.num_layers)
         score = lambda x: torch_port.bilstm_scores(x, p, pre, hw, hb, D, m.hidden_size, m.num_layers, lstm=lstm)
     ncores = os.cpu_count() or 1
-    xs = [torch.from_numpy(R.features(T, 1, D, 1000 + i)) for i, T in enumerate(lens)]
+    xs = [torch.from_numpy(R.features(T, 1, D, seed_base + i)) for i, T in enumerate(lens)]      # = the GPU batch of that rank (main: 1000 * rank + i)
     # (an intra-op pool as wide as a 256-cpu host is pathological on these sizes -- 95 frames/s for VASNet, minutes per video for
     #  the LSTMs -- so the sweep stops at 64 threads)
     cands = sorted({t for t in (1, 8, 16, 32, 64, min(ncores, 64)) if t <= ncores})
@@ -594,7 +594,7 @@ def main():
             out["folded_vo_bf16x6_mode"] = folded6
         if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
             try:
-                out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None)
+                out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None, seed_base=1000 * rank)
                 # the headline batch against the oracle port, every video (gate 1e-4): what `value` times is what was checked
                 out["parity_max_abs_diff_vs_port"] = out["cpu_baseline"].pop("parity_max_abs_diff_vs_port")
                 out["parity_gate"] = 1e-4

@@ -25,6 +25,8 @@ struct GemmKArgs {
   float alpha;
   int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores, 2 = in-kernel cycle stamps
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
+  int32_t* queue;                // != nullptr: dynamic tile queue (GemmLaunch::queue)
+  int32_t cu_blocks;             // host-side only (launch_epi): blocks per CU the LDS padding admits, 0 = no padding
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
 };

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : (X3 ? NS * BK * MCP_A / 4 : BK * BM);
   constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : (X3 ? NS * BK * MCP_B / 4 : BK * BN);
   __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
+  __shared__ int s_next[2];      // dynamic tile queue: thread 0's draw for the tile after this one (double-buffered by tile parity)
   float* sA = lds;
   float* sB = lds + A_ELEMS;
 
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   if (!setup(tile, cur)) return;   // (remapped walk: a rectangle's tiles are exhausted in increasing order)
   gload(cur, 0);
   unsigned long long t_begin = 0, t_k = 0, t_e = 0, n_t = 0;
+  int n_q = 0;
   if (ka.dbg & 2) t_begin = __builtin_amdgcn_s_memtime();
 
   while (true) {
@@ -224,8 +226,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
 
-    const int next_tile = tile + gridDim.x;
-    bool has_next = next_tile < ka.total_tiles;
+    int next_tile = tile + gridDim.x;
+    if (ka.queue != nullptr && tid == 0)     // drawn now, read by everyone behind the barriers of the k-loop (at its last k-tile)
+      s_next[n_q & 1] = (int)gridDim.x + __hip_atomic_fetch_add(ka.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool has_next = false;
     const int K = cur.K;
     for (int k0 = 0; k0 < K; k0 += BK) {
       __syncthreads();
@@ -234,8 +238,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       __syncthreads();
       if (k0 + BK < K) {
         gload(cur, k0 + BK);
-      } else if (has_next) {   // last k-tile: fetch the NEXT tile's first operands under this tile's last 64 MFMAs
-        has_next = setup(next_tile, nxt);
+      } else {   // last k-tile: fetch the NEXT tile's first operands under this tile's last 64 MFMAs
+        if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
+        has_next = next_tile < ka.total_tiles;
+        if (has_next) has_next = setup(next_tile, nxt);
         if (has_next) gload(nxt, 0);
       }
       if constexpr (X3) {
@@ -333,6 +339,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     if (!has_next) break;
     tile = next_tile;
     cur = nxt;
+    ++n_q;
   }
   if ((ka.dbg & 2) && ka.dbg_buf && tid == 0 && blockIdx.x < 2048) {
     unsigned long long* o = ka.dbg_buf + (size_t)blockIdx.x * 4;
@@ -347,6 +354,22 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
   constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : 8));
   static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
   dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
+  if (ka.cu_blocks > 0 && epi == EPI_NONE) {
+    // balanced persistent launch: pad the block's LDS allocation (dynamic bytes nobody touches) so that exactly cu_blocks blocks fit
+    // in a CU's 160 KiB, and launch at most 256 * cu_blocks of them: every one is resident at once and no CU holds more than its share
+    static size_t static_lds = 0;
+    if (!static_lds) {
+      hipFuncAttributes fa;
+      SUMK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>)));
+      static_lds = fa.sharedSizeBytes;
+    }
+    const size_t target = ((size_t)163840 / ka.cu_blocks) & ~(size_t)1023;
+    const size_t pad = target > static_lds ? target - static_lds : 0;
+    grid = dim3(std::min(tiles, 256 * ka.cu_blocks));
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>), grid, block, pad, s, ka);
+    return SUMK_OK;
+  }
+  SUMK_ARG(ka.queue == nullptr || epi == EPI_NONE, "gemm: the dynamic tile queue goes with the plain epilogue");
   switch (epi) {
     case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>), grid, block, 0, s, ka); break;
     case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL, X3>), grid, block, 0, s, ka); break;

@@ -74,6 +74,13 @@ struct GemmLaunch {
   // drop_thr == 0 disables it.  Element index of the mask = row * N + col.
   uint64_t drop_seed = 0; uint32_t drop_thr = 0, drop_site = 0; float drop_scale = 1.f;
   float* moments = nullptr;            // EPI_RESIDUAL_MOMENTS output
+  // Balanced persistent launch (grouped per-video products): cu_blocks > 0 pads every block's LDS allocation so that EXACTLY cu_blocks
+  // blocks fit on a CU and launches min(tiles, 256 * cu_blocks) of them -- all resident, none stacked deeper than cu_blocks on one CU
+  // (the dispatcher otherwise packs 3, 4 or 5 one-tile blocks per CU and the launch lasts as long as its fullest CU).  queue != nullptr
+  // (a zeroed int32 in device memory): blocks pull their 2nd, 3rd ... tile from an atomic counter instead of walking a fixed stride, so
+  // ragged tiles spread by finishing order.  Speed only: every tile is still computed whole by one block, results do not change.
+  int32_t cu_blocks = 0;
+  int32_t* queue = nullptr;
   int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
   // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],

@@ -29,10 +29,11 @@ enum { TB_S = 0, TB_PV = 1, TB_DV = 2, TB_DP = 3, TB_DQ = 4, TB_DK = 5, TB_COUNT
 constexpr int ROW_PROBS = 8;
 constexpr int SPLITK_PROBS = 64;
 constexpr int COLSUM_CHUNKS = 128;
+constexpr int QUEUE_WORDS = 64;     // one counter per grouped launch of a call, each on its own 16-byte slot
 
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
-  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, total;
+  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, queue, total;
   size_t pl_x, pl_a, pl_w;   // inference only: bf16 planes of x, of the current activation (CTX, then Y1) and of the five weights
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
@@ -69,6 +70,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
   w->stats = take(R * 4 * 4);  // mean/rstd of both LayerNorm applications (training)
   w->scores = take(R * 4);
+  w->queue = take(QUEUE_WORDS * 4);   // dynamic tile-queue counters of the per-video GEMM launches (zeroed by every call)
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
   w->pl_x = w->pl_a = w->pl_w = 0;
@@ -626,7 +628,18 @@ static int rowwise_small_tile(int M, int N) {
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
   int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv;
+  int cub_s, cub_pv;   // balanced persistent launch of the per-video products: blocks per CU (0 = plain launch), see balanced_blocks
 };
+
+// Blocks per CU for a grouped launch of `tiles` 64x64 tiles (GemmLaunch::cu_blocks).  A launch of one-tile blocks lasts as long as its
+// FULLEST CU: left to the dispatcher, the 919 Q.K^T tiles of the S-TVSum batch sit 3, 4 or 5 to a CU (in-kernel stamps, DESIGN
+// section 6) although ceil(919 / 256) = 4 would do.  kmax = what the kernel's registers allow.
+static int balanced_blocks(int tiles, int kmax, const char* env_name) {
+  if (const char* e = getenv(env_name)) return atoi(e);            // tuning override (0 = plain launch)
+  if (tiles <= 256) return 0;
+  const int k = (tiles + 255) / 256;
+  return k <= kmax ? k : kmax;
+}
 
 static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry* G) {
   SUMK_TRY(carve(D, n_seq, off, training, &G->L));
@@ -646,6 +659,8 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
     int T = off[s + 1] - off[s];
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
+  G->cub_s = G->cfg_s == 1 ? balanced_blocks(G->tiles_s, 6, "SUMK_S_CUB") : 0;
+  G->cub_pv = G->cfg_pv == 1 ? balanced_blocks(G->tiles_pv, 6, "SUMK_PV_CUB") : 0;
   return SUMK_OK;
 }
 
@@ -756,6 +771,9 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
+  int32_t* queue = (int32_t*)(ws + L.queue);
+  static const bool dynq = !(getenv("SUMK_DYNQ") && getenv("SUMK_DYNQ")[0] == '0');
+  if (dynq && (G.cub_s > 0 || G.cub_pv > 0)) SUMK_HIP(hipMemsetAsync(queue, 0, QUEUE_WORDS * 4, stream));
 
   // Split-bf16 inference: the three row-wise projections run on PRE-SPLIT bf16 planes (gemm_planes.hip) -- weights split once
   // per call (12 us), x / CTX / Y1 by a streaming kernel -- instead of splitting both operands inside every k-loop.
@@ -786,6 +804,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
     g.total_tiles = G.tiles_s; g.prof_tag = SUMK_PROF_GEMM_QKT;
+    g.cu_blocks = G.cub_s; if (dynq && G.cub_s > 0) g.queue = queue;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
@@ -821,6 +840,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
+    if (!Wvo) { g.cu_blocks = G.cub_pv; if (dynq && G.cub_pv > 0) g.queue = queue + 4; }
     if (Wvo && fused_ln) g.moments = ln_moments;
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
     if (Wvo && fused_ln) {

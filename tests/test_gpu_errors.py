@@ -46,12 +46,16 @@ def test_status_codes_and_messages():
         kernels.vasnet_forward_packed(torch.zeros(8, 64, device=dev), sb, dict(m.named_parameters()), dict(scale=1, eps=1e-6))
     with pytest.raises(SumkError):
         kernels.SeqBatch([3, 0], dev)
-    # loss-glue entries: more episodes than the kernel's register budget / null pointers are refused, not clamped
+    # loss-glue entries: any number of episodes runs (the reference takes any num_episodes, dsn.py:53; 17 > one register chunk of 16);
+    # a non-positive count / null pointers are refused
     pr = torch.rand(9, device=dev); ac = torch.zeros(17, 9, device=dev); rw = torch.zeros(17, 1, device=dev); bs = torch.zeros(1, device=dev)
     lv = torch.zeros(1, device=dev); mp = torch.zeros(1, device=dev)
     rc = lib.sumk_dsn_policy_loss_forward(pr.data_ptr(), ac.data_ptr(), rw.data_ptr(), bs.data_ptr(), 1, 9, sb.off_dev_p, 17, 0.01, 0.5,
                                           lv.data_ptr(), mp.data_ptr(), st)
-    assert rc == -1 and b"episodes=17" in lib.sumk_last_error()
+    assert rc == 0
+    rc = lib.sumk_dsn_policy_loss_forward(pr.data_ptr(), ac.data_ptr(), rw.data_ptr(), bs.data_ptr(), 1, 9, sb.off_dev_p, 0, 0.01, 0.5,
+                                          lv.data_ptr(), mp.data_ptr(), st)
+    assert rc == -1 and b"episodes=0" in lib.sumk_last_error()
     assert lib.sumk_segment_mse_forward(pr.data_ptr(), None, 1, sb.off_dev_p, lv.data_ptr(), st) == -1
     assert lib.sumk_adam_step_dev(pr.data_ptr(), pr.data_ptr(), pr.data_ptr(), pr.data_ptr(), 9, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, 1.0,
                                   None, 0.0, st) == -1

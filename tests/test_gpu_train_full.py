@@ -271,7 +271,7 @@ def vasnet_port_50_inference():
     torch.set_num_threads(8)
     D, lens = 1024, _tvsum_lens()
     w = R.vasnet_weights(D, 41)
-    xs = [R.features(T, 1, D, 1000 + i) for i, T in enumerate(lens)]         # bench.py's inputs
+    xs = [R.features(T, 1, D, i) for i, T in enumerate(lens)]                # bench.py's rank-0 inputs (seed 1000 * rank + i)
     p = {k: torch.from_numpy(v) for k, v in w.items()}
     with torch.no_grad():
         scores = np.concatenate([torch_port.vasnet_scores(torch.from_numpy(x), p)[:, 0, 0].numpy() for x in xs])
