@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsumk.so")
+# SUMK_LIB_PATH: load another build of the same library (the diagnostic build libsumk_diag.so of `make DIAG=1`, for scripts/probes)
+LIB_PATH = os.environ.get("SUMK_LIB_PATH") or os.path.join(_HERE, "libsumk.so")
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p

@@ -27,6 +27,8 @@ struct GemmKArgs {
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
   int32_t* queue;                // != nullptr: dynamic tile queue (GemmLaunch::queue)
   int32_t cu_blocks;             // host-side only (launch_epi): blocks per CU the LDS padding admits, 0 = no padding
+  int32_t prio_mode;             // != 0: the block's waves take an issue priority from their place among the co-resident blocks (gemm_regstage.h)
+  int32_t dbuf;                  // host-side only: 1 = the one-barrier-per-k-tile kernel (64-row tiles, plain epilogue, fp32)
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
 };
@@ -259,6 +261,8 @@ __device__ __forceinline__ void residual_init(const GemmKArgs& ka, const TileCtx
   }
 }
 
+// gemm_lean.hip: 64x64 exact-fp32 tiles with a VALU-free main loop (NT / NN, plain epilogue) for the per-video products
+int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStream_t stream);
 // gemm_split.hip: the register-staged kernel with fp32 operands split into bf16 planes on their way into LDS
 // (SUMK_PRECISION_BF16 / BF16X3 / BF16X6).
 int launch_gemm_split(int precision, GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);

@@ -25,7 +25,7 @@ namespace sumk {
 // one 64 KB stamp buffer per process, allocated on first use under SUMK_GEMM_DBG=2
 static unsigned long long* gemm_stamp_buffer() {
   static unsigned long long* buf = nullptr;
-  if (!buf && hipMalloc(&buf, 2048 * 4 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+  if (!buf && hipMalloc(&buf, 2048 * 12 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
   return buf;
 }
 
@@ -56,7 +56,10 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (only_tag < 0 || only_tag == g.prof_tag) ka.dbg_buf = gemm_stamp_buffer(); else ka.dbg &= ~2;
   }
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
-  ka.queue = g.queue; ka.cu_blocks = g.cu_blocks;
+  ka.queue = g.queue; ka.cu_blocks = g.cu_blocks; ka.dbuf = g.dbuf;
+  static const int prio_mode = getenv("SUMK_GEMM_PRIO") ? atoi(getenv("SUMK_GEMM_PRIO")) : 0;
+  static const int prio_tags = getenv("SUMK_GEMM_PRIO_TAGS") ? atoi(getenv("SUMK_GEMM_PRIO_TAGS")) : -1;
+  ka.prio_mode = (g.prof_tag < 0 || ((prio_tags >> g.prof_tag) & 1)) ? prio_mode : 0;
   SUMK_ARG(!g.queue || g.xcd_M == 0, "gemm: the dynamic tile queue is for grouped launches (no XCD rectangle map)");
   ka.moments = g.moments; ka.ln_stats = g.ln_stats; ka.ln_c1 = g.ln_c1; ka.ln_c2 = g.ln_c2;
   SUMK_ARG(epi != EPI_RESIDUAL_MOMENTS || g.moments, "gemm: the moments epilogue needs an output buffer");
@@ -70,6 +73,17 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
+  // 64x64 tiles, plain epilogue, K-contiguous A, exact fp32: the lean kernel (gemm_lean.hip; SUMK_LEAN=0 keeps the generic one)
+  static const bool lean_on = !(getenv("SUMK_LEAN") && getenv("SUMK_LEAN")[0] == '0');
+  if (lean_on && g.precision == SUMK_PRECISION_FP32 && g.small_tile == 1 && epi == EPI_NONE && (layout == GEMM_NT || layout == GEMM_NN) &&
+      g.n_group == 0 && ka.xcd_tiles_m == 0 && !g.queue && !g.dbuf) {
+    rc = launch_gemm_lean(layout, ka, ka.total_tiles, stream);
+    prof_end(SUMK_PROF_GEMM_ALL, stream);
+    if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
+    if (rc != SUMK_OK) return rc;
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
   if (g.precision != SUMK_PRECISION_FP32) {   // bf16-plane arithmetics: instantiated in gemm_split.hip
@@ -78,6 +92,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   if (g.small_tile == 1) rc = bk64 ? launch_layout<64, 64, 64>(layout, epi, ka, ka.total_tiles, stream)
                                    : launch_layout<64, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
   else if (g.small_tile == 2) rc = launch_layout<128, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
+  else if (g.small_tile == 3) rc = launch_layout<64, 128, 32>(layout, epi, ka, ka.total_tiles, stream);
   else rc = launch_layout<128, 128, 32>(layout, epi, ka, ka.total_tiles, stream);
   prof_end(SUMK_PROF_GEMM_ALL, stream);
   if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
@@ -381,8 +396,10 @@ extern "C" int sumk_prof_gemm_stamps(uint64_t* out, int32_t n_blocks) {
 #else
   constexpr bool on = false;
 #endif
-  SUMK_ARG(on && out && n_blocks > 0 && n_blocks <= 2048, "gemm stamps: needs a diagnostic build (make -C summarizer_amd/csrc DIAG=1) started with SUMK_GEMM_DBG=2 (n_blocks <= 2048)");
+  SUMK_ARG(on && out && n_blocks != 0 && n_blocks <= 2048 && n_blocks >= -2048, "gemm stamps: needs a diagnostic build (make -C summarizer_amd/csrc DIAG=1) started with SUMK_GEMM_DBG=2 (n_blocks <= 2048)");
   SUMK_HIP(hipDeviceSynchronize());
+  // n_blocks < 0: the fine records of SUMK_GEMM_DBG & 4 (8 values per block, -n_blocks of them)
+  if (n_blocks < 0) { SUMK_HIP(hipMemcpy(out, gemm_stamp_buffer() + 2048 * 4, (size_t)(-n_blocks) * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost)); return SUMK_OK; }
   SUMK_HIP(hipMemcpy(out, gemm_stamp_buffer(), (size_t)n_blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SUMK_OK;
 }

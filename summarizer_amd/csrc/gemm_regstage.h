@@ -44,7 +44,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
 // instead of eight fp32 ones at 1/16 of their cost; the three dropped terms are <= 3 * 2^-24 relative, i.e. the result is
 // fp32-grade (the fp32 tolerances of tests/test_gpu_vasnet.py::test_gemm_layouts_vs_float64 hold).  The KC image row
 // becomes [x1 | x2 | x3] = 6 BK bytes + 16 B pad (pitch 52 dwords at BK = 32: 16 rows still hit 16 distinct 16-byte slots).
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0>
+// DBUF: two LDS images per operand and ONE workgroup barrier per k-tile (small tiles only).  With 16 MFMAs per wave between
+// two barriers (64x64 tile), the two-barrier loop leaves each wave's share of the matrix pipe idle from its last MFMA issue through
+// "barrier, wait for the prefetch, LDS write, barrier, first fragment read" of the next k-tile, and the 3-4 co-resident blocks of a CU
+// only partly fill that (measured 79 % MFMA utilisation with every operand L2-resident).  Here k-tile t+1 is written into the OTHER
+// image while k-tile t is being multiplied: [write t+1 | issue loads of t+2 | fragment reads + MFMAs of t | barrier].
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0, bool DBUF = false>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   constexpr bool X3 = NS > 0;
   static_assert(NS >= 0 && NS <= 3, "operand split: 0 (fp32), 1 (plain bf16), 2 or 3 bf16 planes");
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   constexpr int MCP_A = 2 * BM + 64, MCP_B = 2 * BN + 64;   // X3: byte pitch of one k-row of a [k][row] bf16 plane
   constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : (X3 ? NS * BK * MCP_A / 4 : BK * BM);
   constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : (X3 ? NS * BK * MCP_B / 4 : BK * BN);
-  __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * STAGE];
   __shared__ int s_next[2];      // dynamic tile queue: thread 0's draw for the tile after this one (double-buffered by tile parity)
   float* sA = lds;
   float* sB = lds + A_ELEMS;
@@ -153,6 +159,29 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       }
     }
   };
+  // the same masks without the wave-uniform early-out (selects only): keeps the one-barrier loop body a single basic block
+  auto ktail_u = [&](int K, int k0) {
+#pragma unroll
+    for (int p = 0; p < NLDA; ++p) {
+      if constexpr (A_KC) {
+        const int k = k0 + kq4;
+        ra[p].x = k < K ? ra[p].x : 0.f; ra[p].y = k + 1 < K ? ra[p].y : 0.f; ra[p].z = k + 2 < K ? ra[p].z : 0.f; ra[p].w = k + 3 < K ? ra[p].w : 0.f;
+      } else {
+        const bool in = k0 + tid / TPRA + KROWSA * p < K;
+        ra[p].x = in ? ra[p].x : 0.f; ra[p].y = in ? ra[p].y : 0.f; ra[p].z = in ? ra[p].z : 0.f; ra[p].w = in ? ra[p].w : 0.f;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NLDB; ++p) {
+      if constexpr (B_KC) {
+        const int k = k0 + kq4;
+        rb[p].x = k < K ? rb[p].x : 0.f; rb[p].y = k + 1 < K ? rb[p].y : 0.f; rb[p].z = k + 2 < K ? rb[p].z : 0.f; rb[p].w = k + 3 < K ? rb[p].w : 0.f;
+      } else {
+        const bool in = k0 + tid / TPRB + KROWSB * p < K;
+        rb[p].x = in ? rb[p].x : 0.f; rb[p].y = in ? rb[p].y : 0.f; rb[p].z = in ? rb[p].z : 0.f; rb[p].w = in ? rb[p].w : 0.f;
+      }
+    }
+  };
   // planes p = 0 .. NS-1 of this thread's 4 values: x_p = bf16(remainder), remainder -= x_p  (each subtraction is exact)
   auto split_planes = [&](float4 v, bf16x4 (&pl)[3]) {
     f32x4 r = {v.x, v.y, v.z, v.w};
@@ -176,7 +205,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
 #pragma unroll
     for (int q = 0; q < (NS > 0 ? NS : 1); ++q) *reinterpret_cast<bf16x4*>(r8 + q * BK * pitch) = pl[q];
   };
-  auto swrite = [&]() {
+  auto swrite = [&](float* sA, float* sB) {
     if constexpr (X3) {
 #pragma unroll
       for (int p = 0; p < NLDA; ++p) {
@@ -202,52 +231,14 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile >= ka.total_tiles) return;
-  TileCtx cur, nxt;
-  if (!setup(tile, cur)) return;   // (remapped walk: a rectangle's tiles are exhausted in increasing order)
-  gload(cur, 0);
-  unsigned long long t_begin = 0, t_k = 0, t_e = 0, n_t = 0;
-  int n_q = 0;
-  if (ka.dbg & 2) t_begin = __builtin_amdgcn_s_memtime();
-
-  while (true) {
-    unsigned long long ta = 0;
-    if (ka.dbg & 2) ta = __builtin_amdgcn_s_memtime();
-    f32x16 acc[TM][TN];
-    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_MOMENTS) {
-      residual_init<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
-    } else {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
-
-    int next_tile = tile + gridDim.x;
-    if (ka.queue != nullptr && tid == 0)     // drawn now, read by everyone behind the barriers of the k-loop (at its last k-tile)
-      s_next[n_q & 1] = (int)gridDim.x + __hip_atomic_fetch_add(ka.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool has_next = false;
-    const int K = cur.K;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-      __syncthreads();
-      ktail(K, k0);
-      swrite();
-      __syncthreads();
-      if (k0 + BK < K) {
-        gload(cur, k0 + BK);
-      } else {   // last k-tile: fetch the NEXT tile's first operands under this tile's last 64 MFMAs
-        if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
-        has_next = next_tile < ka.total_tiles;
-        if (has_next) has_next = setup(next_tile, nxt);
-        if (has_next) gload(nxt, 0);
-      }
+  // fragment reads + MFMAs of ONE k-tile whose operand images start at sA / sB
+  // (half = 0 / 1: only the first / second half of the k-tile; -1: all of it)
+  auto compute = [&](const float* sA, const float* sB, f32x16 (&acc)[TM][TN], int half = -1) {
       if constexpr (X3) {
         constexpr int NP = NS > 0 ? NS : 1;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+          if (half >= 0 && (ks >= BK / 32) != (half == 1)) continue;
           bf16x8 af[NP][TM], bf[NP][TN];      // [plane][tile]: 8 consecutive k of this lane's row
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
@@ -292,6 +283,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       } else {
 #pragma unroll
       for (int kk = 0; kk < BK / 8; ++kk) {
+        if (half >= 0 && (kk >= BK / 16) != (half == 1)) continue;
         float av[TM][4], bv[TN][4];
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
@@ -322,6 +314,126 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm][j], bv[tn][j], acc[tm][tn], 0, 0, 0);
       }
       }
+  };
+
+  // Co-resident blocks of one launch start together, run the same program and share each SIMD's matrix pipe turn by turn: they stay in
+  // LOCKSTEP -- all of them multiply at once (each at 1/3 or 1/4 of the pipe), then all of them sit in "barrier, wait, LDS write,
+  // barrier" at once with the pipe idle (in-kernel stamps of the 64x64 Q.K^T launch: 73-81 % matrix-pipe utilisation with every
+  // operand L2-resident).  Distinct issue priorities break the tie: the SIMD serves its highest-priority ready wave, so one block's
+  // synchronisation phase runs under another block's MFMAs.  Speed only; which blocks share a CU is the dispatcher's business.
+  if (ka.prio_mode) {
+    int p;
+    if (ka.prio_mode == 1) p = (blockIdx.x >> 8) & 3;                                  // blocks b, b + 256, ... tend to share a CU
+    else if (ka.prio_mode == 2) p = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;       // HW_ID.wave_id: the wave's slot on its SIMD
+    else if (ka.prio_mode == 3) p = 3 - ((blockIdx.x >> 8) & 3);
+    else p = (blockIdx.x >> 3) & 3;
+    p = __builtin_amdgcn_readfirstlane(p);
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  int tile = blockIdx.x;
+  if (tile >= ka.total_tiles) return;
+  TileCtx cur, nxt;
+  if (!setup(tile, cur)) return;   // (remapped walk: a rectangle's tiles are exhausted in increasing order)
+  gload(cur, 0);
+  unsigned long long t_begin = 0, t_k = 0, t_e = 0, n_t = 0;
+#ifdef SUMK_DIAG
+  unsigned long long d_b1 = 0, d_wr = 0, d_b2 = 0, d_cp = 0;     // SUMK_GEMM_DBG & 4: shares of the k-loop (barrier 1, wait + LDS write, barrier 2, issue + compute)
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+  int n_q = 0;
+  if (ka.dbg & 2) t_begin = __builtin_amdgcn_s_memtime();
+
+  while (true) {
+    unsigned long long ta = 0;
+    if (ka.dbg & 2) ta = __builtin_amdgcn_s_memtime();
+    f32x16 acc[TM][TN];
+    if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_MOMENTS) {
+      residual_init<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * WTN, li, lh);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+
+    int next_tile = tile + gridDim.x;
+    if (ka.queue != nullptr && tid == 0)     // drawn now, read by everyone behind the barriers of the k-loop (at its last k-tile)
+      s_next[n_q & 1] = (int)gridDim.x + __hip_atomic_fetch_add(ka.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool has_next = false;
+    const int K = cur.K;
+    if constexpr (DBUF) {
+      // one barrier per k-tile: image `buf` holds k-tile k0, the staging registers hold k-tile k0 + BK (in flight)
+      int buf = 0;
+      ktail(K, 0);
+      swrite(lds, lds + A_ELEMS);
+      if (BK < K) gload(cur, BK);
+      __syncthreads();
+      // The wave's own bookkeeping rides BETWEEN its MFMAs (each 32x32x2 MFMA holds the pipe 64 cycles and the next one of the chain
+      // cannot issue before it is done): first half of the k-tile, the LDS write of k-tile k0 + BK into the other image, second half,
+      // the loads of k-tile k0 + 2 BK (clamped: past K they fetch bytes nobody uses) -- a single basic block the scheduler can
+      // interleave; what stays exposed per k-tile is the barrier and the first fragment read.  The last k-tile is peeled.
+      int k0 = 0;
+      for (; k0 + BK < K; k0 += BK) {
+        float* im = lds + buf * STAGE;
+        float* om = lds + (buf ^ 1) * STAGE;       // last read one k-tile ago, behind the barrier that ended that k-tile
+        compute(im, im + A_ELEMS, acc, 0);
+        ktail_u(K, k0 + BK);
+        swrite(om, om + A_ELEMS);
+        compute(im, im + A_ELEMS, acc, 1);
+        gload(cur, k0 + 2 * BK);
+        __syncthreads();
+        buf ^= 1;
+      }
+      {   // last k-tile: fetch the NEXT tile's first operands under this tile's last MFMAs
+        float* im = lds + buf * STAGE;
+        if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
+        has_next = next_tile < ka.total_tiles;
+        if (has_next) has_next = setup(next_tile, nxt);
+        if (has_next) gload(nxt, 0);
+        compute(im, im + A_ELEMS, acc);
+        __syncthreads();
+        buf ^= 1;
+      }
+    } else {
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#ifdef SUMK_DIAG
+      unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      if (ka.dbg & 4) s0 = __builtin_amdgcn_s_memtime();
+#endif
+      __syncthreads();
+#ifdef SUMK_DIAG
+      if (ka.dbg & 4) s1 = __builtin_amdgcn_s_memtime();
+#endif
+      ktail(K, k0);
+      swrite(sA, sB);
+#ifdef SUMK_DIAG
+      if (ka.dbg & 4) { __builtin_amdgcn_s_waitcnt(0); s2 = __builtin_amdgcn_s_memtime(); }
+#endif
+      __syncthreads();
+#ifdef SUMK_DIAG
+      if (ka.dbg & 4) s3 = __builtin_amdgcn_s_memtime();
+#endif
+      if (k0 + BK < K) {
+        gload(cur, k0 + BK);
+      } else {   // last k-tile: fetch the NEXT tile's first operands under this tile's last 64 MFMAs
+        if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
+        has_next = next_tile < ka.total_tiles;
+        if (has_next) has_next = setup(next_tile, nxt);
+        if (has_next) gload(nxt, 0);
+      }
+      compute(sA, sB, acc);
+#ifdef SUMK_DIAG
+      if (ka.dbg & 4) {
+        asm volatile("" :: "v"(acc[0][0][0]));
+        const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+        d_b1 += s1 - s0; d_wr += s2 - s1; d_b2 += s3 - s2; d_cp += s4 - s3;
+      }
+#endif
+    }
     }
 
     // ---- epilogue of `cur` (gemm_device.h)
@@ -344,6 +456,13 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   if ((ka.dbg & 2) && ka.dbg_buf && tid == 0 && blockIdx.x < 2048) {
     unsigned long long* o = ka.dbg_buf + (size_t)blockIdx.x * 4;
     o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_k; o[2] = t_e; o[3] = n_t;
+#ifdef SUMK_DIAG
+    if (ka.dbg & 4) {   // second record, behind the 2048 first ones: k-loop shares, wall-clock window (100 MHz), placement
+      unsigned long long* q = ka.dbg_buf + (size_t)2048 * 4 + (size_t)blockIdx.x * 8;
+      q[0] = d_b1; q[1] = d_wr; q[2] = d_b2; q[3] = d_cp; q[4] = rt_begin; q[5] = __builtin_amdgcn_s_memrealtime();
+      q[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
   }
 }
 
@@ -351,23 +470,26 @@ template <int BM, int BN, int BK, bool A_KC, bool B_KC, int X3 = 0>
 static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
   // every block then loops over tiles  b, b+grid, ...
-  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : 8));
+  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : (BN == 128 ? 5 : 8)));
   static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
   dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
-  if (ka.cu_blocks > 0 && epi == EPI_NONE) {
-    // balanced persistent launch: pad the block's LDS allocation (dynamic bytes nobody touches) so that exactly cu_blocks blocks fit
-    // in a CU's 160 KiB, and launch at most 256 * cu_blocks of them: every one is resident at once and no CU holds more than its share
-    static size_t static_lds = 0;
-    if (!static_lds) {
-      hipFuncAttributes fa;
-      SUMK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>)));
-      static_lds = fa.sharedSizeBytes;
+  if constexpr (BM == 64 && BK == 32 && X3 == 0) {
+    if (epi == EPI_NONE && (ka.cu_blocks > 0 || ka.dbuf)) {
+      // balanced persistent launch: pad the block's LDS allocation (dynamic bytes nobody touches) so that exactly cu_blocks blocks
+      // fit in a CU's 160 KiB, and launch at most 256 * cu_blocks of them: every one is resident at once and no CU holds more than
+      // its share; dbuf: the one-barrier-per-k-tile loop (two LDS images)
+      auto fn = ka.dbuf ? &gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3, true> : &gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3, false>;
+      size_t pad = 0;
+      if (ka.cu_blocks > 0) {
+        hipFuncAttributes fa;
+        SUMK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
+        const size_t target = ((size_t)163840 / ka.cu_blocks) & ~(size_t)1023;
+        pad = target > fa.sharedSizeBytes ? target - fa.sharedSizeBytes : 0;
+        grid = dim3(std::min(tiles, 256 * ka.cu_blocks));
+      }
+      hipLaunchKernelGGL(fn, grid, block, pad, s, ka);
+      return SUMK_OK;
     }
-    const size_t target = ((size_t)163840 / ka.cu_blocks) & ~(size_t)1023;
-    const size_t pad = target > static_lds ? target - static_lds : 0;
-    grid = dim3(std::min(tiles, 256 * ka.cu_blocks));
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>), grid, block, pad, s, ka);
-    return SUMK_OK;
   }
   SUMK_ARG(ka.queue == nullptr || epi == EPI_NONE, "gemm: the dynamic tile queue goes with the plain epilogue");
   switch (epi) {

@@ -102,6 +102,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
 // row-wise single-problem entries (threads of block 1).
 struct RowProbSpec { int32_t M, N, K, lda, ldb, ldc, ldr, small; };
 struct SetupArgs {
+  int32_t fake_seq0;     // diagnostic builds only: every video READS video 0's Q / K / V rows (operands stay L2-resident)
   const int32_t* off; int32_t n_seq, D;
   SeqInfo* seq; GemmProb* tabs;   // tabs[TB_COUNT][n_seq]
   int32_t s_tm, s_tn, pv_tm, pv_tn;  // block-tile dims of the (T x T) and (T x D) per-video products
@@ -172,9 +173,10 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   a.seq[s] = si;
   const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
   const int n = a.n_seq;
+  const int64_t qr = a.fake_seq0 ? 0 : q0;     // where Q / K / V are READ (q0 except in the diagnostic aliasing experiment)
   // forward
-  put_prob(a.tabs + TB_S * n + s, q0, q0 + D, eoff, T, T, D, 3 * D, 3 * D, ldE, ts, tm);            // E = Q K^T        (NT)
-  put_prob(a.tabs + TB_PV * n + s, eoff, q0 + 2 * D, c0, T, D, T, ldE, 3 * D, D, tpv, tn);           // C = alpha V      (NN)
+  put_prob(a.tabs + TB_S * n + s, qr, qr + D, eoff, T, T, D, 3 * D, 3 * D, ldE, ts, tm);            // E = Q K^T        (NT)
+  put_prob(a.tabs + TB_PV * n + s, eoff, qr + 2 * D, c0, T, D, T, ldE, 3 * D, D, tpv, tn);           // C = alpha V      (NN)
   a.tabs[TB_PV * n + s].r_off = c0; a.tabs[TB_PV * n + s].ldr = D;   // folded inference path: + X in the epilogue (same rows as C)
   // backward
   put_prob(a.tabs + TB_DV * n + s, eoff, c0, q0 + 2 * D, T, D, T, ldE, D, 3 * D, tpv, tn);           // dV = alpha^T dC  (TN)
@@ -636,9 +638,8 @@ struct Geometry {  // what both forward and backward derive from the batch
 // section 6) although ceil(919 / 256) = 4 would do.  kmax = what the kernel's registers allow.
 static int balanced_blocks(int tiles, int kmax, const char* env_name) {
   if (const char* e = getenv(env_name)) return atoi(e);            // tuning override (0 = plain launch)
-  if (tiles <= 256) return 0;
-  const int k = (tiles + 255) / 256;
-  return k <= kmax ? k : kmax;
+  (void)tiles; (void)kmax;
+  return 0;     // measured: the dispatcher already deals one-tile blocks evenly (scripts/probes/census.hip: 919 blocks -> 3 or 4 per CU)
 }
 
 static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry* G) {
@@ -653,14 +654,14 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
   static const char* env = getenv("SUMK_ATTN_CFG");   // tuning override "<cfg_s><cfg_pv>", e.g. "20"
   const int cfg_auto = (G->R / n_seq >= 1024) ? 0 : 1;
   G->cfg_s = cfg_auto; G->cfg_pv = cfg_auto;
-  if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
+  if (env && env[0] >= '0' && env[0] <= '3' && env[1] >= '0' && env[1] <= '3') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
     int T = off[s + 1] - off[s];
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
-  G->cub_s = G->cfg_s == 1 ? balanced_blocks(G->tiles_s, 6, "SUMK_S_CUB") : 0;
-  G->cub_pv = G->cfg_pv == 1 ? balanced_blocks(G->tiles_pv, 6, "SUMK_PV_CUB") : 0;
+  G->cub_s = (G->cfg_s == 1 || G->cfg_s == 3) ? balanced_blocks(G->tiles_s, 6, "SUMK_S_CUB") : 0;
+  G->cub_pv = (G->cfg_pv == 1 || G->cfg_pv == 3) ? balanced_blocks(G->tiles_pv, 6, "SUMK_PV_CUB") : 0;
   return SUMK_OK;
 }
 
@@ -669,6 +670,10 @@ enum { RP_QKV = 0, RP_DD = 1, RP_DX = 2 };
 
 static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off_dev, char* ws, hipStream_t stream) {
   SetupArgs a;
+  a.fake_seq0 = 0;
+#ifdef SUMK_DIAG
+  if (getenv("SUMK_FAKE_SEQ0")) a.fake_seq0 = 1;    // wrong results by design: timing experiment (are the per-video GEMMs bound by where their operands come from?)
+#endif
   a.off = off_dev; a.n_seq = n_seq; a.D = D;
   a.seq = (SeqInfo*)(ws + G.L.seq); a.tabs = (GemmProb*)(ws + G.L.prob_seq); a.prow = (GemmProb*)(ws + G.L.prob_row);
   const int R = G.R;
@@ -805,6 +810,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
     g.total_tiles = G.tiles_s; g.prof_tag = SUMK_PROF_GEMM_QKT;
     g.cu_blocks = G.cub_s; if (dynq && G.cub_s > 0) g.queue = queue;
+    static const int dbuf_s = getenv("SUMK_S_DBUF") ? atoi(getenv("SUMK_S_DBUF")) : 0;
+    g.dbuf = dbuf_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
@@ -841,6 +848,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
     if (!Wvo) { g.cu_blocks = G.cub_pv; if (dynq && G.cub_pv > 0) g.queue = queue + 4; }
+    static const int dbuf_pv = getenv("SUMK_PV_DBUF") ? atoi(getenv("SUMK_PV_DBUF")) : 0;
+    if (!Wvo) g.dbuf = dbuf_pv;
     if (Wvo && fused_ln) g.moments = ln_moments;
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
     if (Wvo && fused_ln) {

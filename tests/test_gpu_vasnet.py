@@ -426,6 +426,26 @@ def test_planes_gemm_path_matches_inloop_split_path(dev, tmp_path):
             assert d_path < tol_path and d_fp32 < tol_fp32, (k, d_path, d_fp32)
 
 
+def test_lean_gemm_equals_generic_kernel(tmp_path):
+    """csrc/gemm_lean.hip (the 64x64 per-video products with a VALU-free main loop, persistent tile walk, peeled K tail) against the
+    generic register-staged kernel (SUMK_LEAN=0) on a ragged batch -- T = 1 ... 333, inference scores, training-mode scores, dX and
+    every parameter gradient -- and on plain NT / NN GEMMs with K tails: BIT-identical (same k order, one fmaf chain per element)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    probe = os.path.join(ROOT, "scripts", "probes", "lean_equiv.py")
+    outs = {}
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"lean{flag}.npz")
+        r = subprocess.run([sys.executable, probe, f], env=dict(os.environ, SUMK_LEAN=flag), capture_output=True, text=True, cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[flag] = np.load(f)
+    a, b = outs["1"], outs["0"]
+    assert set(a.files) == set(b.files) and len(a.files) > 15
+    for k in a.files:
+        assert np.isfinite(a[k]).all() or k.startswith("scores"), k
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_fused_inference_tail_equals_separate_kernels(tmp_path):
     """The fused inference tail (LayerNorm 1 applied to the k1 product, LayerNorm 2 + k2 taken from the k1 epilogue: neither
     activation matrix is stored) against the separate LayerNorm kernels on the S-TVSum batch (50 videos, D = 1024): the
