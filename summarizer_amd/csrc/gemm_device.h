@@ -28,6 +28,7 @@ struct GemmKArgs {
   int32_t* queue;                // != nullptr: dynamic tile queue (GemmLaunch::queue)
   int32_t cu_blocks;             // host-side only (launch_epi): blocks per CU the LDS padding admits, 0 = no padding
   int32_t prio_mode;             // != 0: the block's waves take an issue priority from their place among the co-resident blocks (gemm_regstage.h)
+  int32_t lean;                  // host-side only: 1 = NT 128x128 launch eligible for the buffer-load (VALU-free k-loop) instances
   int32_t dbuf;                  // host-side only: 1 = the one-barrier-per-k-tile kernel (64-row tiles, plain epilogue, fp32)
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
@@ -54,6 +55,7 @@ static_assert(offsetof(GemmProb, M) == 32 && offsetof(GemmProb, tile_start) == 6
 struct TileCtx {
   int64_t c_off, r_off;
   int32_t M, N, K, lda, ldb, ldc, ldr, m0, n0, klast;
+  const float* ab; const float* bb;   // LEAN kernels: operand bases of the problem (buffer descriptors; per-thread byte offsets beside them)
 };
 
 // Which sub-problem / tile does persistent tile id `tile` name?  Wave-uniform scalar work.  Returns false when a remapped

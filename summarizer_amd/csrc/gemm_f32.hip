@@ -57,6 +57,9 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   }
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
   ka.queue = g.queue; ka.cu_blocks = g.cu_blocks; ka.dbuf = g.dbuf;
+  static const bool lean128_on = !(getenv("SUMK_LEAN128") && getenv("SUMK_LEAN128")[0] == '0');
+  ka.lean = (lean128_on && g.lean && g.nprob == 1 && layout == GEMM_NT && g.small_tile == 0 && g.precision == SUMK_PRECISION_FP32 &&
+             (g.n_group == 0 || g.n_group % 128 == 0)) ? 1 : 0;
   static const int prio_mode = getenv("SUMK_GEMM_PRIO") ? atoi(getenv("SUMK_GEMM_PRIO")) : 0;
   static const int prio_tags = getenv("SUMK_GEMM_PRIO_TAGS") ? atoi(getenv("SUMK_GEMM_PRIO_TAGS")) : -1;
   ka.prio_mode = (g.prof_tag < 0 || ((prio_tags >> g.prof_tag) & 1)) ? prio_mode : 0;

@@ -49,8 +49,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
 // "barrier, wait for the prefetch, LDS write, barrier, first fragment read" of the next k-tile, and the 3-4 co-resident blocks of a CU
 // only partly fill that (measured 79 % MFMA utilisation with every operand L2-resident).  Here k-tile t+1 is written into the OTHER
 // image while k-tile t is being multiplied: [write t+1 | issue loads of t+2 | fragment reads + MFMAs of t | barrier].
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0, bool DBUF = false>
+// LEAN (NT, exact fp32, K % BK == 0, one B group per tile): operands are fetched with buffer loads -- per-thread byte offset fixed per
+// tile, the k advance a scalar soffset -- so the k-loop carries no address arithmetic.  v_mfma_f32_32x32x2_f32 shares its SIMD's
+// vector ALU (gemm_lean.hip header): the ~28 64-bit pointer instructions per k-tile of the plain form cost 3-4 % of the matrix rate.
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0, bool DBUF = false, bool LEAN = false>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
+  static_assert(!LEAN || (A_KC && B_KC && NS == 0 && !DBUF), "LEAN: NT fp32 two-barrier instances only");
   constexpr bool X3 = NS > 0;
   static_assert(NS >= 0 && NS <= 3, "operand split: 0 (fp32), 1 (plain bf16), 2 or 3 bf16 planes");
   constexpr int KC_PITCH = (NS == 0 ? BK : NS * BK / 2) + 4;   // +4 floats: conflict-free ds_read_b128 (pitch 20 / 36 / 52 dwords at BK = 32: 16 rows hit 16 distinct slots)
@@ -82,11 +86,23 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   // output rows/columns the epilogue never stores.  Only the K tail must contribute zeros: masked before the LDS write.
   const float* pa[NLDA];
   const float* pb[NLDB];
+  int voa[NLDA], vob[NLDB];      // LEAN: byte offsets of this thread's rows (+ its k chunk) from TileCtx::ab / bb
 
   // ---- tile decode (wave-uniform scalar work, gemm_device.h) + this thread's row pointers
   auto setup = [&](int tile, TileCtx& c) -> bool {
     GemmProb P;
     if (!decode_tile<BM, BN>(ka, tile, c, P)) return false;
+    if constexpr (LEAN) {
+      c.ab = ka.A + P.a_off;
+      int g = 0, ng = 0;                              // the tile's rows of B lie in ONE group (host: n_group % BN == 0)
+      if (ka.n_group > 0) { g = c.n0 / ka.n_group; ng = g * ka.n_group; }
+      c.bb = (g == 0 ? ka.B[0] : g == 1 ? ka.B[1] : g == 2 ? ka.B[2] : ka.B[3]) + P.b_off;
+#pragma unroll
+      for (int p = 0; p < NLDA; ++p) voa[p] = (min(c.m0 + tid / TPK + RPP * p, P.M - 1) * P.lda + kq4) * 4;
+#pragma unroll
+      for (int p = 0; p < NLDB; ++p) vob[p] = ((min(c.n0 + tid / TPK + RPP * p, P.N - 1) - ng) * P.ldb + kq4) * 4;
+      return true;
+    }
     if constexpr (A_KC) {
 #pragma unroll
       for (int p = 0; p < NLDA; ++p) {
@@ -120,6 +136,16 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   float4 ra[NLDA], rb[NLDB];
 
   auto gload = [&](const TileCtx& c, int k0) {
+    if constexpr (LEAN) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.ab), (short)0, 0x7FFFFFFF, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.bb), (short)0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < NLDA; ++p) ra[p] = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rA, voa[p], k0 * 4, 0));
+#pragma unroll
+      for (int p = 0; p < NLDB; ++p) rb[p] = __builtin_bit_cast(float4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rB, vob[p], k0 * 4, 0));
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NLDA; ++p) {
       if constexpr (A_KC) ra[p] = ldg4(pa[p] + min(k0 + kq4, c.klast));
@@ -339,7 +365,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   gload(cur, 0);
   unsigned long long t_begin = 0, t_k = 0, t_e = 0, n_t = 0;
 #ifdef SUMK_DIAG
-  unsigned long long d_b1 = 0, d_wr = 0, d_b2 = 0, d_cp = 0;     // SUMK_GEMM_DBG & 4: shares of the k-loop (barrier 1, wait + LDS write, barrier 2, issue + compute)
   const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 #endif
   int n_q = 0;
@@ -399,41 +424,26 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
         buf ^= 1;
       }
     } else {
-    for (int k0 = 0; k0 < K; k0 += BK) {
-#ifdef SUMK_DIAG
-      unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-      if (ka.dbg & 4) s0 = __builtin_amdgcn_s_memtime();
-#endif
+      // all k-tiles but the last: nothing but "barrier, LDS write, barrier, next loads, MFMAs"; the last one is peeled -- it carries
+      // the K-tail masks and fetches the NEXT tile's first operands under this tile's last MFMAs (its decode would otherwise sit in
+      // the loop as a merge of two register sets, copied every k-tile)
+      int k0 = 0;
+      for (; k0 + BK < K; k0 += BK) {
+        __syncthreads();
+        swrite(sA, sB);
+        __syncthreads();
+        gload(cur, k0 + BK);
+        compute(sA, sB, acc);
+      }
       __syncthreads();
-#ifdef SUMK_DIAG
-      if (ka.dbg & 4) s1 = __builtin_amdgcn_s_memtime();
-#endif
       ktail(K, k0);
       swrite(sA, sB);
-#ifdef SUMK_DIAG
-      if (ka.dbg & 4) { __builtin_amdgcn_s_waitcnt(0); s2 = __builtin_amdgcn_s_memtime(); }
-#endif
       __syncthreads();
-#ifdef SUMK_DIAG
-      if (ka.dbg & 4) s3 = __builtin_amdgcn_s_memtime();
-#endif
-      if (k0 + BK < K) {
-        gload(cur, k0 + BK);
-      } else {   // last k-tile: fetch the NEXT tile's first operands under this tile's last 64 MFMAs
-        if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
-        has_next = next_tile < ka.total_tiles;
-        if (has_next) has_next = setup(next_tile, nxt);
-        if (has_next) gload(nxt, 0);
-      }
+      if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
+      has_next = next_tile < ka.total_tiles;
+      if (has_next) has_next = setup(next_tile, nxt);
+      if (has_next) gload(nxt, 0);
       compute(sA, sB, acc);
-#ifdef SUMK_DIAG
-      if (ka.dbg & 4) {
-        asm volatile("" :: "v"(acc[0][0][0]));
-        const unsigned long long s4 = __builtin_amdgcn_s_memtime();
-        d_b1 += s1 - s0; d_wr += s2 - s1; d_b2 += s3 - s2; d_cp += s4 - s3;
-      }
-#endif
-    }
     }
 
     // ---- epilogue of `cur` (gemm_device.h)
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
 #ifdef SUMK_DIAG
     if (ka.dbg & 4) {   // second record, behind the 2048 first ones: k-loop shares, wall-clock window (100 MHz), placement
       unsigned long long* q = ka.dbg_buf + (size_t)2048 * 4 + (size_t)blockIdx.x * 8;
-      q[0] = d_b1; q[1] = d_wr; q[2] = d_b2; q[3] = d_cp; q[4] = rt_begin; q[5] = __builtin_amdgcn_s_memrealtime();
+      q[0] = 0; q[1] = 0; q[2] = 0; q[3] = t_k; q[4] = rt_begin; q[5] = __builtin_amdgcn_s_memrealtime();
       q[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); q[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
@@ -492,6 +502,17 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
     }
   }
   SUMK_ARG(ka.queue == nullptr || epi == EPI_NONE, "gemm: the dynamic tile queue goes with the plain epilogue");
+  if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC && X3 == 0) {
+    if (ka.lean) {   // buffer-load instances (launch_gemm checked: one problem, NT, fp32, K % 32 == 0, one B group per tile)
+#define SUMK_LEAN_CASE(E) case E: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, true, E, 0, false, true>), grid, block, 0, s, ka); return SUMK_OK;
+      switch (epi) {
+        SUMK_LEAN_CASE(EPI_NONE) SUMK_LEAN_CASE(EPI_RESIDUAL) SUMK_LEAN_CASE(EPI_BIAS_RELU) SUMK_LEAN_CASE(EPI_BIAS2)
+        SUMK_LEAN_CASE(EPI_BIAS_RESIDUAL) SUMK_LEAN_CASE(EPI_BIAS_RELU_HEAD) SUMK_LEAN_CASE(EPI_RESIDUAL_MOMENTS)
+        default: break;      // (EPI_ACCUM: the plain instance below)
+      }
+#undef SUMK_LEAN_CASE
+    }
+  }
   switch (epi) {
     case EPI_NONE: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3>), grid, block, 0, s, ka); break;
     case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_RESIDUAL, X3>), grid, block, 0, s, ka); break;

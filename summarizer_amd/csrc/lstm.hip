@@ -1485,7 +1485,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     g.A = x; g.B[0] = w->w_ih[0]; g.B[1] = w->w_ih[1]; g.n_group = 4 * H;
     g.bias0[0] = w->b_ih[0]; g.bias0[1] = w->b_ih[1]; g.bias1[0] = w->b_hh[0]; g.bias1[1] = w->b_hh[1];
     g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 8 * H, small);
-    g.precision = precision;
+    g.precision = precision; g.lean = gemm_lean_ok(R, 4 * H, In, In, In);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
@@ -1792,6 +1792,7 @@ extern "C" int sumk_lstm_layer_forward(const float* x, int32_t In, int32_t H, in
     GemmLaunch g;   // G = X W_ih^T + b_ih + b_hh
     g.A = x; g.B[0] = w->w_ih; g.bias0[0] = w->b_ih; g.bias1[0] = w->b_hh;
     g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 4 * H, small); g.precision = precision;
+    g.lean = gemm_lean_ok(R, 4 * H, In, In, In);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
   if (n_seq <= GV_MAXB) {      // a few sequences: bandwidth-shaped mat-vec steps
@@ -2289,7 +2290,7 @@ extern "C" int sumk_linear_forward(const float* x, const float* w, const float* 
   SUMK_TRY(fill_single_prob(prob, M, N, K, K, K, N, 0, small, stream));
   GemmLaunch g;
   g.A = x; g.B[0] = w; g.bias0[0] = b; g.C = y; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(M, N, small);
-  g.precision = precision;
+  g.precision = precision; g.lean = gemm_lean_ok(M, N, K, K, K);
   return launch_gemm(GEMM_NT, b ? EPI_BIAS2 : EPI_NONE, g, stream);
 }
 extern "C" int sumk_linear_backward(const float* x, const float* w, const float* dy, int32_t M, int32_t N, int32_t K, float* dx,

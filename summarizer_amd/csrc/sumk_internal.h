@@ -81,6 +81,9 @@ struct GemmLaunch {
   // ragged tiles spread by finishing order.  Speed only: every tile is still computed whole by one block, results do not change.
   int32_t cu_blocks = 0;
   int32_t* queue = nullptr;
+  // 1: the caller asserts a single problem with K % 32 == 0 whose operand byte offsets (row * ld * 4) stay below 2^31 -- NT launches on
+  // 128x128 tiles then run the instances whose k-loop fetches with buffer loads + a scalar k offset (no VALU address arithmetic)
+  int32_t lean = 0;
   int32_t dbuf = 0;                    // 1: one barrier per k-tile on two LDS images (64-row tiles, plain epilogue, exact fp32)
   int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
@@ -98,6 +101,11 @@ inline int gemm_tiles(int M, int N, int cfg) {
   return ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
 }
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream);
+// GemmLaunch::lean for a single NT problem C(M,N) = A(M,K) B(N,K)^T: K a whole number of 32-wide k-tiles and every operand row
+// within 2^31 bytes of its base (the buffer-load instances address with 32-bit offsets)
+inline int gemm_lean_ok(int64_t M, int64_t N, int K, int lda, int ldb) {
+  return (K % 32 == 0 && M * lda * 4 < ((int64_t)1 << 31) && N * ldb * 4 < ((int64_t)1 << 31)) ? 1 : 0;
+}
 // Fills ONE GemmProb (device) for a plain single problem; returns SUMK_OK.
 int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int small_tile,
                      hipStream_t stream);

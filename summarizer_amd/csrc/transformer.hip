@@ -270,7 +270,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     {  // packed in-projection  [Q|K|V] = h Win^T + bin
       GemmLaunch g; g.precision = opts->precision;
       g.A = hin; g.B[0] = W.in_proj_w; g.bias0[0] = W.in_proj_b; g.C = QKV; g.probs = prow + P_QKV; g.small_tile = G.c_qkv;
-      g.total_tiles = gemm_tiles(R, 3 * D, G.c_qkv); g.xcd_M = R; g.xcd_N = 3 * D;
+      g.total_tiles = gemm_tiles(R, 3 * D, G.c_qkv); g.xcd_M = R; g.xcd_N = 3 * D; g.lean = gemm_lean_ok(R, 3 * D, D, D, D);
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
     }
     {  // logits per (video, head)
@@ -289,7 +289,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     {  // out-projection + bias (+dropout1) + residual
       GemmLaunch g; g.precision = opts->precision;
       g.A = CTX; g.B[0] = W.out_proj_w; g.bias0[0] = W.out_proj_b; g.R = hin; g.C = T1a; g.probs = prow + P_DD; g.small_tile = G.c_dd;
-      g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D;
+      g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 1;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
     }
@@ -297,14 +297,14 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     {  // feed-forward 1: bias + ReLU (+dropout)
       GemmLaunch g; g.precision = opts->precision;
       g.A = hmid; g.B[0] = W.lin1_w; g.bias0[0] = W.lin1_b; g.C = FF; g.probs = prow + P_DF; g.small_tile = G.c_df;
-      g.total_tiles = gemm_tiles(R, F, G.c_df); g.xcd_M = R; g.xcd_N = F;
+      g.total_tiles = gemm_tiles(R, F, G.c_df); g.xcd_M = R; g.xcd_N = F; g.lean = gemm_lean_ok(R, F, D, D, D);
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 2;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
     }
     {  // feed-forward 2: bias (+dropout2) + residual
       GemmLaunch g; g.precision = opts->precision;
       g.A = FF; g.B[0] = W.lin2_w; g.bias0[0] = W.lin2_b; g.R = hmid; g.C = T1b; g.probs = prow + P_FD; g.small_tile = G.c_dd;
-      g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D;
+      g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, F, F, F);
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 3;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
     }
@@ -323,7 +323,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = hfin; g.B[0] = head->k1_w; g.bias0[0] = head->k1_b; g.C = Z; g.probs = prow + P_DD; g.small_tile = G.c_dd;
-    g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D;
+    g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   SUMK_TRY(launch_ln_head_drop(Z, head->ln_w, head->ln_b, head->k2_w, head->k2_b, scores, R, D, opts->final_eps,

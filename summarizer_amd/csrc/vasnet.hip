@@ -793,11 +793,14 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
       if (!(i == 3 && Wvo)) SUMK_TRY(launch_split_planes(Ws[i], (void*)wplanes(i), DD, DD, opts->precision, stream));
     SUMK_TRY(launch_split_planes(x, PLX, RD, RD, opts->precision, stream));
   }
+  // row-wise NT GEMMs with K = D: eligible for the buffer-load instances when D is a whole number of k-tiles and byte offsets fit 31 bits
+  const int lean_rows = (D % 32 == 0 && (int64_t)R * 3 * D * 4 < ((int64_t)1 << 31)) ? 1 : 0;
   {  // 1: QKV projection
     GemmLaunch g; g.precision = opts->precision;
     g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = Wvo ? Wvo : w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
+    g.lean = lean_rows;
     if (planes) {
       g.A = (const float*)PLX; g.B[0] = wplanes(0); g.B[1] = wplanes(1); g.B[2] = wplanes(2);
       SUMK_TRY(launch_gemm_planes(EPI_NONE, g, RD, DD, stream));
@@ -862,6 +865,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
+    g.lean = lean_rows;
     if (fused_ln) {
       g.moments = ln_moments;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL_MOMENTS, g, stream));
@@ -889,6 +893,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.C = Z;                       // reused as float4[R][D / 32] moments (R * D / 8 floats of the R * D region)
     g.probs = prow + RP_DD; g.small_tile = 0;
     g.total_tiles = gemm_tiles(R, D, 0); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
+    g.lean = lean_rows;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU_HEAD, g, stream));
     hipLaunchKernelGGL(head_finalize_kernel, dim3((R + 31) / 32), dim3(256), 0, stream, (const float4*)Z, D / 32, R, D, w->ln_w,
                        w->ln_b, w->w2, w->b2, opts->eps, scores);
@@ -899,6 +904,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
+    g.lean = lean_rows;
     if (planes) {
       SUMK_TRY(launch_split_planes(Y1, PLA, RD, RD, opts->precision, stream));
       g.A = (const float*)PLA; g.B[0] = wplanes(4);
