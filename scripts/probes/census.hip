@@ -58,6 +58,22 @@ int main(int argc, char** argv) {
   for (auto& kv : hist) printf("  %d:%d", kv.first, kv.second);
   printf("\n  co-resident at start:");
   for (auto& kv : hist_first) printf("  %d:%d", kv.first, kv.second);
+  {   // which block ids share a CU?  (first 6 CUs in key order)
+    std::map<unsigned long long, std::vector<int>> ids;
+    for (int b = 0; b < grid; ++b) {
+      const unsigned xcc = (unsigned)h[b * 4] & 0xF, hw = (unsigned)h[b * 4 + 1];
+      ids[((unsigned long long)xcc << 16) | (((hw >> 13) & 0x7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)].push_back(b);
+    }
+    int shown = 0;
+    printf("\n  block ids per CU:");
+    for (auto& kv : ids) { if (shown++ >= 6) break; printf(" [xcc%llu:", kv.first >> 16); for (int b : kv.second) printf(" %d", b); printf("]"); }
+    // is {b, b + 256, b + 512, ...} one CU?
+    int same = 0, tot = 0;
+    std::map<int, unsigned long long> cu_of;
+    for (auto& kv : ids) for (int b : kv.second) cu_of[b] = kv.first;
+    for (int b = 0; b + 256 < grid; ++b) { tot++; same += cu_of[b] == cu_of[b + 256]; }
+    printf("\n  blocks b and b + 256 on the same CU: %d of %d", same, tot);
+  }
   printf("\n  first blocks: ");
   for (int b = 0; b < 12 && b < grid; ++b) printf("[b%d xcc%llu hw%08llx] ", b, h[b * 4] & 0xF, h[b * 4 + 1]);
   printf("\n");
