@@ -6,7 +6,8 @@ import csv, glob, json, os, sys, collections
 
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
-KERNEL = "gemm_f32_kernel<128, 128, 32, true, true, 0, 0>"
+# round 3: the QKV projection runs the LEAN (buffer-load) instance of the 128x128 NT tile
+KERNEL = os.environ.get("PMC_KERNEL", "gemm_f32_kernel<128, 128, 32, true, true, 0, 0, false, true>")
 vals = collections.defaultdict(list)
 for f in glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -18,7 +19,7 @@ M, N, K = 12003, 3072, 1024
 fetch_kb, write_kb = mean["FETCH_SIZE"], mean["WRITE_SIZE"]
 doc = {
     "source": "rocprofv3 --kernel-trace --pmc <group> (one group per pass, scripts/pmc_pass.sh + scripts/pmc_to_json.py) on "
-              "`python bench.py --steps 3 --warmup 2`, MI355X, round 2 (scalar problem-table loads, per-tag event mask)",
+              "`python bench.py --steps 3 --warmup 2`, MI355X, round 3 (LEAN buffer-load instance, peeled last k-tile)",
     "kernel": f"sumk::{KERNEL} (QKV projection, M={M} N={N} K={K})",
     "launches_averaged": len(vals["FETCH_SIZE"]),
     "counters_mean_per_launch": mean,
