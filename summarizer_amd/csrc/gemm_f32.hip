@@ -60,9 +60,6 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   static const bool lean128_on = !(getenv("SUMK_LEAN128") && getenv("SUMK_LEAN128")[0] == '0');
   ka.lean = (lean128_on && g.lean && g.nprob == 1 && layout == GEMM_NT && g.small_tile == 0 && g.precision == SUMK_PRECISION_FP32 &&
              (g.n_group == 0 || g.n_group % 128 == 0)) ? 1 : 0;
-  static const int prio_mode = getenv("SUMK_GEMM_PRIO") ? atoi(getenv("SUMK_GEMM_PRIO")) : 0;
-  static const int prio_tags = getenv("SUMK_GEMM_PRIO_TAGS") ? atoi(getenv("SUMK_GEMM_PRIO_TAGS")) : -1;
-  ka.prio_mode = (g.prof_tag < 0 || ((prio_tags >> g.prof_tag) & 1)) ? prio_mode : 0;
   SUMK_ARG(!g.queue || g.xcd_M == 0, "gemm: the dynamic tile queue is for grouped launches (no XCD rectangle map)");
   ka.moments = g.moments; ka.ln_stats = g.ln_stats; ka.ln_c1 = g.ln_c1; ka.ln_c2 = g.ln_c2;
   SUMK_ARG(epi != EPI_RESIDUAL_MOMENTS || g.moments, "gemm: the moments epilogue needs an output buffer");

@@ -342,22 +342,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       }
   };
 
-  // Co-resident blocks of one launch start together, run the same program and share each SIMD's matrix pipe turn by turn: they stay in
-  // LOCKSTEP -- all of them multiply at once (each at 1/3 or 1/4 of the pipe), then all of them sit in "barrier, wait, LDS write,
-  // barrier" at once with the pipe idle (in-kernel stamps of the 64x64 Q.K^T launch: 73-81 % matrix-pipe utilisation with every
-  // operand L2-resident).  Distinct issue priorities break the tie: the SIMD serves its highest-priority ready wave, so one block's
-  // synchronisation phase runs under another block's MFMAs.  Speed only; which blocks share a CU is the dispatcher's business.
-  if (ka.prio_mode) {
-    int p;
-    if (ka.prio_mode == 1) p = (blockIdx.x >> 8) & 3;                                  // blocks b, b + 256, ... tend to share a CU
-    else if (ka.prio_mode == 2) p = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;       // HW_ID.wave_id: the wave's slot on its SIMD
-    else if (ka.prio_mode == 3) p = 3 - ((blockIdx.x >> 8) & 3);
-    else p = (blockIdx.x >> 3) & 3;
-    p = __builtin_amdgcn_readfirstlane(p);
-    if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p == 3) __builtin_amdgcn_s_setprio(3);
-  }
   int tile = blockIdx.x;
   if (tile >= ka.total_tiles) return;
   TileCtx cur, nxt;
