@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Headline batch (S-TVSum, 50 videos, D = 1024, exact fp32): step time and the per-video GEMM launch durations under the
-balanced-launch knobs (SUMK_S_CUB / SUMK_PV_CUB = blocks per CU, SUMK_DYNQ, SUMK_GROUP_REMAP).  The knobs are read once per
-process, so the sweep re-runs itself as a child per configuration:  python scripts/probes/attn_balance_sweep.py"""
+"""Headline batch (S-TVSum, 50 videos, D = 1024, exact fp32): step time and the Q.K^T / alpha.V / QKV launch durations under
+environment knobs (SUMK_LEAN, SUMK_LEAN128, SUMK_LEAN_GRID, SUMK_GROUP_REMAP, SUMK_ATTN_CFG ...).  The knobs are read once per process,
+so the sweep re-runs itself as a child per configuration:
+    python scripts/probes/attn_balance_sweep.py "SUMK_LEAN=0" "SUMK_LEAN=1,SUMK_GROUP_REMAP=2"
+(round 3 used it for the experiments DESIGN.md section 3 lists: residency caps, dynamic tile queue, one-barrier loop, wave priorities,
+staggered slots, heaviest-first tile order -- all since removed -- and for the lean kernels that stayed)."""
 import ctypes as C, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -46,12 +49,7 @@ def child():
 if __name__ == "__main__":
     if os.environ.get("PROBE_CHILD") == "1":
         child(); sys.exit(0)
-    configs = [dict(SUMK_S_CUB="0", SUMK_PV_CUB="0")]
-    for remap in ("1", "2"):
-        for dq in ("1", "0"):
-            for s_cub in ("4", "5"):
-                for pv_cub in ("4", "5", "6"):
-                    configs.append(dict(SUMK_S_CUB=s_cub, SUMK_PV_CUB=pv_cub, SUMK_DYNQ=dq, SUMK_GROUP_REMAP=remap))
+    configs = [dict(SUMK_LEAN="0", SUMK_LEAN128="0"), dict(SUMK_LEAN="1", SUMK_LEAN128="0"), dict(SUMK_LEAN="1", SUMK_LEAN128="1")]
     if len(sys.argv) > 1:
         configs = [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[1:]]
     for cfg in configs:

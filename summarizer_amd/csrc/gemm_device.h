@@ -25,10 +25,7 @@ struct GemmKArgs {
   float alpha;
   int32_t dbg;           // diagnostic switches (SUMK_GEMM_DBG): 1 = skip the epilogue stores, 2 = in-kernel cycle stamps
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
-  int32_t* queue;                // != nullptr: dynamic tile queue (GemmLaunch::queue)
-  int32_t cu_blocks;             // host-side only (launch_epi): blocks per CU the LDS padding admits, 0 = no padding
   int32_t lean;                  // host-side only: 1 = NT 128x128 launch eligible for the buffer-load (VALU-free k-loop) instances
-  int32_t dbuf;                  // host-side only: 1 = the one-barrier-per-k-tile kernel (64-row tiles, plain epilogue, fp32)
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
 };

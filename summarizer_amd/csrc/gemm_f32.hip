@@ -56,11 +56,9 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (only_tag < 0 || only_tag == g.prof_tag) ka.dbg_buf = gemm_stamp_buffer(); else ka.dbg &= ~2;
   }
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
-  ka.queue = g.queue; ka.cu_blocks = g.cu_blocks; ka.dbuf = g.dbuf;
   static const bool lean128_on = !(getenv("SUMK_LEAN128") && getenv("SUMK_LEAN128")[0] == '0');
   ka.lean = (lean128_on && g.lean && g.nprob == 1 && layout == GEMM_NT && g.small_tile == 0 && g.precision == SUMK_PRECISION_FP32 &&
              (g.n_group == 0 || g.n_group % 128 == 0)) ? 1 : 0;
-  SUMK_ARG(!g.queue || g.xcd_M == 0, "gemm: the dynamic tile queue is for grouped launches (no XCD rectangle map)");
   ka.moments = g.moments; ka.ln_stats = g.ln_stats; ka.ln_c1 = g.ln_c1; ka.ln_c2 = g.ln_c2;
   SUMK_ARG(epi != EPI_RESIDUAL_MOMENTS || g.moments, "gemm: the moments epilogue needs an output buffer");
   SUMK_ARG(!g.ln_stats || (epi == EPI_BIAS_RELU_HEAD && g.ln_c1 && g.ln_c2), "gemm: ln_stats goes with the head epilogue and c1 / c2");
@@ -76,7 +74,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   // 64x64 tiles, plain epilogue, K-contiguous A, exact fp32: the lean kernel (gemm_lean.hip; SUMK_LEAN=0 keeps the generic one)
   static const bool lean_on = !(getenv("SUMK_LEAN") && getenv("SUMK_LEAN")[0] == '0');
   if (lean_on && g.precision == SUMK_PRECISION_FP32 && g.small_tile == 1 && epi == EPI_NONE && (layout == GEMM_NT || layout == GEMM_NN) &&
-      g.n_group == 0 && ka.xcd_tiles_m == 0 && !g.queue && !g.dbuf) {
+      g.n_group == 0 && ka.xcd_tiles_m == 0) {
     rc = launch_gemm_lean(layout, ka, ka.total_tiles, stream);
     prof_end(SUMK_PROF_GEMM_ALL, stream);
     if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
@@ -92,7 +90,6 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   if (g.small_tile == 1) rc = bk64 ? launch_layout<64, 64, 64>(layout, epi, ka, ka.total_tiles, stream)
                                    : launch_layout<64, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
   else if (g.small_tile == 2) rc = launch_layout<128, 64, 32>(layout, epi, ka, ka.total_tiles, stream);
-  else if (g.small_tile == 3) rc = launch_layout<64, 128, 32>(layout, epi, ka, ka.total_tiles, stream);
   else rc = launch_layout<128, 128, 32>(layout, epi, ka, ka.total_tiles, stream);
   prof_end(SUMK_PROF_GEMM_ALL, stream);
   if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);

@@ -242,7 +242,7 @@ int launch_gemm_planes(GemmEpi epi, const GemmLaunch& g, int64_t a_plane, int64_
   SUMK_ARG(np > 0, "gemm_planes: precision %d has no bf16 planes", g.precision);
   PlanesKArgs pa;   // (callers guarantee K % 32 == 0 and K >= 128: the fetch cursor runs up to 3 k-tiles ahead, within one tile of the MFMAs)
   GemmKArgs& ka = pa.g;
-  ka.queue = nullptr; ka.cu_blocks = 0; ka.dbuf = 0; ka.lean = 0;
+  ka.lean = 0;
   ka.A = g.A;
   for (int i = 0; i < 4; ++i) { ka.B[i] = g.B[i]; ka.bias0[i] = g.bias0[i]; ka.bias1[i] = g.bias1[i]; }
   ka.C = g.C; ka.R = g.R; ka.probs = g.probs; ka.nprob = 1; ka.n_group = g.n_group; ka.alpha = g.alpha;

@@ -44,17 +44,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int pitch) {
 // instead of eight fp32 ones at 1/16 of their cost; the three dropped terms are <= 3 * 2^-24 relative, i.e. the result is
 // fp32-grade (the fp32 tolerances of tests/test_gpu_vasnet.py::test_gemm_layouts_vs_float64 hold).  The KC image row
 // becomes [x1 | x2 | x3] = 6 BK bytes + 16 B pad (pitch 52 dwords at BK = 32: 16 rows still hit 16 distinct 16-byte slots).
-// DBUF: two LDS images per operand and ONE workgroup barrier per k-tile (small tiles only).  With 16 MFMAs per wave between
-// two barriers (64x64 tile), the two-barrier loop leaves each wave's share of the matrix pipe idle from its last MFMA issue through
-// "barrier, wait for the prefetch, LDS write, barrier, first fragment read" of the next k-tile, and the 3-4 co-resident blocks of a CU
-// only partly fill that (measured 79 % MFMA utilisation with every operand L2-resident).  Here k-tile t+1 is written into the OTHER
-// image while k-tile t is being multiplied: [write t+1 | issue loads of t+2 | fragment reads + MFMAs of t | barrier].
 // LEAN (NT, exact fp32, K % BK == 0, one B group per tile): operands are fetched with buffer loads -- per-thread byte offset fixed per
 // tile, the k advance a scalar soffset -- so the k-loop carries no address arithmetic.  v_mfma_f32_32x32x2_f32 shares its SIMD's
 // vector ALU (gemm_lean.hip header): the ~28 64-bit pointer instructions per k-tile of the plain form cost 3-4 % of the matrix rate.
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0, bool DBUF = false, bool LEAN = false>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, int EPI, int NS = 0, bool LEAN = false>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
-  static_assert(!LEAN || (A_KC && B_KC && NS == 0 && !DBUF), "LEAN: NT fp32 two-barrier instances only");
+  static_assert(!LEAN || (A_KC && B_KC && NS == 0), "LEAN: NT fp32 instances only");
   constexpr bool X3 = NS > 0;
   static_assert(NS >= 0 && NS <= 3, "operand split: 0 (fp32), 1 (plain bf16), 2 or 3 bf16 planes");
   constexpr int KC_PITCH = (NS == 0 ? BK : NS * BK / 2) + 4;   // +4 floats: conflict-free ds_read_b128 (pitch 20 / 36 / 52 dwords at BK = 32: 16 rows hit 16 distinct slots)
@@ -66,8 +61,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
   constexpr int A_ELEMS = A_KC ? BM * KC_PITCH : (X3 ? NS * BK * MCP_A / 4 : BK * BM);
   constexpr int B_ELEMS = B_KC ? BN * KC_PITCH : (X3 ? NS * BK * MCP_B / 4 : BK * BN);
   constexpr int STAGE = A_ELEMS + B_ELEMS;
-  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * STAGE];
-  __shared__ int s_next[2];      // dynamic tile queue: thread 0's draw for the tile after this one (double-buffered by tile parity)
+  __shared__ __attribute__((aligned(16))) float lds[STAGE];
   float* sA = lds;
   float* sB = lds + A_ELEMS;
 
@@ -182,29 +176,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
         if (k + 3 >= K) rb[p].w = 0.f;
       } else {
         if (k0 + tid / TPRB + KROWSB * p >= K) rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  };
-  // the same masks without the wave-uniform early-out (selects only): keeps the one-barrier loop body a single basic block
-  auto ktail_u = [&](int K, int k0) {
-#pragma unroll
-    for (int p = 0; p < NLDA; ++p) {
-      if constexpr (A_KC) {
-        const int k = k0 + kq4;
-        ra[p].x = k < K ? ra[p].x : 0.f; ra[p].y = k + 1 < K ? ra[p].y : 0.f; ra[p].z = k + 2 < K ? ra[p].z : 0.f; ra[p].w = k + 3 < K ? ra[p].w : 0.f;
-      } else {
-        const bool in = k0 + tid / TPRA + KROWSA * p < K;
-        ra[p].x = in ? ra[p].x : 0.f; ra[p].y = in ? ra[p].y : 0.f; ra[p].z = in ? ra[p].z : 0.f; ra[p].w = in ? ra[p].w : 0.f;
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < NLDB; ++p) {
-      if constexpr (B_KC) {
-        const int k = k0 + kq4;
-        rb[p].x = k < K ? rb[p].x : 0.f; rb[p].y = k + 1 < K ? rb[p].y : 0.f; rb[p].z = k + 2 < K ? rb[p].z : 0.f; rb[p].w = k + 3 < K ? rb[p].w : 0.f;
-      } else {
-        const bool in = k0 + tid / TPRB + KROWSB * p < K;
-        rb[p].x = in ? rb[p].x : 0.f; rb[p].y = in ? rb[p].y : 0.f; rb[p].z = in ? rb[p].z : 0.f; rb[p].w = in ? rb[p].w : 0.f;
       }
     }
   };
@@ -351,7 +322,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
 #ifdef SUMK_DIAG
   const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 #endif
-  int n_q = 0;
   if (ka.dbg & 2) t_begin = __builtin_amdgcn_s_memtime();
 
   while (true) {
@@ -369,45 +339,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
 
-    int next_tile = tile + gridDim.x;
-    if (ka.queue != nullptr && tid == 0)     // drawn now, read by everyone behind the barriers of the k-loop (at its last k-tile)
-      s_next[n_q & 1] = (int)gridDim.x + __hip_atomic_fetch_add(ka.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int next_tile = tile + gridDim.x;
     bool has_next = false;
     const int K = cur.K;
-    if constexpr (DBUF) {
-      // one barrier per k-tile: image `buf` holds k-tile k0, the staging registers hold k-tile k0 + BK (in flight)
-      int buf = 0;
-      ktail(K, 0);
-      swrite(lds, lds + A_ELEMS);
-      if (BK < K) gload(cur, BK);
-      __syncthreads();
-      // The wave's own bookkeeping rides BETWEEN its MFMAs (each 32x32x2 MFMA holds the pipe 64 cycles and the next one of the chain
-      // cannot issue before it is done): first half of the k-tile, the LDS write of k-tile k0 + BK into the other image, second half,
-      // the loads of k-tile k0 + 2 BK (clamped: past K they fetch bytes nobody uses) -- a single basic block the scheduler can
-      // interleave; what stays exposed per k-tile is the barrier and the first fragment read.  The last k-tile is peeled.
-      int k0 = 0;
-      for (; k0 + BK < K; k0 += BK) {
-        float* im = lds + buf * STAGE;
-        float* om = lds + (buf ^ 1) * STAGE;       // last read one k-tile ago, behind the barrier that ended that k-tile
-        compute(im, im + A_ELEMS, acc, 0);
-        ktail_u(K, k0 + BK);
-        swrite(om, om + A_ELEMS);
-        compute(im, im + A_ELEMS, acc, 1);
-        gload(cur, k0 + 2 * BK);
-        __syncthreads();
-        buf ^= 1;
-      }
-      {   // last k-tile: fetch the NEXT tile's first operands under this tile's last MFMAs
-        float* im = lds + buf * STAGE;
-        if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
-        has_next = next_tile < ka.total_tiles;
-        if (has_next) has_next = setup(next_tile, nxt);
-        if (has_next) gload(nxt, 0);
-        compute(im, im + A_ELEMS, acc);
-        __syncthreads();
-        buf ^= 1;
-      }
-    } else {
+    {
       // all k-tiles but the last: nothing but "barrier, LDS write, barrier, next loads, MFMAs"; the last one is peeled -- it carries
       // the K-tail masks and fetches the NEXT tile's first operands under this tile's last MFMAs (its decode would otherwise sit in
       // the loop as a merge of two register sets, copied every k-tile)
@@ -423,7 +358,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
       ktail(K, k0);
       swrite(sA, sB);
       __syncthreads();
-      if (ka.queue != nullptr) next_tile = __builtin_amdgcn_readfirstlane(((volatile int*)s_next)[n_q & 1]);
       has_next = next_tile < ka.total_tiles;
       if (has_next) has_next = setup(next_tile, nxt);
       if (has_next) gload(nxt, 0);
@@ -445,7 +379,6 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmKArgs ka) {
     if (!has_next) break;
     tile = next_tile;
     cur = nxt;
-    ++n_q;
   }
   if ((ka.dbg & 2) && ka.dbg_buf && tid == 0 && blockIdx.x < 2048) {
     unsigned long long* o = ka.dbg_buf + (size_t)blockIdx.x * 4;
@@ -464,31 +397,12 @@ template <int BM, int BN, int BK, bool A_KC, bool B_KC, int X3 = 0>
 static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
   // every block then loops over tiles  b, b+grid, ...
-  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : (BN == 128 ? 5 : 8)));
+  constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : 8));
   static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
   dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
-  if constexpr (BM == 64 && BK == 32 && X3 == 0) {
-    if (epi == EPI_NONE && (ka.cu_blocks > 0 || ka.dbuf)) {
-      // balanced persistent launch: pad the block's LDS allocation (dynamic bytes nobody touches) so that exactly cu_blocks blocks
-      // fit in a CU's 160 KiB, and launch at most 256 * cu_blocks of them: every one is resident at once and no CU holds more than
-      // its share; dbuf: the one-barrier-per-k-tile loop (two LDS images)
-      auto fn = ka.dbuf ? &gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3, true> : &gemm_f32_kernel<BM, BN, BK, A_KC, B_KC, EPI_NONE, X3, false>;
-      size_t pad = 0;
-      if (ka.cu_blocks > 0) {
-        hipFuncAttributes fa;
-        SUMK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)));
-        const size_t target = ((size_t)163840 / ka.cu_blocks) & ~(size_t)1023;
-        pad = target > fa.sharedSizeBytes ? target - fa.sharedSizeBytes : 0;
-        grid = dim3(std::min(tiles, 256 * ka.cu_blocks));
-      }
-      hipLaunchKernelGGL(fn, grid, block, pad, s, ka);
-      return SUMK_OK;
-    }
-  }
-  SUMK_ARG(ka.queue == nullptr || epi == EPI_NONE, "gemm: the dynamic tile queue goes with the plain epilogue");
   if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC && X3 == 0) {
     if (ka.lean) {   // buffer-load instances (launch_gemm checked: one problem, NT, fp32, K % 32 == 0, one B group per tile)
-#define SUMK_LEAN_CASE(E) case E: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, true, E, 0, false, true>), grid, block, 0, s, ka); return SUMK_OK;
+#define SUMK_LEAN_CASE(E) case E: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, true, E, 0, true>), grid, block, 0, s, ka); return SUMK_OK;
       switch (epi) {
         SUMK_LEAN_CASE(EPI_NONE) SUMK_LEAN_CASE(EPI_RESIDUAL) SUMK_LEAN_CASE(EPI_BIAS_RELU) SUMK_LEAN_CASE(EPI_BIAS2)
         SUMK_LEAN_CASE(EPI_BIAS_RESIDUAL) SUMK_LEAN_CASE(EPI_BIAS_RELU_HEAD) SUMK_LEAN_CASE(EPI_RESIDUAL_MOMENTS)

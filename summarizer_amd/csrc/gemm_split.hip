@@ -13,7 +13,6 @@ template <int NS>
 static int launch_planes(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream) {
   if (cfg == 1) return launch_layout<64, 64, 32, NS>(layout, epi, ka, tiles, stream);
   if (cfg == 2) return launch_layout<128, 64, 32, NS>(layout, epi, ka, tiles, stream);
-  if (cfg == 3) return launch_layout<64, 128, 32, NS>(layout, epi, ka, tiles, stream);
   return launch_layout<128, 128, 32, NS>(layout, epi, ka, tiles, stream);
 }
 

@@ -65,7 +65,7 @@ struct GemmLaunch {
   int32_t n_group = 0;  // columns of C per B pointer (0 -> single group)
   int32_t total_tiles = 0;
   float alpha = 1.f;
-  int32_t small_tile = 0;  // tile config: 0 -> 128x128, 1 -> 64x64 (ragged per-video problems), 2 -> 128x64, 3 -> 64x128
+  int32_t small_tile = 0;  // tile config: 0 -> 128x128, 1 -> 64x64 (ragged per-video problems), 2 -> 128x64
   int32_t prof_tag = -1;
   int32_t precision = 0;   // 0: exact fp32 MFMA; 1: bf16x3 split on bf16 MFMA (NT layout only; other layouts stay fp32)
   int32_t xcd_M = 0, xcd_N = 0;  // single-problem launches: (M,N) so the kernel may use the XCD-aware tile map
@@ -74,17 +74,9 @@ struct GemmLaunch {
   // drop_thr == 0 disables it.  Element index of the mask = row * N + col.
   uint64_t drop_seed = 0; uint32_t drop_thr = 0, drop_site = 0; float drop_scale = 1.f;
   float* moments = nullptr;            // EPI_RESIDUAL_MOMENTS output
-  // Balanced persistent launch (grouped per-video products): cu_blocks > 0 pads every block's LDS allocation so that EXACTLY cu_blocks
-  // blocks fit on a CU and launches min(tiles, 256 * cu_blocks) of them -- all resident, none stacked deeper than cu_blocks on one CU
-  // (the dispatcher otherwise packs 3, 4 or 5 one-tile blocks per CU and the launch lasts as long as its fullest CU).  queue != nullptr
-  // (a zeroed int32 in device memory): blocks pull their 2nd, 3rd ... tile from an atomic counter instead of walking a fixed stride, so
-  // ragged tiles spread by finishing order.  Speed only: every tile is still computed whole by one block, results do not change.
-  int32_t cu_blocks = 0;
-  int32_t* queue = nullptr;
   // 1: the caller asserts a single problem with K % 32 == 0 whose operand byte offsets (row * ld * 4) stay below 2^31 -- NT launches on
   // 128x128 tiles then run the instances whose k-loop fetches with buffer loads + a scalar k offset (no VALU address arithmetic)
   int32_t lean = 0;
-  int32_t dbuf = 0;                    // 1: one barrier per k-tile on two LDS images (64-row tiles, plain epilogue, exact fp32)
   int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
   // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],
@@ -93,8 +85,8 @@ struct GemmLaunch {
 };
 
 // number of tiles an (M,N) problem takes with the chosen tile size
-inline int gemm_tile_m(int cfg) { return (cfg == 1 || cfg == 3) ? 64 : 128; }
-inline int gemm_tile_n(int cfg) { return (cfg == 0 || cfg == 3) ? 128 : 64; }
+inline int gemm_tile_m(int cfg) { return cfg == 1 ? 64 : 128; }
+inline int gemm_tile_n(int cfg) { return cfg == 0 ? 128 : 64; }
 inline int gemm_tile_dim(int cfg) { return gemm_tile_n(cfg); }   // tiles_n divisor of a config
 inline int gemm_tiles(int M, int N, int cfg) {
   int tm = gemm_tile_m(cfg), tn = gemm_tile_n(cfg);

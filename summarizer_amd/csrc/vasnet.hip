@@ -29,11 +29,10 @@ enum { TB_S = 0, TB_PV = 1, TB_DV = 2, TB_DP = 3, TB_DQ = 4, TB_DK = 5, TB_COUNT
 constexpr int ROW_PROBS = 8;
 constexpr int SPLITK_PROBS = 64;
 constexpr int COLSUM_CHUNKS = 128;
-constexpr int QUEUE_WORDS = 64;     // one counter per grouped launch of a call, each on its own 16-byte slot
 
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
-  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, queue, total;
+  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, total;
   size_t pl_x, pl_a, pl_w;   // inference only: bf16 planes of x, of the current activation (CTX, then Y1) and of the five weights
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
@@ -70,7 +69,6 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
   w->stats = take(R * 4 * 4);  // mean/rstd of both LayerNorm applications (training)
   w->scores = take(R * 4);
-  w->queue = take(QUEUE_WORDS * 4);   // dynamic tile-queue counters of the per-video GEMM launches (zeroed by every call)
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
   w->pl_x = w->pl_a = w->pl_w = 0;
@@ -630,17 +628,7 @@ static int rowwise_small_tile(int M, int N) {
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
   int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv;
-  int cub_s, cub_pv;   // balanced persistent launch of the per-video products: blocks per CU (0 = plain launch), see balanced_blocks
 };
-
-// Blocks per CU for a grouped launch of `tiles` 64x64 tiles (GemmLaunch::cu_blocks).  A launch of one-tile blocks lasts as long as its
-// FULLEST CU: left to the dispatcher, the 919 Q.K^T tiles of the S-TVSum batch sit 3, 4 or 5 to a CU (in-kernel stamps, DESIGN
-// section 6) although ceil(919 / 256) = 4 would do.  kmax = what the kernel's registers allow.
-static int balanced_blocks(int tiles, int kmax, const char* env_name) {
-  if (const char* e = getenv(env_name)) return atoi(e);            // tuning override (0 = plain launch)
-  (void)tiles; (void)kmax;
-  return 0;     // measured: the dispatcher already deals one-tile blocks evenly (scripts/probes/census.hip: 919 blocks -> 3 or 4 per CU)
-}
 
 static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry* G) {
   SUMK_TRY(carve(D, n_seq, off, training, &G->L));
@@ -654,14 +642,12 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
   static const char* env = getenv("SUMK_ATTN_CFG");   // tuning override "<cfg_s><cfg_pv>", e.g. "20"
   const int cfg_auto = (G->R / n_seq >= 1024) ? 0 : 1;
   G->cfg_s = cfg_auto; G->cfg_pv = cfg_auto;
-  if (env && env[0] >= '0' && env[0] <= '3' && env[1] >= '0' && env[1] <= '3') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
+  if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
     int T = off[s + 1] - off[s];
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
-  G->cub_s = (G->cfg_s == 1 || G->cfg_s == 3) ? balanced_blocks(G->tiles_s, 6, "SUMK_S_CUB") : 0;
-  G->cub_pv = (G->cfg_pv == 1 || G->cfg_pv == 3) ? balanced_blocks(G->tiles_pv, 6, "SUMK_PV_CUB") : 0;
   return SUMK_OK;
 }
 
@@ -776,9 +762,6 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
-  int32_t* queue = (int32_t*)(ws + L.queue);
-  static const bool dynq = !(getenv("SUMK_DYNQ") && getenv("SUMK_DYNQ")[0] == '0');
-  if (dynq && (G.cub_s > 0 || G.cub_pv > 0)) SUMK_HIP(hipMemsetAsync(queue, 0, QUEUE_WORDS * 4, stream));
 
   // Split-bf16 inference: the three row-wise projections run on PRE-SPLIT bf16 planes (gemm_planes.hip) -- weights split once
   // per call (12 us), x / CTX / Y1 by a streaming kernel -- instead of splitting both operands inside every k-loop.
@@ -812,9 +795,6 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
     g.total_tiles = G.tiles_s; g.prof_tag = SUMK_PROF_GEMM_QKT;
-    g.cu_blocks = G.cub_s; if (dynq && G.cub_s > 0) g.queue = queue;
-    static const int dbuf_s = getenv("SUMK_S_DBUF") ? atoi(getenv("SUMK_S_DBUF")) : 0;
-    g.dbuf = dbuf_s;
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
@@ -850,9 +830,6 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
-    if (!Wvo) { g.cu_blocks = G.cub_pv; if (dynq && G.cub_pv > 0) g.queue = queue + 4; }
-    static const int dbuf_pv = getenv("SUMK_PV_DBUF") ? atoi(getenv("SUMK_PV_DBUF")) : 0;
-    if (!Wvo) g.dbuf = dbuf_pv;
     if (Wvo && fused_ln) g.moments = ln_moments;
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
     if (Wvo && fused_ln) {
