@@ -265,10 +265,4 @@ int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStrea
 // (SUMK_PRECISION_BF16 / BF16X3 / BF16X6).
 int launch_gemm_split(int precision, GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);
 
-// gemm_planes.hip: row-wise NT GEMMs on operands PRE-SPLIT into bf16 planes ([plane][row][K] bf16), staged by LDS-DMA.
-int planes_of_precision(int precision);     // 3 (bf16x6), 2 (bf16x3), 1 (bf16), 0 (fp32)
-bool gemm_planes_enabled();                 // SUMK_PLANES=0 keeps the in-loop split kernels everywhere
-int launch_split_planes(const float* src, void* dst_bf16, int64_t n, int64_t plane_stride, int precision, hipStream_t stream);
-int launch_gemm_planes(GemmEpi epi, const GemmLaunch& g, int64_t a_plane, int64_t b_plane, hipStream_t stream);
-
 }  // namespace sumk

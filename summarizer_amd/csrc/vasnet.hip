@@ -33,7 +33,6 @@ constexpr int COLSUM_CHUNKS = 128;
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
   size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, total;
-  size_t pl_x, pl_a, pl_w;   // inference only: bf16 planes of x, of the current activation (CTX, then Y1) and of the five weights
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
   size_t slab_elems;
@@ -71,12 +70,6 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->scores = take(R * 4);
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
-  w->pl_x = w->pl_a = w->pl_w = 0;
-  if (!training && gemm_planes_enabled()) {   // room for up to three bf16 planes (opt-in split-bf16 inference path, gemm_planes.hip)
-    w->pl_x = take(R * D * 2 * 3);
-    w->pl_a = take(R * D * 2 * 3);
-    w->pl_w = take((size_t)5 * D * D * 2 * 3);
-  }
   if (training) {
     w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
     w->dz = take(R * D * 4);
@@ -763,19 +756,6 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   }
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
 
-  // Split-bf16 inference: the three row-wise projections run on PRE-SPLIT bf16 planes (gemm_planes.hip) -- weights split once
-  // per call (12 us), x / CTX / Y1 by a streaming kernel -- instead of splitting both operands inside every k-loop.
-  const int np = planes_of_precision(opts->precision);
-  const bool planes = !training && np > 0 && gemm_planes_enabled() && D % 32 == 0 && D >= 128 && G.st_qkv == 0 && G.st_d == 0;
-  char* PLX = ws + L.pl_x; char* PLA = ws + L.pl_a; char* PLW = ws + L.pl_w;
-  const int64_t DD = (int64_t)D * D, RD = (int64_t)R * D;
-  auto wplanes = [&](int i) { return (const float*)(PLW + (size_t)i * np * DD * 2); };
-  if (planes) {
-    const float* Ws[5] = {w->Wq, w->Wk, Wvo ? Wvo : w->Wv, w->Wo, w->W1};
-    for (int i = 0; i < 5; ++i)
-      if (!(i == 3 && Wvo)) SUMK_TRY(launch_split_planes(Ws[i], (void*)wplanes(i), DD, DD, opts->precision, stream));
-    SUMK_TRY(launch_split_planes(x, PLX, RD, RD, opts->precision, stream));
-  }
   // row-wise NT GEMMs with K = D: eligible for the buffer-load instances when D is a whole number of k-tiles and byte offsets fit 31 bits
   const int lean_rows = (D % 32 == 0 && (int64_t)R * 3 * D * 4 < ((int64_t)1 << 31)) ? 1 : 0;
   {  // 1: QKV projection
@@ -784,12 +764,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     g.lean = lean_rows;
-    if (planes) {
-      g.A = (const float*)PLX; g.B[0] = wplanes(0); g.B[1] = wplanes(1); g.B[2] = wplanes(2);
-      SUMK_TRY(launch_gemm_planes(EPI_NONE, g, RD, DD, stream));
-    } else {
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
-    }
+    SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
     GemmLaunch g; g.precision = opts->precision;
@@ -816,7 +791,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   //      weights, c1 / c2, stats) lives in the unused Y1 region, which must be large enough (R >~ 1.1 D).
   static const bool fused_head_on = !(getenv("SUMK_FUSED_HEAD") && getenv("SUMK_FUSED_HEAD")[0] == '0');
   static const bool fused_ln_on = !(getenv("SUMK_FUSED_LN") && getenv("SUMK_FUSED_LN")[0] == '0');
-  const bool fused_tail = fused_head_on && !training && !planes && drop.thr == 0 && G.st_d == 0 && D % 64 == 0;
+  const bool fused_tail = fused_head_on && !training && drop.thr == 0 && G.st_d == 0 && D % 64 == 0;
   // producer of Y0: the output projection (128x128 tiles, D / 32 moment slots per row) or, on the folded path, the per-video
   // alpha.(X Wvo) product with the residual (64x64 tiles, D / 16 slots)
   const int ln_slots = Wvo ? D / 16 : D / 32;
@@ -849,11 +824,6 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
       hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
                          ln_c1 + D, (const float2*)ln_moments, ln_slots, R, opts->eps, (float2*)ln_stats);
       SUMK_HIP(hipGetLastError());
-    } else
-    if (planes) {
-      SUMK_TRY(launch_split_planes(CTX, PLA, RD, RD, opts->precision, stream));
-      g.A = (const float*)PLA; g.B[0] = wplanes(3);
-      SUMK_TRY(launch_gemm_planes(EPI_RESIDUAL, g, RD, DD, stream));
     } else {
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
     }
@@ -882,13 +852,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
     g.lean = lean_rows;
-    if (planes) {
-      SUMK_TRY(launch_split_planes(Y1, PLA, RD, RD, opts->precision, stream));
-      g.A = (const float*)PLA; g.B[0] = wplanes(4);
-      SUMK_TRY(launch_gemm_planes(EPI_BIAS_RELU, g, RD, DD, stream));
-    } else {
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
-    }
+    SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
   launch_ln_rows<true>(Z, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
