@@ -32,7 +32,7 @@ constexpr int COLSUM_CHUNKS = 128;
 
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
-  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, total;
+  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, row_seq, total;
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
   size_t slab_elems;
@@ -68,6 +68,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
   w->stats = take(R * 4 * 4);  // mean/rstd of both LayerNorm applications (training)
   w->scores = take(R * 4);
+  w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
   if (training) {
@@ -93,6 +94,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
 // row-wise single-problem entries (threads of block 1).
 struct RowProbSpec { int32_t M, N, K, lda, ldb, ldc, ldr, small; };
 struct SetupArgs {
+  int32_t* row_seq;      // [n_rows] video index of every packed row
   int32_t fake_seq0;     // diagnostic builds only: every video READS video 0's Q / K / V rows (operands stay L2-resident)
   const int32_t* off; int32_t n_seq, D;
   SeqInfo* seq; GemmProb* tabs;   // tabs[TB_COUNT][n_seq]
@@ -162,6 +164,7 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   const int tm = (T + a.s_tn - 1) / a.s_tn;   // tiles along N of the (T x T) products
   SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0;
   a.seq[s] = si;
+  for (int t = 0; t < T; ++t) a.row_seq[row0 + t] = s;
   const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
   const int n = a.n_seq;
   const int64_t qr = a.fake_seq0 ? 0 : q0;     // where Q / K / V are READ (q0 except in the diagnostic aliasing experiment)
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
-  const int s = find_seq(off, n_seq, row);
+  const int s = off[row];        // `off` = the row -> video table of the setup kernel (VasnetWs::row_seq)
   const SeqInfo si = seq[s];
   const int i = row - si.row0, T = si.T;
   float* e = E + si.eoff + (int64_t)i * si.ldE;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
-  const int s = find_seq(off, n_seq, row);
+  const int s = off[row];        // `off` = the row -> video table of the setup kernel (VasnetWs::row_seq)
   const SeqInfo si = seq[s];
   const int i = row - si.row0, T = si.T;
   const float* p = E + si.eoff + (int64_t)i * si.ldE;
@@ -654,6 +657,7 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   if (getenv("SUMK_FAKE_SEQ0")) a.fake_seq0 = 1;    // wrong results by design: timing experiment (are the per-video GEMMs bound by where their operands come from?)
 #endif
   a.off = off_dev; a.n_seq = n_seq; a.D = D;
+  a.row_seq = (int32_t*)(ws + G.L.row_seq);
   a.seq = (SeqInfo*)(ws + G.L.seq); a.tabs = (GemmProb*)(ws + G.L.prob_seq); a.prow = (GemmProb*)(ws + G.L.prob_row);
   const int R = G.R;
   a.rows[RP_QKV] = RowProbSpec{R, 3 * D, D, D, D, 3 * D, 0, G.st_qkv};   // [Q|K|V] = X W^T
@@ -778,7 +782,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     for (int q = 0; q < n_seq; ++q) t_max = std::max(t_max, seq_off_host[q + 1] - seq_off_host[q]);
     const dim3 sg((R + 3) / 4), sb(256);
     float* e2p = use_e2 ? E2 : nullptr;
-#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, seq_off_dev, n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop)
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop)
     if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
@@ -995,7 +999,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3': softmax (+dropout, +scale) backward, in place on E2
-  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, seq_off_dev, n_seq, R,
+  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
                      opts->scale, drop);
   // 2': dQ = dS K ; dK = dS^T Q
   {
