@@ -704,19 +704,17 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           a.hprev[row * (2 * H) + d * H + j] = hlast;
         }
         hlast = h;
+        if (t + 1 < eT) {   // next step's input-projection slice, one step ahead
+          const int64_t nrow = d == 0 ? row + 1 : row - 1;
+          const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+        }
       }
       // publish step t: every storing wave drains its stores, then one lane signals
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // next step's input-projection slice, one step ahead -- issued BEHIND the publish: in front of it, the drain above (vmcnt counts
-      // loads and stores together) made every step wait for these four L2 / Infinity-Cache loads before it could signal
-      if (erole && t + 1 < eT) {
-        const int64_t nrow = d == 0 ? er0 + t + 1 : er0 + eT - 2 - t;
-        const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
-      }
     }
   }
 }
@@ -938,18 +936,17 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
           a.hprev[row * (2 * H) + d * H + j] = hlast;
         }
         hlast = h;
+        if (t + 1 < eT) {   // next step's input-projection slice, one step ahead
+          const int64_t nrow = d == 0 ? row + 1 : row - 1;
+          const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+        }
       }
       // publish step t: every storing wave drains its stores, then one lane signals
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // next step's input-projection slice, one step ahead -- behind the publish (see lstm_persist_kernel)
-      if (erole && t + 1 < eT) {
-        const int64_t nrow = d == 0 ? er0 + t + 1 : er0 + eT - 2 - t;
-        const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
-      }
     }
   }
 }
@@ -1178,6 +1175,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         dg[j] = d_i; dg[H + j] = d_f; dg[2 * H + j] = d_g; dg[3 * H + j] = d_o;
         sA[ei * 36 + eu] = d_i; sA[ei * 36 + 8 + eu] = d_f; sA[ei * 36 + 16 + eu] = d_g; sA[ei * 36 + 24 + eu] = d_o;
       }
+      if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, one step ahead
       __syncthreads();
       if (t > 0) {   // partial_m(t) is only ever read by step t-1
         float* xo = a.xchg + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * 32) * H;
@@ -1209,7 +1207,6 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, one step ahead; behind the publish: the drain above would wait for them
     }
   }
 }
