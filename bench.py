@@ -242,6 +242,8 @@ def main():
                     help="headline = score (frames scored/sec, features resident in HBM); train = MSE step; reinforce = DSN "
                          "REINFORCE step (BASELINE config 4); stream = PCIe-inclusive scoring: features start in pageable host "
                          "memory and scores end there (summarizer_amd/ingest.py) -- never the headline value")
+    ap.add_argument("--stage-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="--mode stream only: bf16 = the native packer converts while it copies, half the PCIe bytes, LOSSY (scores of bf16(features))")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16x6", "bf16"], default="fp32",
@@ -336,7 +338,7 @@ def main():
         xh = x.cpu().numpy()
         off = np.concatenate([[0], np.cumsum(lens)])
         vids = [(i, xh[off[i]:off[i + 1]]) for i in range(len(lens))]
-        scorer = StreamingScorer(model, max_frames=frames, depth=3)
+        scorer = StreamingScorer(model, max_frames=frames, depth=3, stage_dtype=args.stage_dtype)
         last = [None]
         def run_steps(n):
             def feed():

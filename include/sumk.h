@@ -343,9 +343,27 @@ typedef struct sumk_eval_video {
   float* machine_summary;                      /* out (optional): (sum nfps) 0/1 floats                               */
   int32_t summary_len;                         /* out: sum nfps                                                        */
   double corr, f_avg, f_max;                   /* out: mean Spearman over annotators; mean / max F-score (NaN if skipped) */
+  const float* seg_means;                      /* in (optional): (n_segs) float32 segment means already taken on the DEVICE (sumk_eval_device):
+                                                  upsampling, the means and the correlation are then skipped (corr is left as given) */
 } sumk_eval_video;
 /* method: 0 = knapsack (sumk_knapsack_dp), 1 = rank.  n_threads <= 0: min(16, hardware threads). */
 int sumk_eval_videos(sumk_eval_video* videos, int32_t n_videos, double proportion, int32_t method, int32_t n_threads);
+
+/* Device-side part of the same tail: the batch's scores stay in HBM; one launch (a block per video)
+ * expands them to frame scores, takes the float32 segment means of eval.py:91-94 (numpy's pairwise summation reproduced, so
+ * `int(mean * 1000)` and with it the key-shot selection are unchanged) and the mean Spearman correlation of eval.py:49-72.
+ * The caller copies seg_means / corr back (one small D2H) and finishes on the host with sumk_eval_videos(seg_means given).
+ * All pointers inside the descriptors are DEVICE pointers; picks must be ascending, n_picks <= 4096, n_users <= 32.
+ * user_mean[u] / user_ssq[u] = mean and sum of squared deviations of annotator u's ranks (constants of the video). */
+typedef struct sumk_eval_dev_video {
+  const int32_t* picks; int32_t n_picks; int32_t n_frames; int32_t n_steps;
+  int32_t row0;                                /* first row of this video in the packed score vector                   */
+  int32_t frame0;                              /* offset of this video's frames in frame_scratch                       */
+  const int32_t* cps; int32_t n_segs; int32_t seg0;   /* (n_segs,2) change points; offset of its segments in seg_means */
+  const double* user_ranks; const double* user_mean; const double* user_ssq; int32_t n_users;   /* NULL / 0: no correlation (NaN) */
+} sumk_eval_dev_video;
+int sumk_eval_device(const float* scores_dev, const sumk_eval_dev_video* videos_dev, int32_t n_videos, float* frame_scratch_dev,
+                     float* seg_means_dev, double* corr_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ data-parallel exchange (RCCL)
  * The gradient all-reduce of data-parallel training as a library call: SUM, in place, over one flat bucket, on the caller's
@@ -364,6 +382,10 @@ int sumk_comm_destroy(void* comm);
  * H2D copy then ships) with a pool of memcpy threads; replaces the per-video host->device uploads of the reference's loops
  * (summarizer/models/__init__.py:47-51, vasnet.py:194-205, dsn.py:98-110).  n_threads <= 0: min(16, hardware threads). */
 int sumk_pack_rows(float* dst, const float* const* srcs, const int32_t* n_rows, int32_t n_videos, int32_t D, int32_t n_threads);
+/* The same packing with fp32 -> bf16 (round to nearest even, NaN kept) folded into the copy: half the staging and H2D bytes for
+ * link-bound hosts ("on-the-fly bf16 conversion").  LOSSY -- the scorer then sees bf16(features);
+ * the device side widens with sumk_cast_bf16_f32.  Opt-in: summarizer_amd.ingest.StreamingScorer(stage_dtype="bf16"). */
+int sumk_pack_rows_bf16(uint16_t* dst_bf16, const float* const* srcs, const int32_t* n_rows, int32_t n_videos, int32_t D, int32_t n_threads);
 
 /* Per-kernel timing for bench.py's roofline object: launches tagged t are bracketed with hipEvents ON THE LAUNCH STREAM while
  * bit t of the mask passed to sumk_prof_enable is set (0 = off).  sumk_prof_read synchronises and returns the sums. */

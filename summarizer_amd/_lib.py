@@ -61,7 +61,13 @@ class EvalVideo(C.Structure):
                 ("n_frames", C.c_int32), ("cps", C.c_void_p), ("nfps", C.c_void_p), ("n_segs", C.c_int32),
                 ("user_summary", C.c_void_p), ("n_users", C.c_int32), ("user_ranks", C.c_void_p),
                 ("machine_summary", C.c_void_p), ("summary_len", C.c_int32), ("corr", C.c_double), ("f_avg", C.c_double),
-                ("f_max", C.c_double)]
+                ("f_max", C.c_double), ("seg_means", C.c_void_p)]
+
+
+class EvalDevVideo(C.Structure):      # sumk_eval_dev_video: every pointer is a DEVICE pointer
+    _fields_ = [("picks", C.c_void_p), ("n_picks", C.c_int32), ("n_frames", C.c_int32), ("n_steps", C.c_int32), ("row0", C.c_int32),
+                ("frame0", C.c_int32), ("cps", C.c_void_p), ("n_segs", C.c_int32), ("seg0", C.c_int32), ("user_ranks", C.c_void_p),
+                ("user_mean", C.c_void_p), ("user_ssq", C.c_void_p), ("n_users", C.c_int32)]
 
 
 class LstmLayerWeights(C.Structure):
@@ -148,7 +154,9 @@ _SIGS = {
     "sumk_allreduce_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "sumk_comm_destroy": (C.c_int, [C.c_void_p]),
     "sumk_gemm_nt": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_eval_device": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "sumk_pack_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), HOST_I32P, C.c_int32, C.c_int32, C.c_int32]),
+    "sumk_pack_rows_bf16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), HOST_I32P, C.c_int32, C.c_int32, C.c_int32]),
     "sumk_gemm_prec": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_nn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_tn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

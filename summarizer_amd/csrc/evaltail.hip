@@ -91,6 +91,8 @@ void fscores(const T* m, const float* user_summary, int n_users, int n_frames, T
 
 int eval_one(sumk_eval_video& v, double proportion, int method, Scratch& S) {
   const int n_frames = v.n_frames;
+  const bool from_device = v.seg_means != nullptr;     // upsampling, segment means and correlation were done by sumk_eval_device
+  if (!from_device) {
   // ---- upsample (eval.py:24-34): literal interval assignment, sentinel n_frames appended when the last pick differs
   S.frame_scores.assign((size_t)n_frames, 0.f);
   const int np_ = v.n_picks;
@@ -121,6 +123,7 @@ int eval_one(sumk_eval_video& v, double proportion, int method, Scratch& S) {
     }
     v.corr = acc / (double)v.n_users;
   }
+  }
   // ---- key-shot summary (eval.py:74-123)
   v.f_avg = v.f_max = std::nan("");
   if (v.cps == nullptr || v.n_segs <= 0) return 0;
@@ -129,7 +132,8 @@ int eval_one(sumk_eval_video& v, double proportion, int method, Scratch& S) {
   std::vector<double> seg(S_);
   for (int s = 0; s < S_; ++s) {
     const int lo = std::max(0, std::min(n_frames, v.cps[2 * s])), hi = std::max(lo, std::min(n_frames, v.cps[2 * s + 1] + 1));
-    const float mean = hi > lo ? pairwise_sum(S.frame_scores.data() + lo, (int64_t)(hi - lo)) / (float)(hi - lo) : 0.f;   // float32 mean (numpy gives NaN for an empty segment)
+    const float mean = from_device ? v.seg_means[s]
+                     : hi > lo ? pairwise_sum(S.frame_scores.data() + lo, (int64_t)(hi - lo)) / (float)(hi - lo) : 0.f;   // float32 mean (numpy gives NaN for an empty segment)
     seg[s] = (double)mean;
     S.values[s] = (int64_t)(seg[s] * 1000.0);   // np.int truncation, knapsack.py:13
     S.weights[s] = v.nfps[s];
@@ -176,7 +180,8 @@ extern "C" int sumk_eval_videos(sumk_eval_video* vids, int32_t n_videos, double 
   SUMK_ARG(n_videos >= 0 && (n_videos == 0 || vids != nullptr), "eval_videos: null batch");
   SUMK_ARG(method == 0 || method == 1, "eval_videos: method must be 0 (knapsack) or 1 (rank)");
   for (int i = 0; i < n_videos; ++i) {
-    SUMK_ARG(vids[i].scores && vids[i].picks && vids[i].n_frames > 0 && vids[i].n_steps > 0, "eval_videos: video %d is incomplete", i);
+    SUMK_ARG(vids[i].seg_means || (vids[i].scores && vids[i].picks && vids[i].n_steps > 0), "eval_videos: video %d is incomplete", i);
+    SUMK_ARG(vids[i].n_frames > 0, "eval_videos: video %d has no frames", i);
     SUMK_ARG(vids[i].n_segs == 0 || (vids[i].cps && vids[i].nfps), "eval_videos: video %d has segments but no change points", i);
   }
   int nt = n_threads > 0 ? n_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));

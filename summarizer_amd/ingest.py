@@ -9,6 +9,13 @@ keeps the GPU fed from host memory instead:
     scores come back through a pinned buffer with one asynchronous D2H copy;
   * `depth` staging slots rotate, so packing + H2D of batch i+1 overlap the scoring of batch i.
 Scores are bit-identical to `model.score_packed` on resident features (tests/test_gpu_ingest.py).
+
+Sources: any iterable of (key, float32 (T, D) array), or a feature STORE -- an .npz with "<video>/features" entries, an HDF5 file in
+the reference's schema (summarizer/datasets/README.md:5-42; needs h5py), or a dict-backed dataset -- through `score_store`, which
+reads one video at a time (the store is never held in memory as a whole).
+`stage_dtype="bf16"` (opt-in, LOSSY): the native packer converts fp32 -> bf16 while it copies, so the pinned staging buffer and the
+H2D copy carry half the bytes (the PCIe link is the bound of the split-bf16 scoring modes); the device widens the batch back to fp32
+and scores bf16(features) -- identical to scoring features that were rounded to bf16 beforehand, NOT to the fp32 features.
 """
 import ctypes as C
 from collections import deque
@@ -21,10 +28,11 @@ from ._lib import SumkError
 
 
 class _Slot:
-    def __init__(self, frames, D, dev):
-        self.capacity = frames
-        self.host_x = torch.empty(frames, D, dtype=torch.float32).pin_memory()
+    def __init__(self, frames, D, dev, stage_dtype=torch.float32):
+        self.capacity, self.stage_dtype = frames, stage_dtype
+        self.host_x = torch.empty(frames, D, dtype=stage_dtype).pin_memory()
         self.dev_x = torch.empty(frames, D, dtype=torch.float32, device=dev)
+        self.dev_stage = torch.empty(frames, D, dtype=stage_dtype, device=dev) if stage_dtype != torch.float32 else None
         self.host_s = torch.empty(frames, dtype=torch.float32).pin_memory()
         self.h2d_done = torch.cuda.Event()
         self.all_done = torch.cuda.Event()
@@ -32,7 +40,7 @@ class _Slot:
 
 
 class StreamingScorer:
-    def __init__(self, model, max_frames=16384, depth=2, pack_threads=0):
+    def __init__(self, model, max_frames=16384, depth=2, pack_threads=0, stage_dtype="fp32"):
         if getattr(model, "max_length", None):
             raise SumkError("StreamingScorer packs videos back to back; models with positional embeddings score per video")
         p = next(model.parameters())
@@ -40,7 +48,10 @@ class StreamingScorer:
             raise SumkError("StreamingScorer needs the model on a GPU (summarizer_amd has no CPU path)")
         self.model, self.dev, self.D = model, p.device, int(model.input_size)
         self.max_frames, self.pack_threads = int(max_frames), int(pack_threads)
-        self.slots = [_Slot(self.max_frames, self.D, self.dev) for _ in range(max(1, int(depth)))]
+        if stage_dtype not in ("fp32", "bf16"):
+            raise SumkError(f"StreamingScorer: stage_dtype must be 'fp32' or 'bf16', got {stage_dtype!r}")
+        self.stage_dtype = torch.bfloat16 if stage_dtype == "bf16" else torch.float32
+        self.slots = [_Slot(self.max_frames, self.D, self.dev, self.stage_dtype) for _ in range(max(1, int(depth)))]
         self.copy_stream = torch.cuda.Stream(self.dev)
         self.compute_stream = torch.cuda.Stream(self.dev)
         self.check_stream = torch.cuda.Stream(self.dev)
@@ -58,16 +69,21 @@ class StreamingScorer:
         lens = [a.shape[0] for a in arrs]
         n = int(sum(lens))
         if n > slot.capacity:                                   # a single video longer than the staging buffers: grow this slot
-            slot.__init__(n, self.D, self.dev)
+            slot.__init__(n, self.D, self.dev, self.stage_dtype)
         srcs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         nrows = np.asarray(lens, dtype=np.int32)
-        _lib.check(self._lib.sumk_pack_rows(C.c_void_p(slot.host_x.data_ptr()), srcs, _lib.host_i32(nrows), len(arrs), self.D,
-                                            self.pack_threads), "sumk_pack_rows")
+        bf16 = self.stage_dtype == torch.bfloat16
+        pack = self._lib.sumk_pack_rows_bf16 if bf16 else self._lib.sumk_pack_rows
+        _lib.check(pack(C.c_void_p(slot.host_x.data_ptr()), srcs, _lib.host_i32(nrows), len(arrs), self.D, self.pack_threads),
+                   "sumk_pack_rows_bf16" if bf16 else "sumk_pack_rows")
         with torch.cuda.stream(self.copy_stream):
-            slot.dev_x[:n].copy_(slot.host_x[:n], non_blocking=True)
+            (slot.dev_stage if bf16 else slot.dev_x)[:n].copy_(slot.host_x[:n], non_blocking=True)
             slot.h2d_done.record(self.copy_stream)
         with torch.cuda.stream(self.compute_stream), torch.no_grad():
             self.compute_stream.wait_event(slot.h2d_done)
+            if bf16:                                            # widen on the device (exact): the scorer's operands are fp32
+                from . import kernels
+                kernels.cast_bf16_f32(slot.dev_stage[:n], slot.dev_x[:n])
             scores = self.model.score_packed(slot.dev_x[:n], lens)
             slot.host_s[:n].copy_(scores, non_blocking=True)
             slot.all_done.record(self.compute_stream)
@@ -124,3 +140,28 @@ class StreamingScorer:
 
     def score_dict(self, videos):
         return dict(self.score(videos.items() if hasattr(videos, "items") else videos))
+
+    def score_store(self, store, keys=None, field="features"):
+        """Scores the videos of a feature STORE, reading one video at a time: `store` = path of an .npz whose entries are named
+        "<video>/<field>" (DictDataset.save_npz), path of an HDF5 file in the reference's schema (h5py required), or any object with
+        the h5py mapping protocol (`store[key][field][...]`).  Yields (key, scores) in `keys` order (default: the store's order)."""
+        yield from self.score(iter_store(store, keys, field))
+
+
+def iter_store(store, keys=None, field="features"):
+    """(key, float32 (T, D) array) for every requested video of a feature store, one read per video (models/__init__.py:47-51 reads
+    `dataset[key]["features"][...]` the same way)."""
+    import os
+    if isinstance(store, (str, os.PathLike)) and str(store).endswith(".npz"):
+        with np.load(store, allow_pickle=False) as z:           # NpzFile: members are read (and decompressed) on access only
+            names = {n.rsplit("/", 1)[0]: n for n in z.files if n.endswith("/" + field)}
+            for k in (keys if keys is not None else names):
+                if k not in names:
+                    raise KeyError(f"{store}: no '{k}/{field}' entry")
+                yield k, np.ascontiguousarray(z[names[k]], dtype=np.float32)
+        return
+    if isinstance(store, (str, os.PathLike)):
+        from .utils.datasets import open_dataset
+        store = open_dataset(store, "r")                        # HDF5 (h5py) -- raises ImportError with a pointer to .npz otherwise
+    for k in (keys if keys is not None else list(store.keys())):
+        yield k, np.ascontiguousarray(store[k][field][...], dtype=np.float32)

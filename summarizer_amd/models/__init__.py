@@ -145,9 +145,36 @@ class Trainer:
         self.model.eval()
         test_keys = self._get_train_test_keys(fold)[1]
         with torch.no_grad():
+            dev_res = self._test_on_device(test_keys)
+            if dev_res is not None:          # scores never left HBM: upsample, segment means and Spearman ran on the device
+                corr, f_avg, f_max = dev_res
+                return np.mean(corr), (np.mean(f_avg), np.mean(f_max))
             activations = self._score_keys(test_keys)
         corr, f_avg, f_max, _ = self._evaluate_native(activations, test_keys)
         return np.mean(corr), (np.mean(f_avg), np.mean(f_max))
+
+    def _test_on_device(self, keys, max_frames_per_launch=1 << 17):
+        """Device-side evaluation tail: ONE packed scoring launch, then sumk_eval_device on the scores where they
+        are; a single small D2H carries segment means + correlations to the host knapsack / F-score threads.  None when the batch does
+        not qualify (positional embeddings, more frames than one launch takes, metadata the kernel does not cover): the caller then
+        takes the host tail, which computes the same numbers."""
+        if getattr(self.model, "max_length", None) or not keys or not hasattr(self.model, "score_packed"):
+            return None
+        dev = self._device()
+        if dev.type != "cuda":
+            return None
+        metas = [self._native_meta(k) for k in keys]
+        if not all(eval_native.device_ready(m) for m in metas):
+            return None
+        feats = [self._video_on_device(k, dev)[0] for k in keys]
+        lens = [f.shape[0] for f in feats]
+        if sum(lens) > max_frames_per_launch:
+            return None
+        packed = feats[0] if len(feats) == 1 else torch.cat(feats)
+        scores = self.model.score_packed(packed, lens).detach().contiguous()
+        corr, f_avg, f_max, _ = eval_native.evaluate_batch_device(metas, scores, lens, self.hps.summary_proportion, self.hps.selection_algorithm)
+        kernels.health_check()      # the D2H inside synchronised: fail loudly if a persistent recurrence kernel timed out
+        return corr, f_avg, f_max
 
     def _native_meta(self, key):
         m = self._video_meta(key, "scores")

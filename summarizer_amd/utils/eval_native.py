@@ -60,3 +60,85 @@ def evaluate_batch(videos, scores, proportion=0.15, method="knapsack", want_summ
     corr = np.array([arr[i].corr for i in range(n)]); f_avg = np.array([arr[i].f_avg for i in range(n)])
     f_max = np.array([arr[i].f_max for i in range(n)])
     return corr, f_avg, f_max, (summaries if want_summaries else None)
+
+
+# ---------------------------------------------------------------------------------------------- device-side part (csrc/evaldev.hip)
+def device_ready(v):
+    """Can this video's tail run on the device?  (ascending picks, <= 4096 of them, <= 32 annotators, change points + ranks present)"""
+    p = v["picks"]
+    return ("cps" in v and "user_ranks" in v and 0 < p.shape[0] <= 4096 and v["user_ranks"].shape[0] <= 32
+            and bool(np.all(np.diff(p) >= 0)) and v["user_ranks"].shape[1] == v["n_frames"])
+
+
+def _device_meta(v, device):
+    """The video's constant metadata as device tensors, uploaded once and cached inside the prepare_video dict."""
+    import torch
+    cache = v.setdefault("_dev", {})
+    d = cache.get(str(device))
+    if d is None:
+        ru = v["user_ranks"]
+        mu = ru.sum(axis=1) / ru.shape[1]
+        d = cache[str(device)] = dict(
+            picks=torch.from_numpy(v["picks"]).to(device), cps=torch.from_numpy(v["cps"]).to(device),
+            ranks=torch.from_numpy(ru).to(device), mean=torch.from_numpy(mu).to(device),
+            ssq=torch.from_numpy(((ru - mu[:, None]) ** 2).sum(axis=1)).to(device))
+    return d
+
+
+def evaluate_batch_device(videos, scores_dev, lens, proportion=0.15, method="knapsack", want_summaries=False, n_threads=0):
+    """The same evaluation with the scores still in HBM: `scores_dev` = packed (sum(lens),) float32 device tensor, video i owning rows
+    [sum(lens[:i]), sum(lens[:i + 1])).  One launch (a block per video) does upsample + float32 segment means + Spearman on the device
+    (sumk_eval_device); one small D2H brings the segment means and correlations home; key-shot selection, summary expansion and
+    F-scores finish in the native host threads (sumk_eval_videos with seg_means given).  Same return value as evaluate_batch."""
+    import torch
+    if method not in METHODS:
+        raise KeyError(f"Unknown method {method}")
+    lib = _lib.load()
+    n, dev = len(videos), scores_dev.device
+    if n == 0:
+        return np.zeros(0), np.zeros(0), np.zeros(0), ([] if want_summaries else None)
+    if not scores_dev.is_cuda or scores_dev.dtype != torch.float32 or not scores_dev.is_contiguous():
+        raise _lib.SumkError("evaluate_batch_device: scores must be a contiguous float32 GPU tensor")
+    descr = (_lib.EvalDevVideo * n)()
+    metas, row0, frame0, seg0 = [], 0, 0, 0
+    for i, (v, T) in enumerate(zip(videos, lens)):
+        m = _device_meta(v, dev); metas.append(m)
+        e = descr[i]
+        e.picks, e.n_picks, e.n_frames, e.n_steps = m["picks"].data_ptr(), v["picks"].shape[0], v["n_frames"], int(T)
+        e.row0, e.frame0 = row0, frame0
+        e.cps, e.n_segs, e.seg0 = m["cps"].data_ptr(), v["cps"].shape[0], seg0
+        e.user_ranks, e.user_mean, e.user_ssq, e.n_users = m["ranks"].data_ptr(), m["mean"].data_ptr(), m["ssq"].data_ptr(), v["user_ranks"].shape[0]
+        row0 += int(T); frame0 += v["n_frames"]; seg0 += v["cps"].shape[0]
+    if row0 != scores_dev.numel():
+        raise _lib.SumkError(f"evaluate_batch_device: lens sum to {row0}, scores hold {scores_dev.numel()}")
+    descr_dev = torch.frombuffer(bytearray(bytes(descr)), dtype=torch.uint8).to(dev)
+    scratch = torch.empty(frame0, dtype=torch.float32, device=dev)
+    out = torch.empty(seg0 + 2 * n, dtype=torch.float32, device=dev)      # [segment means | n doubles of correlation] in one buffer -> one D2H
+    corr_dev = out[seg0:].view(torch.float64) if seg0 % 2 == 0 else None
+    if corr_dev is None:                                                   # keep the doubles 8-byte aligned
+        out = torch.empty(seg0 + 1 + 2 * n, dtype=torch.float32, device=dev)
+        corr_dev = out[seg0 + 1:].view(torch.float64)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.sumk_eval_device(scores_dev.data_ptr(), descr_dev.data_ptr(), n, scratch.data_ptr(), out.data_ptr(),
+                                    corr_dev.data_ptr(), st), "sumk_eval_device")
+    host = out.cpu().numpy()                                               # the tail's ONE device -> host transfer
+    seg_means = np.ascontiguousarray(host[:seg0])
+    corr = np.ascontiguousarray(host[host.shape[0] - 2 * n:]).view(np.float64).copy()
+    arr = (_lib.EvalVideo * n)()
+    summaries, seg_at = [], 0
+    for i, v in enumerate(videos):
+        e = arr[i]
+        e.n_frames, e.n_steps = v["n_frames"], int(lens[i])
+        e.cps, e.nfps, e.n_segs = v["cps"].ctypes.data, v["nfps"].ctypes.data, v["cps"].shape[0]
+        e.seg_means = seg_means[seg_at:].ctypes.data
+        seg_at += v["cps"].shape[0]
+        e.corr = corr[i]
+        if want_summaries:
+            o = np.empty(int(v["nfps"].sum()), dtype=np.float32); summaries.append(o); e.machine_summary = o.ctypes.data
+        if "user_summary" in v:
+            if v["user_summary"].shape[1] != v["n_frames"]:
+                raise ValueError(f"user_summary has {v['user_summary'].shape[1]} frames, video has {v['n_frames']}")
+            e.user_summary, e.n_users = v["user_summary"].ctypes.data, v["user_summary"].shape[0]
+    _lib.check(lib.sumk_eval_videos(C.cast(arr, C.c_void_p), n, float(proportion), METHODS[method], int(n_threads)), "sumk_eval_videos")
+    f_avg = np.array([arr[i].f_avg for i in range(n)]); f_max = np.array([arr[i].f_max for i in range(n)])
+    return corr, f_avg, f_max, (summaries if want_summaries else None)

@@ -128,6 +128,31 @@ def test_pack_rows_native_threads():
     assert lib.sumk_pack_rows(C.c_void_p(dst.ctypes.data), bad, _lib.host_i32(np.asarray([3], np.int32)), 1, D, 1) != 0
 
 
+def test_pack_rows_bf16_native_matches_round_to_nearest_even():
+    """sumk_pack_rows_bf16 (host): the same packing with fp32 -> bf16 folded into the copy; bit patterns = torch's round-to-nearest-even
+    conversion, ties, subnormals, infinities and NaNs (which must stay NaNs) included; any thread count."""
+    import ctypes as C
+    import torch
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    D = 16
+    lens = [1, 5, 700, 3, 4100]
+    arrs = [rng.standard_normal((T, D)).astype(np.float32) * np.float32(10.0 ** rng.integers(-30, 30)) for T in lens]
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-40, 3.4e38, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -9,
+                        np.float32(1.00390625), np.float32(1.01171875), 65504.0, -2.5e-39, 7.0, 1e30], dtype=np.float32)   # incl. exact ties
+    arrs[1][0, :] = special
+    want = torch.from_numpy(np.concatenate(arrs)).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    for nt in (0, 1, 3, 16):
+        dst = np.zeros(want.shape, dtype=np.uint16)
+        srcs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        assert lib.sumk_pack_rows_bf16(C.c_void_p(dst.ctypes.data), srcs, _lib.host_i32(np.asarray(lens, np.int32)), len(arrs), D, nt) == 0
+        nan = np.isnan(np.concatenate(arrs))
+        np.testing.assert_array_equal(dst[~nan], want[~nan])
+        assert ((dst[nan] & 0x7F80) == 0x7F80).all() and ((dst[nan] & 0x007F) != 0).all()        # still NaNs
+    assert lib.sumk_pack_rows_bf16(None, None, None, 0, D, 0) == 0
+
+
 # ------------------------------------------------------------------------------------------------ knapsack: the tie-free surface is pinned
 def _all_optimal_subsets(v, w, cap):
     n = len(v)
