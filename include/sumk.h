@@ -317,6 +317,12 @@ int sumk_gemm_nt(const float* A, const float* B, float* C, int32_t M, int32_t N,
  * (SUMK_PRECISION_FP32 | SUMK_PRECISION_BF16X3) */
 int sumk_gemm_prec(int32_t layout, const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t precision,
                    void* stream);
+/* The same three products with bf16 OPERANDS in device memory (fp32 accumulate and output): the GEMM of the mixed-precision
+ * training step (csrc/gemm_b16.hip), exposed for tests and probes.  K-contiguous operands need K % 64 == 0, the others rows of
+ * whole 16-byte chunks.  workspace == NULL: C = product.  workspace given (layout 2 only, 256-byte aligned, >= 8192 + 4 M N
+ * bytes): deterministic split-K over a long K and C += product -- the weight-gradient form of vasnet.py:193-212's backward. */
+int sumk_gemm_bf16src(int32_t layout, const void* A_bf16, const void* B_bf16, float* C, int32_t M, int32_t N, int32_t K,
+                      void* workspace, size_t workspace_bytes, void* stream);
 /* C(M,N) = A(M,K) * B(K,N) */
 int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 /* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */

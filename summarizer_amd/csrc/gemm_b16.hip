@@ -1,0 +1,208 @@
+// bf16-SOURCE GEMM for the mixed-precision training step (SUMK_PRECISION_BF16; BASELINE config 2): operands are bf16 arrays in HBM
+// (shadows written once by the kernels that produce the fp32 activations, csrc/vasnet.hip), accumulation and output are fp32.
+//
+// Why a second kernel family: the plane kernels of gemm_split.hip read fp32 operands and convert every k-tile on the vector ALU --
+// at one v_mfma_f32_32x32x16_bf16 per product that conversion (and twice the operand bytes) is what the step pays for (QKV forward
+// 0.19 of the bf16 matrix peak, weight gradients 0.12: profiles/r02, r03 *_train_bf16_*).  Here a k-tile is 16-byte buffer loads
+// straight into the LDS image: no conversion, half the operand bytes, and no address arithmetic in the k-loop (per-thread byte
+// offset fixed per tile, the k advance a scalar soffset -- the same form as the fp32 lean kernels).
+//
+// 128x128x64 tiles, 256 threads = 2x2 waves of 64x64 (2x2 MFMA tiles of 32x32), three blocks per CU.
+//   KC operand (rows K-contiguous: A of NT / NN, B of NT): LDS image [row][64 bf16 + 16 B pad] (pitch 36 dwords: the 16 rows of a
+//     ds_read_b128 lane group land on 16 distinct 16-byte slots); a lane's fragment is one 16-byte read.
+//   MC operand ([k][row] in memory: B of NN, A and B of TN): LDS image [k][128 bf16 + 64 B pad], read with ds_read_b64_tr_b16
+//     (two per 8-k fragment), exactly the plane image of gemm_regstage.h.
+// Bounds come from the BUFFER DESCRIPTOR: num_records = the bytes from the (sub-)problem's first element to its last, so rows past M / N (KC) and
+// k-rows past K (MC; a split-K slice ends where its descriptor ends) read as zero -- no clamps, no tail masks.  A K-contiguous
+// operand needs K % 64 == 0; an MC operand needs its row length % 8 == 0 (16-byte chunks); byte offsets must fit 31 bits.  The
+// host checks all three (gemm_b16_ok) and the callers fall back to the plane kernels otherwise.
+#include "gemm_regstage.h"
+
+namespace sumk {
+
+namespace {
+
+constexpr int BT = 128, BKH = 64;                 // block tile, k-tile (bf16 elements)
+constexpr int KCP = 2 * BKH + 16;                 // KC image: bytes per row (144)
+constexpr int MCP = 2 * BT + 64;                  // MC image: bytes per k-row (320)
+constexpr int KC_BYTES = BT * KCP, MC_BYTES = BKH * MCP;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_b16_kernel(GemmKArgs ka) {
+  constexpr int A_BYTES = A_KC ? KC_BYTES : MC_BYTES, B_BYTES = B_KC ? KC_BYTES : MC_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[A_BYTES + B_BYTES];
+  char* const sA = lds;
+  char* const sB = lds + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const unsigned short* const A16 = reinterpret_cast<const unsigned short*>(ka.A);
+  const unsigned short* const B16 = reinterpret_cast<const unsigned short*>(ka.B[0]);
+
+  // this thread's four 16-byte chunks per operand and k-tile: KC = rows tid/8 + 32 p, k chunk tid%8; MC = k-rows tid/16 + 16 p, column chunk tid%16
+  const int lds_a = A_KC ? (tid >> 3) * KCP + (tid & 7) * 16 : (tid >> 4) * MCP + (tid & 15) * 16;
+  const int lds_b = B_KC ? (tid >> 3) * KCP + (tid & 7) * 16 : (tid >> 4) * MCP + (tid & 15) * 16;
+  constexpr int LSTEP_A = A_KC ? 32 * KCP : 16 * MCP, LSTEP_B = B_KC ? 32 * KCP : 16 * MCP;
+
+  struct Src { const unsigned short* a; const unsigned short* b; int na, nb, sa, sb; };   // operand bases, descriptor sizes (bytes), k-tile strides (bytes)
+  int voa[4], vob[4];
+  auto setup = [&](int tile, TileCtx& c, Src& s) -> bool {
+    GemmProb P;
+    if (!decode_tile<BT, BT>(ka, tile, c, P)) return false;
+    s.a = A16 + P.a_off; s.b = B16 + P.b_off;
+    if constexpr (A_KC) {
+      s.na = ((P.M - 1) * P.lda + P.K) * 2; s.sa = BKH * 2;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) voa[p] = ((c.m0 + (tid >> 3) + 32 * p) * P.lda + (tid & 7) * 8) * 2;
+    } else {
+      s.na = ((P.K - 1) * P.lda + ((P.M + 7) & ~7)) * 2; s.sa = BKH * P.lda * 2;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) voa[p] = (((tid >> 4) + 16 * p) * P.lda + c.m0 + (tid & 15) * 8) * 2;
+    }
+    if constexpr (B_KC) {
+      s.nb = ((P.N - 1) * P.ldb + P.K) * 2; s.sb = BKH * 2;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) vob[p] = ((c.n0 + (tid >> 3) + 32 * p) * P.ldb + (tid & 7) * 8) * 2;
+    } else {
+      s.nb = ((P.K - 1) * P.ldb + ((P.N + 7) & ~7)) * 2; s.sb = BKH * P.ldb * 2;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) vob[p] = (((tid >> 4) + 16 * p) * P.ldb + c.n0 + (tid & 15) * 8) * 2;
+    }
+    return true;
+  };
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](const Src& s, int kt) {
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(s.a), (short)0, s.na, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(s.b), (short)0, s.nb, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ra[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rA, voa[p], kt * s.sa, 0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rb[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rB, vob[p], kt * s.sb, 0);
+  };
+  auto swrite = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(sA + lds_a + p * LSTEP_A) = ra[p];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(sB + lds_b + p * LSTEP_B) = rb[p];
+  };
+  // fragment bases of this lane (k step ks adds 32 B along a KC row, 16 k-rows of an MC image)
+  const char* const fa = A_KC ? sA + (wm * 64 + li) * KCP + 16 * lh
+                              : sA + (8 * lh + ((lane & 15) >> 2)) * MCP + 2 * (wm * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+  const char* const fb = B_KC ? sB + (wn * 64 + li) * KCP + 16 * lh
+                              : sB + (8 * lh + ((lane & 15) >> 2)) * MCP + 2 * (wn * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+  auto compute = [&](f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < BKH / 16; ++ks) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if constexpr (A_KC) af[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * KCP + 32 * ks);
+        else af[t] = tr_frag(fa + 16 * ks * MCP + 64 * t, MCP);
+        if constexpr (B_KC) bf[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * KCP + 32 * ks);
+        else bf[t] = tr_frag(fb + 16 * ks * MCP + 64 * t, MCP);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ka.total_tiles) return;
+  TileCtx cur, nxt;
+  Src scur, snxt;
+  if (!setup(tile, cur, scur)) return;
+  gload(scur, 0);
+
+  while (true) {
+    f32x16 acc[2][2];
+    if constexpr (EPI == EPI_RESIDUAL) {
+      residual_init<2, 2>(ka, cur, acc, cur.m0 + wm * 64, cur.n0 + wn * 64, li, lh);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const int nk = (cur.K + BKH - 1) / BKH;
+    const int next_tile = tile + gridDim.x;
+    bool has_next = false;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      __syncthreads();
+      swrite();
+      __syncthreads();
+      gload(scur, kt + 1);
+      compute(acc);
+    }
+    // last k-tile: the next tile's decode and first loads go out under its MFMAs
+    __syncthreads();
+    swrite();
+    __syncthreads();
+    has_next = next_tile < ka.total_tiles;
+    if (has_next) has_next = setup(next_tile, nxt, snxt);
+    if (has_next) gload(snxt, 0);
+    compute(acc);
+
+    epilogue_store<EPI, 2, 2, true>(ka, cur, acc, cur.m0 + wm * 64, cur.n0 + wn * 64, li, lh);
+    if (!has_next) break;
+    tile = next_tile; cur = nxt; scur = snxt;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+int launch_epi_b16(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
+  const dim3 grid(std::min(tiles, 256 * 3)), block(256);
+  switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((gemm_b16_kernel<A_KC, B_KC, EPI_NONE>), grid, block, 0, s, ka); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL((gemm_b16_kernel<A_KC, B_KC, EPI_RESIDUAL>), grid, block, 0, s, ka); break;
+    case EPI_BIAS_RELU: hipLaunchKernelGGL((gemm_b16_kernel<A_KC, B_KC, EPI_BIAS_RELU>), grid, block, 0, s, ka); break;
+    case EPI_ACCUM: hipLaunchKernelGGL((gemm_b16_kernel<A_KC, B_KC, EPI_ACCUM>), grid, block, 0, s, ka); break;
+    default: set_error("gemm (bf16 sources): epilogue %d is not instantiated", (int)epi); return SUMK_ERR_ARG;
+  }
+  return SUMK_OK;
+}
+
+}  // namespace
+
+int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t stream) {
+  if (layout == GEMM_NT) return launch_epi_b16<true, true>(epi, ka, tiles, stream);
+  if (layout == GEMM_NN) return launch_epi_b16<true, false>(epi, ka, tiles, stream);
+  return launch_epi_b16<false, false>(epi, ka, tiles, stream);
+}
+
+// ------------------------------------------------------------------------------------------- fp32 -> bf16 shadows
+// dst[r][c] = bf16(src[r][c]) (round to nearest even, like the plane kernels' v_cvt_pk_bf16_f32), up to four equally shaped row
+// groups stacked in dst (the three projection weights become ONE [3D][D] operand); n_cols % 4 == 0.
+struct CastArgs { const float* src[4]; unsigned short* dst; int64_t rows_per_src; int32_t n_src, n_cols, ld_src; };
+__global__ __launch_bounds__(256) void cast_rows_b16_kernel(CastArgs a) {
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = a.n_cols >> 2;
+  const int64_t total = (int64_t)a.n_src * a.rows_per_src * c4;
+  if (i4 >= total) return;
+  const int64_t row = i4 / c4; const int c = (int)(i4 % c4) * 4;
+  const int g = (int)(row / a.rows_per_src); const int64_t rl = row - (int64_t)g * a.rows_per_src;
+  const float* sp = g == 0 ? a.src[0] : g == 1 ? a.src[1] : g == 2 ? a.src[2] : a.src[3];
+  const float4 v = *reinterpret_cast<const float4*>(sp + rl * a.ld_src + c);
+  const f32x4 f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<bf16x4*>(a.dst + row * a.n_cols + c) = __builtin_convertvector(f, bf16x4);
+}
+
+int cast_rows_b16(const float* const src[4], int n_src, int64_t rows_per_src, int n_cols, int ld_src, void* dst, hipStream_t stream) {
+  SUMK_ARG(n_src >= 1 && n_src <= 4 && n_cols % 4 == 0 && ld_src % 4 == 0, "cast_rows_b16: bad shape");
+  CastArgs a;
+  for (int i = 0; i < 4; ++i) a.src[i] = i < n_src ? src[i] : nullptr;
+  a.dst = (unsigned short*)dst; a.rows_per_src = rows_per_src; a.n_src = n_src; a.n_cols = n_cols; a.ld_src = ld_src;
+  const int64_t total = (int64_t)n_src * rows_per_src * (n_cols >> 2);
+  if (total == 0) return SUMK_OK;
+  hipLaunchKernelGGL(cast_rows_b16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+}  // namespace sumk

@@ -27,6 +27,7 @@ struct GemmKArgs {
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
   int32_t lean;                  // host-side only: 1 = NT 128x128 launch eligible for the buffer-load (VALU-free k-loop) instances
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
+  unsigned short* C16;           // EPI_NONE: when set, bf16(C) is stored too, same offsets / leading dimension (operand of a later bf16-source GEMM)
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
 };
 
@@ -139,6 +140,9 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
         }
         if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
         *cp = v;
+        if constexpr (EPI == EPI_NONE) {
+          if (ka.C16) ka.C16[cur.c_off + (int64_t)row * cur.ldc + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
       }
     }
   }
@@ -261,6 +265,8 @@ __device__ __forceinline__ void residual_init(const GemmKArgs& ka, const TileCtx
 
 // gemm_lean.hip: 64x64 exact-fp32 tiles with a VALU-free main loop (NT / NN, plain epilogue) for the per-video products
 int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStream_t stream);
+// gemm_b16.hip: bf16 operands in HBM (A and B[0] point at bf16 data), fp32 accumulate / output; 128x128 tiles
+int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t stream);
 // gemm_split.hip: the register-staged kernel with fp32 operands split into bf16 planes on their way into LDS
 // (SUMK_PRECISION_BF16 / BF16X3 / BF16X6).
 int launch_gemm_split(int precision, GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int cfg, hipStream_t stream);

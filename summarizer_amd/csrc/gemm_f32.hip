@@ -59,6 +59,9 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   static const bool lean128_on = !(getenv("SUMK_LEAN128") && getenv("SUMK_LEAN128")[0] == '0');
   ka.lean = (lean128_on && g.lean && g.nprob == 1 && layout == GEMM_NT && g.small_tile == 0 && g.precision == SUMK_PRECISION_FP32 &&
              (g.n_group == 0 || g.n_group % 128 == 0)) ? 1 : 0;
+  ka.C16 = (unsigned short*)g.C16;
+  SUMK_ARG(!g.C16 || epi == EPI_NONE, "gemm: the bf16 copy of C goes with the plain epilogue");
+  SUMK_ARG(!g.src16 || (g.small_tile == 0 && g.n_group == 0), "gemm: bf16-source launches use 128x128 tiles and one B operand");
   ka.moments = g.moments; ka.ln_stats = g.ln_stats; ka.ln_c1 = g.ln_c1; ka.ln_c2 = g.ln_c2;
   SUMK_ARG(epi != EPI_RESIDUAL_MOMENTS || g.moments, "gemm: the moments epilogue needs an output buffer");
   SUMK_ARG(!g.ln_stats || (epi == EPI_BIAS_RELU_HEAD && g.ln_c1 && g.ln_c2), "gemm: ln_stats goes with the head epilogue and c1 / c2");
@@ -74,7 +77,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   // 64x64 tiles, plain epilogue, K-contiguous A, exact fp32: the lean kernel (gemm_lean.hip; SUMK_LEAN=0 keeps the generic one)
   static const bool lean_on = !(getenv("SUMK_LEAN") && getenv("SUMK_LEAN")[0] == '0');
   if (lean_on && g.precision == SUMK_PRECISION_FP32 && g.small_tile == 1 && epi == EPI_NONE && (layout == GEMM_NT || layout == GEMM_NN) &&
-      g.n_group == 0 && ka.xcd_tiles_m == 0) {
+      g.n_group == 0 && ka.xcd_tiles_m == 0 && !g.C16 && !g.src16) {
     rc = launch_gemm_lean(layout, ka, ka.total_tiles, stream);
     prof_end(SUMK_PROF_GEMM_ALL, stream);
     if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
@@ -84,6 +87,9 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   }
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
+  if (g.src16) {                              // bf16 operands in HBM: gemm_b16.hip
+    rc = launch_gemm_b16(layout, epi, ka, ka.total_tiles, stream);
+  } else
   if (g.precision != SUMK_PRECISION_FP32) {   // bf16-plane arithmetics: instantiated in gemm_split.hip
     rc = launch_gemm_split(g.precision, layout, epi, ka, ka.total_tiles, g.small_tile, stream);
   } else
@@ -174,10 +180,11 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(SlabReduceArgs a) {
 
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream, int precision) {
+                         int ldo, float alpha, hipStream_t stream, int precision, int src16) {
   SUMK_ARG(M > 0 && N > 0 && K > 0, "splitk: bad shape");
   SUMK_ARG(slab_elems >= (size_t)M * N, "splitk: slab too small");
-  const int small = gemm_tiles(M, N, 0) >= 64 ? 0 : 1;
+  SUMK_ARG(!src16 || gemm_b16_ok(M, N, K, lda, ldb, false, false), "splitk: operands not eligible for the bf16-source kernel");
+  const int small = (src16 || gemm_tiles(M, N, 0) >= 64) ? 0 : 1;     // (src16: A and B are bf16 arrays)
   const int tiles = gemm_tiles(M, N, small);
   // K slices so that S x tiles fills the resident slots of the persistent grid ONCE (768 blocks of the 128x128 kernel, 2048 of the
   // 64x64 one): every block then walks exactly one (long) tile.  The first version aimed at >= 1024 tiles: 1152 for the QKV
@@ -187,13 +194,14 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   S = std::min(S, (K + 63) / 64);
   S = std::min(S, (int)std::min<size_t>(slab_elems / ((size_t)M * N), (size_t)probs_cap));
   S = std::max(S, 1);
-  int kchunk = ((K + S - 1) / S + 31) / 32 * 32;
+  const int kq = src16 ? 64 : 32;              // whole k-tiles per slice
+  int kchunk = ((K + S - 1) / S + kq - 1) / kq * kq;
   S = (K + kchunk - 1) / kchunk;
   hipLaunchKernelGGL(splitk_setup_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, probs_dev, S, M, N, K, kchunk, lda, ldb,
                      gemm_tile_dim(small));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = slab; g.probs = probs_dev; g.nprob = S; g.small_tile = small; g.total_tiles = S * tiles;
-  g.precision = precision;
+  g.precision = precision; g.src16 = src16;
   // the tiles of one K slice share their operand rows: keep a slice on one XCD (measured: the bf16 training step 1.35 -> 1.21 ms,
   // fp32 unchanged; the per-video attention products did not gain and are left in plain order)
   g.group_remap = 1;
@@ -411,6 +419,33 @@ extern "C" int sumk_gemm_prec(int32_t layout, const float* A, const float* B, fl
   if (layout == 0) return plain_gemm(sumk::GEMM_NT, A, B, C, M, N, K, K, K, stream, precision);
   if (layout == 1) return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream, precision);
   return plain_gemm(sumk::GEMM_TN, A, B, C, M, N, K, M, N, stream, precision);
+}
+// bf16 operands in HBM (gemm_b16.hip).  workspace == nullptr: C = product.  workspace given (TN only): deterministic split-K,
+// C += product (the weight-gradient form; workspace = [64 problem entries | fp32 slabs], at least 8192 + 4 M N bytes).
+extern "C" int sumk_gemm_bf16src(int32_t layout, const void* A16, const void* B16, float* C, int32_t M, int32_t N, int32_t K,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sumk;
+  SUMK_ARG(layout >= 0 && layout <= 2, "gemm: layout must be 0 (NT), 1 (NN) or 2 (TN), got %d", layout);
+  SUMK_ARG(A16 && B16 && C && M > 0 && N > 0 && K > 0, "gemm_bf16src: bad arguments");
+  const int lda = layout == 2 ? M : K, ldb = layout == 0 ? K : N;
+  SUMK_ARG(gemm_b16_ok(M, N, K, lda, ldb, layout != 2, layout == 0),
+           "gemm_bf16src: M=%d N=%d K=%d is not eligible (K %% 64 for K-contiguous operands, rows %% 8 otherwise, offsets < 2^31)", M, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  if (workspace) {
+    SUMK_ARG(layout == 2, "gemm_bf16src: split-K is the TN form");
+    SUMK_ARG(workspace_bytes >= 8192 + (size_t)M * N * 4 && ((uintptr_t)workspace & 255) == 0, "gemm_bf16src: workspace too small or misaligned");
+    static_assert(sizeof(GemmProb) * 64 <= 8192, "problem table");
+    float* const out[4] = {C, nullptr, nullptr, nullptr};
+    return gemm_tn_splitk_accum((const float*)A16, lda, (const float*)B16, ldb, M, N, K, (float*)((char*)workspace + 8192),
+                                (workspace_bytes - 8192) / 4, (GemmProb*)workspace, 64, out, M, N, 1.f, s, SUMK_PRECISION_BF16, 1);
+  }
+  GemmProb* p = scratch_prob();
+  SUMK_ARG(p != nullptr, "gemm: cannot allocate problem scratch");
+  SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, 0, s));
+  GemmLaunch g;
+  g.A = (const float*)A16; g.B[0] = (const float*)B16; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = 0;
+  g.total_tiles = gemm_tiles(M, N, 0); g.xcd_M = M; g.xcd_N = N; g.precision = SUMK_PRECISION_BF16; g.src16 = 1;
+  return launch_gemm((GemmLayout)layout, EPI_NONE, g, s);
 }
 extern "C" int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {
   return plain_gemm(sumk::GEMM_NN, A, B, C, M, N, K, K, N, stream);

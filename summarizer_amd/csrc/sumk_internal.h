@@ -77,6 +77,10 @@ struct GemmLaunch {
   // 1: the caller asserts a single problem with K % 32 == 0 whose operand byte offsets (row * ld * 4) stay below 2^31 -- NT launches on
   // 128x128 tiles then run the instances whose k-loop fetches with buffer loads + a scalar k offset (no VALU address arithmetic)
   int32_t lean = 0;
+  // 1: A and B[0] point at bf16 arrays (offsets / leading dimensions of the problem table count bf16 elements); 128x128 tiles, fp32
+  // accumulate and output (gemm_b16.hip).  The caller has checked gemm_b16_ok for every sub-problem.
+  int32_t src16 = 0;
+  void* C16 = nullptr;                 // EPI_NONE: also store bf16(C) here, same offsets / ldc (the operand of a later src16 launch)
   int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
   // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],
@@ -93,6 +97,17 @@ inline int gemm_tiles(int M, int N, int cfg) {
   return ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
 }
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream);
+// GemmLaunch::src16 eligibility of one problem: kc_a / kc_b = is that operand K-contiguous (A of NT / NN, B of NT).  A K-contiguous
+// operand needs K % 64 == 0, an M/N-contiguous one rows of whole 16-byte chunks; every byte offset must stay below 2^31.
+inline int gemm_b16_ok(int64_t M, int64_t N, int64_t K, int lda, int ldb, bool kc_a, bool kc_b) {
+  const int64_t lim = (int64_t)1 << 31;
+  if (lda % 8 || ldb % 8) return 0;
+  if (kc_a ? (K % 64 != 0 || (M + 128) * lda * 2 >= lim) : (M % 8 != 0 || (K + 64) * lda * 2 >= lim)) return 0;
+  if (kc_b ? (K % 64 != 0 || (N + 128) * ldb * 2 >= lim) : (N % 8 != 0 || (K + 64) * ldb * 2 >= lim)) return 0;
+  return 1;
+}
+// dst (bf16, [n_src * rows_per_src][n_cols], dense) = the n_src fp32 row groups stacked (gemm_b16.hip)
+int cast_rows_b16(const float* const src[4], int n_src, int64_t rows_per_src, int n_cols, int ld_src, void* dst, hipStream_t stream);
 // GemmLaunch::lean for a single NT problem C(M,N) = A(M,K) B(N,K)^T: K a whole number of 32-wide k-tiles and every operand row
 // within 2^31 bytes of its base (the buffer-load instances address with 32-bit offsets)
 inline int gemm_lean_ok(int64_t M, int64_t N, int K, int lda, int ldb) {
@@ -106,7 +121,7 @@ int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, 
 // for row = g*rows_per_out + rl.  probs_dev must hold probs_cap entries; slab holds slab_elems floats.
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream, int precision = 0);
+                         int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0);   // src16: A and B are bf16 arrays (GemmLaunch::src16)
 // out[c] += sum_r X[r*ld + c]; partial must hold max_chunks*N floats.
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream);
 // out[c] += sum_p partial[p*stride + c]

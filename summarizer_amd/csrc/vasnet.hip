@@ -35,6 +35,8 @@ struct VasnetWs {
   size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, row_seq, total;
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
+  // bf16 shadows of the operands of the row-wise GEMMs (training; used when the step runs on the bf16-source kernels)
+  size_t x16, w16, ctx16, y116, dz16, dy016, dqkv16;
   size_t slab_elems;
   int64_t e_elems;
   int32_t n_rows;
@@ -71,6 +73,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
+  w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = 0;
   if (training) {
     w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
     w->dz = take(R * D * 4);
@@ -83,6 +86,13 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->slab_elems = (size_t)32 * D * D;
     w->slab = take(w->slab_elems * 4);
     w->prob_sk = take(SPLITK_PROBS * sizeof(GemmProb));
+    w->x16 = take(R * D * 2);
+    w->w16 = take((size_t)5 * D * D * 2);      // [Wq; Wk; Wv] stacked (one 3D x D operand), Wo, W1
+    w->ctx16 = take(R * D * 2);
+    w->y116 = take(R * D * 2);
+    w->dz16 = take(R * D * 2);
+    w->dy016 = take(R * D * 2);
+    w->dqkv16 = take(R * 3 * D * 2);
   }
   w->total = p;
   return SUMK_OK;
@@ -180,6 +190,13 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- wave helpers
+// four consecutive bf16 (round to nearest even, v_cvt_pk_bf16_f32 -- what the plane GEMM kernels do to the same fp32 values)
+__device__ __forceinline__ void store_bf16x4(unsigned short* p, float4 v) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<bf16x4_t*>(p) = __builtin_convertvector(f, bf16x4_t);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -314,7 +331,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ scores, int n_rows, int D, float eps,
-                                                        float* __restrict__ stats, Drop drop, uint32_t site) {
+                                                        float* __restrict__ stats, Drop drop, uint32_t site,
+                                                        unsigned short* __restrict__ Y16) {   // !HEAD: bf16(y) too (Y may then be null)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -363,7 +381,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       float4 gg = g4[c], bv = b4[c], o;
       o.x = (v.x - mean) * rstd * gg.x + bv.x; o.y = (v.y - mean) * rstd * gg.y + bv.y;
       o.z = (v.z - mean) * rstd * gg.z + bv.z; o.w = (v.w - mean) * rstd * gg.w + bv.w;
-      y4[c] = o;
+      if (Y != nullptr) y4[c] = o;
+      if (Y16 != nullptr) store_bf16x4(Y16 + (int64_t)row * D + 4 * c, o);
     };
     if constexpr (NQ > 0) {
 #pragma unroll
@@ -467,10 +486,11 @@ __global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restr
 // one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
 template <bool HEAD>
 static void launch_ln_rows(const float* X, float* Y, const float* g, const float* b, const float* w2, const float* b2, float* scores,
-                           int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream) {
+                           int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream,
+                           unsigned short* y16 = nullptr) {
   const dim3 grid((n_rows + 3) / 4), block(256);
   const int D4 = D >> 2;
-#define SUMK_LN(NQ) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site)
+#define SUMK_LN(NQ) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site, y16)
   if (D4 <= 64) SUMK_LN(1); else if (D4 <= 128) SUMK_LN(2); else if (D4 <= 256) SUMK_LN(4); else if (D4 <= 512) SUMK_LN(8); else SUMK_LN(0);
 #undef SUMK_LN
 }
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ scores,
                                                             const float* __restrict__ dscores, float* __restrict__ dX,
                                                             float* __restrict__ part, int n_rows, int D, Drop drop,
-                                                            uint32_t site) {
+                                                            uint32_t site, unsigned short* __restrict__ dX16) {   // bf16(dX) too (dX may then be null)
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * 4;
@@ -563,7 +583,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.y = rstd * (dxh[q].y - s1 - xh[q].y * s2) * keep[q].y;
         o.z = rstd * (dxh[q].z - s1 - xh[q].z * s2) * keep[q].z;
         o.w = rstd * (dxh[q].w - s1 - xh[q].w * s2) * keep[q].w;
-        reinterpret_cast<float4*>(dX + (int64_t)row * D)[c] = o;
+        if (dX != nullptr) reinterpret_cast<float4*>(dX + (int64_t)row * D)[c] = o;
+        if (dX16 != nullptr) store_bf16x4(dX16 + (int64_t)row * D + 4 * c, o);
         if constexpr (HEAD) { ax[q].x += o.x; ax[q].y += o.y; ax[q].z += o.z; ax[q].w += o.w; }
       }
     }
@@ -645,6 +666,17 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
   return SUMK_OK;
+}
+
+// Does the training step run its row-wise GEMMs on the bf16-source kernels (gemm_b16.hip)?  A function of the batch geometry and the
+// options only: forward and backward must agree (the forward leaves the bf16 shadows the backward reads).  SUMK_BF16_SRC=0 keeps
+// the plane kernels (fp32 operands converted per k-tile) -- the A/B switch.
+static bool use_b16(const Geometry& G, int D, const sumk_vasnet_opts* o, int training) {
+  static const bool on = !(getenv("SUMK_BF16_SRC") && getenv("SUMK_BF16_SRC")[0] == '0');
+  const int R = G.R;
+  return on && training && o->precision == SUMK_PRECISION_BF16 && G.st_qkv == 0 && G.st_d == 0 &&
+         gemm_b16_ok(R, 3 * D, D, D, D, true, true) && gemm_b16_ok(R, D, D, D, D, true, false) &&
+         gemm_b16_ok(R, D, D, 3 * D, D, true, false) && gemm_b16_ok(3 * D, D, R, 3 * D, D, false, false);
 }
 
 // row-wise problem slots (index into prob_row)
@@ -759,6 +791,20 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
+  // mixed-precision training: bf16 shadows of x and of the five weight matrices, then every row-wise GEMM reads bf16 from HBM
+  const bool b16 = use_b16(G, D, opts, training);
+  unsigned short* x16 = (unsigned short*)(ws + L.x16);
+  unsigned short* Wqkv16 = (unsigned short*)(ws + L.w16);
+  unsigned short* Wo16 = Wqkv16 + (size_t)3 * D * D;
+  unsigned short* W116 = Wo16 + (size_t)D * D;
+  if (b16) {
+    const float* xs[4] = {x, nullptr, nullptr, nullptr};
+    SUMK_TRY(cast_rows_b16(xs, 1, R, D, D, x16, stream));
+    const float* wqkv[4] = {w->Wq, w->Wk, w->Wv, nullptr};
+    SUMK_TRY(cast_rows_b16(wqkv, 3, D, D, D, Wqkv16, stream));
+    const float* wo1[4] = {w->Wo, w->W1, nullptr, nullptr};
+    SUMK_TRY(cast_rows_b16(wo1, 2, D, D, D, Wo16, stream));
+  }
 
   // row-wise NT GEMMs with K = D: eligible for the buffer-load instances when D is a whole number of k-tiles and byte offsets fit 31 bits
   const int lean_rows = (D % 32 == 0 && (int64_t)R * 3 * D * 4 < ((int64_t)1 << 31)) ? 1 : 0;
@@ -768,6 +814,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     g.lean = lean_rows;
+    if (b16) { g.A = (const float*)x16; g.B[0] = (const float*)Wqkv16; g.B[1] = g.B[2] = nullptr; g.n_group = 0; g.src16 = 1; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
@@ -810,6 +857,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
     if (Wvo && fused_ln) g.moments = ln_moments;
+    if (b16) g.C16 = ws + L.ctx16;
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
     if (Wvo && fused_ln) {
       hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
@@ -829,11 +877,14 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
                          ln_c1 + D, (const float2*)ln_moments, ln_slots, R, opts->eps, (float2*)ln_stats);
       SUMK_HIP(hipGetLastError());
     } else {
+      if (b16) { g.A = (const float*)(ws + L.ctx16); g.B[0] = (const float*)Wo16; g.src16 = 1; }
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
     }
   }
   // 6: dropout + LayerNorm
-  if (!fused_ln) launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
+  // (b16: the LayerNorm output is consumed by bf16-source GEMMs only -- k1 here, dW1 in the backward -- so only its bf16 form is written)
+  if (!fused_ln) launch_ln_rows<false>(Y0, b16 ? nullptr : Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream,
+                                       b16 ? (unsigned short*)(ws + L.y116) : nullptr);
   // 7 + 8 fused (inference, 128x128 tiles): k1 + bias + ReLU with the LayerNorm + k2 moments taken in the GEMM epilogue -- the
   // (R, D) activation matrix is neither written (49 MB in the lock-stepped store burst of this single-round launch) nor read
   // back by a LayerNorm kernel.
@@ -856,6 +907,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
     g.lean = lean_rows;
+    if (b16) { g.A = (const float*)(ws + L.y116); g.B[0] = (const float*)W116; g.src16 = 1; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
@@ -886,14 +938,14 @@ extern "C" int sumk_vasnet_forward_folded(float* x, int32_t D, int32_t n_seq, co
 template <bool HEAD>
 static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const float* g, const float* b,
                          const float* dY, const float* w2, const float* scores, const float* dscores, float* dX,
-                         float* part, Drop drop, uint32_t site, int* n_waves_out, hipStream_t stream) {
+                         float* part, Drop drop, uint32_t site, int* n_waves_out, hipStream_t stream, unsigned short* dX16 = nullptr) {
   const int D4 = D >> 2;
   const int nq = (D4 + 63) / 64;
   int blocks = std::min((R + 3) / 4, LNB_MAX_WAVES / 4);
   blocks = std::max(blocks, 1);
   *n_waves_out = blocks;              // slots written: one per block
   dim3 grid(blocks), block(256);
-#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site)
+#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16)
   if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
   else { set_error("vasnet_backward: D=%d > 2048 is not supported by the LayerNorm backward kernel", D); return SUMK_ERR_ARG; }
 #undef LNB
@@ -959,28 +1011,45 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   const Drop drop = make_drop(opts);
   const bool use_e2 = drop.thr != 0;
   int nw = 0;
+  // bf16-source row-wise GEMMs (see the forward): dZ and dY0 are produced in bf16 by the LayerNorm backward kernels, dQKV by the
+  // per-video GEMM epilogues; fp32 dZ is never needed, fp32 dY0 only for the residual branch of dx
+  const bool b16 = use_b16(G, D, opts, 1);
+  const float* x16 = (const float*)(ws + L.x16);
+  const unsigned short* Wqkv16 = (const unsigned short*)(ws + L.w16);
+  const float* Wo16 = (const float*)(Wqkv16 + (size_t)3 * D * D);
+  const float* W116 = (const float*)(Wqkv16 + (size_t)4 * D * D);
+  const float* CTX16 = (const float*)(ws + L.ctx16);
+  const float* Y116 = (const float*)(ws + L.y116);
+  unsigned short* dZ16 = (unsigned short*)(ws + L.dz16);
+  unsigned short* dY016 = (unsigned short*)(ws + L.dy016);
+  unsigned short* dQKV16 = (unsigned short*)(ws + L.dqkv16);
 
   // 8': head + second LayerNorm + dropout + ReLU  ->  dZ (w.r.t. the k1 pre-activation), dw2, db2, dgamma, dbeta
-  SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, dZ, lnpart,
-                               drop, 2u, &nw, stream));
+  SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, b16 ? nullptr : dZ, lnpart,
+                               drop, 2u, &nw, stream, b16 ? dZ16 : nullptr));
   SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, gr->w2, gr->b2, gr->b1, stream));   // db1 = column sums of dZ, from the same slots
   // 7': k1
   {
     float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dZ, D, Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
+    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dZ16 : dZ, D, b16 ? Y116 : Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f,
+                                  stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dY1 = dZ . W1
     g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
+    if (b16) { g.A = (const float*)dZ16; g.B[0] = W116; g.src16 = 1; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // 6': first LayerNorm + dropout -> dY0 (gradient of the residual sum)
-  SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, dY1, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream));
+  SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, dY1, nullptr, nullptr, nullptr, (b16 && !dx) ? nullptr : dY0, lnpart, drop, 1u, &nw, stream,
+                                b16 ? dY016 : nullptr));
   SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
   // 5': output projection (+ residual branch into dx)
   {
     float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dY0, D, CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
+    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dY016 : dY0, D, b16 ? CTX16 : CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f,
+                                  stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
+    if (b16) { g.A = (const float*)dY016; g.B[0] = Wo16; g.src16 = 1; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // Wo, W1, b1, w2, b2 (the tail of the parameter order) are final from here on: a data-parallel caller starts their
@@ -991,6 +1060,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
+    if (b16) g.C16 = dQKV16;
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   {
@@ -1005,17 +1075,20 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
+    if (b16) g.C16 = dQKV16;
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
+    if (b16) g.C16 = dQKV16;
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X
   {
     float* out[4] = {gr->Wq, gr->Wk, gr->Wv, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dQKV, 3 * D, x, D, 3 * D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision));
+    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dQKV16 : dQKV, 3 * D, b16 ? x16 : x, D, 3 * D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f,
+                                  stream, opts->precision, b16));
   }
   if (dx) {  // dX = dY0 (residual) + dQ Wq + dK Wk + dV Wv
     SUMK_HIP(hipMemcpyAsync(dx, dY0, (size_t)R * D * 4, hipMemcpyDeviceToDevice, stream));
@@ -1024,6 +1097,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
       GemmLaunch g; g.precision = opts->precision;
       g.A = dQKV + (size_t)part * D; g.B[0] = Ws[part]; g.C = dx; g.probs = prow + RP_DX; g.small_tile = G.st_d;
       g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
+      if (b16) { g.A = (const float*)(dQKV16 + (size_t)part * D); g.B[0] = (const float*)(Wqkv16 + (size_t)part * D * D); g.src16 = 1; }
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_ACCUM, g, stream));
     }
   }

@@ -282,6 +282,53 @@ def test_gemm_plain_bf16_vs_float64(dev, M, N, K):
                 assert err.max() > 1e-5 * np.abs(ref).max(), "suspiciously exact: is the bf16 path really taken?"
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (1000, 3072, 1024), (1024, 1024, 3011), (264, 1024, 12003)])
+def test_gemm_bf16_sources_vs_float64(dev, M, N, K):
+    """csrc/gemm_b16.hip: bf16 operands in HBM, fp32 accumulate.  The operands ARE bf16 here, so the only error left is the fp32
+    accumulation order: against float64 of the same bf16 values the bound is K * 2^-24 * |A|.|B|^T (a few 1e-6 relative), and small-integer
+    data must come out exact -- in all three layouts, on ragged M / N tiles, K tails of the M/N-contiguous operands (zeroed by the
+    buffer descriptor, not by masks) and through the deterministic split-K weight-gradient form (C += A^T B twice = 2x)."""
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu"); g.manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    B = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    Ai = ((torch.arange(M * K).reshape(M, K) % 7) - 3).to(torch.bfloat16)
+    Bi = (((torch.arange(N * K).reshape(N, K) % 5) - 2) + (torch.arange(N)[:, None] % 3)).to(torch.bfloat16)
+    ws = torch.zeros(8192 + 24 * M * N * 4, dtype=torch.uint8, device=dev)
+    for a16, b16, exact in ((A, B, False), (Ai, Bi, True)):
+        a64, b64 = a16.double().numpy(), b16.double().numpy()
+        ref = a64 @ b64.T
+        bound = (K + 64) * 2.0 ** -24 * (np.abs(a64) @ np.abs(b64).T) + 1e-30
+        for layout, name in ((0, "NT"), (1, "NN"), (2, "TN")):
+            if layout < 2 and K % 64:
+                continue                      # a K-contiguous operand needs whole k-tiles (the caller's eligibility check; refused below)
+            a = (a16 if layout < 2 else a16.T.contiguous()).to(dev)
+            b = (b16 if layout == 0 else b16.T.contiguous()).to(dev)
+            c = torch.full((M, N), float("nan"), device=dev)
+            _lib.check(lib.sumk_gemm_bf16src(layout, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, None, 0, st), "gemm_bf16src")
+            got = c.cpu().numpy().astype(np.float64)
+            if exact:
+                np.testing.assert_array_equal(got, ref, err_msg=name)
+            else:
+                err = np.abs(got - ref)
+                assert (err <= bound).all(), f"{name} max err {err.max()} vs bound {bound.flat[err.argmax()]}"
+            if layout == 2:                    # split-K, accumulating: two calls on a zeroed C
+                c2 = torch.zeros((M, N), device=dev)
+                for _ in range(2):
+                    _lib.check(lib.sumk_gemm_bf16src(2, a.data_ptr(), b.data_ptr(), c2.data_ptr(), M, N, K, ws.data_ptr(), ws.numel(), st), "gemm_bf16src split-K")
+                got2 = c2.cpu().numpy().astype(np.float64)
+                if exact:
+                    np.testing.assert_array_equal(got2, 2 * ref, err_msg="TN split-K")
+                else:
+                    assert (np.abs(got2 - 2 * ref) <= 2 * bound + 1e-6 * np.abs(ref)).all(), "TN split-K"
+    if K % 64:
+        c = torch.zeros((M, N), device=dev)
+        with pytest.raises(_lib.SumkError, match="not eligible"):
+            _lib.check(lib.sumk_gemm_bf16src(0, A.to(dev).data_ptr(), B.to(dev).data_ptr(), c.data_ptr(), M, N, K, None, 0, st), "gemm_bf16src")
+
+
 def test_vasnet_plain_bf16_scores_are_close_but_not_fp32_grade(dev):
     """Plain bf16 arithmetic is a TRAINING mode: scores stay within 3e-2 of the reference goldens but miss the 1e-4 scoring gate
     the fp32-grade paths hold -- it is never the default."""
