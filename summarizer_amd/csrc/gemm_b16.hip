@@ -17,6 +17,7 @@
 // operand needs K % 64 == 0; an MC operand needs its row length % 8 == 0 (16-byte chunks); byte offsets must fit 31 bits.  The
 // host checks all three (gemm_b16_ok) and the callers fall back to the plane kernels otherwise.
 #include "gemm_regstage.h"
+#include <type_traits>
 
 namespace sumk {
 
@@ -168,9 +169,210 @@ int launch_epi_b16(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
   return SUMK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------- wide tiles
+// (192 | 256) x 256 x 64 tiles, 512 threads = 2 x 4 waves of (BM / 2) x 64, one block per CU, DOUBLE-BUFFERED LDS (one barrier per
+// k-tile).  Why: at one bf16 MFMA per product the 128x128 tile asks the L2 for 32 KB per 512 matrix-pipe cycles and CU -- 38 TB/s
+// chip-wide at full rate, twice what the L2s deliver (MI355X_MICROARCH.md: ~17-19 TB/s): measured 9.7 TB/s and 0.25 of the bf16
+// peak.  A 256-wide tile halves the operand bytes per FLOP; BM = 192 exists because 12 003 rows are 63 x 192 (one full round of 252
+// blocks on 256 CUs for an N = 1024 output, three full rounds at N = 3072) but 47 x 256 (0.73 of a round).
+template <int BM, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(512) void gemm_b16_wide_kernel(GemmKArgs ka) {
+  constexpr int BN = 256, TM = BM / 64, TN = 2, WTM = BM / 2;
+  constexpr int MCP_A = 2 * BM + 64, MCP_B = 2 * BN + 64;            // MC images: bytes per k-row (pitch = 64 mod 256: the 4 k-rows of a transposing read hit 4 bank groups)
+  constexpr int A_BYTES = A_KC ? BM * KCP : BKH * MCP_A, B_BYTES = B_KC ? BN * KCP : BKH * MCP_B, STAGE = A_BYTES + B_BYTES;
+  constexpr int NLA = BM / 64, NLB = BN / 64;                        // 16-byte chunks per thread, operand and k-tile
+  constexpr int CPR_A = BM / 8, CPR_B = BN / 8;                      // MC: chunks per k-row
+  extern __shared__ __attribute__((aligned(16))) char lds_w[];       // 2 stages
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
+  const unsigned short* const A16 = reinterpret_cast<const unsigned short*>(ka.A);
+  const unsigned short* const B16 = reinterpret_cast<const unsigned short*>(ka.B[0]);
+
+  struct Src { __amdgpu_buffer_rsrc_t ra, rb; int sa, sb; };   // operand descriptors of the tile's (sub-)problem, k-tile strides (bytes)
+  // (every field is forced into SGPRs: carried around the tile loop the descriptors were classed as divergent and each buffer load
+  //  became a waterfall loop of v_readfirstlane + compare)
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto uni_ptr = [&](const unsigned short* p) {
+    const uint64_t u = (uint64_t)p;
+    return (unsigned short*)(((uint64_t)(uint32_t)uni((int)(u >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)u));
+  };
+  int voa[NLA], vob[NLB], lda_[NLA], ldb_[NLB];     // global byte offsets / LDS byte offsets (inside a stage) of this thread's chunks
+#pragma unroll
+  for (int p = 0; p < NLA; ++p) {
+    const int idx = tid + 512 * p;
+    lda_[p] = A_KC ? (idx >> 3) * KCP + (idx & 7) * 16 : (idx / CPR_A) * MCP_A + (idx % CPR_A) * 16;
+  }
+#pragma unroll
+  for (int p = 0; p < NLB; ++p) {
+    const int idx = tid + 512 * p;
+    ldb_[p] = A_BYTES + (B_KC ? (idx >> 3) * KCP + (idx & 7) * 16 : (idx / CPR_B) * MCP_B + (idx % CPR_B) * 16);
+  }
+  auto setup = [&](int tile, TileCtx& c, Src& s) -> bool {
+    GemmProb P;
+    if (!decode_tile<BM, BN>(ka, tile, c, P)) return false;
+    int na, nb;
+#pragma unroll
+    for (int p = 0; p < NLA; ++p) {
+      const int idx = tid + 512 * p;
+      voa[p] = A_KC ? ((c.m0 + (idx >> 3)) * P.lda + (idx & 7) * 8) * 2 : ((idx / CPR_A) * P.lda + c.m0 + (idx % CPR_A) * 8) * 2;
+    }
+#pragma unroll
+    for (int p = 0; p < NLB; ++p) {
+      const int idx = tid + 512 * p;
+      vob[p] = B_KC ? ((c.n0 + (idx >> 3)) * P.ldb + (idx & 7) * 8) * 2 : ((idx / CPR_B) * P.ldb + c.n0 + (idx % CPR_B) * 8) * 2;
+    }
+    if constexpr (A_KC) { na = ((P.M - 1) * P.lda + P.K) * 2; s.sa = BKH * 2; }
+    else { na = ((P.K - 1) * P.lda + ((P.M + 7) & ~7)) * 2; s.sa = uni(BKH * P.lda * 2); }
+    if constexpr (B_KC) { nb = ((P.N - 1) * P.ldb + P.K) * 2; s.sb = BKH * 2; }
+    else { nb = ((P.K - 1) * P.ldb + ((P.N + 7) & ~7)) * 2; s.sb = uni(BKH * P.ldb * 2); }
+    s.ra = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(A16 + P.a_off), (short)0, uni(na), 0x00020000);
+    s.rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(B16 + P.b_off), (short)0, uni(nb), 0x00020000);
+    return true;
+  };
+
+  u32x4 ra[NLA], rb[NLB];
+  // the staging work of one k-tile is cut into four SLICES, one per 16-deep MFMA step: chunk p of an operand belongs to slice p & 3
+  // (BM = 192: A has chunks 0..2).  Slice q of k-tile kt + 1 is written to the other LDS stage, then the same registers are re-loaded
+  // with k-tile kt + 2, behind the MFMAs of step q of k-tile kt -- the LDS store burst and the load issue are spread over the k-tile
+  // instead of standing between the barrier and the first MFMA.
+  auto gload_slice = [&](const Src& s, int kt, int q) {
+    if (q < NLA) ra[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(s.ra, voa[q], kt * s.sa, 0);
+    if (q < NLB) rb[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(s.rb, vob[q], kt * s.sb, 0);
+  };
+  auto gload = [&](const Src& s, int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gload_slice(s, kt, q);
+  };
+  auto swrite_slice = [&](char* st, int q) {
+    if (q < NLA) *reinterpret_cast<u32x4*>(st + lda_[q]) = ra[q];
+    if (q < NLB) *reinterpret_cast<u32x4*>(st + ldb_[q]) = rb[q];
+  };
+  const int fa = A_KC ? (wm * WTM + li) * KCP + 16 * lh
+                      : (8 * lh + ((lane & 15) >> 2)) * MCP_A + 2 * (wm * WTM + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+  const int fb = A_BYTES + (B_KC ? (wn * 64 + li) * KCP + 16 * lh
+                                 : (8 * lh + ((lane & 15) >> 2)) * MCP_B + 2 * (wn * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)));
+  struct Frags { bf16x8 a[TM], b[TN]; };
+  auto read_frags = [&](const char* st, int ks, Frags& f) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      if constexpr (A_KC) f.a[t] = *reinterpret_cast<const bf16x8*>(st + fa + t * 32 * KCP + 32 * ks);
+      else f.a[t] = tr_frag(st + fa + 16 * ks * MCP_A + 64 * t, MCP_A);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      if constexpr (B_KC) f.b[t] = *reinterpret_cast<const bf16x8*>(st + fb + t * 32 * KCP + 32 * ks);
+      else f.b[t] = tr_frag(st + fb + 16 * ks * MCP_B + 64 * t, MCP_B);
+    }
+  };
+  // One k-tile: the fragments of step ks + 1 are requested BEFORE the MFMAs of step ks (left to itself the scheduler sinks every
+  // ds_read next to its first use and waits lgkmcnt(0) in front of each pair of MFMAs: measured 0.28 of the matrix rate with the
+  // loads, LDS writes and stores all switched off).  sched_barrier pins the order  reads(ks + 1) | MFMAs(ks) + staging slice ks.
+  // MODE 2: write slice of k-tile kt + 1, load k-tile kt + 2; 1: write only; 0: neither (last k-tile of the tile)
+  auto ktile = [&](const char* st, char* nst, const Src& s, int kt, auto mode, f32x16 (&acc)[TM][TN]) {
+    constexpr int MODE = decltype(mode)::value;
+    Frags f[2];
+    read_frags(st, 0, f[0]);
+#pragma unroll
+    for (int ks = 0; ks < BKH / 16; ++ks) {
+      if (ks + 1 < BKH / 16) read_frags(st, ks + 1, f[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].a[tm], f[ks & 1].b[tn], acc[tm][tn], 0, 0, 0);
+      if constexpr (MODE >= 1) swrite_slice(nst, ks);
+      if constexpr (MODE >= 2) gload_slice(s, kt + 2, ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ka.total_tiles) return;
+  TileCtx cur, nxt;
+  Src scur, snxt;
+  if (!setup(tile, cur, scur)) return;
+  gload(scur, 0);
+
+  while (true) {
+    f32x16 acc[TM][TN];
+    if constexpr (EPI == EPI_RESIDUAL) {
+      residual_init<TM, TN>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * 64, li, lh);
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const int nk = (cur.K + BKH - 1) / BKH;
+    const int next_tile = tile + gridDim.x;
+    // stage 0 <- k-tile 0 (every wave is past the previous tile's last barrier: both stages are free)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) swrite_slice(lds_w, q);
+    if (nk > 1) gload(scur, 1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+      ktile(lds_w + (kt & 1) * STAGE, lds_w + ((kt + 1) & 1) * STAGE, scur, kt, std::integral_constant<int, 2>{}, acc);
+      __syncthreads();
+    }
+    if (kt + 1 < nk) {
+      ktile(lds_w + (kt & 1) * STAGE, lds_w + ((kt + 1) & 1) * STAGE, scur, kt, std::integral_constant<int, 1>{}, acc);
+      __syncthreads();
+      ++kt;
+    }
+    // last k-tile: the next tile's decode and first loads go out under its MFMAs
+    bool has_next = next_tile < ka.total_tiles;
+    if (has_next) has_next = setup(next_tile, nxt, snxt);
+    if (has_next) gload(snxt, 0);
+    ktile(lds_w + (kt & 1) * STAGE, nullptr, scur, kt, std::integral_constant<int, 0>{}, acc);
+    __syncthreads();
+    epilogue_store<EPI, TM, TN, true>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * 64, li, lh);
+    if (!has_next) break;
+    tile = next_tile; cur = nxt; scur = snxt;
+  }
+}
+
+template <int BM, bool A_KC, bool B_KC, int EPI>
+int launch_wide_one(const GemmKArgs& ka, int tiles, hipStream_t s) {
+  constexpr int A_BYTES = A_KC ? BM * KCP : BKH * (2 * BM + 64), B_BYTES = B_KC ? 256 * KCP : BKH * (2 * 256 + 64);
+  constexpr int LDS = 2 * (A_BYTES + B_BYTES);
+  static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+  const void* fn = (const void*)gemm_b16_wide_kernel<BM, A_KC, B_KC, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) { SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
+  hipLaunchKernelGGL((gemm_b16_wide_kernel<BM, A_KC, B_KC, EPI>), dim3(std::min(tiles, 256)), dim3(512), LDS, s, ka);
+  return SUMK_OK;
+}
+template <int BM, bool A_KC, bool B_KC>
+int launch_epi_wide(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s) {
+  switch (epi) {
+    case EPI_NONE: return launch_wide_one<BM, A_KC, B_KC, EPI_NONE>(ka, tiles, s);
+    case EPI_RESIDUAL: return launch_wide_one<BM, A_KC, B_KC, EPI_RESIDUAL>(ka, tiles, s);
+    case EPI_BIAS_RELU: return launch_wide_one<BM, A_KC, B_KC, EPI_BIAS_RELU>(ka, tiles, s);
+    case EPI_ACCUM: return launch_wide_one<BM, A_KC, B_KC, EPI_ACCUM>(ka, tiles, s);
+    default: set_error("gemm (bf16 sources): epilogue %d is not instantiated", (int)epi); return SUMK_ERR_ARG;
+  }
+}
+
 }  // namespace
 
-int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t stream) {
+// wide = 0: 128x128 tiles; 192 / 256: BM of the (BM x 256) tile (the problem table's tiles_n / tile_start and `tiles` were built for it)
+int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int wide, hipStream_t stream) {
+  if (wide == 192) {
+    if (layout == GEMM_NT) return launch_epi_wide<192, true, true>(epi, ka, tiles, stream);
+    if (layout == GEMM_NN) return launch_epi_wide<192, true, false>(epi, ka, tiles, stream);
+    return launch_epi_wide<192, false, false>(epi, ka, tiles, stream);
+  }
+  if (wide == 256) {
+    if (layout == GEMM_NT) return launch_epi_wide<256, true, true>(epi, ka, tiles, stream);
+    if (layout == GEMM_NN) return launch_epi_wide<256, true, false>(epi, ka, tiles, stream);
+    return launch_epi_wide<256, false, false>(epi, ka, tiles, stream);
+  }
   if (layout == GEMM_NT) return launch_epi_b16<true, true>(epi, ka, tiles, stream);
   if (layout == GEMM_NN) return launch_epi_b16<true, false>(epi, ka, tiles, stream);
   return launch_epi_b16<false, false>(epi, ka, tiles, stream);

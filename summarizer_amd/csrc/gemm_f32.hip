@@ -69,8 +69,8 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
   static const bool xcd_map = !(getenv("SUMK_XCD_MAP") && getenv("SUMK_XCD_MAP")[0] == '0');
   if (xcd_map && g.nprob == 1 && g.xcd_M > 0) {
-    const int tm = (g.xcd_M + gemm_tile_m(g.small_tile) - 1) / gemm_tile_m(g.small_tile);
-    const int tn = (g.xcd_N + gemm_tile_n(g.small_tile) - 1) / gemm_tile_n(g.small_tile);
+    const int bm = (g.src16 && g.wide16) ? g.wide16 : gemm_tile_m(g.small_tile), bn = (g.src16 && g.wide16) ? 256 : gemm_tile_n(g.small_tile);
+    const int tm = (g.xcd_M + bm - 1) / bm, tn = (g.xcd_N + bn - 1) / bn;
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
@@ -88,7 +88,8 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
   static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
   if (g.src16) {                              // bf16 operands in HBM: gemm_b16.hip
-    rc = launch_gemm_b16(layout, epi, ka, ka.total_tiles, stream);
+    SUMK_ARG(g.wide16 == 0 || g.wide16 == 192 || g.wide16 == 256, "gemm: wide16 must be 0, 192 or 256");
+    rc = launch_gemm_b16(layout, epi, ka, ka.total_tiles, g.wide16, stream);
   } else
   if (g.precision != SUMK_PRECISION_FP32) {   // bf16-plane arithmetics: instantiated in gemm_split.hip
     rc = launch_gemm_split(g.precision, layout, epi, ka, ka.total_tiles, g.small_tile, stream);
@@ -185,11 +186,12 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   SUMK_ARG(slab_elems >= (size_t)M * N, "splitk: slab too small");
   SUMK_ARG(!src16 || gemm_b16_ok(M, N, K, lda, ldb, false, false), "splitk: operands not eligible for the bf16-source kernel");
   const int small = (src16 || gemm_tiles(M, N, 0) >= 64) ? 0 : 1;     // (src16: A and B are bf16 arrays)
-  const int tiles = gemm_tiles(M, N, small);
+  const int wide = (src16 && M >= 512 && N >= 512 && M % 256 == 0 && N % 256 == 0) ? 256 : 0;    // 256x256 tiles, one block per CU
+  const int tiles = wide ? gemm_tiles_wide(M, N, 256) : gemm_tiles(M, N, small);
   // K slices so that S x tiles fills the resident slots of the persistent grid ONCE (768 blocks of the 128x128 kernel, 2048 of the
   // 64x64 one): every block then walks exactly one (long) tile.  The first version aimed at >= 1024 tiles: 1152 for the QKV
   // weight gradient = one and a half rounds, the second half-empty (744 -> 6xx us), 1024 for the D x D ones.
-  const int slots = small ? 2048 : 768;
+  const int slots = wide ? 256 : small ? 2048 : 768;
   int S = std::max(1, slots / tiles);
   S = std::min(S, (K + 63) / 64);
   S = std::min(S, (int)std::min<size_t>(slab_elems / ((size_t)M * N), (size_t)probs_cap));
@@ -198,10 +200,10 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   int kchunk = ((K + S - 1) / S + kq - 1) / kq * kq;
   S = (K + kchunk - 1) / kchunk;
   hipLaunchKernelGGL(splitk_setup_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, probs_dev, S, M, N, K, kchunk, lda, ldb,
-                     gemm_tile_dim(small));
+                     wide ? 256 : gemm_tile_dim(small));
   GemmLaunch g;
   g.A = A; g.B[0] = B; g.C = slab; g.probs = probs_dev; g.nprob = S; g.small_tile = small; g.total_tiles = S * tiles;
-  g.precision = precision; g.src16 = src16;
+  g.precision = precision; g.src16 = src16; g.wide16 = wide;
   // the tiles of one K slice share their operand rows: keep a slice on one XCD (measured: the bf16 training step 1.35 -> 1.21 ms,
   // fp32 unchanged; the per-video attention products did not gain and are left in plain order)
   g.group_remap = 1;
@@ -441,10 +443,13 @@ extern "C" int sumk_gemm_bf16src(int32_t layout, const void* A16, const void* B1
   }
   GemmProb* p = scratch_prob();
   SUMK_ARG(p != nullptr, "gemm: cannot allocate problem scratch");
-  SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, 0, s));
+  int wide = gemm_b16_wide_bm(M, N);
+  if (const char* env = getenv("SUMK_B16_WIDE")) wide = atoi(env);     // probe override: 0 / 192 / 256
+  SUMK_TRY(fill_single_prob(p, M, N, K, lda, ldb, N, 0, wide ? 3 : 0, s));
   GemmLaunch g;
   g.A = (const float*)A16; g.B[0] = (const float*)B16; g.C = C; g.probs = p; g.nprob = 1; g.small_tile = 0;
-  g.total_tiles = gemm_tiles(M, N, 0); g.xcd_M = M; g.xcd_N = N; g.precision = SUMK_PRECISION_BF16; g.src16 = 1;
+  g.total_tiles = wide ? gemm_tiles_wide(M, N, wide) : gemm_tiles(M, N, 0); g.xcd_M = M; g.xcd_N = N; g.precision = SUMK_PRECISION_BF16;
+  g.src16 = 1; g.wide16 = wide;
   return launch_gemm((GemmLayout)layout, EPI_NONE, g, s);
 }
 extern "C" int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream) {

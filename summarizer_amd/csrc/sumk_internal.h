@@ -80,6 +80,9 @@ struct GemmLaunch {
   // 1: A and B[0] point at bf16 arrays (offsets / leading dimensions of the problem table count bf16 elements); 128x128 tiles, fp32
   // accumulate and output (gemm_b16.hip).  The caller has checked gemm_b16_ok for every sub-problem.
   int32_t src16 = 0;
+  // src16 only: 0 = 128x128 tiles; 192 / 256 = BM of the wide (BM x 256) tile -- `probs` (tiles_n, tile_start) and total_tiles must have
+  // been built for that tile (gemm_tiles_wide; problem-table tile code 3 = 256 columns)
+  int32_t wide16 = 0;
   void* C16 = nullptr;                 // EPI_NONE: also store bf16(C) here, same offsets / ldc (the operand of a later src16 launch)
   int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
@@ -90,7 +93,7 @@ struct GemmLaunch {
 
 // number of tiles an (M,N) problem takes with the chosen tile size
 inline int gemm_tile_m(int cfg) { return cfg == 1 ? 64 : 128; }
-inline int gemm_tile_n(int cfg) { return cfg == 0 ? 128 : 64; }
+inline int gemm_tile_n(int cfg) { return cfg == 0 ? 128 : cfg == 3 ? 256 : 64; }   // (3: the wide bf16-source tiles, gemm_b16.hip)
 inline int gemm_tile_dim(int cfg) { return gemm_tile_n(cfg); }   // tiles_n divisor of a config
 inline int gemm_tiles(int M, int N, int cfg) {
   int tm = gemm_tile_m(cfg), tn = gemm_tile_n(cfg);
@@ -105,6 +108,14 @@ inline int gemm_b16_ok(int64_t M, int64_t N, int64_t K, int lda, int ldb, bool k
   if (kc_a ? (K % 64 != 0 || (M + 128) * lda * 2 >= lim) : (M % 8 != 0 || (K + 64) * lda * 2 >= lim)) return 0;
   if (kc_b ? (K % 64 != 0 || (N + 128) * ldb * 2 >= lim) : (N % 8 != 0 || (K + 64) * ldb * 2 >= lim)) return 0;
   return 1;
+}
+inline int gemm_tiles_wide(int M, int N, int bm) { return ((M + bm - 1) / bm) * ((N + 255) / 256); }
+// BM of the wide tile for one (M, N) problem on 256 CUs (one block per CU): the BM whose rounds x rows-per-tile is smaller; 0 = the
+// problem is too small to fill the chip with wide tiles (128x128 tiles instead)
+inline int gemm_b16_wide_bm(int M, int N) {
+  const int t192 = gemm_tiles_wide(M, N, 192), t256 = gemm_tiles_wide(M, N, 256);
+  if (t256 < 96 || N % 256 != 0) return 0;
+  return ((t192 + 255) / 256) * 192 <= ((t256 + 255) / 256) * 256 ? 192 : 256;
 }
 // dst (bf16, [n_src * rows_per_src][n_cols], dense) = the n_src fp32 row groups stacked (gemm_b16.hip)
 int cast_rows_b16(const float* const src[4], int n_src, int64_t rows_per_src, int n_cols, int ld_src, void* dst, hipStream_t stream);

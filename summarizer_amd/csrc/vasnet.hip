@@ -127,7 +127,7 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
     int i = threadIdx.x;
     if (blockIdx.x == 0 && i < a.n_rowprobs) {
       const RowProbSpec r = a.rows[i];
-      int t = r.small ? 64 : 128;
+      int t = r.small == 3 ? 256 : r.small ? 64 : 128;     // (3: the wide bf16-source tiles)
       GemmProb q;
       q.a_off = q.b_off = q.c_off = q.r_off = 0;
       q.M = r.M; q.N = r.N; q.K = r.K; q.lda = r.lda; q.ldb = r.ldb; q.ldc = r.ldc; q.ldr = r.ldr;
@@ -679,8 +679,16 @@ static bool use_b16(const Geometry& G, int D, const sumk_vasnet_opts* o, int tra
          gemm_b16_ok(R, D, D, 3 * D, D, true, false) && gemm_b16_ok(3 * D, D, R, 3 * D, D, false, false);
 }
 
+// put a row-wise launch on the bf16-source kernels: bf16 operands and, where it fills the chip, the wide tile with its problem entry
+static void to_b16(GemmLaunch& g, const void* A16, const void* B16, int M, int N, GemmProb* prow, int slot_wide) {
+  g.A = (const float*)A16; g.B[0] = (const float*)B16; g.B[1] = g.B[2] = g.B[3] = nullptr; g.n_group = 0; g.src16 = 1;
+  static const int force = getenv("SUMK_B16_WIDE") ? atoi(getenv("SUMK_B16_WIDE")) : -1;     // A/B switch: 0 = 128x128 tiles everywhere
+  const int wide = force >= 0 ? force : gemm_b16_wide_bm(M, N);
+  if (wide == 192 || wide == 256) { g.wide16 = wide; g.probs = prow + slot_wide; g.total_tiles = gemm_tiles_wide(M, N, wide); }
+}
+
 // row-wise problem slots (index into prob_row)
-enum { RP_QKV = 0, RP_DD = 1, RP_DX = 2 };
+enum { RP_QKV = 0, RP_DD = 1, RP_DX = 2, RP_QKV_W = 3, RP_DD_W = 4, RP_DX_W = 5 };   // _W: the same problems on 256-column tiles (gemm_b16.hip)
 
 static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off_dev, char* ws, hipStream_t stream) {
   SetupArgs a;
@@ -695,7 +703,10 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   a.rows[RP_QKV] = RowProbSpec{R, 3 * D, D, D, D, 3 * D, 0, G.st_qkv};   // [Q|K|V] = X W^T
   a.rows[RP_DD] = RowProbSpec{R, D, D, D, D, D, D, G.st_d};              // (R,D) = (R,D) x (D,D), any layout
   a.rows[RP_DX] = RowProbSpec{R, D, D, 3 * D, D, D, D, G.st_d};          // dX += dQKV[:, part] W  (A has lda 3D)
-  a.n_rowprobs = 3;
+  a.rows[RP_QKV_W] = a.rows[RP_QKV]; a.rows[RP_QKV_W].small = 3;
+  a.rows[RP_DD_W] = a.rows[RP_DD]; a.rows[RP_DD_W].small = 3;
+  a.rows[RP_DX_W] = a.rows[RP_DX]; a.rows[RP_DX_W].small = 3;
+  a.n_rowprobs = 6;
   a.s_tm = gemm_tile_m(G.cfg_s); a.s_tn = gemm_tile_n(G.cfg_s); a.pv_tm = gemm_tile_m(G.cfg_pv); a.pv_tn = gemm_tile_n(G.cfg_pv);
   hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2), dim3(64), 0, stream, a);
 }
@@ -814,7 +825,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     g.lean = lean_rows;
-    if (b16) { g.A = (const float*)x16; g.B[0] = (const float*)Wqkv16; g.B[1] = g.B[2] = nullptr; g.n_group = 0; g.src16 = 1; }
+    if (b16) to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
@@ -877,7 +888,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
                          ln_c1 + D, (const float2*)ln_moments, ln_slots, R, opts->eps, (float2*)ln_stats);
       SUMK_HIP(hipGetLastError());
     } else {
-      if (b16) { g.A = (const float*)(ws + L.ctx16); g.B[0] = (const float*)Wo16; g.src16 = 1; }
+      if (b16) to_b16(g, ws + L.ctx16, Wo16, R, D, prow, RP_DD_W);
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_RESIDUAL, g, stream));
     }
   }
@@ -907,7 +918,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.C = Z; g.probs = prow + RP_DD; g.small_tile = G.st_d;
     g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D; g.prof_tag = SUMK_PROF_GEMM_K1;
     g.lean = lean_rows;
-    if (b16) { g.A = (const float*)(ws + L.y116); g.B[0] = (const float*)W116; g.src16 = 1; }
+    if (b16) to_b16(g, ws + L.y116, W116, R, D, prow, RP_DD_W);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
@@ -1035,7 +1046,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
                                   stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dY1 = dZ . W1
     g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
-    if (b16) { g.A = (const float*)dZ16; g.B[0] = W116; g.src16 = 1; }
+    if (b16) to_b16(g, dZ16, W116, R, D, prow, RP_DD_W);
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // 6': first LayerNorm + dropout -> dY0 (gradient of the residual sum)
@@ -1049,7 +1060,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
                                   stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
-    if (b16) { g.A = (const float*)dY016; g.B[0] = Wo16; g.src16 = 1; }
+    if (b16) to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W);
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // Wo, W1, b1, w2, b2 (the tail of the parameter order) are final from here on: a data-parallel caller starts their
@@ -1097,7 +1108,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
       GemmLaunch g; g.precision = opts->precision;
       g.A = dQKV + (size_t)part * D; g.B[0] = Ws[part]; g.C = dx; g.probs = prow + RP_DX; g.small_tile = G.st_d;
       g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
-      if (b16) { g.A = (const float*)(dQKV16 + (size_t)part * D); g.B[0] = (const float*)(Wqkv16 + (size_t)part * D * D); g.src16 = 1; }
+      if (b16) to_b16(g, dQKV16 + (size_t)part * D, Wqkv16 + (size_t)part * D * D, R, D, prow, RP_DX_W);
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_ACCUM, g, stream));
     }
   }

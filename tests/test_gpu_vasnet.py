@@ -282,14 +282,18 @@ def test_gemm_plain_bf16_vs_float64(dev, M, N, K):
                 assert err.max() > 1e-5 * np.abs(ref).max(), "suspiciously exact: is the bf16 path really taken?"
 
 
+@pytest.mark.parametrize("wide", [0, 192, 256])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (1000, 3072, 1024), (1024, 1024, 3011), (264, 1024, 12003)])
-def test_gemm_bf16_sources_vs_float64(dev, M, N, K):
+def test_gemm_bf16_sources_vs_float64(dev, M, N, K, wide, monkeypatch):
     """csrc/gemm_b16.hip: bf16 operands in HBM, fp32 accumulate.  The operands ARE bf16 here, so the only error left is the fp32
     accumulation order: against float64 of the same bf16 values the bound is K * 2^-24 * |A|.|B|^T (a few 1e-6 relative), and small-integer
     data must come out exact -- in all three layouts, on ragged M / N tiles, K tails of the M/N-contiguous operands (zeroed by the
-    buffer descriptor, not by masks) and through the deterministic split-K weight-gradient form (C += A^T B twice = 2x)."""
+    buffer descriptor, not by masks) and through the deterministic split-K weight-gradient form (C += A^T B twice = 2x).
+    wide = 0: 128x128 tiles; 192 / 256: the (BM x 256) double-buffered tiles, forced here on shapes the launcher would give to the
+    small tile (ragged M and N tiles, one-tile problems)."""
     from summarizer_amd import _lib
     lib = _lib.load()
+    monkeypatch.setenv("SUMK_B16_WIDE", str(wide))
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     g = torch.Generator(device="cpu"); g.manual_seed(M * 7 + N + K)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16)
