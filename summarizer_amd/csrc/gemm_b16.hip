@@ -14,8 +14,10 @@
 //     (two per 8-k fragment), exactly the plane image of gemm_regstage.h.
 // Bounds come from the BUFFER DESCRIPTOR: num_records = the bytes from the (sub-)problem's first element to its last, so rows past M / N (KC) and
 // k-rows past K (MC; a split-K slice ends where its descriptor ends) read as zero -- no clamps, no tail masks.  A K-contiguous
-// operand needs K % 64 == 0; an MC operand needs its row length % 8 == 0 (16-byte chunks); byte offsets must fit 31 bits.  The
-// host checks all three (gemm_b16_ok) and the callers fall back to the plane kernels otherwise.
+// operand needs K % 64 == 0 OR rows the caller zero-padded to a whole number of 64-wide k-tiles (the per-video attention matrices of
+// csrc/vasnet.hip: ld16 = T rounded up to 64); an MC operand needs its row length % 8 == 0 or the same kind of padding (16-byte
+// chunks); byte offsets must fit 31 bits.  The host checks the row-wise problems (gemm_b16_ok); the callers fall back to the plane
+// kernels otherwise.
 #include "gemm_regstage.h"
 #include <type_traits>
 
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256, 3) void gemm_b16_kernel(GemmKArgs ka) {
     if (!decode_tile<BT, BT>(ka, tile, c, P)) return false;
     s.a = A16 + P.a_off; s.b = B16 + P.b_off;
     if constexpr (A_KC) {
-      s.na = ((P.M - 1) * P.lda + P.K) * 2; s.sa = BKH * 2;
+      s.na = ((P.M - 1) * P.lda + ((P.K + 63) & ~63)) * 2; s.sa = BKH * 2;
 #pragma unroll
       for (int p = 0; p < 4; ++p) voa[p] = ((c.m0 + (tid >> 3) + 32 * p) * P.lda + (tid & 7) * 8) * 2;
     } else {
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256, 3) void gemm_b16_kernel(GemmKArgs ka) {
       for (int p = 0; p < 4; ++p) voa[p] = (((tid >> 4) + 16 * p) * P.lda + c.m0 + (tid & 15) * 8) * 2;
     }
     if constexpr (B_KC) {
-      s.nb = ((P.N - 1) * P.ldb + P.K) * 2; s.sb = BKH * 2;
+      s.nb = ((P.N - 1) * P.ldb + ((P.K + 63) & ~63)) * 2; s.sb = BKH * 2;
 #pragma unroll
       for (int p = 0; p < 4; ++p) vob[p] = ((c.n0 + (tid >> 3) + 32 * p) * P.ldb + (tid & 7) * 8) * 2;
     } else {
@@ -223,9 +225,9 @@ __global__ __launch_bounds__(512) void gemm_b16_wide_kernel(GemmKArgs ka) {
       const int idx = tid + 512 * p;
       vob[p] = B_KC ? ((c.n0 + (idx >> 3)) * P.ldb + (idx & 7) * 8) * 2 : ((idx / CPR_B) * P.ldb + c.n0 + (idx % CPR_B) * 8) * 2;
     }
-    if constexpr (A_KC) { na = ((P.M - 1) * P.lda + P.K) * 2; s.sa = BKH * 2; }
+    if constexpr (A_KC) { na = ((P.M - 1) * P.lda + ((P.K + 63) & ~63)) * 2; s.sa = BKH * 2; }
     else { na = ((P.K - 1) * P.lda + ((P.M + 7) & ~7)) * 2; s.sa = uni(BKH * P.lda * 2); }
-    if constexpr (B_KC) { nb = ((P.N - 1) * P.ldb + P.K) * 2; s.sb = BKH * 2; }
+    if constexpr (B_KC) { nb = ((P.N - 1) * P.ldb + ((P.K + 63) & ~63)) * 2; s.sb = BKH * 2; }
     else { nb = ((P.K - 1) * P.ldb + ((P.N + 7) & ~7)) * 2; s.sb = uni(BKH * P.ldb * 2); }
     s.ra = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(A16 + P.a_off), (short)0, uni(na), 0x00020000);
     s.rb = __builtin_amdgcn_make_buffer_rsrc(uni_ptr(B16 + P.b_off), (short)0, uni(nb), 0x00020000);

@@ -22,6 +22,7 @@ namespace sumk {
 struct SeqInfo {
   int64_t eoff;  // element offset of this video's (T x ldE) logits block in E
   int32_t row0, T, ldE, pad_;
+  int64_t e16off;  // element offset of its (T x ld16) bf16 attention block, ld16 = T rounded up to 64 (bf16-source training step)
 };
 
 // per-video problem tables built on device by vasnet_setup_kernel (index = table id)
@@ -36,7 +37,7 @@ struct VasnetWs {
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
   // bf16 shadows of the operands of the row-wise GEMMs (training; used when the step runs on the bf16-source kernels)
-  size_t x16, w16, ctx16, y116, dz16, dy016, dqkv16;
+  size_t x16, w16, ctx16, y116, dz16, dy016, dqkv16, qkv16, dctx16, p16;
   size_t slab_elems;
   int64_t e_elems;
   int32_t n_rows;
@@ -48,12 +49,13 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   SUMK_ARG(D > 0 && D % 4 == 0, "vasnet: D=%d must be a positive multiple of 4", D);
   SUMK_ARG(n_seq > 0 && off != nullptr, "vasnet: empty batch");
   SUMK_ARG(off[0] == 0, "vasnet: seq_off[0] must be 0");
-  int64_t e = 0;
+  int64_t e = 0, e16 = 0;
   for (int s = 0; s < n_seq; ++s) {
     int T = off[s + 1] - off[s];
     SUMK_ARG(T > 0, "vasnet: video %d has %d frames", s, T);
     SUMK_ARG(T < (1 << 20), "vasnet: video %d has %d frames (limit 2^20)", s, T);
     e += (int64_t)T * round4(T);
+    e16 += (int64_t)T * ((T + 63) & ~63);
   }
   const size_t R = (size_t)off[n_seq];
   size_t p = 0;
@@ -73,7 +75,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
-  w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = 0;
+  w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = w->qkv16 = w->dctx16 = w->p16 = 0;
   if (training) {
     w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
     w->dz = take(R * D * 4);
@@ -93,6 +95,9 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->dz16 = take(R * D * 2);
     w->dy016 = take(R * D * 2);
     w->dqkv16 = take(R * 3 * D * 2);
+    w->qkv16 = take(R * 3 * D * 2);
+    w->dctx16 = take(R * D * 2);
+    w->p16 = take((size_t)e16 * 2);            // per video (T x ld16): alpha (dropped-out alpha) in the forward, dLogits in the backward
   }
   w->total = p;
   return SUMK_OK;
@@ -105,6 +110,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
 struct RowProbSpec { int32_t M, N, K, lda, ldb, ldc, ldr, small; };
 struct SetupArgs {
   int32_t* row_seq;      // [n_rows] video index of every packed row
+  int32_t p16;           // 1: the attention operand of the PV / dV / dQ / dK tables is the bf16 block (e16off, ld16) instead of (eoff, ldE)
   int32_t fake_seq0;     // diagnostic builds only: every video READS video 0's Q / K / V rows (operands stay L2-resident)
   const int32_t* off; int32_t n_seq, D;
   SeqInfo* seq; GemmProb* tabs;   // tabs[TB_COUNT][n_seq]
@@ -158,21 +164,24 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.n_seq) return;
-  int64_t eoff = 0;
+  int64_t eoff = 0, e16off = 0;
   int ts = 0, tpv = 0;
   if (staged) {
-    for (int q = 0; q < s; ++q) { const int T = sT[q]; eoff += (int64_t)T * ((T + 3) & ~3); ts += sTs[q]; tpv += sTpv[q]; }
+    for (int q = 0; q < s; ++q) { const int T = sT[q]; eoff += (int64_t)T * ((T + 3) & ~3); e16off += (int64_t)T * ((T + 63) & ~63); ts += sTs[q]; tpv += sTpv[q]; }
   } else {
     for (int q = 0; q < s; ++q) {
       const int T = a.off[q + 1] - a.off[q];
       eoff += (int64_t)T * ((T + 3) & ~3);
+      e16off += (int64_t)T * ((T + 63) & ~63);
       ts += ((T + a.s_tm - 1) / a.s_tm) * ((T + a.s_tn - 1) / a.s_tn);
       tpv += ((T + a.pv_tm - 1) / a.pv_tm) * tn;
     }
   }
   const int row0 = a.off[s], T = a.off[s + 1] - a.off[s], ldE = (T + 3) & ~3;
   const int tm = (T + a.s_tn - 1) / a.s_tn;   // tiles along N of the (T x T) products
-  SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0;
+  SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0; si.e16off = e16off;
+  const int64_t po = a.p16 ? e16off : eoff;           // the attention matrix as a GEMM operand
+  const int ldp = a.p16 ? ((T + 63) & ~63) : ldE;
   a.seq[s] = si;
   for (int t = 0; t < T; ++t) a.row_seq[row0 + t] = s;
   const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
@@ -180,13 +189,13 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   const int64_t qr = a.fake_seq0 ? 0 : q0;     // where Q / K / V are READ (q0 except in the diagnostic aliasing experiment)
   // forward
   put_prob(a.tabs + TB_S * n + s, qr, qr + D, eoff, T, T, D, 3 * D, 3 * D, ldE, ts, tm);            // E = Q K^T        (NT)
-  put_prob(a.tabs + TB_PV * n + s, eoff, qr + 2 * D, c0, T, D, T, ldE, 3 * D, D, tpv, tn);           // C = alpha V      (NN)
+  put_prob(a.tabs + TB_PV * n + s, po, qr + 2 * D, c0, T, D, T, ldp, 3 * D, D, tpv, tn);             // C = alpha V      (NN)
   a.tabs[TB_PV * n + s].r_off = c0; a.tabs[TB_PV * n + s].ldr = D;   // folded inference path: + X in the epilogue (same rows as C)
   // backward
-  put_prob(a.tabs + TB_DV * n + s, eoff, c0, q0 + 2 * D, T, D, T, ldE, D, 3 * D, tpv, tn);           // dV = alpha^T dC  (TN)
+  put_prob(a.tabs + TB_DV * n + s, po, c0, q0 + 2 * D, T, D, T, ldp, D, 3 * D, tpv, tn);             // dV = alpha^T dC  (TN)
   put_prob(a.tabs + TB_DP * n + s, c0, q0 + 2 * D, eoff, T, T, D, D, 3 * D, ldE, ts, tm);            // dAlpha = dC V^T  (NT)
-  put_prob(a.tabs + TB_DQ * n + s, eoff, q0 + D, q0, T, D, T, ldE, 3 * D, 3 * D, tpv, tn);           // dQ = dS K        (NN)
-  put_prob(a.tabs + TB_DK * n + s, eoff, q0, q0 + D, T, D, T, ldE, 3 * D, 3 * D, tpv, tn);           // dK = dS^T Q      (TN)
+  put_prob(a.tabs + TB_DQ * n + s, po, q0 + D, q0, T, D, T, ldp, 3 * D, 3 * D, tpv, tn);             // dQ = dS K        (NN)
+  put_prob(a.tabs + TB_DK * n + s, po, q0, q0 + D, T, D, T, ldp, 3 * D, 3 * D, tpv, tn);             // dK = dS^T Q      (TN)
 }
 
 // ------------------------------------------------------------------------------------------- wave helpers
@@ -238,7 +247,7 @@ __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int
 template <int NR>
 __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2, const SeqInfo* seq, const int32_t* off,
                                                              int n_seq, int n_rows, float scale, int ignore_self,
-                                                             int aperture, Drop drop) {
+                                                             int aperture, Drop drop, unsigned short* P16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -247,6 +256,10 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   const int i = row - si.row0, T = si.T;
   float* e = E + si.eoff + (int64_t)i * si.ldE;
   float* e2 = E2 ? E2 + si.eoff + (int64_t)i * si.ldE : nullptr;
+  // P16: the matrix the alpha.V / alpha^T.dC products read (dropout(alpha) when there is dropout), as bf16 with the row zero-padded
+  // to ld16 = a whole number of 64-wide k-tiles
+  const int ld16 = (T + 63) & ~63;
+  unsigned short* p16 = P16 ? P16 + si.e16off + (int64_t)i * ld16 : nullptr;
   if constexpr (NR > 0) {
     float v[NR];
     float m = -INFINITY;
@@ -268,11 +281,14 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int j = lane + 64 * r;
+      const float a = j < T ? v[r] / sum : 0.f;
+      float ad = a;
+      if (e2 && drop.thr && j < T) ad = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, a);
       if (j < si.ldE) {
-        const float a = j < T ? v[r] / sum : 0.f;
         e[j] = a;
-        if (e2) e2[j] = drop.thr ? drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, a) : a;
+        if (e2) e2[j] = ad;
       }
+      if (p16 && j < ld16) p16[j] = __builtin_bit_cast(unsigned short, (__bf16)ad);
     }
     return;
   }
@@ -282,18 +298,23 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   float sum = 0.f;
   for (int j = lane; j < T; j += 64) sum += expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m);
   sum = wave_sum(sum);
-  for (int j = lane; j < si.ldE; j += 64) {
+  for (int j = lane; j < (p16 ? ld16 : si.ldE); j += 64) {
     float v = 0.f;
     if (j < T) v = expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m) / sum;
-    e[j] = v;
-    if (e2) e2[j] = drop.thr ? drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, v) : v;
+    float vd = v;
+    if (e2 && drop.thr && j < T) vd = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, v);
+    if (j < si.ldE) {
+      e[j] = v;
+      if (e2) e2[j] = vd;
+    }
+    if (p16) p16[j] = __builtin_bit_cast(unsigned short, (__bf16)vd);
   }
 }
 
 // dLogits(raw) = scale * alpha * (dAlpha - sum_j dAlpha_j alpha_j), dAlpha = dropout'(dAlphaDropped).  In place on E2.
 __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E, float* E2, const SeqInfo* seq,
                                                                  const int32_t* off, int n_seq, int n_rows, float scale,
-                                                                 Drop drop) {
+                                                                 Drop drop, unsigned short* S16) {   // S16: bf16(dLogits), rows zero-padded to ld16
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -309,14 +330,17 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
     dot += d * p[j];
   }
   dot = wave_sum(dot);
-  for (int j = lane; j < si.ldE; j += 64) {
+  const int ld16 = (T + 63) & ~63;
+  unsigned short* s16 = S16 ? S16 + si.e16off + (int64_t)i * ld16 : nullptr;
+  for (int j = lane; j < (s16 ? ld16 : si.ldE); j += 64) {
     float v = 0.f;
     if (j < T) {
       float d = g[j];
       if (drop.thr) d = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d);
       v = p[j] * (d - dot) * scale;
     }
-    g[j] = v;
+    if (j < si.ldE) g[j] = v;
+    if (s16) s16[j] = __builtin_bit_cast(unsigned short, (__bf16)v);
   }
 }
 
@@ -645,9 +669,11 @@ static int rowwise_small_tile(int M, int N) {
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
   int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv;
+  bool b16;          // the mixed-precision training step on the bf16-source kernels (use_b16)
 };
+static bool use_b16(const Geometry& G, int D, int precision, int training);
 
-static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry* G) {
+static int geometry(int D, int n_seq, const int32_t* off, int training, int precision, Geometry* G) {
   SUMK_TRY(carve(D, n_seq, off, training, &G->L));
   G->R = G->L.n_rows;
   G->st_qkv = rowwise_small_tile(G->R, 3 * D);
@@ -660,6 +686,8 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
   const int cfg_auto = (G->R / n_seq >= 1024) ? 0 : 1;
   G->cfg_s = cfg_auto; G->cfg_pv = cfg_auto;
   if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
+  G->b16 = use_b16(*G, D, precision, training);
+  if (G->b16) G->cfg_s = G->cfg_pv = 0;       // the bf16-source kernel has 128x128 tiles
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
     int T = off[s + 1] - off[s];
@@ -671,10 +699,10 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, Geometry
 // Does the training step run its row-wise GEMMs on the bf16-source kernels (gemm_b16.hip)?  A function of the batch geometry and the
 // options only: forward and backward must agree (the forward leaves the bf16 shadows the backward reads).  SUMK_BF16_SRC=0 keeps
 // the plane kernels (fp32 operands converted per k-tile) -- the A/B switch.
-static bool use_b16(const Geometry& G, int D, const sumk_vasnet_opts* o, int training) {
+static bool use_b16(const Geometry& G, int D, int precision, int training) {
   static const bool on = !(getenv("SUMK_BF16_SRC") && getenv("SUMK_BF16_SRC")[0] == '0');
   const int R = G.R;
-  return on && training && o->precision == SUMK_PRECISION_BF16 && G.st_qkv == 0 && G.st_d == 0 &&
+  return on && training && precision == SUMK_PRECISION_BF16 && G.st_qkv == 0 && G.st_d == 0 &&
          gemm_b16_ok(R, 3 * D, D, D, D, true, true) && gemm_b16_ok(R, D, D, D, D, true, false) &&
          gemm_b16_ok(R, D, D, 3 * D, D, true, false) && gemm_b16_ok(3 * D, D, R, 3 * D, D, false, false);
 }
@@ -696,6 +724,7 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
 #ifdef SUMK_DIAG
   if (getenv("SUMK_FAKE_SEQ0")) a.fake_seq0 = 1;    // wrong results by design: timing experiment (are the per-video GEMMs bound by where their operands come from?)
 #endif
+  a.p16 = G.b16 ? 1 : 0;
   a.off = off_dev; a.n_seq = n_seq; a.D = D;
   a.row_seq = (int32_t*)(ws + G.L.row_seq);
   a.seq = (SeqInfo*)(ws + G.L.seq); a.tabs = (GemmProb*)(ws + G.L.prob_seq); a.prow = (GemmProb*)(ws + G.L.prob_row);
@@ -775,7 +804,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   SUMK_ARG(opts->dropout_p == 0.f || training, "vasnet_forward: dropout needs training mode");
   SUMK_ARG(opts->precision >= SUMK_PRECISION_FP32 && opts->precision <= SUMK_PRECISION_MAX, "vasnet_forward: unknown precision %d", opts->precision);
   Geometry G;
-  SUMK_TRY(geometry(D, n_seq, seq_off_host, training, &G));
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, training, opts->precision, &G));
   const VasnetWs& L = G.L;
   if (workspace_bytes < L.total) {
     set_error("vasnet_forward: workspace %zu < required %zu", workspace_bytes, L.total);
@@ -803,7 +832,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   }
   launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
   // mixed-precision training: bf16 shadows of x and of the five weight matrices, then every row-wise GEMM reads bf16 from HBM
-  const bool b16 = use_b16(G, D, opts, training);
+  const bool b16 = G.b16;
   unsigned short* x16 = (unsigned short*)(ws + L.x16);
   unsigned short* Wqkv16 = (unsigned short*)(ws + L.w16);
   unsigned short* Wo16 = Wqkv16 + (size_t)3 * D * D;
@@ -825,13 +854,14 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     g.lean = lean_rows;
-    if (b16) to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W);
+    if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; }   // (+ bf16 Q / K / V for the per-video products)
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
     GemmLaunch g; g.precision = opts->precision;
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
     g.total_tiles = G.tiles_s; g.prof_tag = SUMK_PROF_GEMM_QKT;
+    if (b16) { g.A = g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
@@ -840,7 +870,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     for (int q = 0; q < n_seq; ++q) t_max = std::max(t_max, seq_off_host[q + 1] - seq_off_host[q]);
     const dim3 sg((R + 3) / 4), sb(256);
     float* e2p = use_e2 ? E2 : nullptr;
-#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop)
+    unsigned short* p16 = b16 ? (unsigned short*)(ws + L.p16) : nullptr;
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, p16)
     if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
@@ -868,7 +899,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
     if (Wvo && fused_ln) g.moments = ln_moments;
-    if (b16) g.C16 = ws + L.ctx16;
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = ws + L.ctx16; }
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
     if (Wvo && fused_ln) {
       hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
@@ -991,7 +1022,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   SUMK_ARG(gr->Wk && gr->Wq && gr->Wv && gr->Wo && gr->W1 && gr->b1 && gr->w2 && gr->b2 && gr->ln_w && gr->ln_b,
            "vasnet_backward: null gradient target");
   Geometry G;
-  SUMK_TRY(geometry(D, n_seq, seq_off_host, 1, &G));
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, 1, opts->precision, &G));
   const VasnetWs& L = G.L;
   if (workspace_bytes < L.total) {
     set_error("vasnet_backward: workspace %zu < required %zu (needs the training-mode forward's workspace)", workspace_bytes, L.total);
@@ -1024,7 +1055,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   int nw = 0;
   // bf16-source row-wise GEMMs (see the forward): dZ and dY0 are produced in bf16 by the LayerNorm backward kernels, dQKV by the
   // per-video GEMM epilogues; fp32 dZ is never needed, fp32 dY0 only for the residual branch of dx
-  const bool b16 = use_b16(G, D, opts, 1);
+  const bool b16 = G.b16;
   const float* x16 = (const float*)(ws + L.x16);
   const unsigned short* Wqkv16 = (const unsigned short*)(ws + L.w16);
   const float* Wo16 = (const float*)(Wqkv16 + (size_t)3 * D * D);
@@ -1060,7 +1091,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
                                   stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
-    if (b16) to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W);
+    if (b16) { to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W); g.C16 = ws + L.dctx16; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // Wo, W1, b1, w2, b2 (the tail of the parameter order) are final from here on: a data-parallel caller starts their
@@ -1071,28 +1102,30 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
-    if (b16) g.C16 = dQKV16;
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.dctx16); g.src16 = 1; g.C16 = dQKV16; }
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = dCTX; g.B[0] = QKV; g.C = E2; g.probs = tabs + TB_DP * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s; g.total_tiles = G.tiles_s;
+    if (b16) { g.A = (const float*)(ws + L.dctx16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   // 3': softmax (+dropout, +scale) backward, in place on E2
+  // (b16: bf16(dLogits) goes where bf16(alpha) was -- its last reader, the dV product, is queued before this kernel)
   hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
-                     opts->scale, drop);
+                     opts->scale, drop, b16 ? (unsigned short*)(ws + L.p16) : nullptr);
   // 2': dQ = dS K ; dK = dS^T Q
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
-    if (b16) g.C16 = dQKV16;
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
-    if (b16) g.C16 = dQKV16;
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; }
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X
