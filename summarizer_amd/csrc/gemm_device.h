@@ -27,7 +27,7 @@ struct GemmKArgs {
   unsigned long long* dbg_buf;   // dbg & 2: per block {total, k-loop, epilogue, tiles} shader cycles (scripts/gemm_stamp_probe.py)
   int32_t lean;                  // host-side only: 1 = NT 128x128 launch eligible for the buffer-load (VALU-free k-loop) instances
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
-  unsigned short* C16;           // EPI_NONE: when set, bf16(C) is stored too, same offsets / leading dimension (operand of a later bf16-source GEMM)
+  unsigned short* C16;           // EPI_NONE: when set, bf16(C) is stored too, same offsets / leading dimension (operand of a later bf16-source GEMM); C may then be null
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
 };
 
@@ -139,9 +139,11 @@ __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCt
           v += ka.R[cur.r_off + (int64_t)row * cur.ldr + col];
         }
         if constexpr (EPI == EPI_ACCUM) v = *cp + ka.alpha * v;
-        *cp = v;
-        if constexpr (EPI == EPI_NONE) {
+        if constexpr (EPI == EPI_NONE) {     // C may be null when only the bf16 form has a reader (kernel-uniform branches)
+          if (ka.C) *cp = v;
           if (ka.C16) ka.C16[cur.c_off + (int64_t)row * cur.ldc + col] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        } else {
+          *cp = v;
         }
       }
     }

@@ -30,7 +30,7 @@ static unsigned long long* gemm_stamp_buffer() {
 }
 
 int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t stream) {
-  SUMK_ARG(g.A && g.B[0] && g.C && g.probs, "gemm: null operand");
+  SUMK_ARG(g.A && g.B[0] && (g.C || (g.C16 && epi == EPI_NONE)) && g.probs, "gemm: null operand");
   if (g.total_tiles <= 0) return SUMK_OK;
   GemmKArgs ka;
   ka.A = g.A;

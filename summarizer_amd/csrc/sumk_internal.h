@@ -83,7 +83,7 @@ struct GemmLaunch {
   // src16 only: 0 = 128x128 tiles; 192 / 256 = BM of the wide (BM x 256) tile -- `probs` (tiles_n, tile_start) and total_tiles must have
   // been built for that tile (gemm_tiles_wide; problem-table tile code 3 = 256 columns)
   int32_t wide16 = 0;
-  void* C16 = nullptr;                 // EPI_NONE: also store bf16(C) here, same offsets / ldc (the operand of a later src16 launch)
+  void* C16 = nullptr;                 // EPI_NONE: also store bf16(C) here, same offsets / ldc (the operand of a later src16 launch); C may then be null
   int32_t group_remap = 0;             // grouped launch: deal tile ids so that one XCD walks a contiguous range (gemm_device.h decode_tile)
   // EPI_BIAS_RELU_HEAD on an A operand that is the INPUT of a LayerNorm whose gain was folded into B (B' = B diag(gamma)):
   // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],

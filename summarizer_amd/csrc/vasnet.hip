@@ -854,7 +854,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.small_tile = G.st_qkv; g.total_tiles = gemm_tiles(R, 3 * D, G.st_qkv); g.prof_tag = SUMK_PROF_GEMM_QKV;
     g.xcd_M = R; g.xcd_N = 3 * D;
     g.lean = lean_rows;
-    if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; }   // (+ bf16 Q / K / V for the per-video products)
+    // (b16: Q / K / V are read by bf16-source GEMMs only -- the fp32 form, 147 MB of stores on S-TVSum, is not written at all)
+    if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
   {  // 2: logits per video
@@ -899,7 +900,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
     if (Wvo && fused_ln) g.moments = ln_moments;
-    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = ws + L.ctx16; }
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = ws + L.ctx16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
     if (Wvo && fused_ln) {
       hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
@@ -1091,7 +1092,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
                                   stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
-    if (b16) { to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W); g.C16 = ws + L.dctx16; }
+    if (b16) { to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W); g.C16 = ws + L.dctx16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   // Wo, W1, b1, w2, b2 (the tail of the parameter order) are final from here on: a data-parallel caller starts their
@@ -1102,7 +1103,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
-    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.dctx16); g.src16 = 1; g.C16 = dQKV16; }
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.dctx16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   {
@@ -1119,13 +1120,13 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
-    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; }
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
-    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; }
+    if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
   // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X
