@@ -268,27 +268,38 @@ __global__ __launch_bounds__(512) void gemm_b16_wide_kernel(GemmKArgs ka) {
       else f.b[t] = tr_frag(st + fb + 16 * ks * MCP_B + 64 * t, MCP_B);
     }
   };
-  // One k-tile: the fragments of step ks + 1 are requested BEFORE the MFMAs of step ks (left to itself the scheduler sinks every
-  // ds_read next to its first use and waits lgkmcnt(0) in front of each pair of MFMAs: measured 0.28 of the matrix rate with the
-  // loads, LDS writes and stores all switched off).  sched_barrier pins the order  reads(ks + 1) | MFMAs(ks) + staging slice ks.
-  // MODE 2: write slice of k-tile kt + 1, load k-tile kt + 2; 1: write only; 0: neither (last k-tile of the tile)
-  auto ktile = [&](const char* st, char* nst, const Src& s, int kt, auto mode, f32x16 (&acc)[TM][TN]) {
+  // One k-tile = four 16-deep steps.  The fragments of step ks + 1 are requested BEFORE the MFMAs of step ks (left to itself the
+  // scheduler sinks every ds_read next to its first use and waits lgkmcnt(0) in front of each pair of MFMAs: 0.28 of the matrix rate
+  // with loads, LDS writes and stores switched off); sched_barrier pins that order.  The workgroup barrier sits between steps 2 and 3:
+  // by then this wave has requested its last fragments of the current stage and written all its slices of the next one, so after the
+  // barrier step 0 of the NEXT k-tile can be requested and lands under the MFMAs of step 3 -- no LDS latency is exposed at the k-tile
+  // boundary, where all eight waves would otherwise wait for their first fragments at once.
+  // MODE 2: write k-tile kt + 1 to the other stage and load k-tile kt + 2; 1: write only; 0: neither (last k-tile of the tile).
+  // f[0] holds step 0 of `st` on entry and step 0 of `nst` on exit (MODE >= 1).
+  struct Frags2 { Frags f[2]; };
+  auto mfma_step = [&](const Frags& f, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[tm], f.b[tn], acc[tm][tn], 0, 0, 0);
+  };
+  auto ktile = [&](const char* st, char* nst, const Src& s, int kt, auto mode, Frags2& F, f32x16 (&acc)[TM][TN]) {
     constexpr int MODE = decltype(mode)::value;
-    Frags f[2];
-    read_frags(st, 0, f[0]);
 #pragma unroll
-    for (int ks = 0; ks < BKH / 16; ++ks) {
-      if (ks + 1 < BKH / 16) read_frags(st, ks + 1, f[(ks + 1) & 1]);
+    for (int ks = 0; ks < 3; ++ks) {
+      read_frags(st, ks + 1, F.f[(ks + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].a[tm], f[ks & 1].b[tn], acc[tm][tn], 0, 0, 0);
-      if constexpr (MODE >= 1) swrite_slice(nst, ks);
-      if constexpr (MODE >= 2) gload_slice(s, kt + 2, ks);
+      mfma_step(F.f[ks & 1], acc);
+      // staging slices: 0 behind step 0, 1 behind step 1, 2 and 3 behind step 2
+      if constexpr (MODE >= 1) { swrite_slice(nst, ks); if (ks == 2) swrite_slice(nst, 3); }
+      if constexpr (MODE >= 2) { gload_slice(s, kt + 2, ks); if (ks == 2) gload_slice(s, kt + 2, 3); }
       __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+    if constexpr (MODE >= 1) read_frags(nst, 0, F.f[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(F.f[1], acc);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   int tile = blockIdx.x;
@@ -312,27 +323,25 @@ __global__ __launch_bounds__(512) void gemm_b16_wide_kernel(GemmKArgs ka) {
     }
     const int nk = (cur.K + BKH - 1) / BKH;
     const int next_tile = tile + gridDim.x;
-    // stage 0 <- k-tile 0 (every wave is past the previous tile's last barrier: both stages are free)
+    // stage 0 <- k-tile 0 (every wave is past the previous tile's last barrier and holds no fragment of it: both stages are free)
 #pragma unroll
     for (int q = 0; q < 4; ++q) swrite_slice(lds_w, q);
     if (nk > 1) gload(scur, 1);
     __syncthreads();
+    Frags2 F;
+    read_frags(lds_w, 0, F.f[0]);
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
-      ktile(lds_w + (kt & 1) * STAGE, lds_w + ((kt + 1) & 1) * STAGE, scur, kt, std::integral_constant<int, 2>{}, acc);
-      __syncthreads();
-    }
+    for (; kt + 2 < nk; ++kt)
+      ktile(lds_w + (kt & 1) * STAGE, lds_w + ((kt + 1) & 1) * STAGE, scur, kt, std::integral_constant<int, 2>{}, F, acc);
     if (kt + 1 < nk) {
-      ktile(lds_w + (kt & 1) * STAGE, lds_w + ((kt + 1) & 1) * STAGE, scur, kt, std::integral_constant<int, 1>{}, acc);
-      __syncthreads();
+      ktile(lds_w + (kt & 1) * STAGE, lds_w + ((kt + 1) & 1) * STAGE, scur, kt, std::integral_constant<int, 1>{}, F, acc);
       ++kt;
     }
     // last k-tile: the next tile's decode and first loads go out under its MFMAs
     bool has_next = next_tile < ka.total_tiles;
     if (has_next) has_next = setup(next_tile, nxt, snxt);
     if (has_next) gload(snxt, 0);
-    ktile(lds_w + (kt & 1) * STAGE, nullptr, scur, kt, std::integral_constant<int, 0>{}, acc);
-    __syncthreads();
+    ktile(lds_w + (kt & 1) * STAGE, nullptr, scur, kt, std::integral_constant<int, 0>{}, F, acc);
     epilogue_store<EPI, TM, TN, true>(ka, cur, acc, cur.m0 + wm * WTM, cur.n0 + wn * 64, li, lh);
     if (!has_next) break;
     tile = next_tile; cur = nxt; scur = snxt;

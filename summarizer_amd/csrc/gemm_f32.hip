@@ -126,17 +126,24 @@ int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, 
 // Weight gradients contract over ALL frames (K = n_rows ~ 1e4) into a small (M,N): one tile grid would leave most
 // CUs idle, so K is cut into S slices, each slice writes its own fp32 slab, and a second kernel sums the slabs in a
 // fixed order (deterministic; no float atomics) and ACCUMULATES alpha*sum into up to four row-group outputs.
-__global__ void splitk_setup_kernel(GemmProb* p, int S, int M, int N, int K, int kchunk, int lda, int ldb, int bt) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
+// np same-shaped products share one launch: entry p * S + s = K slice s of product p, whose operands start rel_a[p] / rel_b[p] elements
+// after the launch's A / B pointers; slab layout [S][np * M][N] (slice-major), so the reduce kernel sees ONE (np * M) x N problem
+struct SplitKSetup { GemmProb* p; int64_t rel_a[4], rel_b[4]; int32_t np, S, M, N, K, kchunk, lda, ldb, bt; };
+__global__ void splitk_setup_kernel(SplitKSetup a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.np * a.S) return;
+  const int p = e / a.S, s = e - p * a.S;
   GemmProb q;
-  int k0 = s * kchunk;
-  q.a_off = (int64_t)k0 * lda; q.b_off = (int64_t)k0 * ldb; q.c_off = (int64_t)s * M * N; q.r_off = 0;
-  q.M = M; q.N = N; q.K = min(kchunk, K - k0); q.lda = lda; q.ldb = ldb; q.ldc = N; q.ldr = 0;
-  int tn = (N + bt - 1) / bt, tm = (M + bt - 1) / bt;
-  q.tile_start = s * tm * tn; q.tiles_n = tn;
+  const int k0 = s * a.kchunk;
+  const int64_t ra = p == 0 ? a.rel_a[0] : p == 1 ? a.rel_a[1] : p == 2 ? a.rel_a[2] : a.rel_a[3];
+  const int64_t rb = p == 0 ? a.rel_b[0] : p == 1 ? a.rel_b[1] : p == 2 ? a.rel_b[2] : a.rel_b[3];
+  q.a_off = ra + (int64_t)k0 * a.lda; q.b_off = rb + (int64_t)k0 * a.ldb;
+  q.c_off = ((int64_t)s * a.np + p) * a.M * a.N; q.r_off = 0;
+  q.M = a.M; q.N = a.N; q.K = min(a.kchunk, a.K - k0); q.lda = a.lda; q.ldb = a.ldb; q.ldc = a.N; q.ldr = 0;
+  const int tn = (a.N + a.bt - 1) / a.bt, tm = (a.M + a.bt - 1) / a.bt;
+  q.tile_start = e * tm * tn; q.tiles_n = tn;
   for (int i = 0; i < 7; ++i) q.pad_[i] = 0;
-  p[s] = q;
+  a.p[e] = q;
 }
 
 struct SlabReduceArgs { const float* slab; float* out[4]; int32_t S, M, N, rows_per_out, ldo; float alpha; };
@@ -179,30 +186,38 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(SlabReduceArgs a) {
   *reinterpret_cast<float4*>(o) = c;
 }
 
-int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
-                         size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream, int precision, int src16) {
-  SUMK_ARG(M > 0 && N > 0 && K > 0, "splitk: bad shape");
-  SUMK_ARG(slab_elems >= (size_t)M * N, "splitk: slab too small");
+int gemm_tn_splitk_accum_multi(int np, const float* const A[], const float* const B[], int lda, int ldb, int M, int N, int K, float* slab,
+                               size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
+                               int ldo, float alpha, hipStream_t stream, int precision, int src16) {
+  SUMK_ARG(np >= 1 && np <= 4 && M > 0 && N > 0 && K > 0, "splitk: bad shape");
+  SUMK_ARG(np == 1 || rows_per_out == M, "splitk: several products take one output each");
+  SUMK_ARG(slab_elems >= (size_t)np * M * N, "splitk: slab too small");
   SUMK_ARG(!src16 || gemm_b16_ok(M, N, K, lda, ldb, false, false), "splitk: operands not eligible for the bf16-source kernel");
   const int small = (src16 || gemm_tiles(M, N, 0) >= 64) ? 0 : 1;     // (src16: A and B are bf16 arrays)
   const int wide = (src16 && M >= 512 && N >= 512 && M % 256 == 0 && N % 256 == 0) ? 256 : 0;    // 256x256 tiles, one block per CU
-  const int tiles = wide ? gemm_tiles_wide(M, N, 256) : gemm_tiles(M, N, small);
+  const int tiles = np * (wide ? gemm_tiles_wide(M, N, 256) : gemm_tiles(M, N, small));
   // K slices so that S x tiles fills the resident slots of the persistent grid ONCE (768 blocks of the 128x128 kernel, 2048 of the
-  // 64x64 one): every block then walks exactly one (long) tile.  The first version aimed at >= 1024 tiles: 1152 for the QKV
-  // weight gradient = one and a half rounds, the second half-empty (744 -> 6xx us), 1024 for the D x D ones.
+  // 64x64 one, 256 of the wide one): every block then walks exactly one (long) tile.  The first version aimed at >= 1024 tiles: 1152
+  // for the QKV weight gradient = one and a half rounds, the second half-empty (744 -> 6xx us), 1024 for the D x D ones.
   const int slots = wide ? 256 : small ? 2048 : 768;
   int S = std::max(1, slots / tiles);
   S = std::min(S, (K + 63) / 64);
-  S = std::min(S, (int)std::min<size_t>(slab_elems / ((size_t)M * N), (size_t)probs_cap));
+  S = std::min(S, (int)std::min<size_t>(slab_elems / ((size_t)np * M * N), (size_t)(probs_cap / np)));
   S = std::max(S, 1);
   const int kq = src16 ? 64 : 32;              // whole k-tiles per slice
   int kchunk = ((K + S - 1) / S + kq - 1) / kq * kq;
   S = (K + kchunk - 1) / kchunk;
-  hipLaunchKernelGGL(splitk_setup_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, probs_dev, S, M, N, K, kchunk, lda, ldb,
-                     wide ? 256 : gemm_tile_dim(small));
+  SplitKSetup su;
+  su.p = probs_dev; su.np = np; su.S = S; su.M = M; su.N = N; su.K = K; su.kchunk = kchunk; su.lda = lda; su.ldb = ldb;
+  su.bt = wide ? 256 : gemm_tile_dim(small);
+  const int64_t esz = src16 ? 2 : 4;
+  for (int p = 0; p < 4; ++p) {
+    su.rel_a[p] = p < np ? ((const char*)A[p] - (const char*)A[0]) / esz : 0;
+    su.rel_b[p] = p < np ? ((const char*)B[p] - (const char*)B[0]) / esz : 0;
+  }
+  hipLaunchKernelGGL(splitk_setup_kernel, dim3((np * S + 63) / 64), dim3(64), 0, stream, su);
   GemmLaunch g;
-  g.A = A; g.B[0] = B; g.C = slab; g.probs = probs_dev; g.nprob = S; g.small_tile = small; g.total_tiles = S * tiles;
+  g.A = A[0]; g.B[0] = B[0]; g.C = slab; g.probs = probs_dev; g.nprob = np * S; g.small_tile = small; g.total_tiles = S * tiles;
   g.precision = precision; g.src16 = src16; g.wide16 = wide;
   // the tiles of one K slice share their operand rows: keep a slice on one XCD (measured: the bf16 training step 1.35 -> 1.21 ms,
   // fp32 unchanged; the per-video attention products did not gain and are left in plain order)
@@ -210,14 +225,23 @@ int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M
   SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   SlabReduceArgs r;
   r.slab = slab; for (int i = 0; i < 4; ++i) r.out[i] = out[i];
-  r.S = S; r.M = M; r.N = N; r.rows_per_out = rows_per_out; r.ldo = ldo; r.alpha = alpha;
-  int64_t mn = (int64_t)M * N;
+  r.S = S; r.M = np * M; r.N = N; r.rows_per_out = rows_per_out; r.ldo = ldo; r.alpha = alpha;
+  int64_t mn = (int64_t)np * M * N;
   bool vec4 = (N % 4 == 0) && (ldo % 4 == 0);
   for (int i = 0; i < 4; ++i) vec4 = vec4 && (out[i] == nullptr || ((uintptr_t)out[i] & 15) == 0);
   if (vec4) hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, stream, r);
   else hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, r);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
+}
+
+int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
+                         size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
+                         int ldo, float alpha, hipStream_t stream, int precision, int src16) {
+  const float* const As[1] = {A};
+  const float* const Bs[1] = {B};
+  return gemm_tn_splitk_accum_multi(1, As, Bs, lda, ldb, M, N, K, slab, slab_elems, probs_dev, probs_cap, out, rows_per_out, ldo, alpha,
+                                    stream, precision, src16);
 }
 
 // ------------------------------------------------------------------------------------------- column sums

@@ -133,6 +133,11 @@ int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, 
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
                          int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0);   // src16: A and B are bf16 arrays (GemmLaunch::src16)
+// np (<= 4) same-shaped products C_p = A_p^T B_p in ONE split-K launch + ONE reduce: out[p] += alpha * C_p (rows_per_out == M when np > 1).
+// Every A_p (B_p) must lie in the same allocation as A_0 (B_0): the kernel addresses them as offsets from it.
+int gemm_tn_splitk_accum_multi(int np, const float* const A[], const float* const B[], int lda, int ldb, int M, int N, int K, float* slab,
+                               size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
+                               int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0);
 // out[c] += sum_r X[r*ld + c]; partial must hold max_chunks*N floats.
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream);
 // out[c] += sum_p partial[p*stride + c]

@@ -1071,12 +1071,9 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, b16 ? nullptr : dZ, lnpart,
                                drop, 2u, &nw, stream, b16 ? dZ16 : nullptr));
   SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, gr->w2, gr->b2, gr->b1, stream));   // db1 = column sums of dZ, from the same slots
-  // 7': k1
+  // 7': k1 -- dY1 = dZ . W1 (its weight gradient is taken together with the output projection's below: one split-K launch)
   {
-    float* out[4] = {gr->W1, nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dZ16 : dZ, D, b16 ? Y116 : Y1, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f,
-                                  stream, opts->precision, b16));
-    GemmLaunch g; g.precision = opts->precision;  // dY1 = dZ . W1
+    GemmLaunch g; g.precision = opts->precision;
     g.A = dZ; g.B[0] = w->W1; g.C = dY1; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     if (b16) to_b16(g, dZ16, W116, R, D, prow, RP_DD_W);
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
@@ -1085,11 +1082,13 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, dY1, nullptr, nullptr, nullptr, (b16 && !dx) ? nullptr : dY0, lnpart, drop, 1u, &nw, stream,
                                 b16 ? dY016 : nullptr));
   SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
-  // 5': output projection (+ residual branch into dx)
+  // 5' + 7': dWo += dY0^T CTX and dW1 += dZ^T Y1 -- two (D x D) products over all R rows in ONE split-K launch (twice as long K
+  // slices per block, one slab reduce) -- then dCTX = dY0 . Wo (+ residual branch into dx)
   {
-    float* out[4] = {gr->Wo, nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dY016 : dY0, D, b16 ? CTX16 : CTX, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f,
-                                  stream, opts->precision, b16));
+    const float* const As[2] = {b16 ? (const float*)dY016 : dY0, b16 ? (const float*)dZ16 : dZ};
+    const float* const Bs[2] = {b16 ? CTX16 : CTX, b16 ? Y116 : Y1};
+    float* out[4] = {gr->Wo, gr->W1, nullptr, nullptr};
+    SUMK_TRY(gemm_tn_splitk_accum_multi(2, As, Bs, D, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision, b16));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     if (b16) { to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W); g.C16 = ws + L.dctx16; g.C = nullptr; }
