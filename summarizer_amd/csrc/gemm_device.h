@@ -103,6 +103,34 @@ __device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileC
 template <int EPI, int TM, int TN, bool RES_DONE = false>
 __device__ __forceinline__ void epilogue_store(const GemmKArgs& ka, const TileCtx& cur, const f32x16 (&acc)[TM][TN], int row0,
                                                int col0, int li, int lh) {
+  if constexpr (EPI == EPI_NONE) {
+    // bf16-only output (C == nullptr): neighbouring lanes hold neighbouring columns of the same rows, so the lane pair (c, c + 1)
+    // swaps one value per row pair over DPP and each lane stores ONE packed bf16x2 -- the even lane rows r, the odd lane rows r + 1 --
+    // half the store instructions of the 2-byte form (kernel-uniform branch; needs even N / ldc / c_off for the 4-byte alignment)
+    if (ka.C == nullptr && ka.C16 != nullptr && ((cur.N | cur.ldc) & 1) == 0 && (cur.c_off & 1) == 0) {
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const bool odd = li & 1;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = col0 + tn * 32 + (li & ~1);          // first column of the pair
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float a0 = acc[tm][tn][r] * ka.alpha, a1 = acc[tm][tn][r + 1] * ka.alpha;
+            const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+            const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a1), 0xB1, 0xF, 0xF, true));
+            const f32x2_t v = odd ? f32x2_t{n1, a1} : f32x2_t{a0, n0};
+            const int row = row0 + tm * 32 + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < cur.M && col < cur.N)
+              *reinterpret_cast<bf16x2_t*>(ka.C16 + cur.c_off + (int64_t)row * cur.ldc + col) = __builtin_convertvector(v, bf16x2_t);
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = col0 + tn * 32 + li;
