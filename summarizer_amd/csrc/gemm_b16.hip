@@ -96,21 +96,30 @@ __global__ __launch_bounds__(256, 3) void gemm_b16_kernel(GemmKArgs ka) {
                               : sA + (8 * lh + ((lane & 15) >> 2)) * MCP + 2 * (wm * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
   const char* const fb = B_KC ? sB + (wn * 64 + li) * KCP + 16 * lh
                               : sB + (8 * lh + ((lane & 15) >> 2)) * MCP + 2 * (wn * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+  // fragments of step ks + 1 are requested before the MFMAs of step ks (pinned with sched_barrier: see the wide kernel below)
+  struct Frags { bf16x8 a[2], b[2]; };
+  auto read_frags = [&](int ks, Frags& f) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if constexpr (A_KC) f.a[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * KCP + 32 * ks);
+      else f.a[t] = tr_frag(fa + 16 * ks * MCP + 64 * t, MCP);
+      if constexpr (B_KC) f.b[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * KCP + 32 * ks);
+      else f.b[t] = tr_frag(fb + 16 * ks * MCP + 64 * t, MCP);
+    }
+  };
   auto compute = [&](f32x16 (&acc)[2][2]) {
+    Frags f[2];
+    read_frags(0, f[0]);
 #pragma unroll
     for (int ks = 0; ks < BKH / 16; ++ks) {
-      bf16x8 af[2], bf[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if constexpr (A_KC) af[t] = *reinterpret_cast<const bf16x8*>(fa + t * 32 * KCP + 32 * ks);
-        else af[t] = tr_frag(fa + 16 * ks * MCP + 64 * t, MCP);
-        if constexpr (B_KC) bf[t] = *reinterpret_cast<const bf16x8*>(fb + t * 32 * KCP + 32 * ks);
-        else bf[t] = tr_frag(fb + 16 * ks * MCP + 64 * t, MCP);
-      }
+      if (ks + 1 < BKH / 16) read_frags(ks + 1, f[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < 2; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].a[tm], f[ks & 1].b[tn], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
