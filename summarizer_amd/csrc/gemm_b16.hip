@@ -399,30 +399,32 @@ int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int til
 }
 
 // ------------------------------------------------------------------------------------------- fp32 -> bf16 shadows
-// dst[r][c] = bf16(src[r][c]) (round to nearest even, like the plane kernels' v_cvt_pk_bf16_f32), up to four equally shaped row
-// groups stacked in dst (the three projection weights become ONE [3D][D] operand); n_cols % 4 == 0.
-struct CastArgs { const float* src[4]; unsigned short* dst; int64_t rows_per_src; int32_t n_src, n_cols, ld_src; };
-__global__ __launch_bounds__(256) void cast_rows_b16_kernel(CastArgs a) {
+// dst_k = bf16(src_k) for up to six dense fp32 arrays in ONE launch (round to nearest even, like the plane kernels' v_cvt_pk_bf16_f32):
+// the features and the five weight matrices of a training step.  Element counts are multiples of 4.
+struct CastArgs { const float* src[6]; unsigned short* dst[6]; int64_t end4[6]; int32_t n; };   // end4: running total of float4 groups
+__global__ __launch_bounds__(256) void cast_flat_b16_kernel(CastArgs a) {
   const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c4 = a.n_cols >> 2;
-  const int64_t total = (int64_t)a.n_src * a.rows_per_src * c4;
-  if (i4 >= total) return;
-  const int64_t row = i4 / c4; const int c = (int)(i4 % c4) * 4;
-  const int g = (int)(row / a.rows_per_src); const int64_t rl = row - (int64_t)g * a.rows_per_src;
-  const float* sp = g == 0 ? a.src[0] : g == 1 ? a.src[1] : g == 2 ? a.src[2] : a.src[3];
-  const float4 v = *reinterpret_cast<const float4*>(sp + rl * a.ld_src + c);
+  if (i4 >= a.end4[a.n - 1]) return;
+  int k = 0;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) k += (q + 1 < a.n && i4 >= a.end4[q]) ? 1 : 0;
+  const int64_t local = i4 - (k == 0 ? 0 : a.end4[k - 1]);
+  const float4 v = reinterpret_cast<const float4*>(a.src[k])[local];
   const f32x4 f = {v.x, v.y, v.z, v.w};
-  *reinterpret_cast<bf16x4*>(a.dst + row * a.n_cols + c) = __builtin_convertvector(f, bf16x4);
+  reinterpret_cast<bf16x4*>(a.dst[k])[local] = __builtin_convertvector(f, bf16x4);
 }
 
-int cast_rows_b16(const float* const src[4], int n_src, int64_t rows_per_src, int n_cols, int ld_src, void* dst, hipStream_t stream) {
-  SUMK_ARG(n_src >= 1 && n_src <= 4 && n_cols % 4 == 0 && ld_src % 4 == 0, "cast_rows_b16: bad shape");
+int cast_flat_b16(int n, const float* const src[], void* const dst[], const int64_t n_elems[], hipStream_t stream) {
+  SUMK_ARG(n >= 1 && n <= 6, "cast_flat_b16: 1..6 arrays");
   CastArgs a;
-  for (int i = 0; i < 4; ++i) a.src[i] = i < n_src ? src[i] : nullptr;
-  a.dst = (unsigned short*)dst; a.rows_per_src = rows_per_src; a.n_src = n_src; a.n_cols = n_cols; a.ld_src = ld_src;
-  const int64_t total = (int64_t)n_src * rows_per_src * (n_cols >> 2);
-  if (total == 0) return SUMK_OK;
-  hipLaunchKernelGGL(cast_rows_b16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  int64_t run = 0;
+  for (int k = 0; k < 6; ++k) {
+    if (k < n) { SUMK_ARG(src[k] && dst[k] && n_elems[k] % 4 == 0, "cast_flat_b16: bad array %d", k); run += n_elems[k] / 4; }
+    a.src[k] = k < n ? src[k] : nullptr; a.dst[k] = k < n ? (unsigned short*)dst[k] : nullptr; a.end4[k] = run;
+  }
+  a.n = n;
+  if (run == 0) return SUMK_OK;
+  hipLaunchKernelGGL(cast_flat_b16_kernel, dim3((unsigned)((run + 255) / 256)), dim3(256), 0, stream, a);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

@@ -117,8 +117,8 @@ inline int gemm_b16_wide_bm(int M, int N) {
   if (t256 < 96 || N % 256 != 0) return 0;
   return ((t192 + 255) / 256) * 192 <= ((t256 + 255) / 256) * 256 ? 192 : 256;
 }
-// dst (bf16, [n_src * rows_per_src][n_cols], dense) = the n_src fp32 row groups stacked (gemm_b16.hip)
-int cast_rows_b16(const float* const src[4], int n_src, int64_t rows_per_src, int n_cols, int ld_src, void* dst, hipStream_t stream);
+// dst[k] (bf16) = src[k] (fp32) for n <= 6 dense arrays of n_elems[k] (% 4 == 0) elements, one launch (gemm_b16.hip)
+int cast_flat_b16(int n, const float* const src[], void* const dst[], const int64_t n_elems[], hipStream_t stream);
 // GemmLaunch::lean for a single NT problem C(M,N) = A(M,K) B(N,K)^T: K a whole number of 32-wide k-tiles and every operand row
 // within 2^31 bytes of its base (the buffer-load instances address with 32-bit offsets)
 inline int gemm_lean_ok(int64_t M, int64_t N, int K, int lda, int ldb) {

@@ -837,13 +837,12 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   unsigned short* Wqkv16 = (unsigned short*)(ws + L.w16);
   unsigned short* Wo16 = Wqkv16 + (size_t)3 * D * D;
   unsigned short* W116 = Wo16 + (size_t)D * D;
-  if (b16) {
-    const float* xs[4] = {x, nullptr, nullptr, nullptr};
-    SUMK_TRY(cast_rows_b16(xs, 1, R, D, D, x16, stream));
-    const float* wqkv[4] = {w->Wq, w->Wk, w->Wv, nullptr};
-    SUMK_TRY(cast_rows_b16(wqkv, 3, D, D, D, Wqkv16, stream));
-    const float* wo1[4] = {w->Wo, w->W1, nullptr, nullptr};
-    SUMK_TRY(cast_rows_b16(wo1, 2, D, D, D, Wo16, stream));
+  if (b16) {   // one launch: x and the five matrices ([Wq; Wk; Wv] land stacked: one 3D x D operand)
+    const float* const src[6] = {x, w->Wq, w->Wk, w->Wv, w->Wo, w->W1};
+    void* const dst[6] = {x16, Wqkv16, Wqkv16 + (size_t)D * D, Wqkv16 + (size_t)2 * D * D, Wo16, W116};
+    const int64_t dd = (int64_t)D * D;
+    const int64_t ne[6] = {(int64_t)R * D, dd, dd, dd, dd, dd};
+    SUMK_TRY(cast_flat_b16(6, src, dst, ne, stream));
   }
 
   // row-wise NT GEMMs with K = D: eligible for the buffer-load instances when D is a whole number of k-tiles and byte offsets fit 31 bits

@@ -339,3 +339,60 @@ def test_vasnet_bench_batch_grads_bf16_vs_torch_port_with_dropout(dev, vasnet_po
     print(f"bf16 grad x: rel max err {_rel(gx, c['gx']):.3e} cosine {_cos(gx, c['gx']):.6f}")
     assert not bad, bad
     assert _rel(gx, c["gx"]) < 1.5e-1 and _cos(gx, c["gx"]) > 0.998
+
+
+_AB_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests/golden"); sys.path.insert(0, ".")
+import recipes as R
+from summarizer_amd import kernels
+from summarizer_amd.autograd import VasnetFunction
+from summarizer_amd.models.vasnet import VASNet
+dev = torch.device("cuda:0")
+D, p, seed = 1024, 0.5, 777
+lens = [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, 50)]
+m = VASNet(input_size=D, precision="bf16")
+m.load_state_dict({k: torch.from_numpy(v) for k, v in R.vasnet_weights(D, 41).items()}); m = m.to(dev)
+xp = torch.from_numpy(np.concatenate([(R.features(T, 1, D, 5000 + i) - 0.1)[:, 0, :] for i, T in enumerate(lens)])).to(dev).requires_grad_(True)
+cw = torch.from_numpy(np.random.default_rng(6).standard_normal(sum(lens)).astype(np.float32)).to(dev)
+sb = kernels.SeqBatch.get(lens, dev)
+opts = dict(scale=float(m.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=p, seed=seed, precision="bf16")
+names = [k for _, k in kernels.VASNET_FIELDS]
+params = dict(m.named_parameters())
+s = VasnetFunction.apply(xp, sb, opts, None, None, names, *[params[n] for n in names])
+(s * cw).sum().backward()
+np.savez(sys.argv[1], scores=s.detach().cpu().numpy(), gx=xp.grad.cpu().numpy(), **{k: params[k].grad.cpu().numpy() for k in names})
+'''
+
+
+def test_bf16_source_step_equals_the_plane_kernel_step(tmp_path):
+    """The bf16-source kernels (csrc/gemm_b16.hip; operands bf16 in HBM, written once by their producers) against the path they
+    replaced (SUMK_BF16_SRC=0: fp32 operands, each k-tile converted in registers) on the 50-video batch with dropout, forward +
+    backward + dX, each in its own process (the switch is read once per process).  Both round the SAME fp32 values to bf16 the same
+    way and feed the MFMAs the same k order, so scores, dX and every gradient that is not a split-K product come out BIT-IDENTICAL; the
+    five weight gradients differ by the fp32 summation order of their K slices only (different slice counts: measured <= 9e-7 of the
+    largest entry; gate 1e-5 -- and > 0 for at least one of them, which is what shows the switch selected two different paths)."""
+    import os, subprocess, sys
+    out = {}
+    for tag, flag in (("src16", "1"), ("planes", "0")):
+        f = tmp_path / f"{tag}.npz"
+        env = dict(os.environ, SUMK_BF16_SRC=flag)
+        r = subprocess.run([sys.executable, "-c", _AB_CHILD, str(f)], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    a, b = out["src16"], out["planes"]
+    np.testing.assert_array_equal(a["scores"], b["scores"])
+    np.testing.assert_array_equal(a["gx"], b["gx"])
+    split_k = ("K.weight", "Q.weight", "V.weight", "attention_head_projection.weight", "k1.weight")
+    diffs = []
+    for k in a:
+        if k in ("scores", "gx"):
+            continue
+        if k in split_k:
+            r = _rel(a[k], b[k]); diffs.append(r)
+            print(f"src16 vs planes {k}: rel max diff {r:.3e}")
+            assert r < 1e-5, (k, r)
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert max(diffs) > 0, "bit-identical weight gradients: did SUMK_BF16_SRC select two different paths?"
