@@ -31,6 +31,7 @@ constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one
 struct LstmWs {
   size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, pstate_b, xchg, partial, total;
   size_t xchg_bytes;
+  size_t ll, ll_bytes;     // forward recurrence hand-off buffer (H <= 256): directly behind pstate, zeroed with it
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
@@ -71,6 +72,9 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
   w->cstate = take((size_t)n_seq * 2 * H * 4);      // running cell state (inference)
   w->prob = take(8 * sizeof(GemmProb));
   w->pstate = take(PSTATE_WORDS * 4);               // persistent-kernel error flag + per-item step counters
+  // flag-in-data hand-off of the H <= 256 forward recurrence: [step parity 2][direction 2][video][H] x {float h, uint32 step tag}
+  w->ll_bytes = H <= 256 ? (size_t)4 * n_seq * H * 8 : 0;
+  w->ll = take(w->ll_bytes);
   w->gates = w->call = w->hprev = w->dg = w->slab = w->dhrec = w->dcstate = w->prob_sk = w->colpart = 0;
   w->pstate_b = w->xchg = 0; w->xchg_bytes = 0;
   w->slab_elems = 0;
@@ -512,6 +516,7 @@ struct PersistArgs {
   float* gates; float* c_all; float* hprev;   // training-mode saves (nullptr in inference)
   const int32_t* off; unsigned* state;
   int32_t n_seq, H, gsize, n_groups, upm, n_active, hout_bytes, n_teams;
+  unsigned long long* ll; int32_t ll_bytes;   // LL instances: the {h, step tag} hand-off buffer [parity 2][direction 2][video][H]
 };
 
 // The hand-off counters of a persistent launch are zeroed by a KERNEL, not hipMemsetAsync: as a graph memset node the fill can
@@ -519,7 +524,7 @@ struct PersistArgs {
 // as replay-to-replay drift of the scores under hipGraphLaunch; scripts/probes/graph_capture_debug.py).  A kernel's stores are
 // ordered with the following kernel's loads at the launch boundary.
 __global__ void zero_words_kernel(unsigned* p, int n) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
 }
 
 // Sticky per-device health word: every persistent kernel ORs 1 into it when a bounded hand-off wait times out, in addition to
@@ -539,8 +544,22 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p
 // MFMA B operands every step needs -- so LDS holds only the staged h_{t-1} panel and the split-K partial tiles.
 // DIRECT: the A fragments (h_{t-1}[video li][k..k+3]) go straight from the sc1 buffer loads into the MFMAs, as in
 // lstm_wide_kernel below -- no LDS panel, one workgroup barrier less per step.
-template <int CPW, bool DIRECT>
+// LL ("flag in the data", the low-latency protocol of collective libraries): h_t is published as ONE 8-byte {value, step tag} store per
+// element into a double-buffered exchange array, and the consumers' OWN loads of h_{t-1} are the poll -- reloaded until every tag
+// they need says t.  An aligned 8-byte store is single-copy atomic, so a matching tag proves its value; no other ordering is needed.
+// Against the counter protocol above this removes, per step, the producers' vmcnt(0) drain + barrier + atomic add and the consumer's
+// counter poll + barrier in front of the loads: two of the ~five dependent L2 round trips of a step (3.94 -> measured in DESIGN.md).
+// Parity = step & 1: a member can publish step t + 1 only after it has read every member's step t, i.e. after all of them finished
+// reading step t - 1 -- the slot it overwrites.  The output matrix Hout is written with plain stores (nobody reads it in this launch).
+// M16 (LL only, groups of <= 16 videos -- DSN's 50-video batch makes 8 items of 13): the step's product runs on v_mfma_f32_16x16x4_f32
+// (two 16-column tiles x 8 MFMAs of 32 cycles per wave) instead of one 32-row tile of v_mfma_f32_32x32x2_f32 (16 x 64 cycles) whose
+// upper half would multiply zeros: half the matrix-pipe time of a step.  Lane group g = lane / 16 takes the CONTIGUOUS k range
+// [32 wave + 8 g, + 8) of both operands (the sum over k does not care which lane group carries which k), so a lane's eight h values are
+// four 16-byte loads.
+template <int CPW, bool DIRECT, bool LL = false, bool M16 = false>
 __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a) {
+  static_assert(!LL || DIRECT, "the flag-in-data hand-off feeds the MFMAs straight from the loads");
+  static_assert(!M16 || (LL && CPW == 4), "the 16-row form exists for the flag-in-data kernel with 32 k per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, P = H + 4;
   float* sH = smem;                       // [gsize][P]  h_{t-1} of the group's videos
@@ -553,12 +572,13 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
   if (slot >= a.n_active) return;
   // buffer descriptor over the output/exchange matrix (wave-uniform: built from kernel arguments only)
   const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(a.Hout, (short)0, a.hout_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(a.ll, (short)0, LL ? a.ll_bytes : 0, 0x00020000);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
   const int n_items = 2 * a.n_groups;
   int loaded_dir = -1;
-  bool dead = false;   // (thread 0 only) a wait timed out: results are invalid, state[0] says so
+  bool dead = false;   // (thread 0 only; LL: every wave) a wait timed out: results are invalid, state[0] says so
 
   float4 wreg[CPW];
   for (int item = team; item < n_items; item += a.n_teams) {
@@ -567,11 +587,22 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
     unsigned* bar = a.state + 16 + item;
     __syncthreads();   // previous item fully done with LDS
     if (loaded_dir != d) {   // this lane's W_hh fragments -> registers (plain loads: weights are never written in this launch)
+      if constexpr (M16) {   // column n = 16 tile + lane % 16 = gate n / 8, unit n % 8; k = 32 wave + 8 (lane / 16) + 0..7
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+          const int n = 16 * tile + (lane & 15);
+          const float* wrow = a.whh[d] + (int64_t)((n >> 3) * H + min(u0 + (n & 7), H - 1)) * H;
+          const int k = wave * 32 + 8 * (lane >> 4);
+          wreg[2 * tile] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+          wreg[2 * tile + 1] = k + 4 < H ? *reinterpret_cast<const float4*>(wrow + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
       const float* wrow = a.whh[d] + (int64_t)((li >> 3) * H + min(u0 + (li & 7), H - 1)) * H;
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave * CPW + c) * 8 + 4 * lh;
         wreg[c] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       }
       loaded_dir = d;
     }
@@ -598,11 +629,12 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
     }
-    const int r0l = sR0[li], Tl = sT[li];      // the video this lane feeds to the MFMAs (DIRECT)
+    const int vl = M16 ? (lane & 15) : li;     // the video (row of the group) this lane feeds to the MFMAs (DIRECT)
+    const int r0l = sR0[vl], Tl = sT[vl];
 
     for (int t = 0; t < Tg; ++t) {
       if (t > 0) {
-        if (tid == 0 && !dead) {   // wait until every member published step t-1
+        if (!LL && tid == 0 && !dead) {   // wait until every member published step t-1
           const unsigned want = (unsigned)t * (unsigned)a.n_active;
           unsigned spins = 0;
           while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -613,10 +645,99 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
             }
           }
         }
-        __syncthreads();
+        if constexpr (!LL) __syncthreads();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (LL && M16) {
+          // h_{t-1}[video lane % 16][k .. k+7], k = 32 wave + 8 (lane / 16): four 16-byte loads of {value, tag} pairs, repeated until
+          // every tag this lane needs says t
+          const bool need_row = t < Tl;
+          const unsigned want = (unsigned)t;
+          const int k0 = wave * 32 + 8 * (lane >> 4);
+          const unsigned rowb = (unsigned)((((unsigned)((t - 1) & 1) * 2u + (unsigned)d) * (unsigned)a.n_seq + (unsigned)(v0 + vl)) * (unsigned)H) * 8u;
+          u32x4 va[4];
+          unsigned spins = 0;
+          while (true) {
+            asm volatile("" ::: "memory");   // the loads below are a poll: they must be re-issued every turn
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const unsigned o = (need_row && k0 + 2 * p < H) ? rowb + 8u * (unsigned)(k0 + 2 * p) : 0x7ffffff0u;     // beyond num_records: zeros
+              va[p] = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, o, 0, 16 /* sc1 */);
+            }
+            bool ok = true;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              if (need_row && k0 + 2 * p < H) ok = ok && va[p][1] == want && va[p][3] == want;
+            if (__all(ok) || dead) break;
+            if (++spins > (PK_SPIN_LIMIT >> 4)) {     // never hang the GPU: flag the failure and stop waiting
+              if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+              dead = true;
+            }
+          }
+          f32x4 hv[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) hv[p] = __builtin_bit_cast(f32x4, va[p]);     // {h_k, tag, h_k+1, tag}
+          f32x4 acc16[2];
+#pragma unroll
+          for (int tile = 0; tile < 2; ++tile) {
+            acc16[tile] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float4 w0 = wreg[2 * tile], w1 = wreg[2 * tile + 1];
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[0][0], w0.x, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[0][2], w0.y, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[1][0], w0.z, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[1][2], w0.w, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[2][0], w1.x, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[2][2], w1.y, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[3][0], w1.z, acc16[tile], 0, 0, 0);
+            acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[3][2], w1.w, acc16[tile], 0, 0, 0);
+          }
+          // C/D map of the 16x16 MFMA: row = 4 (lane / 16) + r, column = lane % 16; same [wave][video][33] partial tiles as the 32-row form
+#pragma unroll
+          for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * 32 + 4 * (lane >> 4) + r) * 33 + 16 * tile + (lane & 15)] = acc16[tile][r];
+          (void)acc;
+        } else
+        if constexpr (LL) {
+          // h_{t-1}[video li][k .. k+3] = two 16-byte loads of {value, tag} pairs, repeated until every tag this lane needs says t
+          const bool need_row = t < Tl;
+          const unsigned want = (unsigned)t;
+          const unsigned rowb = (unsigned)((((unsigned)((t - 1) & 1) * 2u + (unsigned)d) * (unsigned)a.n_seq + (unsigned)(v0 + li)) * (unsigned)H) * 8u;
+          u32x4 va[2 * CPW];
+          unsigned spins = 0;
+          while (true) {
+            asm volatile("" ::: "memory");   // the loads below are a poll: they must be re-issued every turn (a read-only buffer load is otherwise loop invariant)
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+              const int k = (wave * CPW + c) * 8 + 4 * lh;
+              const unsigned o = (need_row && k < H) ? rowb + 8u * (unsigned)k : 0x7ffffff0u;     // beyond num_records: zeros
+              va[2 * c] = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, o, 0, 16 /* sc1 */);
+              va[2 * c + 1] = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, o, 16, 16 /* sc1 */);
+            }
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+              const int k = (wave * CPW + c) * 8 + 4 * lh;
+              if (need_row && k < H)
+                ok = ok && va[2 * c][1] == want && va[2 * c][3] == want && va[2 * c + 1][1] == want && va[2 * c + 1][3] == want;
+            }
+            if (__all(ok) || dead) break;
+            if (++spins > (PK_SPIN_LIMIT >> 4)) {     // never hang the GPU: flag the failure and stop waiting
+              if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+              dead = true;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const float4 bv = wreg[c];
+            const f32x4 p0 = __builtin_bit_cast(f32x4, va[2 * c]), p1 = __builtin_bit_cast(f32x4, va[2 * c + 1]);   // {h_k, tag, h_k+1, tag}, {h_k+2, tag, h_k+3, tag}
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[0], bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[2], bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[0], bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[2], bv.w, acc, 0, 0, 0);
+          }
+        } else
         if constexpr (DIRECT) {
           constexpr unsigned OOB = 0x7ffffff0u;   // beyond num_records: the buffer load returns zeros
           const unsigned basel = t < Tl ? (unsigned)(((int64_t)(d == 0 ? r0l + t - 1 : r0l + Tl - t) * (2 * H) + d * H) * 4) : OOB;
@@ -675,8 +796,10 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
         }
         }
+        if constexpr (!M16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+          for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+        }
         __syncthreads();
       }
       if (erole && t < eT) {
@@ -696,7 +819,13 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
         c = fg * c + ig * gg;
         const float h = og * tanhf(c);
-        st_sc1(a.Hout + row * (2 * H) + d * H + j, h);
+        if constexpr (LL) {
+          const unsigned long long pkt = ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, h);
+          __hip_atomic_store(a.ll + ((int64_t)((t & 1) * 2 + d) * a.n_seq + (v0 + ei)) * H + j, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a.Hout[row * (2 * H) + d * H + j] = h;
+        } else {
+          st_sc1(a.Hout + row * (2 * H) + d * H + j, h);
+        }
         if (a.gates) {
           float* gs = a.gates + row * (8 * H) + d * 4 * H;
           gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
@@ -711,10 +840,14 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
         }
       }
-      // publish step t: every storing wave drains its stores, then one lane signals
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (LL) {
+        __syncthreads();   // the split-K partial tiles in LDS are free again (the published h needs no further signal)
+      } else {
+        // publish step t: every storing wave drains its stores, then one lane signals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -1489,7 +1622,11 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
   }
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
-  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)(ws + L.pstate), (int)PSTATE_WORDS);
+  // (the flag-in-data hand-off buffer lies directly behind the state words: one launch clears both -- a tag of 0 matches no step)
+  {
+    const size_t words = (L.ll + L.ll_bytes - L.pstate) / 4;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(64, (words + 255) / 256)), dim3(256), 0, stream, (unsigned*)(ws + L.pstate), (int)words);
+  }
   static const bool persist_ok = persistent_kernels_usable();
   // H <= 256: 8 XCD teams with an LDS panel; 256 < H <= 1024: the two-team register-resident kernel; otherwise the launch chain
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
@@ -1500,6 +1637,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     pa.hprev = training ? (float*)(ws + L.hprev) : nullptr;
     pa.off = seq_off_dev; pa.state = (unsigned*)(ws + L.pstate);
     pa.n_seq = n_seq; pa.H = H; pa.hout_bytes = (int32_t)std::min<size_t>((size_t)R * 2 * H * 4, 0x7fffffff);
+    pa.ll = (unsigned long long*)(ws + L.ll); pa.ll_bytes = (int32_t)std::min<size_t>(L.ll_bytes, 0x7fffffe0);
     // H <= 256: 8 teams of 32 CUs (one XCD each); larger H: 2 teams of 128 CUs so every member still owns only 8 units
     pa.n_teams = H <= 256 ? PK_TEAMS : 2;
     const int team_size = 256 / pa.n_teams;
@@ -1510,11 +1648,19 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     if (2 * pa.n_groups <= PSTATE_WORDS - 16 && pa.n_active <= team_size) {
       const size_t shmem = std::max<size_t>(((size_t)gsize * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
       static const bool direct = !(getenv("SUMK_LSTM_PANEL") && getenv("SUMK_LSTM_PANEL")[0] == '1');   // 1: stage h through LDS
-      const void* fn = direct ? (const void*)lstm_persist_kernel<4, true> : (const void*)lstm_persist_kernel<4, false>;
-      static bool attr_set[2] = {false, false};
-      if (!attr_set[direct]) {
+      // SUMK_LSTM_LL=0: the counter hand-off (A/B switch); the flag-in-data one needs the exchange buffer's byte offsets in 31 bits
+      static const bool ll_on = !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');
+      const bool ll = direct && ll_on && L.ll_bytes > 0 && L.ll_bytes < 0x7fffffe0;
+      static const bool m16_on = !(getenv("SUMK_LSTM_M16") && getenv("SUMK_LSTM_M16")[0] == '0');
+      const bool m16 = ll && m16_on && gsize <= 16;
+      const int which = m16 ? 3 : ll ? 2 : direct ? 1 : 0;
+      const void* fn = m16 ? (const void*)lstm_persist_kernel<4, true, true, true>
+                     : ll ? (const void*)lstm_persist_kernel<4, true, true>
+                          : direct ? (const void*)lstm_persist_kernel<4, true> : (const void*)lstm_persist_kernel<4, false>;
+      static bool attr_set[4] = {false, false, false, false};
+      if (!attr_set[which]) {
         SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[direct] = true;
+        attr_set[which] = true;
       }
       void* kargs[] = {&pa};
       prof_begin(SUMK_PROF_LSTM_REC, stream);
