@@ -14,6 +14,8 @@
 //    W_hh (1 MB for DSN) stays L2-resident across steps; h_prev is read from the output rows written one step
 //    earlier (t-1 for the forward direction, t+1 for the reverse one), so no separate state buffer exists.
 #include "sumk_internal.h"
+#include <cstring>
+#include <cstdio>
 #include <math.h>
 #include <algorithm>
 #include <cstdlib>
@@ -32,6 +34,7 @@ struct LstmWs {
   size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, pstate_b, xchg, partial, total;
   size_t xchg_bytes;
   size_t ll, ll_bytes;     // forward recurrence hand-off buffer (H <= 256): directly behind pstate, zeroed with it
+  size_t llb, llb_bytes;   // backward recurrence hand-off buffer (H <= 256): directly behind pstate_b, zeroed with it
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
@@ -76,7 +79,7 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
   w->ll_bytes = H <= 256 ? (size_t)4 * n_seq * H * 8 : 0;
   w->ll = take(w->ll_bytes);
   w->gates = w->call = w->hprev = w->dg = w->slab = w->dhrec = w->dcstate = w->prob_sk = w->colpart = 0;
-  w->pstate_b = w->xchg = 0; w->xchg_bytes = 0;
+  w->pstate_b = w->xchg = 0; w->xchg_bytes = 0; w->llb = 0; w->llb_bytes = 0;
   w->slab_elems = 0;
   if (training) {
     w->gates = take(R * 8 * H * 4);                 // post-nonlinearity i,f,g,o per row and direction
@@ -90,6 +93,12 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
     w->prob_sk = take(64 * sizeof(GemmProb));
     w->colpart = take((size_t)128 * 8 * H * 4);
     w->pstate_b = take(PSTATE_WORDS * 4);
+    {  // flag-in-data exchange of the H <= 256 BPTT: [step parity 2][item][member 32][video < gsize][H] x {float partial, uint32 step tag}
+      const int gsz = std::min(32, std::max(1, (2 * n_seq + 7) / 8));
+      const int items = 2 * ((n_seq + gsz - 1) / gsz);
+      w->llb_bytes = H <= 256 ? (size_t)2 * items * 32 * gsz * H * 8 : 0;
+      w->llb = take(w->llb_bytes);
+    }
     {  // persistent BPTT exchange: [parity 2][item][member 32][video 32][H] partial sums of dh (H <= 256 only)
       int gsize = std::min(32, std::max(1, (2 * n_seq + 7) / 8));
       int items = 2 * ((n_seq + gsize - 1) / gsize);
@@ -1206,9 +1215,16 @@ struct PersistBwdArgs {
   const float* whh[2]; const float* dHout; const float* gates; const float* c_all;
   float* dG; float* xchg; const int32_t* off; unsigned* state;
   int32_t n_seq, H, gsize, n_groups, upm, n_active, n_items;
+  unsigned long long* ll;     // LL instances: {partial, step tag} packets [parity 2][item][member 32][video < gsize][H]
 };
 
+// LL / M16: as in lstm_persist_kernel -- the partial products travel as 8-byte {value, step tag} packets and the consumers' loads
+// are the poll (no counter, no vmcnt(0) drain, no atomic); groups of <= 16 videos multiply on v_mfma_f32_16x16x4_f32 with the W_hh
+// fragments of the wave's 32 output columns held in REGISTERS for the whole item (the 32-row form re-reads them from LDS every step).
+// Tag of the partials of step s (s = Tg-1 .. 1): Tg - s >= 1; the buffer is zeroed before the launch (0 matches no step).
+template <bool LL = false, bool M16 = false>
 __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
+  static_assert(!M16 || LL, "the 16-row form exists for the flag-in-data kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, P = H + 4;
   float* sW = smem;                       // [32][P]  W_hh rows (gate*8+unit) of this member, all H columns
@@ -1225,12 +1241,25 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
   const int H4 = 4 * H;
   int loaded_dir = -1;
   bool dead = false;
+  float wB[2][8];     // M16: this lane's W_hh fragments
 
   for (int item = team; item < a.n_items; item += PK_TEAMS) {
     const int g = item >> 1, d = item & 1;
     const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
     unsigned* bar = a.state + 16 + item;
     __syncthreads();
+    if (M16 && loaded_dir != d) {   // B fragments: W_hh[row k = 8 (lane / 16) + m of this member's 32][column 32 wave + 16 tile + lane % 16]
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+        const int n = wave * 32 + 16 * tile + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int r = 8 * (lane >> 4) + m;
+          wB[tile][m] = n < H ? a.whh[d][(int64_t)((r >> 3) * H + min(u0 + (r & 7), H - 1)) * H + n] : 0.f;
+        }
+      }
+      loaded_dir = d;
+    }
     if (loaded_dir != d) {
       for (int idx = tid; idx < 32 * (H >> 2); idx += PK_THREADS) {
         const int r = idx / (H >> 2), k4 = (idx % (H >> 2)) * 4;
@@ -1270,7 +1299,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
     for (int t = Tg - 1; t >= 0; --t) {
       // zero this step's A tile (rows of inactive videos and columns of absent units must contribute nothing)
       for (int idx = tid; idx < 32 * 36; idx += PK_THREADS) sA[idx] = 0.f;
-      if (t < Tg - 1) {
+      if (!LL && t < Tg - 1) {
         if (tid == 0 && !dead) {   // wait until every member published step t+1
           const unsigned want = (unsigned)(Tg - 1 - t) * (unsigned)a.n_active;
           unsigned spins = 0;
@@ -1284,8 +1313,39 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         }
       }
       __syncthreads();
+      float rec_ll = 0.f;
+      if constexpr (LL) {   // the 32 members' partials of step t+1: the loads are the poll (every wave of the epilogue role spins for itself)
+        if (tid < 256) {
+          const bool need = erole && t + 1 < eT;
+          const unsigned want = (unsigned)(Tg - 1 - t);
+          const unsigned long long* xp = a.ll + ((((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * a.gsize + (need ? ei : 0)) * H + (need ? j : 0);
+          unsigned spins = 0;
+          while (true) {
+            unsigned long long pv[32];
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+              pv[m] = (need && m < a.n_active) ? __hip_atomic_load(xp + (int64_t)m * a.gsize * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            bool ok = true;
+            float rec = 0.f;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+              if (need && m < a.n_active) ok = ok && (unsigned)(pv[m] >> 32) == want;
+              rec += __builtin_bit_cast(float, (unsigned)pv[m]);       // fixed order m = 0 .. 31 (absent members add +0)
+            }
+            rec_ll = rec;
+            if (__all(ok) || dead) break;
+            if (++spins > (PK_SPIN_LIMIT >> 4)) {
+              if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+              dead = true;
+            }
+          }
+        }
+      }
       if (erole && t < eT) {
         float dh = sv_dh;
+        if (LL) {
+          if (t + 1 < eT) dh += rec_ll;
+        } else
         if (t + 1 < eT) {   // recurrent part: fixed-order sum of the 32 members' partials of step t+1 (sc1 loads)
           const float* xp = a.xchg + ((((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * 32 + ei) * H + j;
           float pv[32];
@@ -1311,7 +1371,40 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
       if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, one step ahead
       __syncthreads();
       if (t > 0) {   // partial_m(t) is only ever read by step t-1
+        if constexpr (M16) {
+          // 16 videos x (this wave's 32 columns, two 16-column tiles) x K = 32: lane group g = lane / 16 carries k = 8 g .. 8 g + 7
+          const int i16 = lane & 15, g4 = lane >> 4;
+          const float4 a0 = *reinterpret_cast<const float4*>(&sA[i16 * 36 + 8 * g4]);
+          const float4 a1 = *reinterpret_cast<const float4*>(&sA[i16 * 36 + 8 * g4 + 4]);
+          const unsigned tag = (unsigned)(Tg - t);
+          unsigned long long* xo = a.ll + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * a.gsize) * H;
+#pragma unroll
+          for (int tile = 0; tile < 2; ++tile) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wB[tile][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wB[tile][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wB[tile][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wB[tile][3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wB[tile][4], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wB[tile][5], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wB[tile][6], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wB[tile][7], acc, 0, 0, 0);
+            const int n = wave * 32 + 16 * tile + i16;
+            if (n < H) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = 4 * g4 + r;      // C/D map of the 16x16 MFMA: row = 4 (lane / 16) + r, column = lane % 16
+                const float pv_ = acc[r];     // (a scalar copy: __builtin_bit_cast applied to a vector ELEMENT read element 0 with this compiler)
+                if (i < nv && t < sT[i])
+                  __hip_atomic_store(xo + (int64_t)i * H + n, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv_),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+        } else {
         float* xo = a.xchg + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * 32) * H;
+        unsigned long long* xl = a.ll + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * a.gsize) * H;
+        const unsigned tag = (unsigned)(Tg - t);
         const int ntile = (H + 31) >> 5;
         for (int nt = wave; nt < ntile; nt += 8) {
           const int n = nt * 32 + li, nc = min(n, H - 1);
@@ -1332,14 +1425,26 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-              if (i < nv && t < sT[i]) st_sc1(xo + (int64_t)i * H + n, acc[r]);
+              if (i < nv && t < sT[i]) {
+                if constexpr (LL) {
+                  const float pv_ = acc[r];   // (scalar copy: see the 16-row form)
+                  __hip_atomic_store(xl + (int64_t)i * H + n, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv_),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else
+                  st_sc1(xo + (int64_t)i * H + n, acc[r]);
+              }
             }
           }
         }
+        }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (LL) {
+        __syncthreads();   // the A tile in LDS is free again (the published partials need no further signal)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -1749,7 +1854,10 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
 
   static const bool persist_ok = persistent_kernels_usable();
-  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)(ws + L.pstate_b), (int)PSTATE_WORDS);
+  {   // state words + (directly behind them) the flag-in-data exchange buffer: a tag of 0 matches no step
+    const size_t words = (L.llb + L.llb_bytes - L.pstate_b) / 4;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (words + 255) / 256)), dim3(256), 0, stream, (unsigned*)(ws + L.pstate_b), (int)words);
+  }
   bool done = false;
   if (persist_ok && H <= 256 && L.xchg_bytes > 0) {
     PersistBwdArgs pa;
@@ -1762,14 +1870,21 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize; pa.n_items = 2 * pa.n_groups;
     if (pa.n_items <= PSTATE_WORDS - 16) {
       const size_t shmem = std::max<size_t>(((size_t)32 * (H + 4) + 32 * 36 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
-      static bool attr_set = false;
-      if (!attr_set) {
-        SUMK_HIP(hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+      pa.ll = (unsigned long long*)(ws + L.llb);
+      static const bool ll_on = getenv("SUMK_LSTM_LL_BWD") ? getenv("SUMK_LSTM_LL_BWD")[0] != '0'
+                                                           : !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');   // 0: the counter hand-off (A/B switch)
+      static const bool m16_on = !(getenv("SUMK_LSTM_M16") && getenv("SUMK_LSTM_M16")[0] == '0');
+      const bool ll = ll_on && L.llb_bytes > 0, m16 = ll && m16_on && gsize <= 16;
+      const int which = m16 ? 2 : ll ? 1 : 0;
+      const void* fn = m16 ? (const void*)lstm_persist_bwd_kernel<true, true> : ll ? (const void*)lstm_persist_bwd_kernel<true, false>
+                                                                                    : (const void*)lstm_persist_bwd_kernel<false, false>;
+      static bool attr_set[3] = {false, false, false};
+      if (!attr_set[which]) {
+        SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[which] = true;
       }
       void* kargs[] = {&pa};
-      SUMK_HIP(hipLaunchCooperativeKernel((const void*)lstm_persist_bwd_kernel, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs,
-                                          (unsigned)shmem, stream));
+      SUMK_HIP(hipLaunchCooperativeKernel(fn, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs, (unsigned)shmem, stream));
       done = true;
     }
   }

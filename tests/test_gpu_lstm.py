@@ -182,3 +182,40 @@ def test_persistent_recurrences_are_bitwise_repeatable_under_foreign_traffic():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probes", "wide_bptt_soak.py"), "6"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 differed" in r.stdout
+
+
+_HANDOFF_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests/golden"); sys.path.insert(0, ".")
+import recipes as R
+from summarizer_amd.models.dsn import DSN
+D, H, lens = 128, int(sys.argv[2]), [int(v) for v in sys.argv[3].split(",")]
+w = R.lstm_weights("rnn.", D, H, 1, 21, "out.0.")
+m = DSN(D, H, 1); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to("cuda:0")
+xp = torch.from_numpy(np.concatenate([(R.features(T, 1, D, 80 + i) - 0.2)[:, 0, :] for i, T in enumerate(lens)])).to("cuda:0").requires_grad_(True)
+s = m.score_packed(xp, lens)
+cw = torch.from_numpy(np.random.default_rng(4).standard_normal(sum(lens)).astype(np.float32)).to("cuda:0")
+(s * cw).sum().backward()
+np.savez(sys.argv[1], scores=s.detach().cpu().numpy(), gx=xp.grad.cpu().numpy(), **{k: p.grad.cpu().numpy() for k, p in m.named_parameters()})
+'''
+
+
+@pytest.mark.parametrize("H,lens", [(32, [20, 10, 20, 1, 20, 10, 20, 7, 20]), (40, [50, 1, 33, 7] + [4] * 30), (256, [37, 64, 12] * 14)])
+def test_flag_in_data_handoff_equals_counter_handoff(tmp_path, H, lens):
+    """The persistent recurrences hand h_t (forward) and the partial products of dh (BPTT) from member to member either through a step
+    counter (SUMK_LSTM_LL=0: stores, vmcnt(0) drain, barrier, atomic add; consumers poll the counter) or as 8-byte {value, step tag}
+    packets whose own loads are the poll (default), on 32-row or -- groups of <= 16 videos -- 16-row MFMAs.  Same arithmetic in the same
+    order for the forward pass and the cell backward: scores and every gradient must agree to fp32 re-association of the 16- vs 32-row
+    k order (1e-6 of the largest entry) -- on ragged groups of SEVERAL videos (rows > 0 of a group's exchange block; a one-video group
+    cannot see a row mix-up), with one-frame videos, H not a multiple of 32, and groups of more than 16 videos."""
+    import os, subprocess, sys
+    out = {}
+    for tag, env in (("ll", {}), ("counter", {"SUMK_LSTM_LL": "0"})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _HANDOFF_CHILD, str(f), str(H), ",".join(map(str, lens))], env=dict(os.environ, **env),
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    for k in out["ll"]:
+        a, b = out["ll"][k], out["counter"][k]
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() + 1e-12, (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
