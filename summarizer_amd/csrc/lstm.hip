@@ -1224,7 +1224,6 @@ struct PersistBwdArgs {
 // Tag of the partials of step s (s = Tg-1 .. 1): Tg - s >= 1; the buffer is zeroed before the launch (0 matches no step).
 template <bool LL = false, bool M16 = false>
 __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwdArgs a) {
-  static_assert(!M16 || LL, "the 16-row form exists for the flag-in-data kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, P = H + 4;
   float* sW = smem;                       // [32][P]  W_hh rows (gate*8+unit) of this member, all H columns
@@ -1378,6 +1377,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
           const float4 a1 = *reinterpret_cast<const float4*>(&sA[i16 * 36 + 8 * g4 + 4]);
           const unsigned tag = (unsigned)(Tg - t);
           unsigned long long* xo = a.ll + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * a.gsize) * H;
+          float* xf = a.xchg + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * 32) * H;        // counter hand-off: fp32 partials
 #pragma unroll
           for (int tile = 0; tile < 2; ++tile) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1395,9 +1395,13 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
               for (int r = 0; r < 4; ++r) {
                 const int i = 4 * g4 + r;      // C/D map of the 16x16 MFMA: row = 4 (lane / 16) + r, column = lane % 16
                 const float pv_ = acc[r];     // (a scalar copy: __builtin_bit_cast applied to a vector ELEMENT read element 0 with this compiler)
-                if (i < nv && t < sT[i])
-                  __hip_atomic_store(xo + (int64_t)i * H + n, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv_),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < nv && t < sT[i]) {
+                  if constexpr (LL)
+                    __hip_atomic_store(xo + (int64_t)i * H + n, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv_),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  else
+                    st_sc1(xf + (int64_t)i * H + n, pv_);
+                }
               }
             }
           }
@@ -1854,8 +1858,9 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
 
   static const bool persist_ok = persistent_kernels_usable();
-  {   // state words + (directly behind them) the flag-in-data exchange buffer: a tag of 0 matches no step
-    const size_t words = (L.llb + L.llb_bytes - L.pstate_b) / 4;
+  {   // state words + (flag-in-data hand-off only: directly behind them) the exchange buffer: a tag of 0 matches no step
+    static const bool ll_bwd = getenv("SUMK_LSTM_LL_BWD") && getenv("SUMK_LSTM_LL_BWD")[0] == '1';
+    const size_t words = ll_bwd ? (L.llb + L.llb_bytes - L.pstate_b) / 4 : (size_t)PSTATE_WORDS;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(256, (words + 255) / 256)), dim3(256), 0, stream, (unsigned*)(ws + L.pstate_b), (int)words);
   }
   bool done = false;
@@ -1871,14 +1876,16 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     if (pa.n_items <= PSTATE_WORDS - 16) {
       const size_t shmem = std::max<size_t>(((size_t)32 * (H + 4) + 32 * 36 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
       pa.ll = (unsigned long long*)(ws + L.llb);
-      static const bool ll_on = getenv("SUMK_LSTM_LL_BWD") ? getenv("SUMK_LSTM_LL_BWD")[0] != '0'
-                                                           : !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');   // 0: the counter hand-off (A/B switch)
+      // The BPTT keeps the COUNTER hand-off by default: its exchange is a reduce-scatter of 32 partials per element (each epilogue thread
+      // polls 32 packets, the exchange bytes double), and the flag-in-data form measured SLOWER here (DSN training step 3.93 vs 3.76 ms);
+      // SUMK_LSTM_LL_BWD=1 selects it.  The 16-row MFMA form (groups of <= 16 videos) is independent of the hand-off.
+      static const bool ll_on = getenv("SUMK_LSTM_LL_BWD") && getenv("SUMK_LSTM_LL_BWD")[0] == '1';
       static const bool m16_on = !(getenv("SUMK_LSTM_M16") && getenv("SUMK_LSTM_M16")[0] == '0');
-      const bool ll = ll_on && L.llb_bytes > 0, m16 = ll && m16_on && gsize <= 16;
-      const int which = m16 ? 2 : ll ? 1 : 0;
-      const void* fn = m16 ? (const void*)lstm_persist_bwd_kernel<true, true> : ll ? (const void*)lstm_persist_bwd_kernel<true, false>
-                                                                                    : (const void*)lstm_persist_bwd_kernel<false, false>;
-      static bool attr_set[3] = {false, false, false};
+      const bool ll = ll_on && L.llb_bytes > 0, m16 = m16_on && gsize <= 16;
+      const int which = (ll ? 2 : 0) + (m16 ? 1 : 0);
+      const void* fn = ll ? (m16 ? (const void*)lstm_persist_bwd_kernel<true, true> : (const void*)lstm_persist_bwd_kernel<true, false>)
+                          : (m16 ? (const void*)lstm_persist_bwd_kernel<false, true> : (const void*)lstm_persist_bwd_kernel<false, false>);
+      static bool attr_set[4] = {false, false, false, false};
       if (!attr_set[which]) {
         SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[which] = true;

@@ -203,19 +203,22 @@ np.savez(sys.argv[1], scores=s.detach().cpu().numpy(), gx=xp.grad.cpu().numpy(),
 @pytest.mark.parametrize("H,lens", [(32, [20, 10, 20, 1, 20, 10, 20, 7, 20]), (40, [50, 1, 33, 7] + [4] * 30), (256, [37, 64, 12] * 14)])
 def test_flag_in_data_handoff_equals_counter_handoff(tmp_path, H, lens):
     """The persistent recurrences hand h_t (forward) and the partial products of dh (BPTT) from member to member either through a step
-    counter (SUMK_LSTM_LL=0: stores, vmcnt(0) drain, barrier, atomic add; consumers poll the counter) or as 8-byte {value, step tag}
-    packets whose own loads are the poll (default), on 32-row or -- groups of <= 16 videos -- 16-row MFMAs.  Same arithmetic in the same
-    order for the forward pass and the cell backward: scores and every gradient must agree to fp32 re-association of the 16- vs 32-row
-    k order (1e-6 of the largest entry) -- on ragged groups of SEVERAL videos (rows > 0 of a group's exchange block; a one-video group
-    cannot see a row mix-up), with one-frame videos, H not a multiple of 32, and groups of more than 16 videos."""
+    counter (stores, vmcnt(0) drain, barrier, atomic add; consumers poll the counter) or as 8-byte {value, step tag} packets whose own
+    loads are the poll, on 32-row or -- groups of <= 16 videos -- 16-row MFMAs.  Defaults: forward flag-in-data, BPTT counter (its
+    32-way reduce-scatter measured slower with packets), 16-row MFMAs in both.  Reference here = the round-2 path (counter hand-off,
+    32-row MFMAs: SUMK_LSTM_LL=0 SUMK_LSTM_M16=0); against it the default and the all-packets variant (SUMK_LSTM_LL_BWD=1) must agree
+    to fp32 re-association of the 16- vs 32-row k order (1e-6 of the largest entry) in scores and every gradient -- on ragged groups
+    of SEVERAL videos (rows > 0 of a group's exchange block: a one-video group cannot see a row mix-up), with one-frame videos, H not
+    a multiple of 32, and groups of more than 16 videos."""
     import os, subprocess, sys
     out = {}
-    for tag, env in (("ll", {}), ("counter", {"SUMK_LSTM_LL": "0"})):
+    for tag, env in (("ref", {"SUMK_LSTM_LL": "0", "SUMK_LSTM_M16": "0"}), ("default", {}), ("packets", {"SUMK_LSTM_LL_BWD": "1"})):
         f = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, "-c", _HANDOFF_CHILD, str(f), str(H), ",".join(map(str, lens))], env=dict(os.environ, **env),
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = dict(np.load(f))
-    for k in out["ll"]:
-        a, b = out["ll"][k], out["counter"][k]
-        assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() + 1e-12, (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    for tag in ("default", "packets"):
+        for k in out[tag]:
+            a, b = out[tag][k], out["ref"][k]
+            assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() + 1e-12, (tag, k, float(np.abs(a - b).max()), float(np.abs(b).max()))
