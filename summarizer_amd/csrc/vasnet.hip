@@ -668,7 +668,7 @@ static int rowwise_small_tile(int M, int N) {
 
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
-  int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv;
+  int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv, t_max;
   bool b16;          // the mixed-precision training step on the bf16-source kernels (use_b16)
 };
 static bool use_b16(const Geometry& G, int D, int precision, int training);
@@ -686,6 +686,8 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
   const int cfg_auto = (G->R / n_seq >= 1024) ? 0 : 1;
   G->cfg_s = cfg_auto; G->cfg_pv = cfg_auto;
   if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
+  G->t_max = 0;
+  for (int s = 0; s < n_seq; ++s) G->t_max = std::max(G->t_max, off[s + 1] - off[s]);
   G->b16 = use_b16(*G, D, precision, training);
   if (G->b16) G->cfg_s = G->cfg_pv = 0;       // the bf16-source kernel has 128x128 tiles
   G->tiles_s = G->tiles_pv = 0;
@@ -702,6 +704,9 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
 static bool use_b16(const Geometry& G, int D, int precision, int training) {
   static const bool on = !(getenv("SUMK_BF16_SRC") && getenv("SUMK_BF16_SRC")[0] == '0');
   const int R = G.R;
+  // (per-video attention blocks: T x ld16 bf16 with ld16 = T rounded up to 64 -- their byte offsets must fit 31 bits too)
+  const int64_t ld16 = ((int64_t)G.t_max + 63) & ~(int64_t)63;
+  if (((int64_t)G.t_max + 128) * ld16 * 2 >= ((int64_t)1 << 31)) return false;
   return on && training && precision == SUMK_PRECISION_BF16 && G.st_qkv == 0 && G.st_d == 0 &&
          gemm_b16_ok(R, 3 * D, D, D, D, true, true) && gemm_b16_ok(R, D, D, D, D, true, false) &&
          gemm_b16_ok(R, D, D, 3 * D, D, true, false) && gemm_b16_ok(3 * D, D, R, 3 * D, D, false, false);

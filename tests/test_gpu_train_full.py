@@ -349,8 +349,8 @@ from summarizer_amd import kernels
 from summarizer_amd.autograd import VasnetFunction
 from summarizer_amd.models.vasnet import VASNet
 dev = torch.device("cuda:0")
-D, p, seed = 1024, 0.5, 777
-lens = [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, 50)]
+D, p, seed = int(sys.argv[2]), 0.5, 777
+lens = [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, 50)] if sys.argv[3] == "tvsum" else [int(v) for v in sys.argv[3].split(",")]
 m = VASNet(input_size=D, precision="bf16")
 m.load_state_dict({k: torch.from_numpy(v) for k, v in R.vasnet_weights(D, 41).items()}); m = m.to(dev)
 xp = torch.from_numpy(np.concatenate([(R.features(T, 1, D, 5000 + i) - 0.1)[:, 0, :] for i, T in enumerate(lens)])).to(dev).requires_grad_(True)
@@ -365,9 +365,11 @@ np.savez(sys.argv[1], scores=s.detach().cpu().numpy(), gx=xp.grad.cpu().numpy(),
 '''
 
 
-def test_bf16_source_step_equals_the_plane_kernel_step(tmp_path):
+@pytest.mark.parametrize("D,lens", [(1024, "tvsum"), (2048, "3000,1500,70")])
+def test_bf16_source_step_equals_the_plane_kernel_step(tmp_path, D, lens):
     """The bf16-source kernels (csrc/gemm_b16.hip; operands bf16 in HBM, written once by their producers) against the path they
-    replaced (SUMK_BF16_SRC=0: fp32 operands, each k-tile converted in registers) on the 50-video batch with dropout, forward +
+    replaced (SUMK_BF16_SRC=0: fp32 operands, each k-tile converted in registers) on the 50-video batch with dropout and on a D = 2048
+    batch with long videos (per-video products with K = T = 3000, thousands of tiles per video; BASELINE config 5's shape class), forward +
     backward + dX, each in its own process (the switch is read once per process).  Both round the SAME fp32 values to bf16 the same
     way and feed the MFMAs the same k order, so scores, dX and every gradient that is not a split-K product come out BIT-IDENTICAL; the
     five weight gradients differ by the fp32 summation order of their K slices only (different slice counts: measured <= 9e-7 of the
@@ -377,7 +379,7 @@ def test_bf16_source_step_equals_the_plane_kernel_step(tmp_path):
     for tag, flag in (("src16", "1"), ("planes", "0")):
         f = tmp_path / f"{tag}.npz"
         env = dict(os.environ, SUMK_BF16_SRC=flag)
-        r = subprocess.run([sys.executable, "-c", _AB_CHILD, str(f)], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+        r = subprocess.run([sys.executable, "-c", _AB_CHILD, str(f), str(D), lens], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = dict(np.load(f))
