@@ -114,6 +114,11 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// Gate math of the persistent H <= 256 recurrence, whose per-step latency chain contains it: v_exp_f32 / v_rcp_f32 forms (a few ulp:
+// ~3e-7 relative for the sigmoid, ~1e-7 ABSOLUTE for tanh) instead of the library expf / IEEE division / tanhf (~170 instructions per
+// step and thread against ~30).  tanh(x) = 1 - 2 / (1 + e^{2x}) saturates correctly at both ends (e^{2x} -> inf gives 1, -> 0 gives -1).
+__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * v)); }
 
 // ------------------------------------------------------------------------------------------- small-batch (mat-vec) steps
 // With a handful of sequences (SumGAN trains one video at a time) a recurrence step is a matrix-VECTOR product: nothing to
@@ -572,8 +577,12 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, P = H + 4;
   float* sH = smem;                       // [gsize][P]  h_{t-1} of the group's videos
-  float* part = sH + a.gsize * P;         // [8][32][33] split-K partial tiles
-  int* sR0 = reinterpret_cast<int*>(part + 8 * 32 * 33);   // [32] first row of each video
+  // [8 waves][32 rows][PP] split-K partial tiles; PP = 32: the epilogue's float4 read (a 16-lane group = 2 videos x 8 units x 16 B)
+  // covers the 64 banks exactly once -- the pitch 33 + scalar reads of the first version were 8-way conflicted (ei + eu collides
+  // along anti-diagonals); the MFMA-side scalar writes are 2-way at most, which a ds_write_b32 absorbs
+  constexpr int PP = 32;
+  float* part = sH + a.gsize * P;
+  int* sR0 = reinterpret_cast<int*>(part + 8 * 32 * PP);   // [32] first row of each video
   int* sT = sR0 + 32;                     // [32] length of each video
   int* sTg = sT + 32;                     // [1]  longest video of the group
 
@@ -590,23 +599,29 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
   bool dead = false;   // (thread 0 only; LL: every wave) a wait timed out: results are invalid, state[0] says so
 
   float4 wreg[CPW];
+#ifdef SUMK_DIAG   // `make DIAG=1`: per-phase shader cycles of the flag-in-data 16-row path, waves 0 and 7 of member 0 of team 0 -> state words 600..
+  unsigned long long dg_wait = 0, dg_mfma = 0, dg_bar1 = 0, dg_epi = 0, dg_bar2 = 0, dg_spins = 0;
+  const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int item = team; item < n_items; item += a.n_teams) {
     const int g = item >> 1, d = item & 1;
     const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
     unsigned* bar = a.state + 16 + item;
     __syncthreads();   // previous item fully done with LDS
     if (loaded_dir != d) {   // this lane's W_hh fragments -> registers (plain loads: weights are never written in this launch)
-      if constexpr (M16) {   // column n = 16 tile + lane % 16 = gate n / 8, unit n % 8; k = 32 wave + 8 (lane / 16) + 0..7
+      // Column order of the member's 32 gate columns: n = 4 unit + gate -- the four gates of a unit side by side, so that the cell
+      // update reads ONE float4 per wave partial (8 LDS reads per thread and step instead of 32).
+      if constexpr (M16) {   // column n = 16 tile + lane % 16; k = 32 wave + 8 (lane / 16) + 0..7
 #pragma unroll
         for (int tile = 0; tile < 2; ++tile) {
           const int n = 16 * tile + (lane & 15);
-          const float* wrow = a.whh[d] + (int64_t)((n >> 3) * H + min(u0 + (n & 7), H - 1)) * H;
+          const float* wrow = a.whh[d] + (int64_t)((n & 3) * H + min(u0 + (n >> 2), H - 1)) * H;
           const int k = wave * 32 + 8 * (lane >> 4);
           wreg[2 * tile] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
           wreg[2 * tile + 1] = k + 4 < H ? *reinterpret_cast<const float4*>(wrow + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       } else {
-      const float* wrow = a.whh[d] + (int64_t)((li >> 3) * H + min(u0 + (li & 7), H - 1)) * H;
+      const float* wrow = a.whh[d] + (int64_t)((li & 3) * H + min(u0 + (li >> 2), H - 1)) * H;
 #pragma unroll
       for (int c = 0; c < CPW; ++c) {
         const int k = (wave * CPW + c) * 8 + 4 * lh;
@@ -659,6 +674,9 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if constexpr (LL && M16) {
+#ifdef SUMK_DIAG
+          const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
           // h_{t-1}[video lane % 16][k .. k+7], k = 32 wave + 8 (lane / 16): four 16-byte loads of {value, tag} pairs, repeated until
           // every tag this lane needs says t
           const bool need_row = t < Tl;
@@ -684,6 +702,10 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
               dead = true;
             }
           }
+#ifdef SUMK_DIAG
+          const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+          dg_wait += st1 - st0; dg_spins += spins;
+#endif
           f32x4 hv[4];
 #pragma unroll
           for (int p = 0; p < 4; ++p) hv[p] = __builtin_bit_cast(f32x4, va[p]);     // {h_k, tag, h_k+1, tag}
@@ -705,8 +727,11 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
 #pragma unroll
           for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(wave * 32 + 4 * (lane >> 4) + r) * 33 + 16 * tile + (lane & 15)] = acc16[tile][r];
+            for (int r = 0; r < 4; ++r) part[(wave * 32 + 4 * (lane >> 4) + r) * PP + 16 * tile + (lane & 15)] = acc16[tile][r];
           (void)acc;
+#ifdef SUMK_DIAG
+          dg_mfma += __builtin_amdgcn_s_memtime() - st1;
+#endif
         } else
         if constexpr (LL) {
           // h_{t-1}[video li][k .. k+3] = two 16-byte loads of {value, tag} pairs, repeated until every tag this lane needs says t
@@ -807,27 +832,34 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
         }
         if constexpr (!M16) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+          for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PP + li] = acc[r];
         }
+#ifdef SUMK_DIAG
+        const unsigned long long sb0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef SUMK_DIAG
+        dg_bar1 += __builtin_amdgcn_s_memtime() - sb0;
+#endif
       }
+#ifdef SUMK_DIAG
+      const unsigned long long se0 = __builtin_amdgcn_s_memtime();
+#endif
       if (erole && t < eT) {
         const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
-        float pre[4];
+        float pre[4] = {gcur[0], gcur[1], gcur[2], gcur[3]};
+        if (t > 0) {
+          float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = gcur[q];
-          if (t > 0) {
-            float ps = 0.f;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) ps += part[(w8 * 32 + ei) * 33 + q * 8 + eu];
-            v += ps;
+          for (int w8 = 0; w8 < 8; ++w8) {     // fixed order: wave 0 .. 7
+            const float4 pw = *reinterpret_cast<const float4*>(&part[(w8 * 32 + ei) * PP + 4 * eu]);
+            ps.x += pw.x; ps.y += pw.y; ps.z += pw.z; ps.w += pw.w;
           }
-          pre[q] = v;
+          pre[0] += ps.x; pre[1] += ps.y; pre[2] += ps.z; pre[3] += ps.w;
         }
-        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+        const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]), gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
         c = fg * c + ig * gg;
-        const float h = og * tanhf(c);
+        const float h = og * fast_tanh(c);
         if constexpr (LL) {
           const unsigned long long pkt = ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, h);
           __hip_atomic_store(a.ll + ((int64_t)((t & 1) * 2 + d) * a.n_seq + (v0 + ei)) * H + j, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -850,7 +882,14 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
         }
       }
       if constexpr (LL) {
+#ifdef SUMK_DIAG
+        const unsigned long long se1 = __builtin_amdgcn_s_memtime();
+        dg_epi += se1 - se0;
+#endif
         __syncthreads();   // the split-K partial tiles in LDS are free again (the published h needs no further signal)
+#ifdef SUMK_DIAG
+        dg_bar2 += __builtin_amdgcn_s_memtime() - se1;
+#endif
       } else {
         // publish step t: every storing wave drains its stores, then one lane signals
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -859,6 +898,12 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
       }
     }
   }
+#ifdef SUMK_DIAG
+  if (LL && M16 && blockIdx.x < 12 && lane == 0 && (wave == 0 || wave == 7)) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(a.state + 600) + (blockIdx.x * 2 + (wave == 7)) * 8;
+    q[0] = __builtin_amdgcn_s_memtime() - dg_t0; q[1] = dg_wait; q[2] = dg_mfma; q[3] = dg_bar1; q[4] = dg_epi; q[5] = dg_bar2; q[6] = dg_spins;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- wide persistent recurrence
@@ -1755,7 +1800,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     int gsize = std::min(gmax, std::max(1, (2 * n_seq + pa.n_teams - 1) / pa.n_teams));
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize;
     if (2 * pa.n_groups <= PSTATE_WORDS - 16 && pa.n_active <= team_size) {
-      const size_t shmem = std::max<size_t>(((size_t)gsize * (H + 4) + 8 * 32 * 33 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
+      const size_t shmem = std::max<size_t>(((size_t)gsize * (H + 4) + 8 * 32 * 32 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
       static const bool direct = !(getenv("SUMK_LSTM_PANEL") && getenv("SUMK_LSTM_PANEL")[0] == '1');   // 1: stage h through LDS
       // SUMK_LSTM_LL=0: the counter hand-off (A/B switch); the flag-in-data one needs the exchange buffer's byte offsets in 31 bits
       static const bool ll_on = !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');
@@ -1775,6 +1820,19 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
       prof_begin(SUMK_PROF_LSTM_REC, stream);
       SUMK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(PK_THREADS), kargs, (unsigned)shmem, stream));
       prof_end(SUMK_PROF_LSTM_REC, stream);
+#ifdef SUMK_DIAG
+      if (getenv("SUMK_LSTM_STAMPS") && m16) {
+        unsigned long long q[12 * 2 * 8];
+        SUMK_HIP(hipStreamSynchronize(stream));
+        SUMK_HIP(hipMemcpy(q, (const char*)(ws + L.pstate) + 600 * 4, sizeof(q), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 12; b += 5)
+          for (int wv = 0; wv < 2; ++wv) {
+            const unsigned long long* e = q + (b * 2 + wv) * 8;
+            fprintf(stderr, "[lstm stamps] block %d wave %d: total %llu  wait %llu (spins %llu)  mfma+part %llu  barrier1 %llu  epilogue %llu  barrier2 %llu\n",
+                    b, wv ? 7 : 0, e[0], e[1], e[6], e[2], e[3], e[4], e[5]);
+          }
+      }
+#endif
       return SUMK_OK;
     }
   }
