@@ -96,7 +96,8 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
     {  // flag-in-data exchange of the H <= 256 BPTT: [step parity 2][item][member 32][video < gsize][H] x {float partial, uint32 step tag}
       const int gsz = std::min(32, std::max(1, (2 * n_seq + 7) / 8));
       const int items = 2 * ((n_seq + gsz - 1) / gsz);
-      w->llb_bytes = H <= 256 ? (size_t)2 * items * 32 * gsz * H * 8 : 0;
+      static const bool ll_bwd = getenv("SUMK_LSTM_LL_BWD") && getenv("SUMK_LSTM_LL_BWD")[0] == '1';   // (opt-in variant: no buffer otherwise)
+      w->llb_bytes = (ll_bwd && H <= 256) ? (size_t)2 * items * 32 * gsz * H * 8 : 0;
       w->llb = take(w->llb_bytes);
     }
     {  // persistent BPTT exchange: [parity 2][item][member 32][video 32][H] partial sums of dh (H <= 256 only)
