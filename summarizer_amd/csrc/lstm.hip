@@ -940,8 +940,11 @@ template <bool X3>
 __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H;
-  float* part = smem;                                     // [8 waves][64 videos][33] split-K partial tiles
-  int* sR0 = reinterpret_cast<int*>(part + 8 * 64 * 33);  // [64] first row of each video
+  // [8 waves][64 videos][PP] split-K partial tiles; gate columns ordered n = 4 unit + gate and PP = 32, so that the cell update reads
+  // ONE conflict-free float4 per wave partial (as in lstm_persist_kernel: the pitch-33 scalar reads of the first version were 8-way)
+  constexpr int PP = 32;
+  float* part = smem;
+  int* sR0 = reinterpret_cast<int*>(part + 8 * 64 * PP);  // [64] first row of each video
   int* sT = sR0 + 64;                                     // [64] length of each video (0 past the group)
   int* sTg = sT + 64;                                     // [1]  longest video of the group
 
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
   float4 wreg[X3 ? 1 : WK_CPW];
   bf16x8 whi[X3 ? NS : 1], wlo[X3 ? NS : 1];
   {
-    const float* wrow = a.whh[d] + (int64_t)((li >> 3) * H + min(u0 + (li & 7), H - 1)) * H;
+    const float* wrow = a.whh[d] + (int64_t)((li & 3) * H + min(u0 + (li >> 2), H - 1)) * H;     // column li = 4 unit + gate
     if constexpr (X3) {
 #pragma unroll
       for (int sidx = 0; sidx < NS; ++sidx) {
@@ -1094,28 +1097,26 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          part[(wave * 64 + row) * 33 + li] = acc0[r];
-          part[(wave * 64 + 32 + row) * 33 + li] = acc1[r];
+          part[(wave * 64 + row) * PP + li] = acc0[r];
+          part[(wave * 64 + 32 + row) * PP + li] = acc1[r];
         }
         __syncthreads();
       }
       if (erole && t < eT) {
         const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
-        float pre[4];
+        float pre[4] = {gcur[0], gcur[1], gcur[2], gcur[3]};
+        if (t > 0) {
+          float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = gcur[q];
-          if (t > 0) {
-            float ps = 0.f;
-#pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) ps += part[(w8 * 64 + ei) * 33 + q * 8 + eu];
-            v += ps;
+          for (int w8 = 0; w8 < 8; ++w8) {     // fixed order: wave 0 .. 7
+            const float4 pw = *reinterpret_cast<const float4*>(&part[(w8 * 64 + ei) * PP + 4 * eu]);
+            ps.x += pw.x; ps.y += pw.y; ps.z += pw.z; ps.w += pw.w;
           }
-          pre[q] = v;
+          pre[0] += ps.x; pre[1] += ps.y; pre[2] += ps.z; pre[3] += ps.w;
         }
-        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+        const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]), gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
         c = fg * c + ig * gg;
-        const float h = og * tanhf(c);
+        const float h = og * fast_tanh(c);
         st_sc1(a.Hout + row * (2 * H) + d * H + j, h);
         if (a.gates) {
           float* gs = a.gates + row * (8 * H) + d * 4 * H;
