@@ -129,6 +129,17 @@ __device__ inline void put_prob(GemmProb* p, int64_t a_off, int64_t b_off, int64
 }
 
 __global__ void vasnet_setup_kernel(SetupArgs a) {
+  if (blockIdx.y >= 2) {   // row -> video table: every row by binary search, rows dealt over the extra blocks (one thread per video writing
+    // its T rows one after the other made this the longest part of the launch)
+    const int n_rows = a.off[a.n_seq];
+    for (int r = (blockIdx.y - 2) * blockDim.x + threadIdx.x; r < n_rows; r += (gridDim.y - 2) * blockDim.x) {
+      if (blockIdx.x != 0) break;
+      int lo = 0, hi = a.n_seq - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.off[mid] <= r) lo = mid; else hi = mid - 1; }
+      a.row_seq[r] = lo;
+    }
+    return;
+  }
   if (blockIdx.y == 1) {
     int i = threadIdx.x;
     if (blockIdx.x == 0 && i < a.n_rowprobs) {
@@ -183,7 +194,6 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   const int64_t po = a.p16 ? e16off : eoff;           // the attention matrix as a GEMM operand
   const int ldp = a.p16 ? ((T + 63) & ~63) : ldE;
   a.seq[s] = si;
-  for (int t = 0; t < T; ++t) a.row_seq[row0 + t] = s;
   const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
   const int n = a.n_seq;
   const int64_t qr = a.fake_seq0 ? 0 : q0;     // where Q / K / V are READ (q0 except in the diagnostic aliasing experiment)
@@ -742,7 +752,7 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   a.rows[RP_DX_W] = a.rows[RP_DX]; a.rows[RP_DX_W].small = 3;
   a.n_rowprobs = 6;
   a.s_tm = gemm_tile_m(G.cfg_s); a.s_tn = gemm_tile_n(G.cfg_s); a.pv_tm = gemm_tile_m(G.cfg_pv); a.pv_tn = gemm_tile_n(G.cfg_pv);
-  hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2 + 32), dim3(64), 0, stream, a);   // y: 0 per-video tables, 1 row problems, 2.. row -> video table
 }
 
 static Drop make_drop(const sumk_vasnet_opts* o) { return make_drop(o->dropout_p, o->seed); }
