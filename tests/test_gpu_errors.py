@@ -20,6 +20,18 @@ def test_status_codes_and_messages():
     assert lib.sumk_gemm_nt(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 6, st) == -1        # K not a multiple of 4
     assert b"multiples of 4" in lib.sumk_last_error()
     assert lib.sumk_gemm_nt(None, a.data_ptr(), a.data_ptr(), 8, 8, 8, st) == -1
+    # bf16-source GEMM: ineligible shapes and bad split-K workspaces are refused with a message, nothing is launched
+    a16 = torch.zeros(128, 128, dtype=torch.bfloat16, device=dev); c32 = torch.zeros(128, 128, device=dev)
+    assert lib.sumk_gemm_bf16src(0, a16.data_ptr(), a16.data_ptr(), c32.data_ptr(), 128, 128, 96, None, 0, st) == -1     # K % 64 for K-contiguous operands
+    assert b"not eligible" in lib.sumk_last_error()
+    assert lib.sumk_gemm_bf16src(2, a16.data_ptr(), a16.data_ptr(), c32.data_ptr(), 100, 128, 128, None, 0, st) == -1   # M % 8 for an M-contiguous operand
+    assert lib.sumk_gemm_bf16src(3, a16.data_ptr(), a16.data_ptr(), c32.data_ptr(), 128, 128, 128, None, 0, st) == -1   # no such layout
+    wsb = torch.zeros(8192 + 128 * 128 * 4, dtype=torch.uint8, device=dev)
+    assert lib.sumk_gemm_bf16src(0, a16.data_ptr(), a16.data_ptr(), c32.data_ptr(), 128, 128, 128, wsb.data_ptr(), wsb.numel(), st) == -1   # split-K is the TN form
+    assert b"TN form" in lib.sumk_last_error()
+    assert lib.sumk_gemm_bf16src(2, a16.data_ptr(), a16.data_ptr(), c32.data_ptr(), 128, 128, 128, wsb.data_ptr(), 1024, st) == -1        # workspace too small
+    assert b"workspace" in lib.sumk_last_error()
+    assert lib.sumk_gemm_bf16src(2, a16.data_ptr(), a16.data_ptr(), c32.data_ptr(), 128, 128, 128, wsb.data_ptr(), wsb.numel(), st) == 0
     off = np.array([0, 5, 5], dtype=np.int32)                                                    # empty video
     assert lib.sumk_vasnet_workspace_bytes(64, 2, _lib.host_i32(off), 0) == 0
     assert b"has 0 frames" in lib.sumk_last_error()
