@@ -84,6 +84,7 @@ _SIGS = {
     "sumk_version": (C.c_int, []),
     "sumk_device_count": (C.c_int, []),
     "sumk_vasnet_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_vasnet_workspace_bytes_for": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32, C.c_int32]),
     "sumk_vasnet_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
                                       C.POINTER(VasnetOpts), c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
                                       C.c_int32, C.c_void_p]),

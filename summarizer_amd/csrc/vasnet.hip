@@ -34,6 +34,7 @@ constexpr int COLSUM_CHUNKS = 128;
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
   size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, row_seq, total;
+  size_t total_core;     // without the bf16 shadows at the end (all a step needs unless it runs on the bf16-source kernels)
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
   // bf16 shadows of the operands of the row-wise GEMMs (training; used when the step runs on the bf16-source kernels)
@@ -88,6 +89,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->slab_elems = (size_t)32 * D * D;
     w->slab = take(w->slab_elems * 4);
     w->prob_sk = take(SPLITK_PROBS * sizeof(GemmProb));
+    w->total_core = p;
     w->x16 = take(R * D * 2);
     w->w16 = take((size_t)5 * D * D * 2);      // [Wq; Wk; Wv] stacked (one 3D x D operand), Wo, W1
     w->ctx16 = take(R * D * 2);
@@ -100,6 +102,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->p16 = take((size_t)e16 * 2);            // per video (T x ld16): alpha (dropped-out alpha) in the forward, dLogits in the backward
   }
   w->total = p;
+  if (!training) w->total_core = p;
   return SUMK_OK;
 }
 
@@ -683,7 +686,7 @@ struct Geometry {  // what both forward and backward derive from the batch
 };
 static bool use_b16(const Geometry& G, int D, int precision, int training);
 
-static int geometry(int D, int n_seq, const int32_t* off, int training, int precision, Geometry* G) {
+static int geometry(int D, int n_seq, const int32_t* off, int training, int precision, size_t workspace_bytes, Geometry* G) {
   SUMK_TRY(carve(D, n_seq, off, training, &G->L));
   G->R = G->L.n_rows;
   G->st_qkv = rowwise_small_tile(G->R, 3 * D);
@@ -698,7 +701,8 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
   if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
   G->t_max = 0;
   for (int s = 0; s < n_seq; ++s) G->t_max = std::max(G->t_max, off[s + 1] - off[s]);
-  G->b16 = use_b16(*G, D, precision, training);
+  // (a workspace sized without the bf16 shadows -- sumk_vasnet_workspace_bytes_for of another arithmetic -- keeps the plane kernels)
+  G->b16 = use_b16(*G, D, precision, training) && workspace_bytes >= G->L.total;
   if (G->b16) G->cfg_s = G->cfg_pv = 0;       // the bf16-source kernel has 128x128 tiles
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
@@ -799,6 +803,11 @@ extern "C" size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const in
   if (carve(D, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
   return w.total;
 }
+extern "C" size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training, int32_t precision) {
+  VasnetWs w;
+  if (carve(D, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
+  return (training && precision == SUMK_PRECISION_BF16) ? w.total : w.total_core;
+}
 
 // Wvo != nullptr: inference with the value and output projections FOLDED (Wvo = Wo . Wv, computed once per weight change by the
 // caller): (alpha V) Wo^T = alpha (X Wv^T Wo^T) = alpha (X Wvo^T), so the third slice of the packed projection is U = X Wvo^T,
@@ -819,10 +828,10 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   SUMK_ARG(opts->dropout_p == 0.f || training, "vasnet_forward: dropout needs training mode");
   SUMK_ARG(opts->precision >= SUMK_PRECISION_FP32 && opts->precision <= SUMK_PRECISION_MAX, "vasnet_forward: unknown precision %d", opts->precision);
   Geometry G;
-  SUMK_TRY(geometry(D, n_seq, seq_off_host, training, opts->precision, &G));
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, training, opts->precision, workspace_bytes, &G));
   const VasnetWs& L = G.L;
-  if (workspace_bytes < L.total) {
-    set_error("vasnet_forward: workspace %zu < required %zu", workspace_bytes, L.total);
+  if (workspace_bytes < (G.b16 ? L.total : L.total_core)) {
+    set_error("vasnet_forward: workspace %zu < required %zu", workspace_bytes, G.b16 ? L.total : L.total_core);
     return SUMK_ERR_WORKSPACE;
   }
   char* ws = (char*)workspace;
@@ -1037,10 +1046,10 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   SUMK_ARG(gr->Wk && gr->Wq && gr->Wv && gr->Wo && gr->W1 && gr->b1 && gr->w2 && gr->b2 && gr->ln_w && gr->ln_b,
            "vasnet_backward: null gradient target");
   Geometry G;
-  SUMK_TRY(geometry(D, n_seq, seq_off_host, 1, opts->precision, &G));
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, 1, opts->precision, workspace_bytes, &G));
   const VasnetWs& L = G.L;
-  if (workspace_bytes < L.total) {
-    set_error("vasnet_backward: workspace %zu < required %zu (needs the training-mode forward's workspace)", workspace_bytes, L.total);
+  if (workspace_bytes < (G.b16 ? L.total : L.total_core)) {
+    set_error("vasnet_backward: workspace %zu < required %zu (needs the training-mode forward's workspace)", workspace_bytes, G.b16 ? L.total : L.total_core);
     return SUMK_ERR_WORKSPACE;
   }
   char* ws = (char*)workspace;

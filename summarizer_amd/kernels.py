@@ -139,9 +139,9 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
         raise SumkError(f"vasnet input must be contiguous (n_rows={sb.n_rows}, D), got {tuple(x.shape)}")
     D = x.shape[1]
     w, o = _vasnet_structs(params, opts)
-    nbytes = lib.sumk_vasnet_workspace_bytes(D, sb.n_seq, sb.off_host_p, int(training))
+    nbytes = lib.sumk_vasnet_workspace_bytes_for(D, sb.n_seq, sb.off_host_p, int(training), int(o.precision))
     if nbytes == 0:
-        _lib.check(-1, "sumk_vasnet_workspace_bytes")
+        _lib.check(-1, "sumk_vasnet_workspace_bytes_for")
     ws = workspace(nbytes, x.device, persistent=training)
     scores = torch.empty(sb.n_rows, dtype=torch.float32, device=x.device)
     if wvo is not None:
