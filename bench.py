@@ -208,6 +208,76 @@ def make_reinforce_step(model, x, lens, dev):
     return run_step, opt
 
 
+def single_video_leg(dev, D=1024, T=300, iters=200):
+    """The reference's OWN calling pattern, driver-timed: ONE TVSum-sized video per forward (models/__init__.py:45-54) and ONE
+    optimiser step per video (vasnet.py:193-212, dsn.py:96-156) -- what `main.py` unchanged runs with the default batch_videos = 1.
+    VASNet and DSN, scoring and training step, each eager (the Python call per video) and as a HIP-graph replay (what the trainers do
+    from their second epoch on: the step of a video captured once, replayed).  us per video and frames/s."""
+    import recipes as R
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import SegmentMseFunction
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.training import FlatAdam
+    x3 = torch.from_numpy(R.features(T, 1, D, 4242)).to(dev)            # (T, 1, D): the reference's input layout
+    x2 = x3.view(T, D)
+    target = torch.rand(T, device=dev)
+    sb = kernels.SeqBatch.get([T], dev)
+
+    def timed(fn, n=iters, warm=20):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    def graphed(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g.replay
+
+    out = {}
+    for name, ctor in (("vasnet", VASNet), ("dsn", DSN)):
+        torch.manual_seed(1234)
+        m = ctor(input_size=D).to(dev).eval()
+        def score():
+            with torch.no_grad():
+                return m(x3)
+        t_eager = timed(score)
+        t_graph = timed(graphed(score))
+        m.train()
+        opt = FlatAdam(m.parameters(), lr=5e-5, weight_decay=1e-5)
+        seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        if name == "vasnet":
+            m.graph_seed = seed
+        def step():
+            opt.zero_grad()
+            loss = SegmentMseFunction.apply(m.score_packed(x2, [T]), target, sb).mean()
+            loss.backward()
+            opt.step(grad_scale=1.0, max_norm=5.0 if name == "dsn" else None)
+            seed.add_(1)
+        tt_eager = timed(step, n=iters // 2, warm=10)
+        tt_graph = timed(graphed(step), n=iters // 2, warm=10)
+        kernels.health_check()
+        rec = lambda t: dict(us_per_video=round(t * 1e6, 1), frames_per_s=round(T / t, 1))
+        out[name] = dict(score_eager=rec(t_eager), score_graph=rec(t_graph), train_step_eager=rec(tt_eager), train_step_graph=rec(tt_graph))
+    out["note"] = (f"one video per call (T={T}, D={D}, fp32), features resident in HBM; score = model.forward((T,1,D)); train step = zero_grad + "
+                   "forward + per-video MSE + backward + fused Adam (DSN: + grad-norm clip), dropout on; graph = the same call captured once "
+                   "into a HIP graph and replayed")
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: THIS process has not touched the GPU yet (torch is imported, nothing is
     initialised), so it starts N fresh rank processes through torch.distributed.run as CHILDREN (never an exec), lets rank 0's JSON
@@ -559,6 +629,12 @@ def main():
             if dist is not None:
                 raise                   # a rank that drops out of a collective leg would leave the others waiting: fail the job
             reinforce_leg = dict(error=f"{type(e).__name__}: {e}"[:300])
+    single = None
+    if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only and rank == 0:
+        try:          # rank 0 only, no collectives inside: the other ranks wait at destroy_process_group
+            single = single_video_leg(dev)
+        except Exception as e:          # noqa: BLE001
+            single = dict(error=f"{type(e).__name__}: {e}"[:300])
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
@@ -594,12 +670,17 @@ def main():
             out["bf16x3_mode"] = alt
             out["folded_vo_mode"] = folded
             out["folded_vo_bf16x6_mode"] = folded6
+        if single is not None:
+            out["single_video_mode"] = single
         if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
             try:
                 out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None, seed_base=1000 * rank)
                 # the headline batch against the oracle port, every video (gate 1e-4): what `value` times is what was checked
                 out["parity_max_abs_diff_vs_port"] = out["cpu_baseline"].pop("parity_max_abs_diff_vs_port")
                 out["parity_gate"] = 1e-4
+                if single is not None and "vasnet" in single and args.model == "vasnet":      # the same one-video-per-call pattern on the host cores
+                    cpu = out["cpu_baseline"]["value"]
+                    single["vasnet"]["score_vs_cpu_port"] = {k: round(single["vasnet"][k]["frames_per_s"] / cpu, 1) for k in ("score_eager", "score_graph")}
             except Exception as e:          # noqa: BLE001
                 out["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         print(json.dumps(out), flush=True)

@@ -68,6 +68,10 @@ typedef struct sumk_vasnet_opts {
      SUMK_PRECISION_BF16X3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: ~2^-16 relative
      per product, scores stay within ~1e-5 of the fp32 path -- DESIGN.md "bf16x3").  Storage is fp32 either way. */
   int32_t precision;
+  /* NULL, or a device word the kernels ADD to `seed` when they run: the masks of a call are then a function of (seed + *seed_dev),
+     read at execution time.  For steps captured into a HIP graph: kernel arguments are frozen at capture, the device word is not --
+     the caller increments it between replays (after the backward pass of a step) and every replay draws fresh masks. */
+  const uint64_t* seed_dev;
 } sumk_vasnet_opts;
 
 /* Bytes of workspace sumk_vasnet_forward / _backward need for this batch (seq_off_host has n_seq+1 entries). */

@@ -31,7 +31,7 @@ class VasnetGrads(C.Structure):
 
 class VasnetOpts(C.Structure):
     _fields_ = [("scale", C.c_float), ("eps", C.c_float), ("ignore_self", C.c_int32), ("aperture", C.c_int32),
-                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32)]
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32), ("seed_dev", C.c_void_p)]
 
 
 class LstmDirWeights(C.Structure):

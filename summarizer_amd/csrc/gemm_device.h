@@ -29,6 +29,8 @@ struct GemmKArgs {
   float* moments;                // EPI_RESIDUAL_MOMENTS: float2[M][N / 32]
   unsigned short* C16;           // EPI_NONE: when set, bf16(C) is stored too, same offsets / leading dimension (operand of a later bf16-source GEMM); C may then be null
   const float* ln_stats; const float* ln_c1; const float* ln_c2;   // EPI_BIAS_RELU_HEAD with the LayerNorm of A applied to the product
+  // SK instances of gemm_lean_kernel (GemmLaunch::sk): run-time epilogue (a GemmEpi), partial tiles, tickets, outputs 1..3
+  int32_t sk_epi; float* sk_part; unsigned* sk_cnt; float* Csel[4];
 };
 
 // Scalar reads of the problem table (CONSTANT address space + wave-uniform index -> s_load, lgkmcnt).  As vector loads they
@@ -58,7 +60,7 @@ struct TileCtx {
 // Which sub-problem / tile does persistent tile id `tile` name?  Wave-uniform scalar work.  Returns false when a remapped
 // (XCD-aware) walk has run past its rectangle.
 template <int BM, int BN>
-__device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileCtx& c, GemmProb& P) {
+__device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileCtx& c, GemmProb& P, int* prob_idx = nullptr) {
   if (ka.group_remap) {
     // Grouped launches number their tiles sub-problem by sub-problem, and block b runs on XCD b % 8 (round-robin dispatch; speed
     // only): dealt as they are, the tiles of one sub-problem land on all eight XCDs and each of the eight private L2s pulls that
@@ -74,6 +76,7 @@ __device__ __forceinline__ bool decode_tile(const GemmKArgs& ka, int tile, TileC
     if (prob_tile_start(ka.probs, mid) <= tile) lo = mid; else hi = mid - 1;
   }
   P = load_prob(ka.probs, lo);
+  if (prob_idx) *prob_idx = lo;
   int mt, nt;
   if (ka.xcd_tiles_m > 0) {
     // XCD-aware map (speed only; correctness never depends on placement).  Blocks b and b+8 share an XCD and its 4 MB
@@ -294,7 +297,8 @@ __device__ __forceinline__ void residual_init(const GemmKArgs& ka, const TileCtx
 }
 
 // gemm_lean.hip: 64x64 exact-fp32 tiles with a VALU-free main loop (NT / NN, plain epilogue) for the per-video products
-int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStream_t stream);
+int launch_gemm_direct(GemmLayout layout, const GemmKArgs& ka, int tiles, int waves, hipStream_t stream);   // gemm_direct.hip: 32x32 tile per workgroup, K over its waves
+int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStream_t stream, int sk = 0);   // sk: the small-batch (in-launch split-K) instances
 // gemm_b16.hip: bf16 operands in HBM (A and B[0] point at bf16 data), fp32 accumulate / output; 128x128 tiles or (192 | 256) x 256
 int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int wide, hipStream_t stream);
 // gemm_split.hip: the register-staged kernel with fp32 operands split into bf16 planes on their way into LDS

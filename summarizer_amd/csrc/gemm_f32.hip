@@ -55,7 +55,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     static const int only_tag = getenv("SUMK_STAMP_TAG") ? atoi(getenv("SUMK_STAMP_TAG")) : -1;
     if (only_tag < 0 || only_tag == g.prof_tag) ka.dbg_buf = gemm_stamp_buffer(); else ka.dbg &= ~2;
   }
-  ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop_site = g.drop_site;
+  ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop.seed_dev = nullptr; ka.drop_site = g.drop_site;
   static const bool lean128_on = !(getenv("SUMK_LEAN128") && getenv("SUMK_LEAN128")[0] == '0');
   ka.lean = (lean128_on && g.lean && g.nprob == 1 && layout == GEMM_NT && g.small_tile == 0 && g.precision == SUMK_PRECISION_FP32 &&
              (g.n_group == 0 || g.n_group % 128 == 0)) ? 1 : 0;
@@ -74,6 +74,21 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (tn % 4 == 0 && tm >= 16) { ka.xcd_tiles_m = tm; ka.total_tiles = 8 * ((tm + 1) / 2) * (tn / 4); }
   }
   int rc;
+  ka.sk_epi = (int32_t)epi; ka.sk_part = g.sk_part; ka.sk_cnt = g.sk_cnt;
+  for (int i = 0; i < 4; ++i) ka.Csel[i] = g.Csel[i];
+  if (g.sk) {   // small-batch launch: in-launch split-K on 64x64 exact-fp32 tiles (gemm_lean.hip, SK instances)
+    SUMK_ARG(g.precision == SUMK_PRECISION_FP32 && g.small_tile == 1 && g.n_group == 0 && !g.src16 && !g.C16 && g.C,
+             "gemm: an SK launch is exact fp32 on 64x64 tiles with one B group per table entry");
+    SUMK_ARG(epi == EPI_NONE || epi == EPI_RESIDUAL || epi == EPI_BIAS_RELU || epi == EPI_ACCUM, "gemm: epilogue %d has no SK form", (int)epi);
+    SUMK_ARG(g.drop_thr == 0, "gemm: SK launches have no epilogue dropout");
+    ka.group_remap = 0; ka.xcd_tiles_m = 0;
+    rc = g.sk == 2 ? launch_gemm_direct(layout, ka, ka.total_tiles, g.dk_waves, stream) : launch_gemm_lean(layout, ka, ka.total_tiles, stream, 1);
+    prof_end(SUMK_PROF_GEMM_ALL, stream);
+    if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
+    if (rc != SUMK_OK) return rc;
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   // 64x64 tiles, plain epilogue, K-contiguous A, exact fp32: the lean kernel (gemm_lean.hip; SUMK_LEAN=0 keeps the generic one)
   static const bool lean_on = !(getenv("SUMK_LEAN") && getenv("SUMK_LEAN")[0] == '0');
   if (lean_on && g.precision == SUMK_PRECISION_FP32 && g.small_tile == 1 && epi == EPI_NONE && (layout == GEMM_NT || layout == GEMM_NN) &&

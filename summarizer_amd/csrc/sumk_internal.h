@@ -32,9 +32,17 @@ struct GemmProb {
   int32_t lda, ldb, ldc, ldr;
   int32_t tile_start;  // first tile id of this problem in the launch
   int32_t tiles_n;     // tiles along N
-  int32_t pad_[7];
+  int32_t pad_[7];     // zero, except in the tables of the small-batch (in-launch split-K) launches: indices SK_* below
 };
 static_assert(sizeof(GemmProb) == 96, "GemmProb layout");
+// GemmProb::pad_ indices read by the SK instances of gemm_lean_kernel (gemm_lean.hip).  An SK table holds one entry per
+// (problem, K slice): a_off / b_off / K describe the slice, M / N / c_off / r_off / ld* the whole problem, and
+//   SK_N     number of K slices of this problem (0 or 1: not split),   SK_IDX  this entry's slice,
+//   SK_TILE0 index of the problem's first tile in the launch's ticket / partial-tile arrays (the same for all its slices),
+//   SK_BSEL  which of GemmLaunch::B[0..3] is this entry's B operand,   SK_CSEL  which of C / Csel[1..3] its output,
+//   SK_PART0 index of the problem's first partial tile: tile j's slice s is partial SK_PART0 + j SK_N + s (problems of one launch may
+//            have different slice counts, so this is not SK_TILE0 x SK_N).
+enum { SK_N = 0, SK_IDX = 1, SK_TILE0 = 2, SK_BSEL = 3, SK_CSEL = 4, SK_PART0 = 5 };
 
 enum GemmLayout { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 enum GemmEpi {
@@ -89,7 +97,28 @@ struct GemmLaunch {
   // v = rstd_r (acc - mean_r c1[n]) + c2[n] + bias0[n] with ln_stats = float2[M] {mean, rstd}, c1[n] = sum_k gamma_k B[n][k],
   // c2[n] = sum_k beta_k B[n][k] -- the LayerNorm is applied to the PRODUCT, the normalised matrix never exists.
   const float* ln_stats = nullptr; const float* ln_c1 = nullptr; const float* ln_c2 = nullptr;
+  // Small-batch launches (gemm_lean.hip, SK instances; 64x64 tiles, exact fp32, NT / NN / TN, epilogues NONE / RESIDUAL /
+  // BIAS_RELU / ACCUM): sk = 1 selects them; `probs` is an SK table (above), total_tiles counts (tile, slice) blocks.  sk_part holds
+  // 4096 floats per (tile, slice), sk_cnt one zeroed word per tile (the reducer leaves it zero again); Csel[1..3] are the outputs
+  // entries with SK_CSEL = 1..3 write (C is output 0).
+  int32_t sk = 0; float* sk_part = nullptr; unsigned* sk_cnt = nullptr; float* Csel[4] = {nullptr, nullptr, nullptr, nullptr};
+  // sk = 2: the direct small-batch kernel (gemm_direct.hip): ONE 32x32 tile per workgroup, K split over its dk_waves waves (in-block
+  // LDS reduce); `probs` counts 32x32 tiles (no K slices: SK_N = 0), the SK_BSEL / SK_CSEL choices and the run-time epilogues apply.
+  int32_t dk_waves = 1;
 };
+int gemm_direct_waves(int tiles, int K);     // waves per tile for a launch of `tiles` 32x32 tiles contracting over K
+// K slices for an SK launch of `tiles` 64x64 tiles contracting over K: enough (tile, slice) blocks for ~3-4 per CU, slices of whole
+// 32-wide k-tiles, at least four k-tiles each, at most SK_MAX_SLICES.  Returns S and the slice length in *kchunk.
+constexpr int SK_MAX_SLICES = 8;
+inline int sk_slices(int tiles, int K, int* kchunk) {
+  int S = tiles > 0 ? 1024 / tiles : 1;
+  S = S < 1 ? 1 : S > SK_MAX_SLICES ? SK_MAX_SLICES : S;
+  if (S > K / 128) S = K / 128 < 1 ? 1 : K / 128;
+  int kc = ((K + S - 1) / S + 31) / 32 * 32;
+  S = (K + kc - 1) / kc;
+  *kchunk = kc;
+  return S;
+}
 
 // number of tiles an (M,N) problem takes with the chosen tile size
 inline int gemm_tile_m(int cfg) { return cfg == 1 ? 64 : 128; }
@@ -166,15 +195,35 @@ inline uint32_t dropout_threshold(float p) {
 }
 struct Drop {  // dropout descriptor of one call; thr == 0 means "no dropout"
   uint64_t seed; uint32_t thr; float scale;
+  // non-null: the kernels add this device word to `seed` when they run (drop_resolve) -- a step captured into a HIP graph then draws
+  // fresh masks on every replay, the caller bumping the word between replays (sumk_vasnet_opts::seed_dev)
+  const uint64_t* seed_dev;
 };
+__device__ __forceinline__ Drop drop_resolve(Drop d) {
+  if (d.thr && d.seed_dev) d.seed += *d.seed_dev;
+  d.seed_dev = nullptr;
+  return d;
+}
 inline Drop make_drop(float p, uint64_t seed) {
-  Drop d; d.seed = seed; d.thr = 0; d.scale = 1.f;
+  Drop d; d.seed = seed; d.thr = 0; d.scale = 1.f; d.seed_dev = nullptr;
   if (p > 0.f) { d.thr = dropout_threshold(p); d.scale = 1.0f / (1.0f - p); }
   return d;
 }
 __host__ __device__ inline float drop_apply(const Drop& d, uint32_t site, uint64_t idx, float v) {
   return dropout_keep(d.seed, site, idx, d.thr) ? v * d.scale : 0.f;
 }
+
+// Optional pre-reduction of a row kernel's input (small-batch path: the producing GEMM was cut into K slices that each stored their
+// own slab with plain stores -- no in-launch reduction, no tickets -- and the row kernel that consumes the matrix anyway adds them):
+//   value(r, c) = sum_{s < n} X[s * stride + r * ld + c]  (slab order)  [+ add[r * ld + c]]  [+ bias[c]]  [relu]
+// n <= 1 and no add / bias: X is read as is.  `store` (same shape as one slab) receives the reduced value -- what a later kernel
+// (the backward pass) reads as the matrix itself.
+struct SlabIn {
+  int32_t n = 0; int32_t relu = 0;
+  int64_t stride = 0;
+  const float* add = nullptr; const float* bias = nullptr;
+  float* store = nullptr;
+};
 
 // ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
 // Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.

@@ -42,7 +42,20 @@ struct VasnetWs {
   size_t slab_elems;
   int64_t e_elems;
   int32_t n_rows;
+  // small-batch path (SK launches, gemm_lean.hip): partial tiles, tickets, sliced problem tables -- present when sk_rows_ok(n_rows)
+  size_t sk_part, sk_cnt, sk_tabs;
 };
+
+// ---- small-batch path: every GEMM of the step as an in-launch split-K launch on 64x64 tiles (gemm_lean.hip, SK instances) ----
+// Taken for batches of at most SK_MAX_ROWS frames (one to three TVSum-sized videos: the reference's one-video-per-call pattern),
+// exact fp32 only.  Summation order differs from the large-batch kernels (K slices added in slice order), so scores agree with
+// them to fp32 rounding (~1e-7), not bit for bit; each path is deterministic and independent of what else is in the batch.
+constexpr int SK_MAX_ROWS = 1024;
+constexpr int SK_TICKETS = 4096;
+// row-wise SK tables (entries: groups x slices each) and where they start in the table region, in entries
+enum { SR_QKV = 0, SR_OPROJ, SR_K1, SR_DY1, SR_DCTX, SR_DWO, SR_DW1, SR_DWQKV, SR_COUNT };
+constexpr int SK_ROW_ENTRIES = 3 * SK_MAX_SLICES;
+static inline bool sk_rows_ok(int64_t R) { return R <= SK_MAX_ROWS; }
 
 static inline int round4(int v) { return (v + 3) & ~3; }
 
@@ -77,6 +90,16 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
   w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = w->qkv16 = w->dctx16 = w->p16 = 0;
+  w->sk_part = w->sk_cnt = w->sk_tabs = 0;
+  auto take_sk = [&]() {     // small-batch path: inside the core size (every arithmetic's workspace holds it)
+    if (!sk_rows_ok((int64_t)R)) return;
+    w->sk_cnt = take((size_t)SK_TICKETS * 4);
+    // scratch of the SK launches: partial tiles of the slices that meet inside a launch, or the K-slice slabs a row kernel adds
+    // (partial tiles: 4 slices of the QKV projection or 8 of a (R, D) one -- sk_plan's caps; slabs: 8 of (R, D) or of the E layout)
+    const size_t t64 = (R + 63) / 64, part_tiles = std::max(4 * t64 * ((3 * (size_t)D + 63) / 64), 8 * t64 * (((size_t)D + 63) / 64)) + 64;
+    w->sk_part = take(std::max(part_tiles * 64 * 64, (size_t)SK_MAX_SLICES * std::max(R * (size_t)D, (size_t)e)) * 4);
+    w->sk_tabs = take(((size_t)SR_COUNT * SK_ROW_ENTRIES + (size_t)TB_COUNT * n_seq * SK_MAX_SLICES) * sizeof(GemmProb));
+  };
   if (training) {
     w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
     w->dz = take(R * D * 4);
@@ -89,6 +112,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->slab_elems = (size_t)32 * D * D;
     w->slab = take(w->slab_elems * 4);
     w->prob_sk = take(SPLITK_PROBS * sizeof(GemmProb));
+    take_sk();
     w->total_core = p;
     w->x16 = take(R * D * 2);
     w->w16 = take((size_t)5 * D * D * 2);      // [Wq; Wk; Wv] stacked (one 3D x D operand), Wo, W1
@@ -101,6 +125,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->dctx16 = take(R * D * 2);
     w->p16 = take((size_t)e16 * 2);            // per video (T x ld16): alpha (dropped-out alpha) in the forward, dLogits in the backward
   }
+  if (!training) take_sk();
   w->total = p;
   if (!training) w->total_core = p;
   return SUMK_OK;
@@ -211,6 +236,126 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   put_prob(a.tabs + TB_DK * n + s, po, q0, q0 + D, T, D, T, ldp, 3 * D, 3 * D, tpv, tn);             // dK = dS^T Q      (TN)
 }
 
+
+__device__ __forceinline__ int find_seq(const int32_t* off, int n_seq, int row) {
+  int lo = 0, hi = n_seq - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------- small-batch (SK) tables
+// K slices of ONE problem contracting over K when its launch asked for S_req: slices of whole 32-wide k-tiles (host: sk_slices)
+__host__ __device__ inline void sk_slice(int K, int S_req, int* kc, int* S) {
+  const int c = ((K + S_req - 1) / S_req + 31) / 32 * 32;
+  *kc = c; *S = (K + c - 1) / c;
+}
+// ... of one VIDEO's sub-problem in per-video table t: at most S_req, never slices shorter than four k-tiles
+__host__ __device__ inline void sk_slice_seq(int K, int S_req, int* kc, int* S) {
+  int r = K / 128; r = r < 1 ? 1 : r; r = r < S_req ? r : S_req;
+  sk_slice(K, r, kc, S);
+}
+// (M, N, K) of video T's sub-problem in per-video table t
+__host__ __device__ inline void sk_seq_dims(int t, int T, int D, int* M, int* N, int* K) {
+  if (t == TB_S || t == TB_DP) { *M = T; *N = T; *K = D; } else { *M = T; *N = D; *K = T; }
+}
+struct SkTab { int entries, blocks, tiles, S_req, S; };    // table entries, (tile, slice) blocks, tiles (= tickets), requested slices, slices of a K = S_req-defining problem
+// per group g: a_off = g a_goff, c_off = g c_goff, B / C pointer g when bsel / csel.  slab != 0: slice s stores its own (M x N) matrix
+// at c_off + s slab with a plain epilogue (no tickets: the consuming ROW kernel adds the slabs, SlabIn) instead of meeting the other
+// slices in the launch.
+struct SkRowSpec { int32_t M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel; int64_t slab; };
+struct SkSetupArgs {
+  const int32_t* off; int32_t n_seq, D;
+  SeqInfo* seq; int32_t* row_seq; unsigned* cnt;
+  GemmProb* tabs;                    // [SR_COUNT][SK_ROW_ENTRIES], then [TB_COUNT][n_seq * SK_MAX_SLICES]
+  SkRowSpec rows[SR_COUNT];
+  int32_t S_seq[TB_COUNT];
+  int64_t slab_seq[TB_COUNT];        // per-video tables: slab stride of the sliced output (0: the slices meet in the launch)
+  int32_t tile;                      // tile edge the tables count in: 64 (gemm_lean.hip SK instances) or 32 (gemm_direct.hip)
+};
+static inline GemmProb* sk_row_tab(GemmProb* tabs, int r) { return tabs + (size_t)r * SK_ROW_ENTRIES; }
+static inline GemmProb* sk_seq_tab(GemmProb* tabs, int t, int n_seq) { return tabs + (size_t)SR_COUNT * SK_ROW_ENTRIES + (size_t)t * n_seq * SK_MAX_SLICES; }
+
+__device__ inline void put_sk(GemmProb* tab, int ent0, int blk0, int tile0, int layout, int64_t a_off, int64_t b_off, int64_t c_off,
+                              int M, int N, int K, int lda, int ldb, int ldc, int ldr, int S_req, int bsel, int csel, int te, int64_t slab,
+                              bool per_video = true) {
+  const int tn = (N + te - 1) / te, tiles = ((M + te - 1) / te) * tn;
+  int kc, S;
+  if (per_video) sk_slice_seq(K, S_req, &kc, &S); else sk_slice(K, S_req, &kc, &S);
+  for (int sl = 0; sl < S; ++sl) {
+    const int k0 = sl * kc;
+    GemmProb q;
+    q.a_off = a_off + (layout == GEMM_TN ? (int64_t)k0 * lda : (int64_t)k0);
+    q.b_off = b_off + (layout == GEMM_NT ? (int64_t)k0 : (int64_t)k0 * ldb);
+    q.c_off = c_off + sl * slab; q.r_off = c_off;         // (the residual, where there is one, has the layout of C)
+    q.M = M; q.N = N; q.K = min(kc, K - k0); q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldr = ldr;
+    q.tile_start = blk0 + sl * tiles; q.tiles_n = tn;
+    for (int i = 0; i < 7; ++i) q.pad_[i] = 0;
+    q.pad_[SK_N] = (S > 1 && slab == 0) ? S : 0; q.pad_[SK_IDX] = sl; q.pad_[SK_TILE0] = tile0; q.pad_[SK_BSEL] = bsel; q.pad_[SK_CSEL] = csel; q.pad_[SK_PART0] = blk0;
+    tab[ent0 + sl] = q;
+  }
+}
+
+// One launch per call: SeqInfo, the row -> video table, zeroed tickets and every sliced problem table of the step.
+__global__ void vasnet_sk_setup_kernel(SkSetupArgs a) {
+  const int n_rows = a.off[a.n_seq];
+  if (blockIdx.y >= 2) {   // row -> video table, tickets
+    const int i0 = (blockIdx.y - 2) * blockDim.x + threadIdx.x, stride = (gridDim.y - 2) * blockDim.x;
+    for (int r = i0; r < n_rows; r += stride) a.row_seq[r] = find_seq(a.off, a.n_seq, r);
+    for (int i = i0; i < SK_TICKETS; i += stride) a.cnt[i] = 0u;
+    return;
+  }
+  if (blockIdx.y == 1) {   // row-wise tables: one thread per table
+    const int r = threadIdx.x;
+    if (r >= SR_COUNT) return;
+    const SkRowSpec sp = a.rows[r];
+    if (sp.groups <= 0) return;
+    GemmProb* tab = a.tabs + (size_t)r * SK_ROW_ENTRIES;
+    const int te = a.tile;
+    const int tiles = ((sp.M + te - 1) / te) * ((sp.N + te - 1) / te);
+    int kc, S;
+    sk_slice(sp.K, sp.S_req, &kc, &S);
+    for (int g = 0; g < sp.groups; ++g)
+      put_sk(tab, g * S, g * S * tiles, g * tiles, sp.layout, (int64_t)g * sp.a_goff, 0, (int64_t)g * sp.c_goff, sp.M, sp.N, sp.K, sp.lda, sp.ldb,
+             sp.ldc, sp.ldr, sp.S_req, sp.bsel ? g : 0, sp.csel ? g : 0, te, sp.slab, false);
+    return;
+  }
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_seq) return;
+  const int D = a.D;
+  int64_t eoff = 0, e16off = 0;
+  int ent[TB_COUNT], blk[TB_COUNT], til[TB_COUNT];
+  for (int t = 0; t < TB_COUNT; ++t) ent[t] = blk[t] = til[t] = 0;
+  for (int q = 0; q < s; ++q) {
+    const int T = a.off[q + 1] - a.off[q];
+    eoff += (int64_t)T * ((T + 3) & ~3);
+    e16off += (int64_t)T * ((T + 63) & ~63);
+    for (int t = 0; t < TB_COUNT; ++t) {
+      int M, N, K, kc, S;
+      sk_seq_dims(t, T, D, &M, &N, &K);
+      sk_slice_seq(K, a.S_seq[t], &kc, &S);
+      const int tiles = ((M + a.tile - 1) / a.tile) * ((N + a.tile - 1) / a.tile);
+      ent[t] += S; blk[t] += S * tiles; til[t] += tiles;
+    }
+  }
+  const int row0 = a.off[s], T = a.off[s + 1] - a.off[s], ldE = (T + 3) & ~3;
+  SeqInfo si; si.eoff = eoff; si.row0 = row0; si.T = T; si.ldE = ldE; si.pad_ = 0; si.e16off = e16off;
+  a.seq[s] = si;
+  const int64_t q0 = (int64_t)row0 * 3 * D, c0 = (int64_t)row0 * D;
+  GemmProb* base = a.tabs + (size_t)SR_COUNT * SK_ROW_ENTRIES;
+  const size_t cap = (size_t)a.n_seq * SK_MAX_SLICES;
+  // forward (operands as in vasnet_setup_kernel)
+  put_sk(base + TB_S * cap, ent[TB_S], blk[TB_S], til[TB_S], GEMM_NT, q0, q0 + D, eoff, T, T, D, 3 * D, 3 * D, ldE, 0, a.S_seq[TB_S], 0, 0, a.tile, a.slab_seq[TB_S]);           // E = Q K^T
+  put_sk(base + TB_PV * cap, ent[TB_PV], blk[TB_PV], til[TB_PV], GEMM_NN, eoff, q0 + 2 * D, c0, T, D, T, ldE, 3 * D, D, D, a.S_seq[TB_PV], 0, 0, a.tile, a.slab_seq[TB_PV]);     // C = alpha V
+  // backward
+  put_sk(base + TB_DV * cap, ent[TB_DV], blk[TB_DV], til[TB_DV], GEMM_TN, eoff, c0, q0 + 2 * D, T, D, T, ldE, D, 3 * D, 0, a.S_seq[TB_DV], 0, 0, a.tile, a.slab_seq[TB_DV]);     // dV = alpha^T dC
+  put_sk(base + TB_DP * cap, ent[TB_DP], blk[TB_DP], til[TB_DP], GEMM_NT, c0, q0 + 2 * D, eoff, T, T, D, D, 3 * D, ldE, 0, a.S_seq[TB_DP], 0, 0, a.tile, a.slab_seq[TB_DP]);     // dAlpha = dC V^T
+  put_sk(base + TB_DQ * cap, ent[TB_DQ], blk[TB_DQ], til[TB_DQ], GEMM_NN, eoff, q0 + D, q0, T, D, T, ldE, 3 * D, 3 * D, 0, a.S_seq[TB_DQ], 0, 0, a.tile, a.slab_seq[TB_DQ]);     // dQ = dS K
+  put_sk(base + TB_DK * cap, ent[TB_DK], blk[TB_DK], til[TB_DK], GEMM_TN, eoff, q0, q0 + D, T, D, T, ldE, 3 * D, 3 * D, 0, a.S_seq[TB_DK], 0, 0, a.tile, a.slab_seq[TB_DK]);     // dK = dS^T Q
+}
+
 // ------------------------------------------------------------------------------------------- wave helpers
 // four consecutive bf16 (round to nearest even, v_cvt_pk_bf16_f32 -- what the plane GEMM kernels do to the same fp32 values)
 __device__ __forceinline__ void store_bf16x4(unsigned short* p, float4 v) {
@@ -230,13 +375,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ int find_seq(const int32_t* off, int n_seq, int row) {
-  int lo = 0, hi = n_seq - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (off[mid] <= row) lo = mid; else hi = mid - 1;
-  }
-  return lo;
+// Sum of n K-slice slabs (SlabIn), slab order, with all n loads in flight: n is kernel-uniform and one of 1, 2, 4, 8 (the host
+// only builds such slab sets: sk_plan), so each case is a fully unrolled run of independent loads behind ONE scalar branch.  (A
+// run-time trip count made these loads -- and the row kernels -- a chain of n dependent round trips: softmax 5.8 -> 13.5 us.)
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float add4(float a, float b) { return a + b; }
+template <int NS, typename V>
+__device__ __forceinline__ V slab_sum_n(const V* p, int64_t stride) {
+  V t[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) t[s] = p[s * stride];
+  V v = t[0];
+#pragma unroll
+  for (int s = 1; s < NS; ++s) v = add4(v, t[s]);
+  return v;
+}
+template <typename V>
+__device__ __forceinline__ V slab_sum(const V* p, int n, int64_t stride) {    // stride in units of V
+  if (n <= 1) return p[0];
+  if (n == 2) return slab_sum_n<2, V>(p, stride);
+  if (n == 4) return slab_sum_n<4, V>(p, stride);
+  return slab_sum_n<8, V>(p, stride);
 }
 
 // Masked, scaled logit exactly as vasnet.py:119-127 produces it.
@@ -257,10 +416,14 @@ __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int
 // can stream K in float4 units.  Training with dropout (vasnet.py:130) also writes dropout(alpha) to E2.
 // NR > 0: the row (T <= 64 * NR keys) is held in registers -- one read of the logits, one exp per element, one write.  NR == 0:
 // any length, three passes over the (L2-resident) row.  Same operations per element either way, so the results are identical.
+// Eraw / n_slab / slab_stride: where the raw logits are read -- E itself (n_slab <= 1), or n_slab K-slice slabs of the E layout
+// (small-batch path, SlabIn) that are added in slab order on load.
 template <int NR>
 __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2, const SeqInfo* seq, const int32_t* off,
                                                              int n_seq, int n_rows, float scale, int ignore_self,
-                                                             int aperture, Drop drop, unsigned short* P16) {
+                                                             int aperture, Drop drop_in, unsigned short* P16,
+                                                             const float* Eraw, int n_slab, int64_t slab_stride) {
+  const Drop drop = drop_resolve(drop_in);
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -269,6 +432,8 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   const int i = row - si.row0, T = si.T;
   float* e = E + si.eoff + (int64_t)i * si.ldE;
   float* e2 = E2 ? E2 + si.eoff + (int64_t)i * si.ldE : nullptr;
+  const float* er = Eraw + si.eoff + (int64_t)i * si.ldE;
+  auto raw = [&](int j) { return slab_sum(er + j, n_slab, slab_stride); };
   // P16: the matrix the alpha.V / alpha^T.dC products read (dropout(alpha) when there is dropout), as bf16 with the row zero-padded
   // to ld16 = a whole number of 64-wide k-tiles
   const int ld16 = (T + 63) & ~63;
@@ -279,7 +444,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int j = lane + 64 * r;
-      v[r] = j < T ? masked_logit(e[j], scale, i, j, ignore_self, aperture) : -INFINITY;
+      v[r] = j < T ? masked_logit(raw(j), scale, i, j, ignore_self, aperture) : -INFINITY;
       m = fmaxf(m, v[r]);
     }
     m = wave_max(m);
@@ -306,14 +471,14 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
     return;
   }
   float m = -INFINITY;
-  for (int j = lane; j < T; j += 64) m = fmaxf(m, masked_logit(e[j], scale, i, j, ignore_self, aperture));
+  for (int j = lane; j < T; j += 64) m = fmaxf(m, masked_logit(raw(j), scale, i, j, ignore_self, aperture));
   m = wave_max(m);
   float sum = 0.f;
-  for (int j = lane; j < T; j += 64) sum += expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m);
+  for (int j = lane; j < T; j += 64) sum += expf(masked_logit(raw(j), scale, i, j, ignore_self, aperture) - m);
   sum = wave_sum(sum);
   for (int j = lane; j < (p16 ? ld16 : si.ldE); j += 64) {
     float v = 0.f;
-    if (j < T) v = expf(masked_logit(e[j], scale, i, j, ignore_self, aperture) - m) / sum;
+    if (j < T) v = expf(masked_logit(raw(j), scale, i, j, ignore_self, aperture) - m) / sum;
     float vd = v;
     if (e2 && drop.thr && j < T) vd = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, v);
     if (j < si.ldE) {
@@ -327,7 +492,9 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
 // dLogits(raw) = scale * alpha * (dAlpha - sum_j dAlpha_j alpha_j), dAlpha = dropout'(dAlphaDropped).  In place on E2.
 __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E, float* E2, const SeqInfo* seq,
                                                                  const int32_t* off, int n_seq, int n_rows, float scale,
-                                                                 Drop drop, unsigned short* S16) {   // S16: bf16(dLogits), rows zero-padded to ld16
+                                                                 Drop drop_in, unsigned short* S16,  // S16: bf16(dLogits), rows zero-padded to ld16
+                                                                 const float* Graw, int n_slab, int64_t slab_stride) {   // the incoming dAlphaD: E2 itself, or K-slice slabs (SlabIn)
+  const Drop drop = drop_resolve(drop_in);
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
@@ -336,9 +503,11 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
   const int i = row - si.row0, T = si.T;
   const float* p = E + si.eoff + (int64_t)i * si.ldE;
   float* g = E2 + si.eoff + (int64_t)i * si.ldE;
+  const float* gr = Graw + si.eoff + (int64_t)i * si.ldE;
+  auto gin = [&](int j) { return slab_sum(gr + j, n_slab, slab_stride); };
   float dot = 0.f;
   for (int j = lane; j < T; j += 64) {
-    float d = g[j];
+    float d = gin(j);
     if (drop.thr) d = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d);
     dot += d * p[j];
   }
@@ -348,7 +517,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
   for (int j = lane; j < (s16 ? ld16 : si.ldE); j += 64) {
     float v = 0.f;
     if (j < T) {
-      float d = g[j];
+      float d = gin(j);
       if (drop.thr) d = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d);
       v = p[j] * (d - dot) * scale;
     }
@@ -368,15 +537,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ scores, int n_rows, int D, float eps,
-                                                        float* __restrict__ stats, Drop drop, uint32_t site,
-                                                        unsigned short* __restrict__ Y16) {   // !HEAD: bf16(y) too (Y may then be null)
+                                                        float* __restrict__ stats, Drop drop_in, uint32_t site,
+                                                        unsigned short* __restrict__ Y16,     // !HEAD: bf16(y) too (Y may then be null)
+                                                        SlabIn sl) {                          // small-batch path: X = K-slice slabs (+ residual / bias, ReLU)
+  const Drop drop = drop_resolve(drop_in);
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
   const float4* x4 = reinterpret_cast<const float4*>(X + (int64_t)row * D);
   const int D4 = D >> 2;
   auto ld = [&](int c) {
-    float4 v = x4[c];
+    float4 v = slab_sum(x4 + c, sl.n, sl.stride >> 2);
+    if (sl.n > 1 || sl.add || sl.bias) {     // kernel-uniform
+      if (sl.add) { const float4 t = reinterpret_cast<const float4*>(sl.add + (int64_t)row * D)[c]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (sl.bias) { const float4 t = reinterpret_cast<const float4*>(sl.bias)[c]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      if (sl.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }   // NaN-propagating, like torch.relu
+      if (sl.store) reinterpret_cast<float4*>(sl.store + (int64_t)row * D)[c] = v;
+    }
     if (drop.thr) {
       uint64_t base = (uint64_t)row * D + 4 * c;
       v.x = drop_apply(drop, site, base, v.x); v.y = drop_apply(drop, site, base + 1, v.y);
@@ -524,10 +701,10 @@ __global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restr
 template <bool HEAD>
 static void launch_ln_rows(const float* X, float* Y, const float* g, const float* b, const float* w2, const float* b2, float* scores,
                            int n_rows, int D, float eps, float* stats, Drop drop, uint32_t site, hipStream_t stream,
-                           unsigned short* y16 = nullptr) {
+                           unsigned short* y16 = nullptr, SlabIn sl = SlabIn()) {
   const dim3 grid((n_rows + 3) / 4), block(256);
   const int D4 = D >> 2;
-#define SUMK_LN(NQ) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site, y16)
+#define SUMK_LN(NQ) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site, y16, sl)
   if (D4 <= 64) SUMK_LN(1); else if (D4 <= 128) SUMK_LN(2); else if (D4 <= 256) SUMK_LN(4); else if (D4 <= 512) SUMK_LN(8); else SUMK_LN(0);
 #undef SUMK_LN
 }
@@ -546,8 +723,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dY, const float* __restrict__ w2,
                                                             const float* __restrict__ scores,
                                                             const float* __restrict__ dscores, float* __restrict__ dX,
-                                                            float* __restrict__ part, int n_rows, int D, Drop drop,
-                                                            uint32_t site, unsigned short* __restrict__ dX16) {   // bf16(dX) too (dX may then be null)
+                                                            float* __restrict__ part, int n_rows, int D, Drop drop_in,
+                                                            uint32_t site, unsigned short* __restrict__ dX16,     // bf16(dX) too (dX may then be null)
+                                                            int n_slab, int64_t slab_stride) {                    // !HEAD: dY = n_slab K-slice slabs added on load (SlabIn)
+  const Drop drop = drop_resolve(drop_in);
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * 4;
@@ -598,7 +777,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           aw[q].x += du * (h.x * gg.x + bv.x); aw[q].y += du * (h.y * gg.y + bv.y);
           aw[q].z += du * (h.z * gg.z + bv.z); aw[q].w += du * (h.w * gg.w + bv.w);
         } else {
-          dy = reinterpret_cast<const float4*>(dY + (int64_t)row * D)[c];
+          dy = slab_sum(reinterpret_cast<const float4*>(dY + (int64_t)row * D) + c, n_slab, slab_stride >> 2);
         }
         ag[q].x += dy.x * h.x; ag[q].y += dy.y * h.y; ag[q].z += dy.z * h.z; ag[q].w += dy.w * h.w;
         ab[q].x += dy.x; ab[q].y += dy.y; ab[q].z += dy.z; ab[q].w += dy.w;
@@ -679,12 +858,82 @@ static int rowwise_small_tile(int M, int N) {
   return gemm_tiles(M, N, 0) >= 512 ? 0 : 1;
 }
 
+struct SkPlan { SkTab row[SR_COUNT], seq[TB_COUNT]; SkRowSpec spec[SR_COUNT]; int tile, row_waves[SR_COUNT], seq_waves[TB_COUNT]; int64_t slab_seq[TB_COUNT]; };
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
   int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv, t_max;
   bool b16;          // the mixed-precision training step on the bf16-source kernels (use_b16)
+  int sk;            // the small-batch path (use_sk): 0 off; 2 every GEMM on gemm_direct.hip (32x32 tile per workgroup, K over its waves);
+                     // 1 the in-launch split-K instances of gemm_lean.hip (the first build of this path, kept for the A/B measurement); P = its tables
+  SkPlan P;
 };
 static bool use_b16(const Geometry& G, int D, int precision, int training);
+
+// Small-batch path (SK launches): a function of the batch geometry and the arithmetic only -- forward and backward must agree.
+// SUMK_SK=0 keeps the large-batch kernels for every batch (the A/B switch of tests/test_gpu_vasnet.py::test_small_batch_path_...).
+static int use_sk(int R, int D, int precision) {
+  static const int mode = getenv("SUMK_SK") ? atoi(getenv("SUMK_SK")) : 1;
+  return (mode == 1 || mode == 2) && precision == SUMK_PRECISION_FP32 && sk_rows_ok(R) && D % 4 == 0 ? mode : 0;
+}
+// Every table of the step: requested slices, entries, (tile, slice) blocks and tickets -- the host mirror of vasnet_sk_setup_kernel.
+static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, int64_t e_elems, SkPlan* P) {
+  const int te = direct ? 32 : 64;        // direct: 32x32 tiles, K split over the waves of a workgroup (no table slices)
+  P->tile = te;
+  // slab: the output's consumer is a row kernel that adds K-slice slabs on load (SlabIn) -- the slices then need no in-launch meeting
+  // Slice counts are a function of the contraction length alone (smax > 0: min(smax, K / 128) slices of at least four k-tiles) wherever K
+  // is a property of the model or of one video -- a video's scores and the gradients it contributes then do not depend on what else
+  // is in the batch, exactly as on the large-batch path.  Only the weight gradients, which contract over ALL rows of the batch, are
+  // sliced by launch size (smax = 0).
+  auto row = [&](int r, int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int groups, int a_goff, int c_goff, int bsel, int csel, int smax, bool slab = false) {
+    const int tiles = ((M + te - 1) / te) * ((N + te - 1) / te);
+    int kc, S;
+    int S_req = direct ? 1 : smax > 0 ? std::max(1, std::min(smax, K / 128)) : sk_slices(tiles * groups, K, &kc);
+    if (slab && !direct) for (S_req = 8; S_req > 1; S_req >>= 1) {        // slab sets: exactly 1, 2, 4 or 8 slices (slab_sum), each at least four k-tiles
+      sk_slice(K, S_req, &kc, &S);
+      if (S == S_req && kc >= 128) break;
+    }
+    sk_slice(K, S_req, &kc, &S);
+    P->row_waves[r] = direct ? gemm_direct_waves(tiles * groups, K) : 0;
+    P->spec[r] = SkRowSpec{M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel, (slab && !direct) ? (int64_t)M * ldc : 0};
+    P->row[r] = SkTab{groups * S, groups * S * tiles, groups * tiles, S_req, S};
+  };
+  row(SR_QKV, GEMM_NT, R, D, D, D, D, 3 * D, 0, 3, 0, D, 1, 0, 4);          // [Q|K|V] = X [Wq;Wk;Wv]^T: group g = B pointer g, columns g D..
+  row(SR_OPROJ, GEMM_NT, R, D, D, D, D, D, D, 1, 0, 0, 0, 0, 8, true);      // Y0 = CTX Wo^T + X        (slabs -> LayerNorm kernel, which adds X)
+  row(SR_K1, GEMM_NT, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8, true);         // Z = relu(Y1 W1^T + b1)   (slabs -> LayerNorm + head kernel: + b1, ReLU)
+  row(SR_DY1, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8, true);        // dY1 = dZ W1              (slabs -> LayerNorm backward kernel)
+  row(SR_DCTX, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8);             // dCTX = dY0 Wo
+  row(SR_DWO, GEMM_TN, D, D, R, D, D, D, 0, 1, 0, 0, 0, 0, 0);              // dWo += dY0^T CTX
+  row(SR_DW1, GEMM_TN, D, D, R, D, D, D, 0, 1, 0, 0, 0, 0, 0);              // dW1 += dZ^T Y1
+  row(SR_DWQKV, GEMM_TN, D, D, R, 3 * D, D, D, 0, 3, D, 0, 0, 1, 0);        // d[Wq;Wk;Wv] += dQKV^T X: group g = columns g D.. of dQKV, output g
+  for (int t = 0; t < TB_COUNT; ++t) {
+    int tiles = 0, k_sum = 0;
+    for (int q = 0; q < n_seq; ++q) {
+      int M, N, K;
+      sk_seq_dims(t, off[q + 1] - off[q], D, &M, &N, &K);
+      tiles += ((M + te - 1) / te) * ((N + te - 1) / te); k_sum += K;
+    }
+    int kc;
+    // (per-video products: the request is the cap; vasnet_sk_setup_kernel / sk_slice_seq give a video with K = T_s frames min(4, T_s / 128)
+    //  slices -- a function of that video alone)
+    int S_req = direct ? 1 : 4;
+    P->seq_waves[t] = direct ? gemm_direct_waves(tiles, std::max(1, k_sum / n_seq)) : 0;
+    if (!direct && (t == TB_S || t == TB_DP)) for (S_req = 8; S_req > 1; S_req >>= 1) {     // slab sets (K = D for every video): 1, 2, 4 or 8 slices
+      int S; sk_slice_seq(D, S_req, &kc, &S);          // (the rule vasnet_sk_setup_kernel applies to each video)
+      if (S == S_req) break;
+    }
+    SkTab tb{0, 0, 0, S_req, 1};
+    // Q.K^T and dAlpha = dC V^T (K = D for every video: the same slice count) are consumed by the softmax kernels: slabs
+    P->slab_seq[t] = (!direct && (t == TB_S || t == TB_DP)) ? e_elems : 0;
+    for (int q = 0; q < n_seq; ++q) {
+      int M, N, K, S;
+      sk_seq_dims(t, off[q + 1] - off[q], D, &M, &N, &K);
+      sk_slice_seq(K, S_req, &kc, &S);
+      const int tl = ((M + te - 1) / te) * ((N + te - 1) / te);
+      tb.entries += S; tb.blocks += S * tl; tb.tiles += tl; tb.S = std::max(tb.S, S);
+    }
+    P->seq[t] = tb;
+  }
+}
 
 static int geometry(int D, int n_seq, const int32_t* off, int training, int precision, size_t workspace_bytes, Geometry* G) {
   SUMK_TRY(carve(D, n_seq, off, training, &G->L));
@@ -709,6 +958,8 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
     int T = off[s + 1] - off[s];
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
+  G->sk = G->b16 ? 0 : use_sk(G->R, D, precision);
+  if (G->sk) sk_plan(G->R, D, n_seq, off, G->sk == 2, G->L.e_elems, &G->P);
   return SUMK_OK;
 }
 
@@ -759,18 +1010,55 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2 + 32), dim3(64), 0, stream, a);   // y: 0 per-video tables, 1 row problems, 2.. row -> video table
 }
 
-static Drop make_drop(const sumk_vasnet_opts* o) { return make_drop(o->dropout_p, o->seed); }
+static Drop make_drop(const sumk_vasnet_opts* o) { Drop d = make_drop(o->dropout_p, o->seed); d.seed_dev = o->seed_dev; return d; }
+
+static int launch_sk_setup(const Geometry& G, int D, int n_seq, const int32_t* off_dev, char* ws, hipStream_t stream) {
+  SkSetupArgs a;
+  a.off = off_dev; a.n_seq = n_seq; a.D = D;
+  a.seq = (SeqInfo*)(ws + G.L.seq); a.row_seq = (int32_t*)(ws + G.L.row_seq); a.cnt = (unsigned*)(ws + G.L.sk_cnt);
+  a.tabs = (GemmProb*)(ws + G.L.sk_tabs);
+  a.tile = G.P.tile;
+  const bool tickets = G.sk == 1;        // (the direct kernel has none)
+  for (int r = 0; r < SR_COUNT; ++r) a.rows[r] = G.P.spec[r];
+  for (int t = 0; t < TB_COUNT; ++t) {
+    a.S_seq[t] = G.P.seq[t].S_req; a.slab_seq[t] = G.P.slab_seq[t];
+    SUMK_ARG((!tickets || G.P.seq[t].tiles <= SK_TICKETS) && G.P.seq[t].entries <= n_seq * SK_MAX_SLICES, "vasnet: small-batch table %d out of range", t);
+  }
+  for (int r = 0; r < SR_COUNT; ++r)
+    SUMK_ARG((!tickets || G.P.row[r].tiles <= SK_TICKETS) && G.P.row[r].entries <= SK_ROW_ENTRIES, "vasnet: small-batch row table %d out of range", r);
+  hipLaunchKernelGGL(vasnet_sk_setup_kernel, dim3((n_seq + 63) / 64, 2 + 8), dim3(64), 0, stream, a);   // y: 0 per-video tables, 1 row tables, 2.. row -> video table + tickets
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+static size_t sk_part_bytes(const Geometry& G, int n_seq) { return G.L.sk_tabs - G.L.sk_part; }    // (the table region follows the scratch)
+// one SK launch over table `tb` (row-wise table r >= 0, or per-video table t)
+struct SkCall { const float* A; const float* B[4]; float* C[4]; const float* R; const float* bias; int prof_tag; };
+static int launch_sk(const Geometry& G, int n_seq, char* ws, GemmLayout layout, GemmEpi epi, int row_tab, int seq_tab, const SkCall& c, hipStream_t stream) {
+  const SkTab& tb = row_tab >= 0 ? G.P.row[row_tab] : G.P.seq[seq_tab];
+  GemmProb* tabs = (GemmProb*)(ws + G.L.sk_tabs);
+  GemmLaunch g;
+  g.A = c.A;
+  for (int i = 0; i < 4; ++i) { g.B[i] = c.B[i]; g.Csel[i] = c.C[i]; }
+  g.C = c.C[0]; g.R = c.R; g.bias0[0] = c.bias;
+  g.probs = row_tab >= 0 ? sk_row_tab(tabs, row_tab) : sk_seq_tab(tabs, seq_tab, n_seq);
+  g.nprob = tb.entries; g.total_tiles = tb.blocks; g.small_tile = 1; g.prof_tag = c.prof_tag;
+  g.sk = G.sk; g.sk_part = (float*)(ws + G.L.sk_part); g.sk_cnt = (unsigned*)(ws + G.L.sk_cnt);
+  g.dk_waves = row_tab >= 0 ? G.P.row_waves[row_tab] : G.P.seq_waves[seq_tab];
+  SUMK_ARG(tb.blocks == tb.tiles || (size_t)tb.blocks * 64 * 64 * 4 <= sk_part_bytes(G, n_seq), "vasnet: small-batch launch needs %d partial tiles", tb.blocks);   // (blocks == tiles: nothing is sliced)
+  return launch_gemm(layout, epi, g, stream);
+}
 
 int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,
                      hipStream_t stream) {
-  Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
+  const Drop none = make_drop(0.f, 0);
   launch_ln_rows<false>(X, Y, g, b, nullptr, nullptr, nullptr, n_rows, D, eps, stats, none, 0u, stream);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 int launch_ln_head(const float* Z, const float* g, const float* b, const float* w2, const float* b2, float* scores,
                    int n_rows, int D, float eps, hipStream_t stream) {
-  Drop none; none.seed = 0; none.thr = 0; none.scale = 1.f;
+  const Drop none = make_drop(0.f, 0);
   launch_ln_rows<true>(Z, nullptr, g, b, w2, b2, scores, n_rows, D, eps, nullptr, none, 0u, stream);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
@@ -809,6 +1097,84 @@ extern "C" size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, cons
   return (training && precision == SUMK_PRECISION_BF16) ? w.total : w.total_core;
 }
 
+// The small-batch forward: the same nine stages as vasnet_forward_impl, every GEMM an SK launch (gemm_lean.hip) over the sliced tables
+// of vasnet_sk_setup_kernel, the row kernels unchanged.  Inference and training (the intermediates the backward needs are the same).
+static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
+                             const sumk_vasnet_weights* w, const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
+                             float* scores, char* ws, int32_t training, hipStream_t stream) {
+  const VasnetWs& L = G.L;
+  const int R = G.R;
+  float* QKV = (float*)(ws + L.qkv);
+  float* E = (float*)(ws + L.e);
+  float* E2 = training ? (float*)(ws + L.e2) : nullptr;
+  float* CTX = (float*)(ws + L.ctx);
+  float* Y0 = (float*)(ws + L.y0);
+  float* Y1 = (float*)(ws + L.y1);
+  float* Z = (float*)(ws + L.z);
+  SeqInfo* seq = (SeqInfo*)(ws + L.seq);
+  float* stats = training ? (float*)(ws + L.stats) : nullptr;
+  const Drop drop = make_drop(opts);
+  const bool use_e2 = training && drop.thr != 0;
+  if (pos_table) {
+    int64_t n4 = (int64_t)R * (D >> 2);
+    hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
+  }
+  SUMK_TRY(launch_sk_setup(G, D, n_seq, seq_off_dev, ws, stream));
+  {  // 1: QKV projection (three B pointers, one launch)
+    const SkCall c{x, {w->Wq, w->Wk, w->Wv, nullptr}, {QKV, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKV};
+    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_QKV, -1, c, stream));
+  }
+  // K-slice slabs (SlabIn): where a row kernel consumes a GEMM's output, the slices store their own slab in the scratch and the row
+  // kernel adds them -- S slabs of the E layout / of (R, D); otherwise (direct kernel, or one slice) the GEMM writes the matrix itself
+  float* scratch = (float*)(ws + L.sk_part);
+  const bool slabs = G.sk == 1;
+  {  // 2: logits per video
+    const SkCall c{QKV, {QKV, nullptr, nullptr, nullptr}, {slabs ? scratch : E, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKT};
+    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, -1, TB_S, c, stream));
+  }
+  {  // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
+    const dim3 sg((R + 3) / 4), sb(256);
+    float* e2p = use_e2 ? E2 : nullptr;
+    const float* eraw = slabs ? scratch : E;
+    const int n_slab = slabs ? G.P.seq[TB_S].S : 0;
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, (unsigned short*)nullptr, eraw, n_slab, (int64_t)L.e_elems)
+    if (G.t_max <= 256) SUMK_SOFTMAX(4); else if (G.t_max <= 512) SUMK_SOFTMAX(8); else if (G.t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
+#undef SUMK_SOFTMAX
+  }
+  {  // 4: context
+    const SkCall c{use_e2 ? E2 : E, {QKV, nullptr, nullptr, nullptr}, {CTX, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_PV};
+    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, -1, TB_PV, c, stream));
+  }
+  if (slabs) {
+    // 5 + 6: output projection as K-slice slabs; the LayerNorm kernel adds them and the residual (Y0 itself is kept for the backward pass)
+    const SkCall c{CTX, {w->Wo, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_OPROJ};
+    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_OPROJ, -1, c, stream));
+    SlabIn sl; sl.n = G.P.row[SR_OPROJ].S; sl.stride = (int64_t)R * D; sl.add = x; sl.store = training ? Y0 : nullptr;
+    launch_ln_rows<false>(scratch, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream, nullptr, sl);
+    // 7 + 8: k1 as slabs; the LayerNorm + head kernel adds them, the bias and the ReLU (Z is kept for the backward pass)
+    const SkCall c2{Y1, {w->W1, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_K1};
+    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_K1, -1, c2, stream));
+    SlabIn s2; s2.n = G.P.row[SR_K1].S; s2.stride = (int64_t)R * D; s2.bias = w->b1; s2.relu = 1; s2.store = training ? Z : nullptr;
+    launch_ln_rows<true>(scratch, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream, nullptr, s2);
+  } else {
+    {  // 5: output projection + residual
+      const SkCall c{CTX, {w->Wo, nullptr, nullptr, nullptr}, {Y0, nullptr, nullptr, nullptr}, x, nullptr, SUMK_PROF_GEMM_OPROJ};
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_RESIDUAL, SR_OPROJ, -1, c, stream));
+    }
+    // 6: dropout + LayerNorm
+    launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
+    {  // 7: k1 + bias + ReLU
+      const SkCall c{Y1, {w->W1, nullptr, nullptr, nullptr}, {Z, nullptr, nullptr, nullptr}, nullptr, w->b1, SUMK_PROF_GEMM_K1};
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_BIAS_RELU, SR_K1, -1, c, stream));
+    }
+    // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
+    launch_ln_rows<true>(Z, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
+  }
+  SUMK_HIP(hipGetLastError());
+  if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
+  return SUMK_OK;
+}
+
 // Wvo != nullptr: inference with the value and output projections FOLDED (Wvo = Wo . Wv, computed once per weight change by the
 // caller): (alpha V) Wo^T = alpha (X Wv^T Wo^T) = alpha (X Wvo^T), so the third slice of the packed projection is U = X Wvo^T,
 // the per-video product alpha U lands directly in Y0 with the residual added in its epilogue, and the R x D x D output
@@ -835,6 +1201,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     return SUMK_ERR_WORKSPACE;
   }
   char* ws = (char*)workspace;
+  if (G.sk && !Wvo)
+    return vasnet_forward_sk(G, x, D, n_seq, seq_off_host, seq_off_dev, w, opts, pos_table, pos_rows, scores, ws, training, stream);
   const int R = G.R;
   float* QKV = (float*)(ws + L.qkv);
   float* E = (float*)(ws + L.e);
@@ -895,7 +1263,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     const dim3 sg((R + 3) / 4), sb(256);
     float* e2p = use_e2 ? E2 : nullptr;
     unsigned short* p16 = b16 ? (unsigned short*)(ws + L.p16) : nullptr;
-#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, p16)
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, p16, (const float*)E, 0, (int64_t)0)
     if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
@@ -1004,14 +1372,15 @@ extern "C" int sumk_vasnet_forward_folded(float* x, int32_t D, int32_t n_seq, co
 template <bool HEAD>
 static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const float* g, const float* b,
                          const float* dY, const float* w2, const float* scores, const float* dscores, float* dX,
-                         float* part, Drop drop, uint32_t site, int* n_waves_out, hipStream_t stream, unsigned short* dX16 = nullptr) {
+                         float* part, Drop drop, uint32_t site, int* n_waves_out, hipStream_t stream, unsigned short* dX16 = nullptr,
+                         int n_slab = 0, int64_t slab_stride = 0) {
   const int D4 = D >> 2;
   const int nq = (D4 + 63) / 64;
   int blocks = std::min((R + 3) / 4, LNB_MAX_WAVES / 4);
   blocks = std::max(blocks, 1);
   *n_waves_out = blocks;              // slots written: one per block
   dim3 grid(blocks), block(256);
-#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16)
+#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16, n_slab, slab_stride)
   if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
   else { set_error("vasnet_backward: D=%d > 2048 is not supported by the LayerNorm backward kernel", D); return SUMK_ERR_ARG; }
 #undef LNB
@@ -1090,6 +1459,61 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   unsigned short* dY016 = (unsigned short*)(ws + L.dy016);
   unsigned short* dQKV16 = (unsigned short*)(ws + L.dqkv16);
 
+  if (G.sk && dx) launch_setup(G, D, n_seq, seq_off_dev, ws, stream);   // (dx asked for: the large-batch kernels below; their tables were not built by the SK forward)
+  if (G.sk && !dx) {   // the small-batch backward: the same stages below, every GEMM an SK launch over the tables the forward built
+    const SkCall none{};
+    (void)none;
+    SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, dZ, lnpart, drop, 2u, &nw, stream));
+    SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, gr->w2, gr->b2, gr->b1, stream));
+    float* scratch = (float*)(ws + L.sk_part);
+    const bool slabs = G.sk == 1;          // K-slice slabs added by the consuming row kernel (see the forward)
+    {
+      const SkCall c{dZ, {w->W1, nullptr, nullptr, nullptr}, {slabs ? scratch : dY1, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dY1 = dZ W1
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, SR_DY1, -1, c, stream));
+    }
+    SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, slabs ? scratch : dY1, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream, nullptr,
+                                  slabs ? G.P.row[SR_DY1].S : 0, (int64_t)R * D));
+    SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
+    {
+      const SkCall c{dY0, {CTX, nullptr, nullptr, nullptr}, {gr->Wo, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};     // dWo += dY0^T CTX
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DWO, -1, c, stream));
+    }
+    {
+      const SkCall c{dZ, {Y1, nullptr, nullptr, nullptr}, {gr->W1, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dW1 += dZ^T Y1
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DW1, -1, c, stream));
+    }
+    {
+      const SkCall c{dY0, {w->Wo, nullptr, nullptr, nullptr}, {dCTX, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};     // dCTX = dY0 Wo
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, SR_DCTX, -1, c, stream));
+    }
+    if (tail_grads_ready_event) SUMK_HIP(hipEventRecord((hipEvent_t)tail_grads_ready_event, stream));
+    const float* Pd = use_e2 ? E2 : E;
+    {
+      const SkCall c{Pd, {dCTX, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dV = alphaD^T dC
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_NONE, -1, TB_DV, c, stream));
+    }
+    {
+      const SkCall c{dCTX, {QKV, nullptr, nullptr, nullptr}, {slabs ? scratch : E2, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dAlphaD = dC V^T
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, -1, TB_DP, c, stream));
+    }
+    hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
+                       opts->scale, drop, (unsigned short*)nullptr, (const float*)(slabs ? scratch : E2), slabs ? G.P.seq[TB_DP].S : 0, (int64_t)L.e_elems);
+    {
+      const SkCall c{E2, {QKV, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dQ = dS K
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, -1, TB_DQ, c, stream));
+    }
+    {
+      const SkCall c{E2, {QKV, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dK = dS^T Q
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_NONE, -1, TB_DK, c, stream));
+    }
+    {
+      const SkCall c{dQKV, {x, nullptr, nullptr, nullptr}, {gr->Wq, gr->Wk, gr->Wv, nullptr}, nullptr, nullptr, -1};        // d[Wq;Wk;Wv] += dQKV^T X
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DWQKV, -1, c, stream));
+    }
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
+
   // 8': head + second LayerNorm + dropout + ReLU  ->  dZ (w.r.t. the k1 pre-activation), dw2, db2, dgamma, dbeta
   SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, b16 ? nullptr : dZ, lnpart,
                                drop, 2u, &nw, stream, b16 ? dZ16 : nullptr));
@@ -1137,7 +1561,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   // 3': softmax (+dropout, +scale) backward, in place on E2
   // (b16: bf16(dLogits) goes where bf16(alpha) was -- its last reader, the dV product, is queued before this kernel)
   hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
-                     opts->scale, drop, b16 ? (unsigned short*)(ws + L.p16) : nullptr);
+                     opts->scale, drop, b16 ? (unsigned short*)(ws + L.p16) : nullptr, (const float*)E2, 0, (int64_t)0);
   // 2': dQ = dS K ; dK = dS^T Q
   {
     GemmLaunch g; g.precision = opts->precision;

@@ -115,7 +115,8 @@ def _vasnet_structs(params, opts):
         setattr(w, f, t.data_ptr())
     o = _lib.VasnetOpts(float(opts["scale"]), float(opts["eps"]), int(bool(opts.get("ignore_self", False))),
                         -1 if opts.get("aperture") is None else int(opts["aperture"]),
-                        float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)), precision_code(opts.get("precision")))
+                        float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)), precision_code(opts.get("precision")),
+                        opts["seed_dev"].data_ptr() if opts.get("seed_dev") is not None else None)
     return w, o
 
 

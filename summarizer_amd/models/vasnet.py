@@ -80,6 +80,10 @@ class VASNet(nn.Module):
         if training:
             self._seed_counter += 1
             o.update(dropout_p=float(self.dropout.p), seed=(torch.initial_seed() * 1000003 + self._seed_counter) & (2**63 - 1))
+            # a step captured into a HIP graph (VASNetTrainer): the kernels add this device word to the seed when they RUN, and the
+            # captured step increments it, so every replay draws fresh dropout masks (kernel arguments are frozen at capture)
+            if getattr(self, "graph_seed", None) is not None:
+                o["seed_dev"] = self.graph_seed
         if getattr(self, "tail_grads_ready_event", None) is not None:
             o["tail_grads_ready_event"] = self.tail_grads_ready_event     # data-parallel trainers: see VASNetTrainer.train
         return o
@@ -182,7 +186,14 @@ class VASNetTrainer(Trainer):
 
     Extensions (all default to the reference schedule): extra_params["batch_videos"] = videos per optimiser step on each
     rank (default 1); under torch.distributed the training videos are sharded over ranks (balanced by frames) and the
-    flat gradient bucket is all-reduced once per step (RCCL)."""
+    flat gradient bucket is all-reduced once per step (RCCL).
+
+    The reference schedule itself (one video per optimiser step, vasnet.py:193-212; single process) runs as HIP GRAPHS from the
+    second epoch on: the whole step of a video -- zero the gradient bucket, the small-batch forward (csrc/gemm_lean.hip SK
+    launches), per-video MSE, backward, fused Adam -- is captured once per video (its features and target stay at fixed addresses in
+    the HBM cache) and replayed every later epoch, so the ~45 kernels of a step are not paced by the host (the eager step spends a
+    third of its time waiting for Python between the forward and the backward).  Dropout masks stay fresh per replay through a
+    device-side seed word (sumk_vasnet_opts::seed_dev).  extra_params["hip_graph"] = "0" keeps every step eager."""
 
     def _init_model(self):
         ep = self.hps.extra_params
@@ -227,11 +238,30 @@ class VASNetTrainer(Trainer):
 
         best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
         use_packed = self.model.max_length is None
+        # reference schedule as HIP graphs: one captured step per video, replayed from the second epoch on (class docstring)
+        use_graph = (world == 1 and bv == 1 and use_packed and dev.type == "cuda"
+                     and str(self.hps.extra_params.get("hip_graph", "1")) not in ("0", "False", "false"))
+        graphs, graph_pool = {}, None
+        if use_graph:
+            self.model.graph_seed = torch.zeros(1, dtype=torch.int64, device=dev)
         for epoch in range(self.hps.epochs):
             losses, dist_scores = [], {}
             random.shuffle(my_keys)
             for step in range(steps_per_epoch):
                 keys = my_keys[step * bv:(step + 1) * bv]
+                if use_graph and epoch >= 1 and keys:
+                    ent = graphs.get(keys[0])
+                    if ent is None:
+                        try:
+                            ent = graphs[keys[0]] = self._capture_step(keys[0], dev, graph_pool)
+                            graph_pool = ent[0].pool()
+                        except Exception as e:      # noqa: BLE001  (a configuration that does not capture keeps the eager loop)
+                            self.log.warning(f"HIP graph capture failed ({type(e).__name__}: {e}); training continues eagerly")
+                            use_graph, self.model.graph_seed = False, None
+                    if use_graph:
+                        ent[0].replay()
+                        losses.append(ent[1]); dist_scores[keys[0]] = ent[2]
+                        continue
                 self.optimizer.zero_grad()
                 if keys:
                     vids = [self._load_video(k, dev) for k in keys]
@@ -279,4 +309,34 @@ class VASNetTrainer(Trainer):
                     self.best_weights = self.model.state_dict()     # live references, like vasnet.py:233
 
         self.draw_scores(fold, dist_scores)
+        self.model.graph_seed = None
         return best_corr, best_avg_f_score, best_max_f_score
+
+    def _single_video_step(self, key, dev):
+        """One optimiser step on one video (vasnet.py:193-212): (loss, scores) as detached tensors."""
+        seq, target = self._load_video(key, dev)
+        lens_b = [seq.shape[0]]
+        self.optimizer.zero_grad()
+        scores = self.model.score_packed(seq, lens_b)
+        loss = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev)).mean()
+        loss.backward()
+        self.optimizer.step(grad_scale=1.0)
+        if self.model.graph_seed is not None:
+            self.model.graph_seed.add_(1)            # next replay: other dropout masks
+        return loss.detach(), scores.detach().view(-1, 1, 1)
+
+    def _capture_step(self, key, dev, pool):
+        """(graph, loss, scores): the step of `key` captured into a HIP graph; loss / scores are the graph's static outputs (rewritten
+        by every replay).  All captured steps share one memory pool -- they never run concurrently."""
+        seq, _ = self._load_video(key, dev)          # (uploaded and cached before capture: no H2D copy inside the graph)
+        # the outputs live OUTSIDE the shared graph pool (allocated before the capture, written by a copy inside it): tensors a capture
+        # leaves in the pool were seen to alias those of later captures into the same pool -- the epoch's mean loss then read eight
+        # copies of the last step's loss while the weights were exactly right
+        loss_out = torch.zeros((), dtype=torch.float32, device=dev)
+        scores_out = torch.empty(seq.shape[0], 1, 1, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            loss, scores = self._single_video_step(key, dev)
+            loss_out.copy_(loss); scores_out.copy_(scores)
+        return g, loss_out, scores_out

@@ -42,6 +42,31 @@ def test_reward_goldens_and_batch():
             np.testing.assert_allclose(got[e, s], ref, atol=3e-5, rtol=1e-5, err_msg=f"ep {e} video {s}")
 
 
+def test_reward_at_baseline_size_vs_oracle():
+    """BASELINE config 4 at size: sumk_dsn_reward on the S-TVSum batch (50 videos, T ~ U(150, 320), D = 1024) x 5 Bernoulli
+    episodes -- reward_rows_kernel + the 64x64 Gram GEMMs on 12 003 frames -- against oracle/reward_np.compute_reward
+    (dsn.py:185-236) video by video and episode by episode, default temporal threshold and far_sim."""
+    from oracle import reward_np
+    from summarizer_amd import kernels
+    dev = torch.device("cuda:0")
+    D, E = 1024, 5
+    lens = [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, 50)]
+    xs = [R.features(T, 1, D, 1000 + i) for i, T in enumerate(lens)]
+    rng = np.random.default_rng(11)
+    probs = rng.uniform(0.05, 0.6, sum(lens))
+    acts = (rng.random((E, sum(lens))) < probs[None, :]).astype(np.float32)
+    sb = kernels.SeqBatch.get(lens, dev)
+    x = torch.from_numpy(np.concatenate([v[:, 0, :] for v in xs])).to(dev)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for far in (False, True):
+        got = kernels.dsn_reward(x, sb, torch.from_numpy(acts).to(dev), far_sim=far, temp_dist_thre=20).cpu().numpy()
+        assert got.shape == (E, len(lens))
+        for s_, xv in enumerate(xs if not far else xs[:8]):          # (far_sim: the first 8 videos -- the oracle costs ~0.1 s per call)
+            for e in range(E):
+                ref = reward_np.compute_reward(xv, acts[e, off[s_]:off[s_ + 1]], far_sim=far)
+                np.testing.assert_allclose(got[e, s_], ref, atol=3e-5, rtol=1e-5, err_msg=f"far={far} ep {e} video {s_}")
+
+
 @pytest.mark.parametrize("E", [5, 16, 37])
 def test_policy_loss_kernels_match_the_torch_ops_they_replace(E):
     """sumk_dsn_policy_loss_forward/backward (through PolicyLossFunction) against the element-wise torch formulation of

@@ -308,3 +308,46 @@ def test_c1_summe_fold0_trainer_test_at_size_vs_the_reference(precision):
             m = tr._video_meta(k, "scores")
             c = E.evaluate_scores(E.generate_scores(acts[k], m.n_frames, m.picks), m.user_scores, metric="spearmanr")
             np.testing.assert_allclose(c, float(g[f"corr/{k}"]), atol=5e-5)
+
+
+def test_vasnet_trainer_hip_graph_steps_equal_eager_steps(data):
+    """The reference schedule (one video per optimiser step, vasnet.py:193-212) runs as per-video HIP graphs from the second epoch on
+    (VASNetTrainer.train).  (1) Dropout off: four epochs with the graphs equal four epochs of eager steps BIT FOR BIT -- losses,
+    final weights, reported metrics -- so a replay is the step it captured (zeroed gradient bucket, device-side Adam step counter
+    included).  (2) Dropout on: replays of the SAME captured step draw different masks (device-side seed word), losses stay finite."""
+    from summarizer_amd.models.vasnet import VASNetTrainer
+    from summarizer_amd.utils.hps import make_hps
+    ds, keys = data
+    runs = {}
+    for flag in ("1", "0"):
+        hps = make_hps(ds, _splits(keys), epochs=4, test_every_epochs=2, lr=1e-3, extra_params={"input_size": "128", "hip_graph": flag})
+        torch.manual_seed(7); random.seed(3)
+        tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+        tr.model.dropout.p = 0.0
+        random.seed(3)
+        best = tr.train(0)
+        runs[flag] = (best, [v for _, v in hps.writer.scalars["synthetic/Fold_1/Train/Loss"]],
+                      {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
+    assert runs["1"][0] == runs["0"][0]
+    assert runs["1"][1] == runs["0"][1] and len(runs["1"][1]) == 4
+    for k, v in runs["1"][2].items():
+        assert torch.equal(v, runs["0"][2][k]), k
+    # dropout on: one captured step, replayed -- the masks must change between replays
+    hps = make_hps(ds, _splits(keys), epochs=1, extra_params={"input_size": "128"})
+    torch.manual_seed(7)
+    tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+    tr.model.train()
+    from summarizer_amd.training import FlatAdam
+    tr.optimizer = FlatAdam(tr.model.parameters(), lr=0.0)              # lr = 0: the weights stay put, only the masks differ between replays
+    dev = tr._device()
+    tr.model.graph_seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    tr._single_video_step(keys[5], dev)                                  # eager warm-up
+    g, loss, scores = tr._capture_step(keys[5], dev, None)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append((float(loss), scores.clone()))
+    assert int(tr.model.graph_seed.item()) == 4                          # 1 eager + 3 replays
+    assert all(np.isfinite(v[0]) for v in seen)
+    assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1])
