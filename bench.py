@@ -263,7 +263,7 @@ def single_video_leg(dev, D=1024, T=300, iters=200):
             m.graph_seed = seed
         def step():
             opt.zero_grad()
-            loss = SegmentMseFunction.apply(m.score_packed(x2, [T]), target, sb).mean()
+            loss = SegmentMseFunction.apply(m.score_packed(x2, [T]), target, sb).view(())      # one video (VASNetTrainer._single_video_step)
             loss.backward()
             opt.step(grad_scale=1.0, max_norm=5.0 if name == "dsn" else None)
             seed.add_(1)
@@ -559,24 +559,14 @@ def main():
         sb_t = _k.SeqBatch.get(lens, dev)
         target = torch.rand(frames, device=dev)
 
-        def run_train_leg(precision):
-            """exact fp32, or the mixed-precision mode of BASELINE config 2 (bf16 products, bf16 gradient bucket over the all-reduce)"""
-            model.train(); model.precision = precision
-            opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5, comm_dtype=torch.bfloat16 if precision == "bf16" else None)
-            opt.broadcast()
-            def train_step():
-                opt.zero_grad()
-                loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()
-                loss.backward()
-                opt.step(grad_scale=opt.all_reduce_grads())
-                return loss.detach()
+        def timed_steps(step_fn, n_train=10):
+            """seconds per step, max over ranks, barriers on both sides"""
             for _ in range(3):
-                l = train_step()
+                l = step_fn()
             barrier()
             tt0 = time.perf_counter()
-            n_train = 10
             for _ in range(n_train):
-                l = train_step()
+                l = step_fn()
             barrier()
             tel = time.perf_counter() - tt0
             if dist is not None:
@@ -584,15 +574,80 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 tel = float(t.item())
             assert bool(torch.isfinite(l))
+            return tel / n_train
+
+        def allreduce_alone_us(numel, dtype, n=20):
+            """the step's gradient exchange by itself: one SUM all-reduce of a bucket of that size, timed outside any step (us, max over ranks)"""
+            if dist is None:
+                return None
+            buf = torch.zeros(numel, dtype=dtype, device=dev)
+            for _ in range(5):
+                dist.all_reduce(buf)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                dist.all_reduce(buf)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / n], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(float(t.item()) * 1e6, 1)
+
+        def decompose(rec, ms_step, ms_local, alone_us):
+            """what a SCALE run needs to read a leg: the exchange alone, the step without it, how much of it the step hid"""
+            if dist is None:
+                return rec
+            exposed = max(0.0, (ms_step - ms_local) * 1e3)
+            rec.update(allreduce_alone_us=alone_us, ms_per_step_without_allreduce=round(ms_local, 4), exposed_comm_us=round(exposed, 1),
+                       overlap_hidden_us=round(max(0.0, alone_us - exposed), 1))
+            return rec
+
+        def run_train_leg(precision):
+            """exact fp32, or the mixed-precision mode of BASELINE config 2 (bf16 products, bf16 gradient bucket over the all-reduce).
+            Under data parallelism the exchange is issued as VASNetTrainer issues it: the tail of the bucket (Wo, k1, k2: final halfway
+            through the backward pass) on a side stream under the attention backward, the head after it."""
+            model.train(); model.precision = precision
+            opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5, comm_dtype=torch.bfloat16 if precision == "bf16" else None)
+            opt.broadcast()
+            tail_from = opt.tail_offset(model.attention_head_projection.weight) if dist is not None else None
+            model.tail_grads_ready_event = torch.cuda.Event() if dist is not None else None
+            def train_step(reduce=True):
+                opt.zero_grad()
+                loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()
+                loss.backward()
+                if reduce and tail_from is not None:
+                    opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
+                opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / world)
+                return loss.detach()
+            n_train = 10
+            sec = timed_steps(train_step, n_train)
+            sec_local = timed_steps(lambda: train_step(False), n_train) if dist is not None else sec
+            model.tail_grads_ready_event = None
             model.eval(); model.precision = "fp32"
             bytes_per_elem = 2 if precision == "bf16" else 4
-            return dict(frames_per_s=round(frames * world * n_train / tel, 1), ms_per_step=round(tel / n_train * 1e3, 4), steps=n_train,
-                        allreduce_bytes_per_step=int(opt.flat_grad.numel() * bytes_per_elem) if world > 1 else 0,
-                        collectives_per_step=1 if world > 1 else 0,
-                        note=(f"{precision}; forward + per-video MSE + backward + one all-reduce of the flat gradient bucket "
-                              "(RCCL when world > 1) + fused Adam"))
-        train_leg = run_train_leg("fp32")
-        train_leg_bf16 = run_train_leg("bf16")
+            rec = dict(frames_per_s=round(frames * world / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=n_train,
+                       allreduce_bytes_per_step=int(opt.flat_grad.numel() * bytes_per_elem) if world > 1 else 0,
+                       collectives_per_step=2 if world > 1 else 0,
+                       note=(f"{precision}; forward + per-video MSE + backward + the all-reduce of the flat gradient bucket in two pieces (tail early on a "
+                             "side stream, head after the backward; RCCL when world > 1) + fused Adam"))
+            return decompose(rec, sec * 1e3, sec_local * 1e3,
+                             allreduce_alone_us(opt.flat_grad.numel(), torch.bfloat16 if precision == "bf16" else torch.float32))
+        def collective_leg(fn, *a):
+            """A side leg that contains collectives must not cost the headline line: every rank catches its own exception, then the
+            ranks agree (MIN all-reduce of an ok flag) whether the leg counts -- an error that hits all ranks alike (the usual kind) is
+            reported in the leg's field and the line is still printed."""
+            err, res = None, None
+            try:
+                res = fn(*a)
+            except Exception as e:          # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"[:300]
+            if dist is not None:
+                flag = torch.tensor([0.0 if err else 1.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) == 0.0 and err is None:
+                    err = "failed on another rank"
+            return dict(error=err) if err else res
+        train_leg = collective_leg(run_train_leg, "fp32")
+        train_leg_bf16 = collective_leg(run_train_leg, "bf16")
 
         def run_reinforce_leg():
             """BASELINE config 4: the DSN REINFORCE step, data-parallel by video (every rank its own 50 videos, one all-reduce of the
@@ -602,33 +657,23 @@ def main():
             dsn = DSN(input_size=D).to(dev).train()
             step, opt = make_reinforce_step(dsn, x, lens, dev)
             opt.broadcast()
-            for _ in range(3):
-                l = step()
-            barrier()
-            tt0 = time.perf_counter()
             n_train = 10
-            for _ in range(n_train):
-                l = step()
-            barrier()
-            tel = time.perf_counter() - tt0
-            if dist is not None:
-                t = torch.tensor([tel], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tel = float(t.item())
-            assert bool(torch.isfinite(l))
+            sec = timed_steps(step, n_train)
+            sec_local = sec
+            if dist is not None:          # the same step with the exchange left out (every rank then steps on its own gradient)
+                real = opt.all_reduce_grads
+                opt.all_reduce_grads = lambda average=True: 1.0 / world
+                sec_local = timed_steps(step, n_train)
+                opt.all_reduce_grads = real
             from summarizer_amd import kernels as _kk
             _kk.health_check()                                            # persistent recurrences: no hand-off timed out
-            return dict(frames_per_s=round(frames * world * n_train / tel, 1), ms_per_step=round(tel / n_train * 1e3, 4), steps=n_train,
-                        allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0,
-                        collectives_per_step=1 if world > 1 else 0,
-                        note="DSN (BiLSTM 1024 -> 2 x 256) REINFORCE step: scores, 5 Bernoulli episodes, reward kernel, policy loss, "
-                             "backward, one all-reduce of the flat gradient bucket (RCCL when world > 1), clip + fused Adam")
-        try:
-            reinforce_leg = run_reinforce_leg()
-        except Exception as e:          # noqa: BLE001
-            if dist is not None:
-                raise                   # a rank that drops out of a collective leg would leave the others waiting: fail the job
-            reinforce_leg = dict(error=f"{type(e).__name__}: {e}"[:300])
+            rec = dict(frames_per_s=round(frames * world / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=n_train,
+                       allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0,
+                       collectives_per_step=1 if world > 1 else 0,
+                       note="DSN (BiLSTM 1024 -> 2 x 256) REINFORCE step: scores, 5 Bernoulli episodes, reward kernel, policy loss, "
+                            "backward, one all-reduce of the flat gradient bucket (RCCL when world > 1; no overlap: it needs the whole BPTT), clip + fused Adam")
+            return decompose(rec, sec * 1e3, sec_local * 1e3, allreduce_alone_us(opt.flat_grad.numel(), torch.float32))
+        reinforce_leg = collective_leg(run_reinforce_leg)
     single = None
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only and rank == 0:
         try:          # rank 0 only, no collectives inside: the other ranks wait at destroy_process_group

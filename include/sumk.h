@@ -77,8 +77,9 @@ typedef struct sumk_vasnet_opts {
 /* Bytes of workspace sumk_vasnet_forward / _backward need for this batch (seq_off_host has n_seq+1 entries). */
 size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
 /* The same for a known arithmetic: only the mixed-precision training step (training != 0, SUMK_PRECISION_BF16) needs the bf16
- * operand shadows at the end of the workspace (~ +25 %); every other mode is content with this smaller size.  A bf16 training
- * step given the smaller workspace falls back to the kernels that convert fp32 operands in their k-loops (same results). */
+ * operand shadows at the end of the workspace (~ +25 %); every other mode is content with this smaller size.  Which kernels a step
+ * runs on never depends on the workspace it is handed: a bf16 training step given the smaller workspace is refused
+ * (SUMK_ERR_WORKSPACE), so a forward and a backward pass cannot end up on different paths. */
 size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training, int32_t precision);
 
 /* Replaces VASNet.forward (vasnet.py:92-148) for a packed batch: x (n_rows,D) -> scores (n_rows,), sigmoid

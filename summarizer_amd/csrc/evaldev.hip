@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void eval_device_kernel(const float* __restric
   float* fs = frame_scratch + v.frame0;
   const bool sentinel = np_ == 0 || v.picks[np_ - 1] != n_frames;
   const int n_int = np_ - 1 + (sentinel ? 1 : 0);
+  // the LDS tables are fixed-size: a descriptor past them (the host wrapper refuses such videos; the descriptors live in device memory,
+  // so the entry point cannot) must not write out of bounds -- its results are NaN instead
+  if (n_int > ED_MAX_INT || v.n_users > ED_MAX_USERS || n_int < 0) {
+    for (int s = tid; s < v.n_segs; s += 256) seg_means[v.seg0 + s] = nanf("");
+    if (tid == 0) corr[blockIdx.x] = nan("");
+    return;
+  }
   // ---- upsample (eval.py:24-34): frames default to 0, interval i = [picks[i], picks[i + 1]) takes score i (0 past the scores)
   for (int f = tid; f < n_frames; f += 256) fs[f] = 0.f;
   for (int i = tid; i < n_int; i += 256) {

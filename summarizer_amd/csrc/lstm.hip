@@ -550,6 +550,17 @@ __device__ unsigned g_sumk_health = 0u;
 constexpr int PK_THREADS = 512;
 constexpr int PK_TEAMS = 8;
 constexpr unsigned PK_SPIN_LIMIT = 1u << 20;   // ~1 s of polling; after one timeout the block stops waiting altogether
+// The flag-in-data hand-offs poll with their OWN data loads (a turn = four to thirty-two sc1 loads, ~1 us), so a turn count is a poor
+// clock: they share the counter protocol's ~1 s budget in WALL time -- s_memrealtime, the 100 MHz constant counter -- read every 256
+// turns, the first time at turn 256 (a healthy wait ends long before).  (A count of PK_SPIN_LIMIT / 16 turns was tens of ms: resume skew after a CWSR preemption, or several ranks time-slicing
+// one GPU, could have tripped it on a healthy run.)
+constexpr unsigned long long PK_WAIT_TICKS = 100000000ull;
+__device__ __forceinline__ bool pk_ll_timed_out(unsigned& spins, unsigned long long& t0) {     // (the clock is first read at turn 256: nothing on the fast path)
+  if ((++spins & 255u) != 0u) return false;
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+  if (spins == 256u) { t0 = now; return false; }
+  return now - t0 > PK_WAIT_TICKS;
+}
 
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -686,6 +697,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           const unsigned rowb = (unsigned)((((unsigned)((t - 1) & 1) * 2u + (unsigned)d) * (unsigned)a.n_seq + (unsigned)(v0 + vl)) * (unsigned)H) * 8u;
           u32x4 va[4];
           unsigned spins = 0;
+          unsigned long long ll_t0 = 0;
           while (true) {
             asm volatile("" ::: "memory");   // the loads below are a poll: they must be re-issued every turn
 #pragma unroll
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
             for (int p = 0; p < 4; ++p)
               if (need_row && k0 + 2 * p < H) ok = ok && va[p][1] == want && va[p][3] == want;
             if (__all(ok) || dead) break;
-            if (++spins > (PK_SPIN_LIMIT >> 4)) {     // never hang the GPU: flag the failure and stop waiting
+            if (pk_ll_timed_out(spins, ll_t0)) {     // never hang the GPU: flag the failure and stop waiting
               if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
               dead = true;
             }
@@ -741,6 +753,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
           const unsigned rowb = (unsigned)((((unsigned)((t - 1) & 1) * 2u + (unsigned)d) * (unsigned)a.n_seq + (unsigned)(v0 + li)) * (unsigned)H) * 8u;
           u32x4 va[2 * CPW];
           unsigned spins = 0;
+          unsigned long long ll_t0 = 0;
           while (true) {
             asm volatile("" ::: "memory");   // the loads below are a poll: they must be re-issued every turn (a read-only buffer load is otherwise loop invariant)
 #pragma unroll
@@ -758,7 +771,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
                 ok = ok && va[2 * c][1] == want && va[2 * c][3] == want && va[2 * c + 1][1] == want && va[2 * c + 1][3] == want;
             }
             if (__all(ok) || dead) break;
-            if (++spins > (PK_SPIN_LIMIT >> 4)) {     // never hang the GPU: flag the failure and stop waiting
+            if (pk_ll_timed_out(spins, ll_t0)) {     // never hang the GPU: flag the failure and stop waiting
               if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
               dead = true;
             }
@@ -1366,6 +1379,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
           const unsigned want = (unsigned)(Tg - 1 - t);
           const unsigned long long* xp = a.ll + ((((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * a.gsize + (need ? ei : 0)) * H + (need ? j : 0);
           unsigned spins = 0;
+          unsigned long long ll_t0 = 0;
           while (true) {
             unsigned long long pv[32];
 #pragma unroll
@@ -1380,7 +1394,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
             }
             rec_ll = rec;
             if (__all(ok) || dead) break;
-            if (++spins > (PK_SPIN_LIMIT >> 4)) {
+            if (pk_ll_timed_out(spins, ll_t0)) {
               if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
               dead = true;
             }

@@ -53,7 +53,7 @@ struct VasnetWs {
 constexpr int SK_MAX_ROWS = 1024;
 constexpr int SK_TICKETS = 4096;
 // row-wise SK tables (entries: groups x slices each) and where they start in the table region, in entries
-enum { SR_QKV = 0, SR_OPROJ, SR_K1, SR_DY1, SR_DCTX, SR_DWO, SR_DW1, SR_DWQKV, SR_COUNT };
+enum { SR_QKV = 0, SR_OPROJ, SR_K1, SR_DY1, SR_DCTX, SR_DWO1, SR_DWQKV, SR_COUNT };
 constexpr int SK_ROW_ENTRIES = 3 * SK_MAX_SLICES;
 static inline bool sk_rows_ok(int64_t R) { return R <= SK_MAX_ROWS; }
 
@@ -265,7 +265,7 @@ struct SkTab { int entries, blocks, tiles, S_req, S; };    // table entries, (ti
 // per group g: a_off = g a_goff, c_off = g c_goff, B / C pointer g when bsel / csel.  slab != 0: slice s stores its own (M x N) matrix
 // at c_off + s slab with a plain epilogue (no tickets: the consuming ROW kernel adds the slabs, SlabIn) instead of meeting the other
 // slices in the launch.
-struct SkRowSpec { int32_t M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel; int64_t slab; };
+struct SkRowSpec { int32_t M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel; int64_t slab, a_goff64, b_goff64; };   // a_goff64 / b_goff64: group offsets of A / B beyond 31 bits (two operands of one allocation)
 struct SkSetupArgs {
   const int32_t* off; int32_t n_seq, D;
   SeqInfo* seq; int32_t* row_seq; unsigned* cnt;
@@ -318,7 +318,7 @@ __global__ void vasnet_sk_setup_kernel(SkSetupArgs a) {
     int kc, S;
     sk_slice(sp.K, sp.S_req, &kc, &S);
     for (int g = 0; g < sp.groups; ++g)
-      put_sk(tab, g * S, g * S * tiles, g * tiles, sp.layout, (int64_t)g * sp.a_goff, 0, (int64_t)g * sp.c_goff, sp.M, sp.N, sp.K, sp.lda, sp.ldb,
+      put_sk(tab, g * S, g * S * tiles, g * tiles, sp.layout, (int64_t)g * (sp.a_goff + sp.a_goff64), (int64_t)g * sp.b_goff64, (int64_t)g * sp.c_goff, sp.M, sp.N, sp.K, sp.lda, sp.ldb,
              sp.ldc, sp.ldr, sp.S_req, sp.bsel ? g : 0, sp.csel ? g : 0, te, sp.slab, false);
     return;
   }
@@ -876,7 +876,9 @@ static int use_sk(int R, int D, int precision) {
   return (mode == 1 || mode == 2) && precision == SUMK_PRECISION_FP32 && sk_rows_ok(R) && D % 4 == 0 ? mode : 0;
 }
 // Every table of the step: requested slices, entries, (tile, slice) blocks and tickets -- the host mirror of vasnet_sk_setup_kernel.
-static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, int64_t e_elems, SkPlan* P) {
+static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, const VasnetWs& L, SkPlan* P) {
+  const int64_t e_elems = L.e_elems;
+  const size_t ws_off_dz = L.dz, ws_off_dy0 = L.dy0, ws_off_y1 = L.y1, ws_off_ctx = L.ctx;
   const int te = direct ? 32 : 64;        // direct: 32x32 tiles, K split over the waves of a workgroup (no table slices)
   P->tile = te;
   // slab: the output's consumer is a row kernel that adds K-slice slabs on load (SlabIn) -- the slices then need no in-launch meeting
@@ -894,7 +896,7 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, in
     }
     sk_slice(K, S_req, &kc, &S);
     P->row_waves[r] = direct ? gemm_direct_waves(tiles * groups, K) : 0;
-    P->spec[r] = SkRowSpec{M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel, (slab && !direct) ? (int64_t)M * ldc : 0};
+    P->spec[r] = SkRowSpec{M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel, (slab && !direct) ? (int64_t)M * ldc : 0, 0, 0};
     P->row[r] = SkTab{groups * S, groups * S * tiles, groups * tiles, S_req, S};
   };
   row(SR_QKV, GEMM_NT, R, D, D, D, D, 3 * D, 0, 3, 0, D, 1, 0, 4);          // [Q|K|V] = X [Wq;Wk;Wv]^T: group g = B pointer g, columns g D..
@@ -902,8 +904,11 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, in
   row(SR_K1, GEMM_NT, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8, true);         // Z = relu(Y1 W1^T + b1)   (slabs -> LayerNorm + head kernel: + b1, ReLU)
   row(SR_DY1, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8, true);        // dY1 = dZ W1              (slabs -> LayerNorm backward kernel)
   row(SR_DCTX, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8);             // dCTX = dY0 Wo
-  row(SR_DWO, GEMM_TN, D, D, R, D, D, D, 0, 1, 0, 0, 0, 0, 0);              // dWo += dY0^T CTX
-  row(SR_DW1, GEMM_TN, D, D, R, D, D, D, 0, 1, 0, 0, 0, 0, 0);              // dW1 += dZ^T Y1
+  // dWo += dY0^T CTX and dW1 += dZ^T Y1 in ONE launch: group 1's operands are addressed relative to group 0's (dZ - dY0, Y1 - CTX: all four
+  // are regions of the workspace), its output is C pointer 1
+  row(SR_DWO1, GEMM_TN, D, D, R, D, D, D, 0, 2, 0, 0, 0, 1, 0);
+  P->spec[SR_DWO1].a_goff64 = ((int64_t)ws_off_dz - (int64_t)ws_off_dy0) / 4;
+  P->spec[SR_DWO1].b_goff64 = ((int64_t)ws_off_y1 - (int64_t)ws_off_ctx) / 4;
   row(SR_DWQKV, GEMM_TN, D, D, R, 3 * D, D, D, 0, 3, D, 0, 0, 1, 0);        // d[Wq;Wk;Wv] += dQKV^T X: group g = columns g D.. of dQKV, output g
   for (int t = 0; t < TB_COUNT; ++t) {
     int tiles = 0, k_sum = 0;
@@ -950,8 +955,10 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
   if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
   G->t_max = 0;
   for (int s = 0; s < n_seq; ++s) G->t_max = std::max(G->t_max, off[s + 1] - off[s]);
-  // (a workspace sized without the bf16 shadows -- sumk_vasnet_workspace_bytes_for of another arithmetic -- keeps the plane kernels)
-  G->b16 = use_b16(*G, D, precision, training) && workspace_bytes >= G->L.total;
+  // A function of the batch and the options ONLY (never of workspace_bytes: forward and backward must take the same path -- the
+  // forward leaves the bf16 shadows and table layout the backward reads); a workspace without the shadows is refused below.
+  (void)workspace_bytes;
+  G->b16 = use_b16(*G, D, precision, training);
   if (G->b16) G->cfg_s = G->cfg_pv = 0;       // the bf16-source kernel has 128x128 tiles
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
@@ -959,7 +966,7 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
   G->sk = G->b16 ? 0 : use_sk(G->R, D, precision);
-  if (G->sk) sk_plan(G->R, D, n_seq, off, G->sk == 2, G->L.e_elems, &G->P);
+  if (G->sk) sk_plan(G->R, D, n_seq, off, G->sk == 2, G->L, &G->P);
   return SUMK_OK;
 }
 
@@ -1475,12 +1482,8 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
                                   slabs ? G.P.row[SR_DY1].S : 0, (int64_t)R * D));
     SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
     {
-      const SkCall c{dY0, {CTX, nullptr, nullptr, nullptr}, {gr->Wo, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};     // dWo += dY0^T CTX
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DWO, -1, c, stream));
-    }
-    {
-      const SkCall c{dZ, {Y1, nullptr, nullptr, nullptr}, {gr->W1, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dW1 += dZ^T Y1
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DW1, -1, c, stream));
+      const SkCall c{dY0, {CTX, nullptr, nullptr, nullptr}, {gr->Wo, gr->W1, nullptr, nullptr}, nullptr, nullptr, -1};      // dWo += dY0^T CTX and dW1 += dZ^T Y1 (group 1)
+      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DWO1, -1, c, stream));
     }
     {
       const SkCall c{dY0, {w->Wo, nullptr, nullptr, nullptr}, {dCTX, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};     // dCTX = dY0 Wo

@@ -318,7 +318,7 @@ class VASNetTrainer(Trainer):
         lens_b = [seq.shape[0]]
         self.optimizer.zero_grad()
         scores = self.model.score_packed(seq, lens_b)
-        loss = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev)).mean()
+        loss = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev)).view(())    # one video: the mean over videos is the value itself
         loss.backward()
         self.optimizer.step(grad_scale=1.0)
         if self.model.graph_seed is not None:

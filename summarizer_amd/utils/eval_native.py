@@ -99,6 +99,18 @@ def evaluate_batch_device(videos, scores_dev, lens, proportion=0.15, method="kna
         return np.zeros(0), np.zeros(0), np.zeros(0), ([] if want_summaries else None)
     if not scores_dev.is_cuda or scores_dev.dtype != torch.float32 or not scores_dev.is_contiguous():
         raise _lib.SumkError("evaluate_batch_device: scores must be a contiguous float32 GPU tensor")
+    # the kernel's fixed-size LDS tables and its rank rule: the same conditions Trainer._test_on_device tests before coming here
+    # (a direct caller past them would corrupt LDS silently: the descriptors live in device memory, sumk_eval_device cannot look)
+    for i, (v, T) in enumerate(zip(videos, lens)):
+        if not device_ready(v):
+            raise _lib.SumkError(f"evaluate_batch_device: video {i} does not qualify for the device tail (needs ascending picks, <= 4096 of "
+                                 "them, <= 32 annotators, change points and annotator ranks over n_frames); use evaluate_batch")
+        # eval.py:26-34 (upsample): intervals = picks + the n_frames sentinel; one interval per score -- the host tail returns an error
+        # for more intervals than scores (csrc/evaltail.hip eval_one), where the reference's loop raises IndexError
+        n_picks = v["picks"].shape[0]
+        n_int = n_picks - 1 + (1 if v["picks"][-1] != v["n_frames"] else 0)
+        if n_int > int(T) + 1:
+            raise _lib.SumkError(f"evaluate_batch_device: video {i} has {n_int} pick intervals for {int(T)} scores")
     descr = (_lib.EvalDevVideo * n)()
     metas, row0, frame0, seg0 = [], 0, 0, 0
     for i, (v, T) in enumerate(zip(videos, lens)):
