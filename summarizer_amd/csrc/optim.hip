@@ -11,7 +11,11 @@ namespace sumk {
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // dyn != nullptr: step size, bias correction and gradient scale come from the device block adam_prep_kernel wrote (the
 // sync-free / graph-capturable form: the step counter and the clip coefficient never visit the host).
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// zero_grad: the gradient is set to zero once it has been read -- the next step's zero_grad() folded into this pass (21 MB written
+// here instead of a 21 MB fill kernel plus its launch boundary ahead of every step; the reference's order zero_grad -> backward -> step,
+// vasnet.py:210-212, leaves the same state).
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float step_size, float inv_sqrt_bc2, float grad_scale,
                                                    const float* __restrict__ dyn) {
@@ -30,6 +34,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
     reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    if constexpr (ZERO) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // tail (n not a multiple of 4)
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -37,6 +42,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float mi = b1 * m[i] + (1.f - b1) * gr, vi = b2 * v[i] + (1.f - b2) * gr * gr;
     m[i] = mi; v[i] = vi;
     p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    if constexpr (ZERO) g[i] = 0.f;
   }
 }
 
@@ -129,24 +135,37 @@ extern "C" int sumk_adam_step(float* param, const float* grad, float* exp_avg, f
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+  hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n, lr,
                      beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale, (const float*)nullptr);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 
-extern "C" int sumk_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                                  float beta1, float beta2, float eps, float weight_decay, int32_t* state, float grad_scale,
-                                  const float* sumsq, float max_norm, void* stream) {
+static int adam_step_dev_impl(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int32_t* state, float grad_scale,
+                             const float* sumsq, float max_norm, void* stream, bool zero_grad) {
   SUMK_ARG(param && grad && exp_avg && exp_avg_sq && state, "adam_dev: null pointer");
   SUMK_ARG(n > 0, "adam_dev: n=%lld", (long long)n);
   SUMK_ARG(sumsq == nullptr || max_norm > 0.f, "adam_dev: max_norm=%g with a norm given", (double)max_norm);
   hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2, grad_scale, sumsq, max_norm);
   int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                     beta1, beta2, eps, weight_decay, 0.f, 0.f, 0.f, (const float*)state);
+  if (zero_grad) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                                    beta1, beta2, eps, weight_decay, 0.f, 0.f, 0.f, (const float*)state);
+  else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                          beta1, beta2, eps, weight_decay, 0.f, 0.f, 0.f, (const float*)state);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
+}
+extern "C" int sumk_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int32_t* state, float grad_scale,
+                                  const float* sumsq, float max_norm, void* stream) {
+  return adam_step_dev_impl(param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, grad_scale, sumsq,
+                            max_norm, stream, false);
+}
+extern "C" int sumk_adam_step_dev_zero_grad(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                            float beta1, float beta2, float eps, float weight_decay, int32_t* state, float grad_scale,
+                                            const float* sumsq, float max_norm, void* stream) {
+  return adam_step_dev_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, grad_scale, sumsq, max_norm, stream, true);
 }
 
 extern "C" size_t sumk_sumsq_workspace_bytes(void) { return 1024 * sizeof(float); }

@@ -257,7 +257,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
 
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
-                  sumsq=None, max_norm=0.0):
+                  sumsq=None, max_norm=0.0, zero_grad=False):
     """The same update with the step counter (state[0], int32, incremented by the call) and, when `sumsq` (device scalar, squared
     L2 norm of the unscaled gradient) is given, the clip_grad_norm_ coefficient kept ON THE DEVICE: no host sync, capturable into
     a HIP graph.  `state`: 4 x int32 device block, zeroed once by the owner."""
@@ -268,9 +268,9 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, lr, betas=(0.9, 0.999
             raise SumkError("adam_step_dev: buffers must be contiguous")
     if not state.is_cuda or state.dtype != torch.int32 or state.numel() < 4 or not state.is_contiguous():
         raise SumkError("adam_step_dev: state must be a contiguous int32 GPU tensor of 4 elements")
-    rc = lib.sumk_adam_step_dev(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
-                                weight_decay, _p(state), float(grad_scale), None if sumsq is None else _p(sumsq), float(max_norm),
-                                _stream())
+    fn = lib.sumk_adam_step_dev_zero_grad if zero_grad else lib.sumk_adam_step_dev      # zero_grad: the gradient buffer is left zero
+    rc = fn(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
+            weight_decay, _p(state), float(grad_scale), None if sumsq is None else _p(sumsq), float(max_norm), _stream())
     _lib.check(rc, "sumk_adam_step_dev")
     WEIGHTS_EPOCH[0] += 1
 

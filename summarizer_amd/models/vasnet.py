@@ -241,7 +241,7 @@ class VASNetTrainer(Trainer):
         # reference schedule as HIP graphs: one captured step per video, replayed from the second epoch on (class docstring)
         use_graph = (world == 1 and bv == 1 and use_packed and dev.type == "cuda"
                      and str(self.hps.extra_params.get("hip_graph", "1")) not in ("0", "False", "false"))
-        graphs, graph_pool = {}, None
+        graphs, graph_pool, graphs_zeroed = {}, None, False
         if use_graph:
             self.model.graph_seed = torch.zeros(1, dtype=torch.int64, device=dev)
         for epoch in range(self.hps.epochs):
@@ -259,6 +259,8 @@ class VASNetTrainer(Trainer):
                             self.log.warning(f"HIP graph capture failed ({type(e).__name__}: {e}); training continues eagerly")
                             use_graph, self.model.graph_seed = False, None
                     if use_graph:
+                        if not graphs_zeroed:          # the captured steps keep the gradient bucket zero between them (Adam kernel); the
+                            self.optimizer.zero_grad(); graphs_zeroed = True      # first replay after eager steps starts from an explicit one
                         ent[0].replay()
                         losses.append(ent[1]); dist_scores[keys[0]] = ent[2]
                         continue
@@ -312,15 +314,17 @@ class VASNetTrainer(Trainer):
         self.model.graph_seed = None
         return best_corr, best_avg_f_score, best_max_f_score
 
-    def _single_video_step(self, key, dev):
-        """One optimiser step on one video (vasnet.py:193-212): (loss, scores) as detached tensors."""
+    def _single_video_step(self, key, dev, grads_are_zero=False):
+        """One optimiser step on one video (vasnet.py:193-212): (loss, scores) as detached tensors.  grads_are_zero: the captured
+        form -- the previous step's Adam kernel left the gradient bucket zero and this one does the same, so no fill kernel runs."""
         seq, target = self._load_video(key, dev)
         lens_b = [seq.shape[0]]
-        self.optimizer.zero_grad()
+        if not grads_are_zero:
+            self.optimizer.zero_grad()
         scores = self.model.score_packed(seq, lens_b)
         loss = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev)).view(())    # one video: the mean over videos is the value itself
         loss.backward()
-        self.optimizer.step(grad_scale=1.0)
+        self.optimizer.step(grad_scale=1.0, zero_grad=grads_are_zero)
         if self.model.graph_seed is not None:
             self.model.graph_seed.add_(1)            # next replay: other dropout masks
         return loss.detach(), scores.detach().view(-1, 1, 1)
@@ -337,6 +341,6 @@ class VASNetTrainer(Trainer):
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool):
-            loss, scores = self._single_video_step(key, dev)
+            loss, scores = self._single_video_step(key, dev, grads_are_zero=True)
             loss_out.copy_(loss); scores_out.copy_(scores)
         return g, loss_out, scores_out

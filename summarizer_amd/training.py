@@ -249,7 +249,7 @@ class FlatAdam:
         kernels.sumsq(self.flat_grad, out=self._norm)
         return math.sqrt(float(self._norm.item())) * grad_scale
 
-    def step(self, grad_scale=1.0, max_norm=None):
+    def step(self, grad_scale=1.0, max_norm=None, zero_grad=False):
         """grad_scale: multiplies the gradient first (1/world_size of a DP average).  max_norm: clip_grad_norm_
         semantics applied AFTER the all-reduce, on the averaged gradient (torch: coef = max_norm/(norm+1e-6), clamped to 1).
         The step counter and the clip coefficient stay on the device (sumk_adam_step_dev): no host synchronisation, so a whole
@@ -260,8 +260,9 @@ class FlatAdam:
             kernels.sumsq(self.flat_grad, out=self._norm)
             sumsq = self._norm
         self.step_count += 1          # host mirror (not advanced by graph replays; the device counter in _state[0] is authoritative)
+        # zero_grad: the gradient bucket is left zero by the Adam kernel (the next step's zero_grad(), folded into this pass)
         kernels.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._state, self.lr, self.betas,
-                              self.eps, self.weight_decay, grad_scale, sumsq, 0.0 if max_norm is None else max_norm)
+                              self.eps, self.weight_decay, grad_scale, sumsq, 0.0 if max_norm is None else max_norm, zero_grad=zero_grad)
 
 
 def broadcast_parameters(model, src=0):

@@ -172,7 +172,11 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert out["roofline"]["frac"] > 0 and out["bf16x3_mode"]["max_abs_score_diff_vs_fp32"] < 1e-4
     # the scaling line also carries a data-parallel TRAINING leg, so that a multi-GPU run measures the gradient all-reduce
     tl = out["train_step_mode"]
-    assert tl["frames_per_s"] > 0 and tl["allreduce_bytes_per_step"] > 20e6 and tl["collectives_per_step"] == 1
+    assert tl["frames_per_s"] > 0 and tl["allreduce_bytes_per_step"] > 20e6 and tl["collectives_per_step"] == 2      # tail piece early, head after the backward
+    # ... and what a SCALE run needs to decompose it: the exchange alone, the step without it, exposed and hidden communication
+    for leg in (tl, out["train_step_bf16_mode"], out["dsn_reinforce_step_mode"]):
+        assert leg["allreduce_alone_us"] > 0 and leg["ms_per_step_without_allreduce"] > 0
+        assert leg["exposed_comm_us"] >= 0 and leg["overlap_hidden_us"] >= 0
     tb = out["train_step_bf16_mode"]              # BASELINE config 2: bf16 products and a bf16 gradient bucket (half the bytes)
     assert tb["frames_per_s"] > 0 and 10e6 < tb["allreduce_bytes_per_step"] < 11e6
     rl = out["dsn_reinforce_step_mode"]           # BASELINE config 4: DSN REINFORCE data-parallel (10.5 MB bucket, clip after the reduce)
