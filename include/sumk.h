@@ -417,6 +417,15 @@ int sumk_pack_rows_bf16(uint16_t* dst_bf16, const float* const* srcs, const int3
 #define SUMK_PROF_GEMM_OPROJ 5   /* output projection (+ residual)                                      */
 #define SUMK_PROF_GEMM_K1 6      /* k1 (+ bias, ReLU)                                                   */
 #define SUMK_PROF_NTAGS 8
+/* The small-batch GEMM form by itself (tests, probes): C = epilogue(A . B) for ONE exact-fp32 problem on 64x64 tiles whose K is cut
+ * into `slices` (1 .. 8) slices INSIDE the launch -- every (tile, slice) block stores a partial tile, the last one to arrive adds
+ * them in slice order and runs the epilogue (csrc/gemm_lean.hip, SK instances; what sumk_vasnet_forward / _backward launch for batches
+ * of <= 1024 frames).  layout 0 NT (A (M,K), B (N,K)), 1 NN (B (K,N)), 2 TN (A (K,M), B (K,N)); epilogue 0 C = alpha acc, 1 acc + R,
+ * 2 relu(acc + bias[col]), 4 C += alpha acc.  workspace: sumk_gemm_splitk_workspace_bytes(M, N, slices), 256-byte aligned. */
+size_t sumk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t slices);
+int sumk_gemm_splitk(int32_t layout, const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                     int32_t ldc, int32_t slices, int32_t epilogue, const float* R, int32_t ldr, const float* bias, float alpha,
+                     void* workspace, size_t workspace_bytes, void* stream);
 int sumk_prof_enable(int32_t tag_mask);
 int sumk_prof_read(int32_t tag, double* total_ms, int64_t* launches, int32_t reset);
 /* Diagnostic (process started with SUMK_GEMM_DBG=2): the last GEMM launch's in-kernel shader-cycle stamps, 4 values per block

@@ -148,6 +148,9 @@ _SIGS = {
                                      C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "sumk_adam_step_dev_zero_grad": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                                C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
+    "sumk_gemm_splitk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "sumk_gemm_splitk": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_sumsq_workspace_bytes": (C.c_size_t, []),
     "sumk_sumsq": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_void_p]),
     "sumk_cast_f32_bf16": (C.c_int, [c_f32p, C.c_void_p, C.c_int64, C.c_void_p]),

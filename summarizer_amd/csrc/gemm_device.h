@@ -297,7 +297,6 @@ __device__ __forceinline__ void residual_init(const GemmKArgs& ka, const TileCtx
 }
 
 // gemm_lean.hip: 64x64 exact-fp32 tiles with a VALU-free main loop (NT / NN, plain epilogue) for the per-video products
-int launch_gemm_direct(GemmLayout layout, const GemmKArgs& ka, int tiles, int waves, hipStream_t stream);   // gemm_direct.hip: 32x32 tile per workgroup, K over its waves
 int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStream_t stream, int sk = 0);   // sk: the small-batch (in-launch split-K) instances
 // gemm_b16.hip: bf16 operands in HBM (A and B[0] point at bf16 data), fp32 accumulate / output; 128x128 tiles or (192 | 256) x 256
 int launch_gemm_b16(GemmLayout layout, GemmEpi epi, const GemmKArgs& ka, int tiles, int wide, hipStream_t stream);

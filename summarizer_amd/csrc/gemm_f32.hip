@@ -82,7 +82,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     SUMK_ARG(epi == EPI_NONE || epi == EPI_RESIDUAL || epi == EPI_BIAS_RELU || epi == EPI_ACCUM, "gemm: epilogue %d has no SK form", (int)epi);
     SUMK_ARG(g.drop_thr == 0, "gemm: SK launches have no epilogue dropout");
     ka.group_remap = 0; ka.xcd_tiles_m = 0;
-    rc = g.sk == 2 ? launch_gemm_direct(layout, ka, ka.total_tiles, g.dk_waves, stream) : launch_gemm_lean(layout, ka, ka.total_tiles, stream, 1);
+    rc = launch_gemm_lean(layout, ka, ka.total_tiles, stream, 1);
     prof_end(SUMK_PROF_GEMM_ALL, stream);
     if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
     if (rc != SUMK_OK) return rc;

@@ -102,11 +102,7 @@ struct GemmLaunch {
   // 4096 floats per (tile, slice), sk_cnt one zeroed word per tile (the reducer leaves it zero again); Csel[1..3] are the outputs
   // entries with SK_CSEL = 1..3 write (C is output 0).
   int32_t sk = 0; float* sk_part = nullptr; unsigned* sk_cnt = nullptr; float* Csel[4] = {nullptr, nullptr, nullptr, nullptr};
-  // sk = 2: the direct small-batch kernel (gemm_direct.hip): ONE 32x32 tile per workgroup, K split over its dk_waves waves (in-block
-  // LDS reduce); `probs` counts 32x32 tiles (no K slices: SK_N = 0), the SK_BSEL / SK_CSEL choices and the run-time epilogues apply.
-  int32_t dk_waves = 1;
 };
-int gemm_direct_waves(int tiles, int K);     // waves per tile for a launch of `tiles` 32x32 tiles contracting over K
 // K slices for an SK launch of `tiles` 64x64 tiles contracting over K: enough (tile, slice) blocks for ~3-4 per CU, slices of whole
 // 32-wide k-tiles, at least four k-tiles each, at most SK_MAX_SLICES.  Returns S and the slice length in *kchunk.
 constexpr int SK_MAX_SLICES = 8;

@@ -858,13 +858,12 @@ static int rowwise_small_tile(int M, int N) {
   return gemm_tiles(M, N, 0) >= 512 ? 0 : 1;
 }
 
-struct SkPlan { SkTab row[SR_COUNT], seq[TB_COUNT]; SkRowSpec spec[SR_COUNT]; int tile, row_waves[SR_COUNT], seq_waves[TB_COUNT]; int64_t slab_seq[TB_COUNT]; };
+struct SkPlan { SkTab row[SR_COUNT], seq[TB_COUNT]; SkRowSpec spec[SR_COUNT]; int64_t slab_seq[TB_COUNT]; };
 struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
   int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv, t_max;
   bool b16;          // the mixed-precision training step on the bf16-source kernels (use_b16)
-  int sk;            // the small-batch path (use_sk): 0 off; 2 every GEMM on gemm_direct.hip (32x32 tile per workgroup, K over its waves);
-                     // 1 the in-launch split-K instances of gemm_lean.hip (the first build of this path, kept for the A/B measurement); P = its tables
+  int sk;            // 1: the small-batch path (use_sk) -- every GEMM an in-launch split-K launch of gemm_lean.hip; P = its tables
   SkPlan P;
 };
 static bool use_b16(const Geometry& G, int D, int precision, int training);
@@ -872,15 +871,15 @@ static bool use_b16(const Geometry& G, int D, int precision, int training);
 // Small-batch path (SK launches): a function of the batch geometry and the arithmetic only -- forward and backward must agree.
 // SUMK_SK=0 keeps the large-batch kernels for every batch (the A/B switch of tests/test_gpu_vasnet.py::test_small_batch_path_...).
 static int use_sk(int R, int D, int precision) {
-  static const int mode = getenv("SUMK_SK") ? atoi(getenv("SUMK_SK")) : 1;
-  return (mode == 1 || mode == 2) && precision == SUMK_PRECISION_FP32 && sk_rows_ok(R) && D % 4 == 0 ? mode : 0;
+  static const bool on = !(getenv("SUMK_SK") && getenv("SUMK_SK")[0] == '0');
+  // (D <= 2048: the row kernels that add K-slice slabs hold a row in registers)
+  return on && precision == SUMK_PRECISION_FP32 && sk_rows_ok(R) && D % 4 == 0 && D <= 2048 ? 1 : 0;
 }
 // Every table of the step: requested slices, entries, (tile, slice) blocks and tickets -- the host mirror of vasnet_sk_setup_kernel.
-static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, const VasnetWs& L, SkPlan* P) {
+static void sk_plan(int R, int D, int n_seq, const int32_t* off, const VasnetWs& L, SkPlan* P) {
   const int64_t e_elems = L.e_elems;
   const size_t ws_off_dz = L.dz, ws_off_dy0 = L.dy0, ws_off_y1 = L.y1, ws_off_ctx = L.ctx;
-  const int te = direct ? 32 : 64;        // direct: 32x32 tiles, K split over the waves of a workgroup (no table slices)
-  P->tile = te;
+  constexpr int te = 64;
   // slab: the output's consumer is a row kernel that adds K-slice slabs on load (SlabIn) -- the slices then need no in-launch meeting
   // Slice counts are a function of the contraction length alone (smax > 0: min(smax, K / 128) slices of at least four k-tiles) wherever K
   // is a property of the model or of one video -- a video's scores and the gradients it contributes then do not depend on what else
@@ -889,14 +888,13 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, co
   auto row = [&](int r, int layout, int M, int N, int K, int lda, int ldb, int ldc, int ldr, int groups, int a_goff, int c_goff, int bsel, int csel, int smax, bool slab = false) {
     const int tiles = ((M + te - 1) / te) * ((N + te - 1) / te);
     int kc, S;
-    int S_req = direct ? 1 : smax > 0 ? std::max(1, std::min(smax, K / 128)) : sk_slices(tiles * groups, K, &kc);
-    if (slab && !direct) for (S_req = 8; S_req > 1; S_req >>= 1) {        // slab sets: exactly 1, 2, 4 or 8 slices (slab_sum), each at least four k-tiles
+    int S_req = smax > 0 ? std::max(1, std::min(smax, K / 128)) : sk_slices(tiles * groups, K, &kc);
+    if (slab) for (S_req = 8; S_req > 1; S_req >>= 1) {        // slab sets: exactly 1, 2, 4 or 8 slices (slab_sum), each at least four k-tiles
       sk_slice(K, S_req, &kc, &S);
       if (S == S_req && kc >= 128) break;
     }
     sk_slice(K, S_req, &kc, &S);
-    P->row_waves[r] = direct ? gemm_direct_waves(tiles * groups, K) : 0;
-    P->spec[r] = SkRowSpec{M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel, (slab && !direct) ? (int64_t)M * ldc : 0, 0, 0};
+    P->spec[r] = SkRowSpec{M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel, slab ? (int64_t)M * ldc : 0, 0, 0};
     P->row[r] = SkTab{groups * S, groups * S * tiles, groups * tiles, S_req, S};
   };
   row(SR_QKV, GEMM_NT, R, D, D, D, D, 3 * D, 0, 3, 0, D, 1, 0, 4);          // [Q|K|V] = X [Wq;Wk;Wv]^T: group g = B pointer g, columns g D..
@@ -920,15 +918,14 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, bool direct, co
     int kc;
     // (per-video products: the request is the cap; vasnet_sk_setup_kernel / sk_slice_seq give a video with K = T_s frames min(4, T_s / 128)
     //  slices -- a function of that video alone)
-    int S_req = direct ? 1 : 4;
-    P->seq_waves[t] = direct ? gemm_direct_waves(tiles, std::max(1, k_sum / n_seq)) : 0;
-    if (!direct && (t == TB_S || t == TB_DP)) for (S_req = 8; S_req > 1; S_req >>= 1) {     // slab sets (K = D for every video): 1, 2, 4 or 8 slices
+    int S_req = 4;
+    if (t == TB_S || t == TB_DP) for (S_req = 8; S_req > 1; S_req >>= 1) {     // slab sets (K = D for every video): 1, 2, 4 or 8 slices
       int S; sk_slice_seq(D, S_req, &kc, &S);          // (the rule vasnet_sk_setup_kernel applies to each video)
       if (S == S_req) break;
     }
     SkTab tb{0, 0, 0, S_req, 1};
     // Q.K^T and dAlpha = dC V^T (K = D for every video: the same slice count) are consumed by the softmax kernels: slabs
-    P->slab_seq[t] = (!direct && (t == TB_S || t == TB_DP)) ? e_elems : 0;
+    P->slab_seq[t] = (t == TB_S || t == TB_DP) ? e_elems : 0;
     for (int q = 0; q < n_seq; ++q) {
       int M, N, K, S;
       sk_seq_dims(t, off[q + 1] - off[q], D, &M, &N, &K);
@@ -966,7 +963,7 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
     G->tiles_s += gemm_tiles(T, T, G->cfg_s); G->tiles_pv += gemm_tiles(T, D, G->cfg_pv);
   }
   G->sk = G->b16 ? 0 : use_sk(G->R, D, precision);
-  if (G->sk) sk_plan(G->R, D, n_seq, off, G->sk == 2, G->L, &G->P);
+  if (G->sk) sk_plan(G->R, D, n_seq, off, G->L, &G->P);
   return SUMK_OK;
 }
 
@@ -1024,8 +1021,8 @@ static int launch_sk_setup(const Geometry& G, int D, int n_seq, const int32_t* o
   a.off = off_dev; a.n_seq = n_seq; a.D = D;
   a.seq = (SeqInfo*)(ws + G.L.seq); a.row_seq = (int32_t*)(ws + G.L.row_seq); a.cnt = (unsigned*)(ws + G.L.sk_cnt);
   a.tabs = (GemmProb*)(ws + G.L.sk_tabs);
-  a.tile = G.P.tile;
-  const bool tickets = G.sk == 1;        // (the direct kernel has none)
+  a.tile = 64;
+  const bool tickets = true;
   for (int r = 0; r < SR_COUNT; ++r) a.rows[r] = G.P.spec[r];
   for (int t = 0; t < TB_COUNT; ++t) {
     a.S_seq[t] = G.P.seq[t].S_req; a.slab_seq[t] = G.P.slab_seq[t];
@@ -1050,8 +1047,7 @@ static int launch_sk(const Geometry& G, int n_seq, char* ws, GemmLayout layout, 
   g.C = c.C[0]; g.R = c.R; g.bias0[0] = c.bias;
   g.probs = row_tab >= 0 ? sk_row_tab(tabs, row_tab) : sk_seq_tab(tabs, seq_tab, n_seq);
   g.nprob = tb.entries; g.total_tiles = tb.blocks; g.small_tile = 1; g.prof_tag = c.prof_tag;
-  g.sk = G.sk; g.sk_part = (float*)(ws + G.L.sk_part); g.sk_cnt = (unsigned*)(ws + G.L.sk_cnt);
-  g.dk_waves = row_tab >= 0 ? G.P.row_waves[row_tab] : G.P.seq_waves[seq_tab];
+  g.sk = 1; g.sk_part = (float*)(ws + G.L.sk_part); g.sk_cnt = (unsigned*)(ws + G.L.sk_cnt);
   SUMK_ARG(tb.blocks == tb.tiles || (size_t)tb.blocks * 64 * 64 * 4 <= sk_part_bytes(G, n_seq), "vasnet: small-batch launch needs %d partial tiles", tb.blocks);   // (blocks == tiles: nothing is sliced)
   return launch_gemm(layout, epi, g, stream);
 }
@@ -1093,6 +1089,42 @@ int launch_add_pos(float* x, const float* table, const int32_t* pos_rows, int n_
 
 using namespace sumk;
 
+// ---- the SK launch by itself (tests / probes): ONE problem cut into S K slices that meet inside the launch
+namespace sumk {
+struct SkOneArgs { GemmProb* tab; unsigned* cnt; int32_t tiles, layout, M, N, K, lda, ldb, ldc, ldr, S; };
+__global__ void sk_one_setup_kernel(SkOneArgs a) {
+  for (int i = threadIdx.x; i < a.tiles; i += blockDim.x) a.cnt[i] = 0u;
+  if (threadIdx.x == 0) put_sk(a.tab, 0, 0, 0, a.layout, 0, 0, 0, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.ldr, a.S, 0, 0, 64, 0, false);
+}
+}  // namespace sumk
+extern "C" size_t sumk_gemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t slices) {
+  if (M <= 0 || N <= 0 || slices < 1 || slices > SK_MAX_SLICES) return 0;
+  const size_t tiles = (size_t)((M + 63) / 64) * ((N + 63) / 64);
+  return align_up(SK_MAX_SLICES * sizeof(GemmProb), 256) + align_up(tiles * 4, 256) + tiles * slices * 64 * 64 * 4;
+}
+extern "C" int sumk_gemm_splitk(int32_t layout, const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+                                int32_t ldc, int32_t slices, int32_t epilogue, const float* R, int32_t ldr, const float* bias, float alpha,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(layout >= 0 && layout <= 2 && A && B && C && workspace, "gemm_splitk: bad arguments");
+  SUMK_ARG(M > 0 && N > 0 && K > 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm_splitk: M=%d N=%d K=%d lda=%d ldb=%d (leading dimensions in multiples of 4)", M, N, K, lda, ldb);
+  SUMK_ARG(epilogue == EPI_NONE || (epilogue == EPI_RESIDUAL && R) || (epilogue == EPI_BIAS_RELU && bias) || epilogue == EPI_ACCUM, "gemm_splitk: epilogue %d", epilogue);
+  const size_t need = sumk_gemm_splitk_workspace_bytes(M, N, slices);
+  SUMK_ARG(need != 0 && ((uintptr_t)workspace & 255) == 0, "gemm_splitk: 1 .. %d slices, 256-byte aligned workspace", SK_MAX_SLICES);
+  if (workspace_bytes < need) { set_error("gemm_splitk: workspace %zu < required %zu", workspace_bytes, need); return SUMK_ERR_WORKSPACE; }
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  char* ws = (char*)workspace;
+  int kc, S;
+  sk_slice(K, slices, &kc, &S);
+  SkOneArgs a{(GemmProb*)ws, (unsigned*)(ws + align_up(SK_MAX_SLICES * sizeof(GemmProb), 256)), tiles, layout, M, N, K, lda, ldb, ldc, ldr, slices};
+  hipLaunchKernelGGL(sk_one_setup_kernel, dim3(1), dim3(256), 0, stream, a);
+  GemmLaunch g;
+  g.A = A; g.B[0] = B; g.C = C; g.R = R; g.bias0[0] = bias; g.alpha = alpha;
+  g.probs = a.tab; g.nprob = S; g.total_tiles = S * tiles; g.small_tile = 1;
+  g.sk = 1; g.sk_cnt = a.cnt; g.sk_part = (float*)(ws + align_up(SK_MAX_SLICES * sizeof(GemmProb), 256) + align_up((size_t)tiles * 4, 256));
+  return launch_gemm((GemmLayout)layout, (GemmEpi)epilogue, g, stream);
+}
+
 extern "C" size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training) {
   VasnetWs w;
   if (carve(D, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
@@ -1132,18 +1164,17 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_QKV, -1, c, stream));
   }
   // K-slice slabs (SlabIn): where a row kernel consumes a GEMM's output, the slices store their own slab in the scratch and the row
-  // kernel adds them -- S slabs of the E layout / of (R, D); otherwise (direct kernel, or one slice) the GEMM writes the matrix itself
+  // kernel adds them -- S slabs of the E layout / of (R, D)
   float* scratch = (float*)(ws + L.sk_part);
-  const bool slabs = G.sk == 1;
   {  // 2: logits per video
-    const SkCall c{QKV, {QKV, nullptr, nullptr, nullptr}, {slabs ? scratch : E, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKT};
+    const SkCall c{QKV, {QKV, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKT};
     SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, -1, TB_S, c, stream));
   }
   {  // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
     const dim3 sg((R + 3) / 4), sb(256);
     float* e2p = use_e2 ? E2 : nullptr;
-    const float* eraw = slabs ? scratch : E;
-    const int n_slab = slabs ? G.P.seq[TB_S].S : 0;
+    const float* eraw = scratch;
+    const int n_slab = G.P.seq[TB_S].S;
 #define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, (unsigned short*)nullptr, eraw, n_slab, (int64_t)L.e_elems)
     if (G.t_max <= 256) SUMK_SOFTMAX(4); else if (G.t_max <= 512) SUMK_SOFTMAX(8); else if (G.t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
@@ -1152,7 +1183,7 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     const SkCall c{use_e2 ? E2 : E, {QKV, nullptr, nullptr, nullptr}, {CTX, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_PV};
     SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, -1, TB_PV, c, stream));
   }
-  if (slabs) {
+  {
     // 5 + 6: output projection as K-slice slabs; the LayerNorm kernel adds them and the residual (Y0 itself is kept for the backward pass)
     const SkCall c{CTX, {w->Wo, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_OPROJ};
     SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_OPROJ, -1, c, stream));
@@ -1163,19 +1194,6 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_K1, -1, c2, stream));
     SlabIn s2; s2.n = G.P.row[SR_K1].S; s2.stride = (int64_t)R * D; s2.bias = w->b1; s2.relu = 1; s2.store = training ? Z : nullptr;
     launch_ln_rows<true>(scratch, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream, nullptr, s2);
-  } else {
-    {  // 5: output projection + residual
-      const SkCall c{CTX, {w->Wo, nullptr, nullptr, nullptr}, {Y0, nullptr, nullptr, nullptr}, x, nullptr, SUMK_PROF_GEMM_OPROJ};
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_RESIDUAL, SR_OPROJ, -1, c, stream));
-    }
-    // 6: dropout + LayerNorm
-    launch_ln_rows<false>(Y0, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream);
-    {  // 7: k1 + bias + ReLU
-      const SkCall c{Y1, {w->W1, nullptr, nullptr, nullptr}, {Z, nullptr, nullptr, nullptr}, nullptr, w->b1, SUMK_PROF_GEMM_K1};
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_BIAS_RELU, SR_K1, -1, c, stream));
-    }
-    // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
-    launch_ln_rows<true>(Z, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
   }
   SUMK_HIP(hipGetLastError());
   if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
@@ -1473,13 +1491,12 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     SUMK_TRY(launch_ln_bwd<true>(D, R, Z, stats + 2 * (size_t)R, w->ln_w, w->ln_b, nullptr, w->w2, scores, dscores, dZ, lnpart, drop, 2u, &nw, stream));
     SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, gr->w2, gr->b2, gr->b1, stream));
     float* scratch = (float*)(ws + L.sk_part);
-    const bool slabs = G.sk == 1;          // K-slice slabs added by the consuming row kernel (see the forward)
     {
-      const SkCall c{dZ, {w->W1, nullptr, nullptr, nullptr}, {slabs ? scratch : dY1, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dY1 = dZ W1
+      const SkCall c{dZ, {w->W1, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dY1 = dZ W1 as K-slice slabs: the LayerNorm backward kernel adds them
       SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, SR_DY1, -1, c, stream));
     }
-    SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, slabs ? scratch : dY1, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream, nullptr,
-                                  slabs ? G.P.row[SR_DY1].S : 0, (int64_t)R * D));
+    SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, scratch, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream, nullptr,
+                                  G.P.row[SR_DY1].S, (int64_t)R * D));
     SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
     {
       const SkCall c{dY0, {CTX, nullptr, nullptr, nullptr}, {gr->Wo, gr->W1, nullptr, nullptr}, nullptr, nullptr, -1};      // dWo += dY0^T CTX and dW1 += dZ^T Y1 (group 1)
@@ -1496,11 +1513,11 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
       SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_NONE, -1, TB_DV, c, stream));
     }
     {
-      const SkCall c{dCTX, {QKV, nullptr, nullptr, nullptr}, {slabs ? scratch : E2, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dAlphaD = dC V^T
+      const SkCall c{dCTX, {QKV, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dAlphaD = dC V^T as slabs: the softmax backward kernel adds them
       SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, -1, TB_DP, c, stream));
     }
     hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
-                       opts->scale, drop, (unsigned short*)nullptr, (const float*)(slabs ? scratch : E2), slabs ? G.P.seq[TB_DP].S : 0, (int64_t)L.e_elems);
+                       opts->scale, drop, (unsigned short*)nullptr, (const float*)scratch, G.P.seq[TB_DP].S, (int64_t)L.e_elems);
     {
       const SkCall c{E2, {QKV, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dQ = dS K
       SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, -1, TB_DQ, c, stream));

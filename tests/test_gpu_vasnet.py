@@ -535,3 +535,58 @@ def test_small_batch_path_matches_large_batch_kernels(tmp_path):
         else:
             assert np.abs(a[k] - b[k]).max() <= 2e-4 * max(np.abs(b[k]).max(), 1e-30), (k, np.abs(a[k] - b[k]).max(), np.abs(b[k]).max())
     assert differs, "bit-identical everywhere: did SUMK_SK select two different paths?"
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (64, 64, 128), (65, 130, 300), (300, 1024, 1024), (37, 200, 2048), (128, 96, 260), (333, 77, 161)])
+def test_gemm_splitk_in_launch_vs_float64(dev, M, N, K):
+    """csrc/gemm_lean.hip, SK instances (the small-batch launches of sumk_vasnet_forward / _backward) by themselves through
+    sumk_gemm_splitk: NT / NN / TN, 1 ... 8 K slices that meet inside the launch (partial tiles + tickets, last arriver adds in slice
+    order), every run-time epilogue, ragged M / N tiles, K tails inside the last slice, more slices asked for than K holds -- against
+    float64 with the fp32 dot-product bound, exact on small-integer data, bit-repeatable, and the ticket words left zero (a second
+    launch on the same workspace needs no re-initialisation)."""
+    from summarizer_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cpu"); g.manual_seed(M * 131 + N * 7 + K)
+    Kp, Np, Mp = (K + 3) // 4 * 4, (N + 3) // 4 * 4, (M + 3) // 4 * 4              # leading dimensions in multiples of 4 (16-byte rows)
+    a = torch.zeros(M, Kp); a[:, :K] = torch.randn(M, K, generator=g)
+    b = torch.zeros(N, Kp); b[:, :K] = torch.randn(N, K, generator=g)
+    ai = torch.zeros(M, Kp); ai[:, :K] = ((torch.arange(M * K).reshape(M, K) % 7) - 3).float()
+    bi = torch.zeros(N, Kp); bi[:, :K] = (((torch.arange(N * K).reshape(N, K) % 5) - 2) + (torch.arange(N)[:, None] % 3)).float()
+    res = torch.randn(M, N, generator=g); bias = torch.randn(N, generator=g)
+    for A, B, exact in ((a, b, False), (ai, bi, True)):
+        a64, b64 = A[:, :K].double().numpy(), B[:, :K].double().numpy()
+        prod = a64 @ b64.T
+        bound = (K + 64) * 2.0 ** -23 * (np.abs(a64) @ np.abs(b64).T) + 1e-6
+        for layout, name in ((0, "NT"), (1, "NN"), (2, "TN")):
+            if layout == 0:
+                Ad, Bd, lda, ldb = A.to(dev), B.to(dev), Kp, Kp
+            elif layout == 1:
+                bt = torch.zeros(K, Np); bt[:, :N] = B[:, :K].t()
+                Ad, Bd, lda, ldb = A.to(dev), bt.to(dev), Kp, Np
+            else:
+                at = torch.zeros(K, Mp); at[:, :M] = A[:, :K].t()
+                bt = torch.zeros(K, Np); bt[:, :N] = B[:, :K].t()
+                Ad, Bd, lda, ldb = at.to(dev), bt.to(dev), Mp, Np
+            for S in (1, 2, 3, 8):
+                nb = lib.sumk_gemm_splitk_workspace_bytes(M, N, S)
+                ws = torch.empty(nb + 256, dtype=torch.uint8, device=dev).fill_(0xA5)      # poisoned: tickets are initialised by the call
+                wsp = (ws.data_ptr() + 255) // 256 * 256
+                for epi, ename in ((0, "none"), (1, "residual"), (2, "bias_relu"), (4, "accum")):
+                    c0 = torch.randn(M, N, generator=g)
+                    Cd = c0.clone().to(dev) if epi == 4 else torch.full((M, N), float("nan"), device=dev)
+                    Rd, bd = res.to(dev), bias.to(dev)
+                    outs = []
+                    for rep in range(2):
+                        if epi == 4:
+                            Cd.copy_(c0.to(dev))
+                        _lib.check(lib.sumk_gemm_splitk(layout, Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), M, N, K, lda, ldb, N, S, epi,
+                                                        Rd.data_ptr() if epi == 1 else None, N, bd.data_ptr() if epi == 2 else None, 1.0,
+                                                        wsp, nb, st), "gemm_splitk")
+                        outs.append(Cd.cpu().numpy().astype(np.float64))
+                    assert np.array_equal(outs[0], outs[1]), (name, S, ename)
+                    want = {0: prod, 1: prod + res.double().numpy(), 2: np.maximum(prod + bias.double().numpy()[None, :], 0.0), 4: c0.double().numpy() + prod}[epi]
+                    if exact and epi in (0, 4) and epi == 0:
+                        np.testing.assert_array_equal(outs[0], want, err_msg=f"{name} S={S} {ename}")
+                    else:
+                        assert (np.abs(outs[0] - want) <= bound + 1e-6 * np.abs(want)).all(), (name, S, ename, np.abs(outs[0] - want).max())
