@@ -281,6 +281,57 @@ def single_video_leg(dev, D=1024, T=300, iters=200):
     return out
 
 
+def trainer_test_leg(dev, D=1024, n_videos=50):
+    """SURVEY 8d, the metric as the reference defines it: the `Trainer.test`-style inference loop END TO END -- packed scoring of the
+    fold's 50 test videos (features cached in HBM after the first call), upsample + segment means + Spearman on the device, one small
+    D2H, knapsack key-shot selection + F-scores on the host threads -- wall clock per call and frames/s."""
+    from summarizer_amd.models.vasnet import VASNetTrainer
+    from summarizer_amd.utils.datasets import synthetic_dataset
+    from summarizer_amd.utils.hps import make_hps
+    ds = synthetic_dataset(n_videos, seed=11, D=D, t_range=(150, 320), n_users=20)
+    keys = list(ds.keys())
+    hps = make_hps(ds, [{"train_keys": [], "test_keys": keys}], epochs=1, extra_params={})
+    torch.manual_seed(1234)
+    tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
+    frames = int(sum(ds[k]["features"].shape[0] for k in keys))
+    for _ in range(3):
+        res = tr.test(0)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        res = tr.test(0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    assert all(np.isfinite(v) for v in (res[0], res[1][0], res[1][1]))
+    return dict(ms_per_call=round(dt * 1e3, 3), frames_per_s=round(frames / dt, 1), videos=n_videos, frames=frames,
+                note="Trainer.test(fold) on 50 synthetic TVSum-shaped videos: packed VASNet scoring + device evaluation tail (upsample, segment "
+                     "means, Spearman) + host knapsack / F-scores; features resident in HBM after the first call")
+
+
+def stream_leg(model, x, lens, dev, steps=30):
+    """SURVEY 8d's PCIe-inclusive variant (never `value`): features start in pageable host memory and scores end in host memory every
+    step -- native threaded pack into pinned staging, one H2D, packed scoring, one D2H, three slots in flight (ingest.StreamingScorer)."""
+    from summarizer_amd.ingest import StreamingScorer
+    xh = x.cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    vids = [(i, xh[off[i]:off[i + 1]]) for i in range(len(lens))]
+    frames = int(sum(lens))
+    scorer = StreamingScorer(model, max_frames=frames, depth=3)
+    def run(n):
+        def feed():
+            for _ in range(n):
+                yield from vids
+        for _ in scorer.score(feed()):
+            pass
+    run(5)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(ms_per_step=round(dt * 1e3, 3), frames_per_s=round(frames / dt, 1), h2d_bytes_per_step=int(frames * x.shape[1] * 4),
+                note="host -> host: fp32 features from pageable host memory, scores back to host memory, every step")
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: THIS process has not touched the GPU yet (torch is imported, nothing is
     initialised), so it starts N fresh rank processes through torch.distributed.run as CHILDREN (never an exec), lets rank 0's JSON
@@ -308,7 +359,7 @@ def main():
     ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer", "sumgan"], default="vasnet",
                     help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024; "
                          "sumgan (--mode train only) = one SumGANTrainer video step: selector+encoder, decoder and "
-                         "discriminator updates at the reference's default sizes (350 M parameters)")
+                         "discriminator updates at the reference's default sizes (195 M parameters)")
     ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph after warm-up and time the replays "
                     "(single process; roofline events are not recorded inside a captured step)")
     ap.add_argument("--mode", choices=["score", "train", "reinforce", "stream"], default="score",
@@ -683,6 +734,16 @@ def main():
             single = single_video_leg(dev)
         except Exception as e:          # noqa: BLE001
             single = dict(error=f"{type(e).__name__}: {e}"[:300])
+    e2e = stream = None
+    if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only and rank == 0:
+        def _side(fn, *a):
+            try:
+                return fn(*a)
+            except Exception as e:          # noqa: BLE001
+                return dict(error=f"{type(e).__name__}: {e}"[:300])
+        model.eval(); model.precision = "fp32"
+        e2e = _side(trainer_test_leg, dev)
+        stream = _side(stream_leg, model, x, lens, dev)
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),
@@ -720,6 +781,10 @@ def main():
             out["folded_vo_bf16x6_mode"] = folded6
         if single is not None:
             out["single_video_mode"] = single
+        if e2e is not None:
+            out["trainer_test_mode"] = e2e
+        if stream is not None:
+            out["stream_mode"] = stream
         if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
             try:
                 out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None, seed_base=1000 * rank)

@@ -40,7 +40,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   // SUMK_GROUP_REMAP: 0 never; 1 (default) split-K slices in every arithmetic + the per-video products of the bf16-plane modes, which
   // are bound by operand bytes (bf16 training step 1.35 -> 1.21 ms, bf16x3 / bf16x6 ~1 %); the exact-fp32 per-video products did
   // not gain (alpha.V 85 -> 89 us) and keep the plain order; 2 every grouped launch
-  static const int group_remap = getenv("SUMK_GROUP_REMAP") ? atoi(getenv("SUMK_GROUP_REMAP")) : 1;
+  static const int group_remap = SUMK_TUNE_ENV("SUMK_GROUP_REMAP") ? atoi(SUMK_TUNE_ENV("SUMK_GROUP_REMAP")) : 1;
   // (per-video products only while a video is a handful of tiles: at T = 10 000 a sub-problem is thousands of tiles, a contiguous
   //  range is a band of one video and the plain order was 6 % faster)
   const bool small_groups = (int64_t)g.total_tiles <= (int64_t)256 * g.nprob;
@@ -56,7 +56,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     if (only_tag < 0 || only_tag == g.prof_tag) ka.dbg_buf = gemm_stamp_buffer(); else ka.dbg &= ~2;
   }
   ka.drop.seed = g.drop_seed; ka.drop.thr = g.drop_thr; ka.drop.scale = g.drop_scale; ka.drop.seed_dev = nullptr; ka.drop_site = g.drop_site;
-  static const bool lean128_on = !(getenv("SUMK_LEAN128") && getenv("SUMK_LEAN128")[0] == '0');
+  static const bool lean128_on = !(SUMK_TUNE_ENV("SUMK_LEAN128") && SUMK_TUNE_ENV("SUMK_LEAN128")[0] == '0');
   ka.lean = (lean128_on && g.lean && g.nprob == 1 && layout == GEMM_NT && g.small_tile == 0 && g.precision == SUMK_PRECISION_FP32 &&
              (g.n_group == 0 || g.n_group % 128 == 0)) ? 1 : 0;
   ka.C16 = (unsigned short*)g.C16;
@@ -67,7 +67,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
   SUMK_ARG(!g.ln_stats || (epi == EPI_BIAS_RELU_HEAD && g.ln_c1 && g.ln_c2), "gemm: ln_stats goes with the head epilogue and c1 / c2");
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
-  static const bool xcd_map = !(getenv("SUMK_XCD_MAP") && getenv("SUMK_XCD_MAP")[0] == '0');
+  static const bool xcd_map = !(SUMK_TUNE_ENV("SUMK_XCD_MAP") && SUMK_TUNE_ENV("SUMK_XCD_MAP")[0] == '0');
   if (xcd_map && g.nprob == 1 && g.xcd_M > 0) {
     const int bm = (g.src16 && g.wide16) ? g.wide16 : gemm_tile_m(g.small_tile), bn = (g.src16 && g.wide16) ? 256 : gemm_tile_n(g.small_tile);
     const int tm = (g.xcd_M + bm - 1) / bm, tn = (g.xcd_N + bn - 1) / bn;
@@ -101,7 +101,7 @@ int launch_gemm(GemmLayout layout, GemmEpi epi, const GemmLaunch& g, hipStream_t
     return SUMK_OK;
   }
   // BK = 64 for the 64x64 tile measured no better than BK = 32 on S-TVSum (8.64 vs 8.68 M frames/s): kept selectable
-  static const bool bk64 = getenv("SUMK_BK64") && getenv("SUMK_BK64")[0] == '1';
+  static const bool bk64 = SUMK_TUNE_ENV("SUMK_BK64") && SUMK_TUNE_ENV("SUMK_BK64")[0] == '1';
   if (g.src16) {                              // bf16 operands in HBM: gemm_b16.hip
     SUMK_ARG(g.wide16 == 0 || g.wide16 == 192 || g.wide16 == 256, "gemm: wide16 must be 0, 192 or 256");
     rc = launch_gemm_b16(layout, epi, ka, ka.total_tiles, g.wide16, stream);
@@ -420,7 +420,7 @@ int plain_gemm(sumk::GemmLayout layout, const float* A, const float* B, float* C
   SUMK_ARG(p != nullptr, "gemm: cannot allocate problem scratch");
   hipStream_t s = (hipStream_t)stream;
   int small = (M <= 64 || N <= 64) ? 1 : 0;
-  if (const char* env = getenv("SUMK_ROW_CFG")) if (env[0] >= '0' && env[0] <= '2') small = env[0] - '0';
+  if (const char* env = SUMK_TUNE_ENV("SUMK_ROW_CFG")) if (env[0] >= '0' && env[0] <= '2') small = env[0] - '0';
 #ifdef SUMK_DIAG
   if (getenv("SUMK_FAKE_LD")) { lda = 0; ldb = 0; }   // `make DIAG=1` only: every row aliases row 0 (tiny footprint, all cache hits; wrong results by design)
 #endif

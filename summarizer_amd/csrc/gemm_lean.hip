@@ -402,7 +402,7 @@ int launch_gemm_lean(GemmLayout layout, const GemmKArgs& ka, int tiles, hipStrea
   }
   SUMK_ARG(layout == GEMM_NT || layout == GEMM_NN, "gemm_lean: NT and NN layouts only");
   // persistent: at most 4 blocks per CU (what the two LDS images admit) are resident; block b walks tiles b, b + grid, ...
-  static const int lean_grid = getenv("SUMK_LEAN_GRID") ? atoi(getenv("SUMK_LEAN_GRID")) : 1024;
+  static const int lean_grid = SUMK_TUNE_ENV("SUMK_LEAN_GRID") ? atoi(SUMK_TUNE_ENV("SUMK_LEAN_GRID")) : 1024;
   const dim3 grid(std::min(tiles, lean_grid)), block(256);
   if (layout == GEMM_NT) hipLaunchKernelGGL(gemm_lean_kernel<true>, grid, block, 0, s, ka);
   else hipLaunchKernelGGL(gemm_lean_kernel<false>, grid, block, 0, s, ka);

@@ -398,7 +398,7 @@ static int launch_epi(GemmEpi epi, const GemmKArgs& ka, int tiles, hipStream_t s
   // persistent grid: no more blocks than can be resident (256 CUs x blocks/CU for this tile's LDS/VGPR footprint);
   // every block then loops over tiles  b, b+grid, ...
   constexpr int occ = (BM == 128 && BN == 128) ? 3 : (BM == 128 ? 4 : (BK == 64 ? 4 : 8));
-  static const bool persist = !(getenv("SUMK_PERSIST") && getenv("SUMK_PERSIST")[0] == '0');
+  static const bool persist = !(SUMK_TUNE_ENV("SUMK_PERSIST") && SUMK_TUNE_ENV("SUMK_PERSIST")[0] == '0');
   dim3 grid(persist ? std::min(tiles, 256 * occ) : tiles), block(256);
   if constexpr (BM == 128 && BN == 128 && BK == 32 && A_KC && B_KC && X3 == 0) {
     if (ka.lean) {   // buffer-load instances (launch_gemm checked: one problem, NT, fp32, K % 32 == 0, one B group per tile)

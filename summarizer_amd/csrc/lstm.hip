@@ -1817,7 +1817,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize;
     if (2 * pa.n_groups <= PSTATE_WORDS - 16 && pa.n_active <= team_size) {
       const size_t shmem = std::max<size_t>(((size_t)gsize * (H + 4) + 8 * 32 * 32 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
-      static const bool direct = !(getenv("SUMK_LSTM_PANEL") && getenv("SUMK_LSTM_PANEL")[0] == '1');   // 1: stage h through LDS
+      static const bool direct = !(SUMK_TUNE_ENV("SUMK_LSTM_PANEL") && SUMK_TUNE_ENV("SUMK_LSTM_PANEL")[0] == '1');   // 1: stage h through LDS
       // SUMK_LSTM_LL=0: the counter hand-off (A/B switch); the flag-in-data one needs the exchange buffer's byte offsets in 31 bits
       static const bool ll_on = !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');
       const bool ll = direct && ll_on && L.ll_bytes > 0 && L.ll_bytes < 0x7fffffe0;
@@ -1826,7 +1826,11 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
       const int which = m16 ? 3 : ll ? 2 : direct ? 1 : 0;
       const void* fn = m16 ? (const void*)lstm_persist_kernel<4, true, true, true>
                      : ll ? (const void*)lstm_persist_kernel<4, true, true>
-                          : direct ? (const void*)lstm_persist_kernel<4, true> : (const void*)lstm_persist_kernel<4, false>;
+#ifdef SUMK_DIAG
+                          : direct ? (const void*)lstm_persist_kernel<4, true> : (const void*)lstm_persist_kernel<4, false>;   // (LDS-panel staging: measured slower, diagnostic build only)
+#else
+                          : (const void*)lstm_persist_kernel<4, true>;
+#endif
       static bool attr_set[4] = {false, false, false, false};
       if (!attr_set[which]) {
         SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1969,7 +1973,7 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
       done = true;
     }
   }
-  static const bool wide_bwd = !(getenv("SUMK_LSTM_WIDE_BWD") && getenv("SUMK_LSTM_WIDE_BWD")[0] == '0');
+  static const bool wide_bwd = !(SUMK_TUNE_ENV("SUMK_LSTM_WIDE_BWD") && SUMK_TUNE_ENV("SUMK_LSTM_WIDE_BWD")[0] == '0');
   if (!done && persist_ok && wide_bwd && n_seq > GV_MAXB && H > 256 && H <= 1024 && H % 128 == 0 && L.xchg_bytes > 0 &&
       2 * ((n_seq + WK_GROUP - 1) / WK_GROUP) <= PSTATE_WORDS - 16) {
     WideBwdArgs wa;

@@ -24,6 +24,17 @@ int hip_fail(hipError_t e, const char* what);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Tile-shape / schedule switches left from the tuning work (none changes a result beyond the summation order of another tile shape):
+// read ONLY by the diagnostic build (make DIAG=1 -> libsumk_diag.so, loaded through SUMK_LIB_PATH by scripts/probes); the product
+// library takes the measured-best setting unconditionally.  What the product library does read are the A/B switches that have a
+// test comparing both settings: SUMK_SK, SUMK_LEAN, SUMK_FUSED_HEAD, SUMK_FUSED_LN, SUMK_BF16_SRC, SUMK_B16_WIDE, SUMK_LSTM_PERSIST,
+// SUMK_LSTM_LL, SUMK_LSTM_LL_BWD, SUMK_LSTM_M16.
+#ifdef SUMK_DIAG
+#define SUMK_TUNE_ENV(name) getenv(name)
+#else
+#define SUMK_TUNE_ENV(name) ((const char*)nullptr)
+#endif
+
 // ------------------------------------------------------------------------------------------- GEMM
 // One sub-problem of a grouped launch.  Offsets are in elements from the launch's base pointers.
 struct GemmProb {

@@ -853,7 +853,7 @@ __global__ void add_pos_kernel(float* x, const float* table, const int32_t* pos_
 }
 
 static int rowwise_small_tile(int M, int N) {
-  static const char* env = getenv("SUMK_ROW_CFG");   // tuning override: 0 = 128x128, 1 = 64x64, 2 = 128x64
+  static const char* env = SUMK_TUNE_ENV("SUMK_ROW_CFG");   // tuning override: 0 = 128x128, 1 = 64x64, 2 = 128x64
   if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
   return gemm_tiles(M, N, 0) >= 512 ? 0 : 1;
 }
@@ -897,11 +897,16 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, const VasnetWs&
     P->spec[r] = SkRowSpec{M, N, K, lda, ldb, ldc, ldr, layout, groups, S_req, a_goff, c_goff, bsel, csel, slab ? (int64_t)M * ldc : 0, 0, 0};
     P->row[r] = SkTab{groups * S, groups * S * tiles, groups * tiles, S_req, S};
   };
-  row(SR_QKV, GEMM_NT, R, D, D, D, D, 3 * D, 0, 3, 0, D, 1, 0, 4);          // [Q|K|V] = X [Wq;Wk;Wv]^T: group g = B pointer g, columns g D..
+  // (diagnostic build: SUMK_SK_SMAX="<qkv><dctx>" overrides the two slice caps of the launches whose slices meet in the launch)
+  // QKV: 240 tiles at T = 300 already give every CU a block; 4 slices + the in-launch meeting measured the same 26 us as one chain per
+  // tile (scripts/probes/sk_smax_sweep.py: 112.9 vs 112.7 us per video), so it stays unsliced -- the same k order as the large-batch kernel
+  int smax_qkv = 1, smax_dctx = 8;
+  if (const char* e = SUMK_TUNE_ENV("SUMK_SK_SMAX")) if (e[0] >= '1' && e[0] <= '8' && e[1] >= '1' && e[1] <= '8') { smax_qkv = e[0] - '0'; smax_dctx = e[1] - '0'; }
+  row(SR_QKV, GEMM_NT, R, D, D, D, D, 3 * D, 0, 3, 0, D, 1, 0, smax_qkv);   // [Q|K|V] = X [Wq;Wk;Wv]^T: group g = B pointer g, columns g D..
   row(SR_OPROJ, GEMM_NT, R, D, D, D, D, D, D, 1, 0, 0, 0, 0, 8, true);      // Y0 = CTX Wo^T + X        (slabs -> LayerNorm kernel, which adds X)
   row(SR_K1, GEMM_NT, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8, true);         // Z = relu(Y1 W1^T + b1)   (slabs -> LayerNorm + head kernel: + b1, ReLU)
   row(SR_DY1, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8, true);        // dY1 = dZ W1              (slabs -> LayerNorm backward kernel)
-  row(SR_DCTX, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, 8);             // dCTX = dY0 Wo
+  row(SR_DCTX, GEMM_NN, R, D, D, D, D, D, 0, 1, 0, 0, 0, 0, smax_dctx);     // dCTX = dY0 Wo
   // dWo += dY0^T CTX and dW1 += dZ^T Y1 in ONE launch: group 1's operands are addressed relative to group 0's (dZ - dY0, Y1 - CTX: all four
   // are regions of the workspace), its output is C pointer 1
   row(SR_DWO1, GEMM_TN, D, D, R, D, D, D, 0, 2, 0, 0, 0, 1, 0);
@@ -946,7 +951,7 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
   // with 128x128 for the (T x D) products and 8.28 with 128x128 for both -- bigger tiles waste more on ragged T and
   // under-fill the resident slots); long videos (mean T >= 1024, e.g. BASELINE config 5) take the 128x128 tile, whose
   // 2x2 register blocking halves the LDS traffic per MFMA.
-  static const char* env = getenv("SUMK_ATTN_CFG");   // tuning override "<cfg_s><cfg_pv>", e.g. "20"
+  static const char* env = SUMK_TUNE_ENV("SUMK_ATTN_CFG");   // tuning override "<cfg_s><cfg_pv>", e.g. "20"
   const int cfg_auto = (G->R / n_seq >= 1024) ? 0 : 1;
   G->cfg_s = cfg_auto; G->cfg_pv = cfg_auto;
   if (env && env[0] >= '0' && env[0] <= '2' && env[1] >= '0' && env[1] <= '2') { G->cfg_s = env[0] - '0'; G->cfg_pv = env[1] - '0'; }
