@@ -1301,6 +1301,10 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
   int loaded_dir = -1;
   bool dead = false;
   float wB[2][8];     // M16: this lane's W_hh fragments
+#ifdef SUMK_DIAG   // `make DIAG=1`: per-phase shader cycles of a step, wave 0 (counter poll + epilogue role) and wave 7 of the first members -> state words 600..
+  unsigned long long bg_wait = 0, bg_cell = 0, bg_bar = 0, bg_mfma = 0, bg_drain = 0, bg_steps = 0;
+  const unsigned long long bg_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int item = team; item < a.n_items; item += PK_TEAMS) {
     const int g = item >> 1, d = item & 1;
@@ -1356,6 +1360,9 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
     if (erole && eT > 0 && eT - 1 == Tg - 1) fetch(Tg - 1);
 
     for (int t = Tg - 1; t >= 0; --t) {
+#ifdef SUMK_DIAG
+      const unsigned long long bs0 = __builtin_amdgcn_s_memtime();
+#endif
       // zero this step's A tile (rows of inactive videos and columns of absent units must contribute nothing)
       for (int idx = tid; idx < 32 * 36; idx += PK_THREADS) sA[idx] = 0.f;
       if (!LL && t < Tg - 1) {
@@ -1372,6 +1379,9 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         }
       }
       __syncthreads();
+#ifdef SUMK_DIAG
+      const unsigned long long bs1 = __builtin_amdgcn_s_memtime();
+#endif
       float rec_ll = 0.f;
       if constexpr (LL) {   // the 32 members' partials of step t+1: the loads are the poll (every wave of the epilogue role spins for itself)
         if (tid < 256) {
@@ -1429,7 +1439,13 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         sA[ei * 36 + eu] = d_i; sA[ei * 36 + 8 + eu] = d_f; sA[ei * 36 + 16 + eu] = d_g; sA[ei * 36 + 24 + eu] = d_o;
       }
       if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, one step ahead
+#ifdef SUMK_DIAG
+      const unsigned long long bs2 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+#ifdef SUMK_DIAG
+      const unsigned long long bs3 = __builtin_amdgcn_s_memtime();
+#endif
       if (t > 0) {   // partial_m(t) is only ever read by step t-1
         if constexpr (M16) {
           // 16 videos x (this wave's 32 columns, two 16-column tiles) x K = 32: lane group g = lane / 16 carries k = 8 g .. 8 g + 7
@@ -1439,6 +1455,30 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
           const unsigned tag = (unsigned)(Tg - t);
           unsigned long long* xo = a.ll + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * a.gsize) * H;
           float* xf = a.xchg + ((((int64_t)(t & 1) * a.n_items + item) * 32 + slot) * 32) * H;        // counter hand-off: fp32 partials
+          if constexpr (!LL) {
+            // Counter hand-off: the operands SWAPPED (W as "A", dG as "B") -- the tile comes out transposed, D^T[n][i], so a lane holds
+            // FOUR CONSECUTIVE COLUMNS n = 4 (lane / 16) + r of video i = lane % 16 and the publish is ONE 16-byte sc1 store per tile
+            // instead of four dword ones (dword sc1 stores cost ~6x per byte: the stamps of profiles/r04_lstm_bptt_phase_stamps.txt
+            // had 2 700 of a step's 11 250 cycles in this block, 512 of them MFMA).  Same products, same k order: the same bits.
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][0], a0.x, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][1], a0.y, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][2], a0.z, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][3], a0.w, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][4], a1.x, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][5], a1.y, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][6], a1.z, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[tile][7], a1.w, acc, 0, 0, 0);
+              const int n4 = wave * 32 + 16 * tile + 4 * g4;           // first of this lane's four columns (H % 4 == 0: all four inside or outside)
+              if (n4 < H && i16 < nv && t < sT[i16]) {
+                typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xf, (short)0, 0x7FFFFFFF, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc), xr, (unsigned)((i16 * H + n4) * 4), 0, 16 /* sc1 */);
+              }
+            }
+          } else
 #pragma unroll
           for (int tile = 0; tile < 2; ++tile) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1503,6 +1543,9 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         }
         }
       }
+#ifdef SUMK_DIAG
+      const unsigned long long bs4 = __builtin_amdgcn_s_memtime();
+#endif
       if constexpr (LL) {
         __syncthreads();   // the A tile in LDS is free again (the published partials need no further signal)
       } else {
@@ -1510,8 +1553,17 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+#ifdef SUMK_DIAG
+      bg_wait += bs1 - bs0; bg_cell += bs2 - bs1; bg_bar += bs3 - bs2; bg_mfma += bs4 - bs3; bg_drain += __builtin_amdgcn_s_memtime() - bs4; bg_steps += 1;
+#endif
     }
   }
+#ifdef SUMK_DIAG
+  if (!LL && M16 && blockIdx.x < 96 && (blockIdx.x % PK_TEAMS) == 0 && lane == 0 && (wave == 0 || wave == 7)) {      // members 0 .. 11 of team 0
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(a.state + 600) + ((blockIdx.x / PK_TEAMS) * 2 + (wave == 7)) * 8;
+    q[0] = __builtin_amdgcn_s_memtime() - bg_t0; q[1] = bg_wait; q[2] = bg_cell; q[3] = bg_bar; q[4] = bg_mfma; q[5] = bg_drain; q[6] = bg_steps;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- wide persistent BPTT
@@ -1971,6 +2023,21 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
       void* kargs[] = {&pa};
       SUMK_HIP(hipLaunchCooperativeKernel(fn, dim3(PK_TEAMS * 32), dim3(PK_THREADS), kargs, (unsigned)shmem, stream));
       done = true;
+#ifdef SUMK_DIAG
+      if (getenv("SUMK_LSTM_STAMPS") && !ll && m16) {      // phase table of the BPTT step (scripts/probes: profiles/r04_lstm_bptt_phase_stamps.txt)
+        unsigned long long q[12 * 2 * 8];
+        SUMK_HIP(hipStreamSynchronize(stream));
+        SUMK_HIP(hipMemcpy(q, (const char*)pa.state + 600 * 4, sizeof(q), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 12; b += 5)
+          for (int wv = 0; wv < 2; ++wv) {
+            const unsigned long long* e = q + (b * 2 + wv) * 8;
+            const double n = e[6] ? (double)e[6] : 1.0;
+            fprintf(stderr, "[lstm bptt stamps] member %d wave %d: steps %llu  cycles/step: total %.0f = wait for the counter %.0f + partial sums, cell backward, dG stores %.0f + "
+                            "barrier %.0f + MFMAs, partial stores %.0f + drain, barrier, signal %.0f\n",
+                    b, wv ? 7 : 0, e[6], (double)(e[1] + e[2] + e[3] + e[4] + e[5]) / n, e[1] / n, e[2] / n, e[3] / n, e[4] / n, e[5] / n);
+          }
+      }
+#endif
     }
   }
   static const bool wide_bwd = !(SUMK_TUNE_ENV("SUMK_LSTM_WIDE_BWD") && SUMK_TUNE_ENV("SUMK_LSTM_WIDE_BWD")[0] == '0');
