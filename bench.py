@@ -744,6 +744,8 @@ def main():
         model.eval(); model.precision = "fp32"
         e2e = _side(trainer_test_leg, dev)
         stream = _side(stream_leg, model, x, lens, dev)
+    if dist is not None and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
+        barrier()          # the rank-0-only legs above take a few seconds: the other ranks wait here, not inside destroy_process_group
     if rank == 0:
         flops_frame = 10 * D * D + 4 * (sum(t * t for t in lens) / frames) * D + 2 * D
         out = dict(metric="frames scored/sec (T x 1024)", value=round(frames * world * args.steps / elapsed, 1),

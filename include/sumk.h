@@ -72,6 +72,12 @@ typedef struct sumk_vasnet_opts {
      read at execution time.  For steps captured into a HIP graph: kernel arguments are frozen at capture, the device word is not --
      the caller increments it between replays (after the backward pass of a step) and every replay draws fresh masks. */
   const uint64_t* seed_dev;
+  /* NULL, or the batch's problem tables prebuilt by sumk_vasnet_build_tables for the SAME (D, seq_off, training, precision): the call
+     then launches no table-setup kernel (5-7 us per call: 5 % of a single-video forward).  The tables depend on the batch geometry
+     only -- not on weights, inputs or the workspace -- so a caller builds them once per distinct batch (SeqBatch in kernels.py) and
+     may share them between forward, backward and any number of calls ON ONE STREAM AT A TIME (they hold the tickets of the
+     in-launch split-K launches, which every launch leaves zero).  Wrong tables give wrong results, not errors: device memory. */
+  void* tables;
 } sumk_vasnet_opts;
 
 /* Bytes of workspace sumk_vasnet_forward / _backward need for this batch (seq_off_host has n_seq+1 entries). */
@@ -81,6 +87,12 @@ size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_
  * runs on never depends on the workspace it is handed: a bf16 training step given the smaller workspace is refused
  * (SUMK_ERR_WORKSPACE), so a forward and a backward pass cannot end up on different paths. */
 size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training, int32_t precision);
+
+/* Problem tables of a batch, separately (sumk_vasnet_opts::tables): size, and the one-time build (the setup kernels of a call, run into
+ * `tables` instead of the workspace).  256-byte aligned device buffer. */
+size_t sumk_vasnet_tables_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host);
+int sumk_vasnet_build_tables(int32_t D, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev, int32_t training,
+                             int32_t precision, void* tables, size_t tables_bytes, void* stream);
 
 /* Replaces VASNet.forward (vasnet.py:92-148) for a packed batch: x (n_rows,D) -> scores (n_rows,), sigmoid
  * outputs in (0,1).  If pos_rows != NULL, x[r,:] += pos_table[pos_rows[r],:] is applied IN PLACE first

@@ -43,7 +43,11 @@ struct VasnetWs {
   int64_t e_elems;
   int32_t n_rows;
   // small-batch path (SK launches, gemm_lean.hip): partial tiles, tickets, sliced problem tables -- present when sk_rows_ok(n_rows)
-  size_t sk_part, sk_cnt, sk_tabs;
+  size_t sk_part, sk_cnt, sk_tabs, sk_part_bytes;
+  // seq, row_seq, prob_row, prob_seq, sk_cnt, sk_tabs form ONE block at the FRONT of the workspace (tab_bytes): everything the setup
+  // kernels write and nothing else.  A caller may keep that block in a buffer of its own (sumk_vasnet_opts::tables, built once per
+  // batch geometry by sumk_vasnet_build_tables): the offsets are the same, the base pointer differs, and no setup kernel runs per call.
+  size_t tab_bytes;
 };
 
 // ---- small-batch path: every GEMM of the step as an in-launch split-K launch on 64x64 tiles (gemm_lean.hip, SK instances) ----
@@ -75,30 +79,36 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   size_t p = 0;
   auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
   w->n_rows = (int32_t)R; w->e_elems = e;
+  // the table block (see VasnetWs::tab_bytes)
+  w->seq = take((size_t)n_seq * sizeof(SeqInfo));
+  w->prob_row = take(ROW_PROBS * sizeof(GemmProb));
+  w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
+  w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
+  w->sk_cnt = w->sk_tabs = 0;
+  if (sk_rows_ok((int64_t)R)) {
+    w->sk_cnt = take((size_t)SK_TICKETS * 4);
+    w->sk_tabs = take(((size_t)SR_COUNT * SK_ROW_ENTRIES + (size_t)TB_COUNT * n_seq * SK_MAX_SLICES) * sizeof(GemmProb));
+  }
+  w->tab_bytes = p;
   w->qkv = take(R * 3 * D * 4);
   w->e = take((size_t)e * 4);
   w->ctx = take(R * D * 4);
   w->y0 = take(R * D * 4);
   w->y1 = take(R * D * 4);
   w->z = take(R * D * 4);
-  w->seq = take((size_t)n_seq * sizeof(SeqInfo));
-  w->prob_row = take(ROW_PROBS * sizeof(GemmProb));
-  w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
   w->stats = take(R * 4 * 4);  // mean/rstd of both LayerNorm applications (training)
   w->scores = take(R * 4);
-  w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
   w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = w->qkv16 = w->dctx16 = w->p16 = 0;
-  w->sk_part = w->sk_cnt = w->sk_tabs = 0;
+  w->sk_part = w->sk_part_bytes = 0;
   auto take_sk = [&]() {     // small-batch path: inside the core size (every arithmetic's workspace holds it)
     if (!sk_rows_ok((int64_t)R)) return;
-    w->sk_cnt = take((size_t)SK_TICKETS * 4);
     // scratch of the SK launches: partial tiles of the slices that meet inside a launch, or the K-slice slabs a row kernel adds
     // (partial tiles: 4 slices of the QKV projection or 8 of a (R, D) one -- sk_plan's caps; slabs: 8 of (R, D) or of the E layout)
     const size_t t64 = (R + 63) / 64, part_tiles = std::max(4 * t64 * ((3 * (size_t)D + 63) / 64), 8 * t64 * (((size_t)D + 63) / 64)) + 64;
-    w->sk_part = take(std::max(part_tiles * 64 * 64, (size_t)SK_MAX_SLICES * std::max(R * (size_t)D, (size_t)e)) * 4);
-    w->sk_tabs = take(((size_t)SR_COUNT * SK_ROW_ENTRIES + (size_t)TB_COUNT * n_seq * SK_MAX_SLICES) * sizeof(GemmProb));
+    w->sk_part_bytes = std::max(part_tiles * 64 * 64, (size_t)SK_MAX_SLICES * std::max(R * (size_t)D, (size_t)e)) * 4;
+    w->sk_part = take(w->sk_part_bytes);
   };
   if (training) {
     w->e2 = take((size_t)e * 4);     // dropped-out alpha in forward, then dAlpha / dLogits in backward
@@ -997,7 +1007,7 @@ static void to_b16(GemmLaunch& g, const void* A16, const void* B16, int M, int N
 // row-wise problem slots (index into prob_row)
 enum { RP_QKV = 0, RP_DD = 1, RP_DX = 2, RP_QKV_W = 3, RP_DD_W = 4, RP_DX_W = 5 };   // _W: the same problems on 256-column tiles (gemm_b16.hip)
 
-static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off_dev, char* ws, hipStream_t stream) {
+static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off_dev, char* ws, hipStream_t stream) {     // ws: the TABLE base (workspace front, or the caller's table buffer)
   SetupArgs a;
   a.fake_seq0 = 0;
 #ifdef SUMK_DIAG
@@ -1040,19 +1050,19 @@ static int launch_sk_setup(const Geometry& G, int D, int n_seq, const int32_t* o
   return SUMK_OK;
 }
 
-static size_t sk_part_bytes(const Geometry& G, int n_seq) { return G.L.sk_tabs - G.L.sk_part; }    // (the table region follows the scratch)
+static size_t sk_part_bytes(const Geometry& G, int n_seq) { return G.L.sk_part_bytes; }
 // one SK launch over table `tb` (row-wise table r >= 0, or per-video table t)
 struct SkCall { const float* A; const float* B[4]; float* C[4]; const float* R; const float* bias; int prof_tag; };
-static int launch_sk(const Geometry& G, int n_seq, char* ws, GemmLayout layout, GemmEpi epi, int row_tab, int seq_tab, const SkCall& c, hipStream_t stream) {
+static int launch_sk(const Geometry& G, int n_seq, char* ws, char* tbase, GemmLayout layout, GemmEpi epi, int row_tab, int seq_tab, const SkCall& c, hipStream_t stream) {
   const SkTab& tb = row_tab >= 0 ? G.P.row[row_tab] : G.P.seq[seq_tab];
-  GemmProb* tabs = (GemmProb*)(ws + G.L.sk_tabs);
+  GemmProb* tabs = (GemmProb*)(tbase + G.L.sk_tabs);
   GemmLaunch g;
   g.A = c.A;
   for (int i = 0; i < 4; ++i) { g.B[i] = c.B[i]; g.Csel[i] = c.C[i]; }
   g.C = c.C[0]; g.R = c.R; g.bias0[0] = c.bias;
   g.probs = row_tab >= 0 ? sk_row_tab(tabs, row_tab) : sk_seq_tab(tabs, seq_tab, n_seq);
   g.nprob = tb.entries; g.total_tiles = tb.blocks; g.small_tile = 1; g.prof_tag = c.prof_tag;
-  g.sk = 1; g.sk_part = (float*)(ws + G.L.sk_part); g.sk_cnt = (unsigned*)(ws + G.L.sk_cnt);
+  g.sk = 1; g.sk_part = (float*)(ws + G.L.sk_part); g.sk_cnt = (unsigned*)(tbase + G.L.sk_cnt);
   SUMK_ARG(tb.blocks == tb.tiles || (size_t)tb.blocks * 64 * 64 * 4 <= sk_part_bytes(G, n_seq), "vasnet: small-batch launch needs %d partial tiles", tb.blocks);   // (blocks == tiles: nothing is sliced)
   return launch_gemm(layout, epi, g, stream);
 }
@@ -1130,6 +1140,26 @@ extern "C" int sumk_gemm_splitk(int32_t layout, const float* A, const float* B, 
   return launch_gemm((GemmLayout)layout, (GemmEpi)epilogue, g, stream);
 }
 
+// ---- the table block by itself: built once per batch geometry, handed to every call through sumk_vasnet_opts::tables
+extern "C" size_t sumk_vasnet_tables_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host) {
+  VasnetWs w;
+  if (carve(D, n_seq, seq_off_host, 0, &w) != SUMK_OK) return 0;
+  return w.tab_bytes;
+}
+extern "C" int sumk_vasnet_build_tables(int32_t D, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev, int32_t training,
+                                        int32_t precision, void* tables, size_t tables_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(seq_off_dev && tables && ((uintptr_t)tables & 255) == 0, "vasnet_build_tables: null or misaligned (256 B) pointer");
+  SUMK_ARG(precision >= SUMK_PRECISION_FP32 && precision <= SUMK_PRECISION_MAX, "vasnet_build_tables: unknown precision %d", precision);
+  Geometry G;
+  SUMK_TRY(geometry(D, n_seq, seq_off_host, training, precision, 0, &G));
+  if (tables_bytes < G.L.tab_bytes) { set_error("vasnet_build_tables: %zu bytes < required %zu", tables_bytes, G.L.tab_bytes); return SUMK_ERR_WORKSPACE; }
+  launch_setup(G, D, n_seq, seq_off_dev, (char*)tables, stream);                 // the large-batch tables (also what a dX-producing backward uses)
+  if (G.sk) SUMK_TRY(launch_sk_setup(G, D, n_seq, seq_off_dev, (char*)tables, stream));   // the small-batch tables + zeroed tickets
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
 extern "C" size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training) {
   VasnetWs w;
   if (carve(D, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
@@ -1145,7 +1175,7 @@ extern "C" size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, cons
 // of vasnet_sk_setup_kernel, the row kernels unchanged.  Inference and training (the intermediates the backward needs are the same).
 static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev,
                              const sumk_vasnet_weights* w, const sumk_vasnet_opts* opts, const float* pos_table, const int32_t* pos_rows,
-                             float* scores, char* ws, int32_t training, hipStream_t stream) {
+                             float* scores, char* ws, char* tb, int32_t training, hipStream_t stream) {     // tb: table base (ws, or opts->tables: then already built)
   const VasnetWs& L = G.L;
   const int R = G.R;
   float* QKV = (float*)(ws + L.qkv);
@@ -1155,7 +1185,7 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
   float* Y0 = (float*)(ws + L.y0);
   float* Y1 = (float*)(ws + L.y1);
   float* Z = (float*)(ws + L.z);
-  SeqInfo* seq = (SeqInfo*)(ws + L.seq);
+  SeqInfo* seq = (SeqInfo*)(tb + L.seq);
   float* stats = training ? (float*)(ws + L.stats) : nullptr;
   const Drop drop = make_drop(opts);
   const bool use_e2 = training && drop.thr != 0;
@@ -1163,40 +1193,40 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     int64_t n4 = (int64_t)R * (D >> 2);
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
-  SUMK_TRY(launch_sk_setup(G, D, n_seq, seq_off_dev, ws, stream));
+  if (tb == ws) SUMK_TRY(launch_sk_setup(G, D, n_seq, seq_off_dev, tb, stream));
   {  // 1: QKV projection (three B pointers, one launch)
     const SkCall c{x, {w->Wq, w->Wk, w->Wv, nullptr}, {QKV, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKV};
-    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_QKV, -1, c, stream));
+    SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, SR_QKV, -1, c, stream));
   }
   // K-slice slabs (SlabIn): where a row kernel consumes a GEMM's output, the slices store their own slab in the scratch and the row
   // kernel adds them -- S slabs of the E layout / of (R, D)
   float* scratch = (float*)(ws + L.sk_part);
   {  // 2: logits per video
     const SkCall c{QKV, {QKV, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKT};
-    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, -1, TB_S, c, stream));
+    SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, -1, TB_S, c, stream));
   }
   {  // 3: softmax (+ dropout of alpha into E2 when training with p > 0)
     const dim3 sg((R + 3) / 4), sb(256);
     float* e2p = use_e2 ? E2 : nullptr;
     const float* eraw = scratch;
     const int n_slab = G.P.seq[TB_S].S;
-#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, (unsigned short*)nullptr, eraw, n_slab, (int64_t)L.e_elems)
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(tb + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, (unsigned short*)nullptr, eraw, n_slab, (int64_t)L.e_elems)
     if (G.t_max <= 256) SUMK_SOFTMAX(4); else if (G.t_max <= 512) SUMK_SOFTMAX(8); else if (G.t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
   {  // 4: context
     const SkCall c{use_e2 ? E2 : E, {QKV, nullptr, nullptr, nullptr}, {CTX, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_PV};
-    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, -1, TB_PV, c, stream));
+    SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NN, EPI_NONE, -1, TB_PV, c, stream));
   }
   {
     // 5 + 6: output projection as K-slice slabs; the LayerNorm kernel adds them and the residual (Y0 itself is kept for the backward pass)
     const SkCall c{CTX, {w->Wo, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_OPROJ};
-    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_OPROJ, -1, c, stream));
+    SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, SR_OPROJ, -1, c, stream));
     SlabIn sl; sl.n = G.P.row[SR_OPROJ].S; sl.stride = (int64_t)R * D; sl.add = x; sl.store = training ? Y0 : nullptr;
     launch_ln_rows<false>(scratch, Y1, w->ln_w, w->ln_b, nullptr, nullptr, nullptr, R, D, opts->eps, stats, drop, 1u, stream, nullptr, sl);
     // 7 + 8: k1 as slabs; the LayerNorm + head kernel adds them, the bias and the ReLU (Z is kept for the backward pass)
     const SkCall c2{Y1, {w->W1, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_K1};
-    SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, SR_K1, -1, c2, stream));
+    SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, SR_K1, -1, c2, stream));
     SlabIn s2; s2.n = G.P.row[SR_K1].S; s2.stride = (int64_t)R * D; s2.bias = w->b1; s2.relu = 1; s2.store = training ? Z : nullptr;
     launch_ln_rows<true>(scratch, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream, nullptr, s2);
   }
@@ -1231,8 +1261,9 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     return SUMK_ERR_WORKSPACE;
   }
   char* ws = (char*)workspace;
+  char* tb = opts->tables ? (char*)opts->tables : ws;      // table base: the caller's prebuilt block, or the front of the workspace (built per call)
   if (G.sk && !Wvo)
-    return vasnet_forward_sk(G, x, D, n_seq, seq_off_host, seq_off_dev, w, opts, pos_table, pos_rows, scores, ws, training, stream);
+    return vasnet_forward_sk(G, x, D, n_seq, seq_off_host, seq_off_dev, w, opts, pos_table, pos_rows, scores, ws, tb, training, stream);
   const int R = G.R;
   float* QKV = (float*)(ws + L.qkv);
   float* E = (float*)(ws + L.e);
@@ -1241,9 +1272,9 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   float* Y0 = (float*)(ws + L.y0);
   float* Y1 = (float*)(ws + L.y1);
   float* Z = (float*)(ws + L.z);
-  SeqInfo* seq = (SeqInfo*)(ws + L.seq);
-  GemmProb* prow = (GemmProb*)(ws + L.prob_row);
-  GemmProb* tabs = (GemmProb*)(ws + L.prob_seq);
+  SeqInfo* seq = (SeqInfo*)(tb + L.seq);
+  GemmProb* prow = (GemmProb*)(tb + L.prob_row);
+  GemmProb* tabs = (GemmProb*)(tb + L.prob_seq);
   float* stats = training ? (float*)(ws + L.stats) : nullptr;
   const Drop drop = make_drop(opts);
   const bool use_e2 = training && drop.thr != 0;
@@ -1252,7 +1283,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     int64_t n4 = (int64_t)R * (D >> 2);
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
-  launch_setup(G, D, n_seq, seq_off_dev, ws, stream);
+  if (tb == ws) launch_setup(G, D, n_seq, seq_off_dev, tb, stream);
   // mixed-precision training: bf16 shadows of x and of the five weight matrices, then every row-wise GEMM reads bf16 from HBM
   const bool b16 = G.b16;
   unsigned short* x16 = (unsigned short*)(ws + L.x16);
@@ -1293,7 +1324,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     const dim3 sg((R + 3) / 4), sb(256);
     float* e2p = use_e2 ? E2 : nullptr;
     unsigned short* p16 = b16 ? (unsigned short*)(ws + L.p16) : nullptr;
-#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(ws + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, p16, (const float*)E, 0, (int64_t)0)
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(tb + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, p16, (const float*)E, 0, (int64_t)0)
     if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
@@ -1469,9 +1500,10 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   float* slab = (float*)(ws + L.slab);
   float* stats = (float*)(ws + L.stats);
   const float* scores = (const float*)(ws + L.scores);
-  SeqInfo* seq = (SeqInfo*)(ws + L.seq);
-  GemmProb* prow = (GemmProb*)(ws + L.prob_row);
-  GemmProb* tabs = (GemmProb*)(ws + L.prob_seq);
+  char* tb = opts->tables ? (char*)opts->tables : ws;      // as in the forward
+  SeqInfo* seq = (SeqInfo*)(tb + L.seq);
+  GemmProb* prow = (GemmProb*)(tb + L.prob_row);
+  GemmProb* tabs = (GemmProb*)(tb + L.prob_seq);
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
   const Drop drop = make_drop(opts);
   const bool use_e2 = drop.thr != 0;
@@ -1489,7 +1521,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   unsigned short* dY016 = (unsigned short*)(ws + L.dy016);
   unsigned short* dQKV16 = (unsigned short*)(ws + L.dqkv16);
 
-  if (G.sk && dx) launch_setup(G, D, n_seq, seq_off_dev, ws, stream);   // (dx asked for: the large-batch kernels below; their tables were not built by the SK forward)
+  if (G.sk && dx && tb == ws) launch_setup(G, D, n_seq, seq_off_dev, tb, stream);   // (dx asked for: the large-batch kernels below; their tables were not built by the SK forward)
   if (G.sk && !dx) {   // the small-batch backward: the same stages below, every GEMM an SK launch over the tables the forward built
     const SkCall none{};
     (void)none;
@@ -1498,42 +1530,42 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     float* scratch = (float*)(ws + L.sk_part);
     {
       const SkCall c{dZ, {w->W1, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dY1 = dZ W1 as K-slice slabs: the LayerNorm backward kernel adds them
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, SR_DY1, -1, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NN, EPI_NONE, SR_DY1, -1, c, stream));
     }
     SUMK_TRY(launch_ln_bwd<false>(D, R, Y0, stats, w->ln_w, w->ln_b, scratch, nullptr, nullptr, nullptr, dY0, lnpart, drop, 1u, &nw, stream, nullptr,
                                   G.P.row[SR_DY1].S, (int64_t)R * D));
     SUMK_TRY(ln_bwd_reduce(lnpart, nw, D, gr->ln_w, gr->ln_b, nullptr, nullptr, nullptr, stream));
     {
       const SkCall c{dY0, {CTX, nullptr, nullptr, nullptr}, {gr->Wo, gr->W1, nullptr, nullptr}, nullptr, nullptr, -1};      // dWo += dY0^T CTX and dW1 += dZ^T Y1 (group 1)
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DWO1, -1, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_TN, EPI_ACCUM, SR_DWO1, -1, c, stream));
     }
     {
       const SkCall c{dY0, {w->Wo, nullptr, nullptr, nullptr}, {dCTX, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};     // dCTX = dY0 Wo
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, SR_DCTX, -1, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NN, EPI_NONE, SR_DCTX, -1, c, stream));
     }
     if (tail_grads_ready_event) SUMK_HIP(hipEventRecord((hipEvent_t)tail_grads_ready_event, stream));
     const float* Pd = use_e2 ? E2 : E;
     {
       const SkCall c{Pd, {dCTX, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};       // dV = alphaD^T dC
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_NONE, -1, TB_DV, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_TN, EPI_NONE, -1, TB_DV, c, stream));
     }
     {
       const SkCall c{dCTX, {QKV, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dAlphaD = dC V^T as slabs: the softmax backward kernel adds them
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NT, EPI_NONE, -1, TB_DP, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, -1, TB_DP, c, stream));
     }
-    hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
+    hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(tb + L.row_seq), n_seq, R,
                        opts->scale, drop, (unsigned short*)nullptr, (const float*)scratch, G.P.seq[TB_DP].S, (int64_t)L.e_elems);
     {
       const SkCall c{E2, {QKV, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dQ = dS K
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_NN, EPI_NONE, -1, TB_DQ, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NN, EPI_NONE, -1, TB_DQ, c, stream));
     }
     {
       const SkCall c{E2, {QKV, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dK = dS^T Q
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_NONE, -1, TB_DK, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_TN, EPI_NONE, -1, TB_DK, c, stream));
     }
     {
       const SkCall c{dQKV, {x, nullptr, nullptr, nullptr}, {gr->Wq, gr->Wk, gr->Wv, nullptr}, nullptr, nullptr, -1};        // d[Wq;Wk;Wv] += dQKV^T X
-      SUMK_TRY(launch_sk(G, n_seq, ws, GEMM_TN, EPI_ACCUM, SR_DWQKV, -1, c, stream));
+      SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_TN, EPI_ACCUM, SR_DWQKV, -1, c, stream));
     }
     SUMK_HIP(hipGetLastError());
     return SUMK_OK;
@@ -1585,7 +1617,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   }
   // 3': softmax (+dropout, +scale) backward, in place on E2
   // (b16: bf16(dLogits) goes where bf16(alpha) was -- its last reader, the dV product, is queued before this kernel)
-  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(ws + L.row_seq), n_seq, R,
+  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(tb + L.row_seq), n_seq, R,
                      opts->scale, drop, b16 ? (unsigned short*)(ws + L.p16) : nullptr, (const float*)E2, 0, (int64_t)0);
   // 2': dQ = dS K ; dK = dS^T Q
   {

@@ -105,6 +105,28 @@ def precision_code(p):
     return PRECISIONS[p]
 
 
+def vasnet_tables(sb, D, training, precision_id):
+    """The batch's problem tables (sumk_vasnet_opts.tables), built once per (SeqBatch, D, training, arithmetic) and kept with the
+    SeqBatch: they depend on the batch geometry only, so no table-setup kernel runs per call.  One buffer per CURRENT stream (the tables
+    hold the tickets of the in-launch split-K launches: calls on different streams must not share them)."""
+    key = (int(D), int(bool(training)), int(precision_id), torch.cuda.current_stream(sb.device).cuda_stream)
+    tabs = getattr(sb, "_vasnet_tables", None)
+    if tabs is None:
+        tabs = sb._vasnet_tables = {}
+    t = tabs.get(key)
+    if t is None:
+        lib = _lib.load()
+        nb = lib.sumk_vasnet_tables_bytes(int(D), sb.n_seq, sb.off_host_p)
+        if nb == 0:
+            _lib.check(-1, "sumk_vasnet_tables_bytes")
+        t = torch.empty(nb + 256, dtype=torch.uint8, device=sb.device)
+        base = (t.data_ptr() + 255) // 256 * 256
+        _lib.check(lib.sumk_vasnet_build_tables(int(D), sb.n_seq, sb.off_host_p, sb.off_dev_p, key[1], key[2], C.c_void_p(base), nb, _stream()),
+                   "sumk_vasnet_build_tables")
+        t = tabs[key] = (t, base)
+    return t[1]
+
+
 def _vasnet_structs(params, opts):
     w = _lib.VasnetWeights()
     for f, k in VASNET_FIELDS:
@@ -116,7 +138,7 @@ def _vasnet_structs(params, opts):
     o = _lib.VasnetOpts(float(opts["scale"]), float(opts["eps"]), int(bool(opts.get("ignore_self", False))),
                         -1 if opts.get("aperture") is None else int(opts["aperture"]),
                         float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)), precision_code(opts.get("precision")),
-                        opts["seed_dev"].data_ptr() if opts.get("seed_dev") is not None else None)
+                        opts["seed_dev"].data_ptr() if opts.get("seed_dev") is not None else None, opts.get("tables"))
     return w, o
 
 
@@ -139,6 +161,14 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
     if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
         raise SumkError(f"vasnet input must be contiguous (n_rows={sb.n_rows}, D), got {tuple(x.shape)}")
     D = x.shape[1]
+    if "tables" not in opts and not torch.cuda.is_current_stream_capturing():      # (built outside a capture; a captured call reuses what exists)
+        opts["tables"] = vasnet_tables(sb, D, training, precision_code(opts.get("precision")))
+    elif "tables" not in opts:
+        # inside a capture nothing may be allocated or built for the (private) capture stream: the step reuses the tables an eager call
+        # of the same geometry built before (a replay runs where the eager calls ran); none yet -> the setup kernel is captured instead
+        want = (int(D), int(bool(training)), precision_code(opts.get("precision")))
+        hit = [v for k, v in getattr(sb, "_vasnet_tables", {}).items() if k[:3] == want]
+        opts["tables"] = hit[-1][1] if hit else None
     w, o = _vasnet_structs(params, opts)
     nbytes = lib.sumk_vasnet_workspace_bytes_for(D, sb.n_seq, sb.off_host_p, int(training), int(o.precision))
     if nbytes == 0:

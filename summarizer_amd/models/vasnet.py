@@ -343,4 +343,6 @@ class VASNetTrainer(Trainer):
         with torch.cuda.graph(g, pool=pool):
             loss, scores = self._single_video_step(key, dev, grads_are_zero=True)
             loss_out.copy_(loss); scores_out.copy_(scores)
-        return g, loss_out, scores_out
+        # (the graph holds raw addresses of the batch descriptor's device arrays -- sequence offsets, prebuilt problem tables: keep the
+        #  SeqBatch alive beside it, whatever happens to kernels.SeqBatch's cache)
+        return g, loss_out, scores_out, kernels.SeqBatch.get([seq.shape[0]], dev)

@@ -342,7 +342,7 @@ def test_vasnet_trainer_hip_graph_steps_equal_eager_steps(data):
     dev = tr._device()
     tr.model.graph_seed = torch.zeros(1, dtype=torch.int64, device=dev)
     tr._single_video_step(keys[5], dev)                                  # eager warm-up
-    g, loss, scores = tr._capture_step(keys[5], dev, None)
+    g, loss, scores, _sb = tr._capture_step(keys[5], dev, None)
     seen = []
     for _ in range(3):
         g.replay()

@@ -590,3 +590,44 @@ def test_gemm_splitk_in_launch_vs_float64(dev, M, N, K):
                         np.testing.assert_array_equal(outs[0], want, err_msg=f"{name} S={S} {ename}")
                     else:
                         assert (np.abs(outs[0] - want) <= bound + 1e-6 * np.abs(want)).all(), (name, S, ename, np.abs(outs[0] - want).max())
+
+
+def test_prebuilt_problem_tables_equal_per_call_setup(dev):
+    """sumk_vasnet_opts.tables (round 4): the batch's problem tables built ONCE per geometry (kernels.vasnet_tables, kept with the SeqBatch)
+    against the per-call setup kernels (tables = None): inference and training (scores, every gradient, dX), a single video (small-batch
+    path: sliced tables + tickets, used by several consecutive calls) and a 12-video batch (large-batch tables) -- bit-identical, and a
+    second SeqBatch of another geometry in between does not disturb the first one's tables."""
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import VasnetFunction
+    D = 256
+    model = _model(dev, D, R.vasnet_weights(D, 9))
+    names = [k for _, k in kernels.VASNET_FIELDS]
+    params = dict(model.named_parameters())
+    for lens in ([300], [150, 320, 211, 64, 1, 77, 305, 256, 199, 160, 313, 240]):
+        x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 40 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+        sb = kernels.SeqBatch(lens, dev)                    # a fresh descriptor: no tables yet
+        other = kernels.SeqBatch([lens[0] + 3], dev)
+        xo = torch.from_numpy(R.features(lens[0] + 3, 1, D, 99)[:, 0, :]).to(dev)
+        with torch.no_grad():
+            ref, _ = kernels.vasnet_forward_packed(x, sb, model._params(), dict(model._opts(False), tables=None))
+            assert not getattr(sb, "_vasnet_tables", None)
+            a, _ = kernels.vasnet_forward_packed(x, sb, model._params(), model._opts(False))
+            assert len(sb._vasnet_tables) == 1
+            kernels.vasnet_forward_packed(xo, other, model._params(), model._opts(False))
+            b, _ = kernels.vasnet_forward_packed(x, sb, model._params(), model._opts(False))
+            assert len(sb._vasnet_tables) == 1
+        assert torch.equal(ref, a) and torch.equal(ref, b)
+        outs = []
+        for tables in (None, "auto", "auto"):
+            for p in params.values():
+                p.grad = None
+            opts = dict(scale=float(model.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=0.5, seed=5, precision="fp32")
+            if tables is None:
+                opts["tables"] = None
+            xg = x.clone().requires_grad_(True)
+            s_ = VasnetFunction.apply(xg, sb, opts, None, None, names, *[params[n] for n in names])
+            (s_ * torch.linspace(-1, 1, s_.numel(), device=dev)).sum().backward()
+            outs.append([s_.detach().clone(), xg.grad.clone()] + [params[n].grad.clone() for n in names])
+        for o in outs[1:]:
+            for u, v in zip(outs[0], o):
+                assert torch.equal(u, v)
