@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-batch (in-launch split-K) path of VASNet against the large-batch kernels: scores in eval and training mode (dropout on),
 every parameter gradient, with and without dX, for (a) ONE TVSum-sized video at D = 1024 -- the reference's calling pattern --
-(b) a ragged batch with T = 1 ... 333 at D = 256, (c) three videos at D = 1024 with local attention + ignore_self.  Written to an
+(b) a ragged batch with T = 1 ... 333 at D = 256, (c) three videos at D = 1024 with local attention + ignore_self, (d) D = 400 (K tails in every slice).  Written to an
 .npz; run once with SUMK_SK=1 (default) and once with SUMK_SK=0 and compare (tests/test_gpu_vasnet.py).
 usage: python scripts/probes/sk_equiv.py out.npz"""
 import os, sys
@@ -16,7 +16,8 @@ from summarizer_amd.models.vasnet import VASNet
 dev = torch.device("cuda:0")
 out = {}
 cases = [("one", 1024, [300], {}), ("ragged", 256, [1, 37, 64, 65, 200, 333, 128, 31], {}),
-         ("three", 1024, [211, 320, 150], dict(ignore_self=True, attention_aperture=40))]
+         ("three", 1024, [211, 320, 150], dict(ignore_self=True, attention_aperture=40)),
+         ("odd", 400, [100, 45, 129], {})]       # D = 400: K tails in every slice set, 4 + 2 slabs
 for tag, D, lens, kw in cases:
     w = R.vasnet_weights(D, 77)
     m = VASNet(input_size=D, **kw); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)

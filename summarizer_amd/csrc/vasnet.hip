@@ -1193,6 +1193,8 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     int64_t n4 = (int64_t)R * (D >> 2);
     hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos_table, pos_rows, R, D);
   }
+  for (int S : {G.P.seq[TB_S].S, G.P.seq[TB_DP].S, G.P.row[SR_OPROJ].S, G.P.row[SR_K1].S, G.P.row[SR_DY1].S})     // slab sets the row kernels add: slab_sum's cases
+    SUMK_ARG(S == 1 || S == 2 || S == 4 || S == 8, "vasnet: slab set of %d slices (internal: sk_plan builds 1, 2, 4 or 8)", S);
   if (tb == ws) SUMK_TRY(launch_sk_setup(G, D, n_seq, seq_off_dev, tb, stream));
   {  // 1: QKV projection (three B pointers, one launch)
     const SkCall c{x, {w->Wq, w->Wk, w->Wv, nullptr}, {QKV, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_QKV};

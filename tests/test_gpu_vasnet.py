@@ -510,7 +510,7 @@ def test_small_batch_path_matches_large_batch_kernels(tmp_path):
     """The small-batch path (round 4; taken for batches of <= 1024 frames, i.e. the reference's one-video-per-call pattern,
     vasnet.py:193-212: every GEMM on csrc/gemm_direct.hip -- a 32x32 tile per workgroup, K split over its waves) against the
     large-batch kernels (SUMK_SK=0): ONE T = 300 video at D = 1024, a ragged batch with T = 1 ... 333, three videos with local
-    attention + ignore_self; eval scores, training-mode scores with dropout, every parameter gradient, with and without dX.  The
+    attention + ignore_self, D = 400; eval scores, training-mode scores with dropout, every parameter gradient, with and without dX.  The
     partial sums of a tile's waves are added in wave order, so the two paths agree to fp32 re-association, not bit for bit:
     scores 1e-5 (measured 3e-6 with dropout), gradients 2e-4 of the tensor's largest entry (k2.bias, a cancelling sum over all frames, measured 7e-5; the matrices 1e-6).  The small-batch path itself is bit-repeatable."""
     import os, subprocess, sys
@@ -524,7 +524,7 @@ def test_small_batch_path_matches_large_batch_kernels(tmp_path):
         outs[flag] = np.load(f)
     a, b = outs["1"], outs["0"]
     assert set(a.files) == set(b.files) and len(a.files) > 60
-    for tag in ("one", "ragged", "three"):
+    for tag in ("one", "ragged", "three", "odd"):
         np.testing.assert_array_equal(a[f"{tag}_scores_eval"], a[f"{tag}_scores_eval_again"])
     differs = False
     for k in a.files:
