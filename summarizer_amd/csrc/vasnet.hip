@@ -899,7 +899,11 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, const VasnetWs&
     const int tiles = ((M + te - 1) / te) * ((N + te - 1) / te);
     int kc, S;
     int S_req = smax > 0 ? std::max(1, std::min(smax, K / 128)) : sk_slices(tiles * groups, K, &kc);
-    if (slab) for (S_req = 8; S_req > 1; S_req >>= 1) {        // slab sets: exactly 1, 2, 4 or 8 slices (slab_sum), each at least four k-tiles
+    // (R, D) projections consumed by the LayerNorm kernels: 4 slabs measured 2.4 us per video better than 8 -- the row kernel's extra loads cost
+    // what the shorter GEMM chains gain -- and equal to 2; Q.K^T / dAlpha stay at 8 (scripts/probes/sk_smax_sweep.py, third / fourth digit)
+    int slab_cap = 4;
+    if (const char* e = SUMK_TUNE_ENV("SUMK_SK_SMAX")) if (e[0] && e[1] && (e[2] == '1' || e[2] == '2' || e[2] == '4' || e[2] == '8')) slab_cap = e[2] - '0';
+    if (slab) for (S_req = slab_cap; S_req > 1; S_req >>= 1) {        // slab sets: exactly 1, 2, 4 or 8 slices (slab_sum), each at least four k-tiles
       sk_slice(K, S_req, &kc, &S);
       if (S == S_req && kc >= 128) break;
     }
@@ -934,7 +938,9 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, const VasnetWs&
     // (per-video products: the request is the cap; vasnet_sk_setup_kernel / sk_slice_seq give a video with K = T_s frames min(4, T_s / 128)
     //  slices -- a function of that video alone)
     int S_req = 4;
-    if (t == TB_S || t == TB_DP) for (S_req = 8; S_req > 1; S_req >>= 1) {     // slab sets (K = D for every video): 1, 2, 4 or 8 slices
+    int slab_cap = 8;
+    if (const char* e = SUMK_TUNE_ENV("SUMK_SK_SMAX")) if (e[0] && e[1] && e[2] && (e[3] == '1' || e[3] == '2' || e[3] == '4' || e[3] == '8')) slab_cap = e[3] - '0';   // (fourth digit: Q.K^T / dAlpha)
+    if (t == TB_S || t == TB_DP) for (S_req = slab_cap; S_req > 1; S_req >>= 1) {     // slab sets (K = D for every video): 1, 2, 4 or 8 slices
       int S; sk_slice_seq(D, S_req, &kc, &S);          // (the rule vasnet_sk_setup_kernel applies to each video)
       if (S == S_req) break;
     }
