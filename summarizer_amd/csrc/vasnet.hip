@@ -408,6 +408,47 @@ __device__ __forceinline__ V slab_sum(const V* p, int n, int64_t stride) {    //
   return slab_sum_n<8, V>(p, stride);
 }
 
+// Small-batch path, register-resident rows: every slab / residual / bias load of the row's NQ column chunks is issued before the
+// first add, so the row costs one memory round trip instead of one per chunk.  Columns past D4 are clamped (loaded, never used).
+template <int NQ, int NS, bool ADD, bool BIAS, typename V>
+__device__ __forceinline__ void ln_gather(V (&xr)[NQ], const V* x4, const V* add4p, const V* bias4, int lane, int D4, int64_t stride4) {
+  V t[NQ][NS], ta[NQ], tb[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = min(lane + 64 * q, D4 - 1);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) t[q][s] = x4[s * stride4 + c];
+    if constexpr (ADD) ta[q] = add4p[c];
+    if constexpr (BIAS) tb[q] = bias4[c];
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    V v = t[q][0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) v = add4(v, t[q][s]);      // slab order, as slab_sum
+    if constexpr (ADD) v = add4(v, ta[q]);
+    if constexpr (BIAS) v = add4(v, tb[q]);
+    xr[q] = v;
+  }
+}
+template <int NQ, int NS>
+__device__ __forceinline__ void ln_gather_n(float4 (&xr)[NQ], const float4* x4, const float4* add4p, const float4* bias4, int lane,
+                                            int D4, int64_t stride4) {
+  if (add4p && bias4) ln_gather<NQ, NS, true, true>(xr, x4, add4p, bias4, lane, D4, stride4);
+  else if (add4p) ln_gather<NQ, NS, true, false>(xr, x4, add4p, bias4, lane, D4, stride4);
+  else if (bias4) ln_gather<NQ, NS, false, true>(xr, x4, add4p, bias4, lane, D4, stride4);
+  else ln_gather<NQ, NS, false, false>(xr, x4, add4p, bias4, lane, D4, stride4);
+}
+
+// the slabs alone, set size chosen at run time (kernel-uniform)
+template <int NQ, typename V>
+__device__ __forceinline__ void row_gather(V (&xr)[NQ], const V* p, int lane, int n, int n_slab, int64_t stride) {
+  if (n_slab <= 1) ln_gather<NQ, 1, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
+  else if (n_slab == 2) ln_gather<NQ, 2, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
+  else if (n_slab == 4) ln_gather<NQ, 4, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
+  else ln_gather<NQ, 8, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
+}
+
 // Masked, scaled logit exactly as vasnet.py:119-127 produces it.
 __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int j, int ignore_self, int aperture) {
   float e = raw * scale;
@@ -428,7 +469,7 @@ __device__ __forceinline__ float masked_logit(float raw, float scale, int i, int
 // any length, three passes over the (L2-resident) row.  Same operations per element either way, so the results are identical.
 // Eraw / n_slab / slab_stride: where the raw logits are read -- E itself (n_slab <= 1), or n_slab K-slice slabs of the E layout
 // (small-batch path, SlabIn) that are added in slab order on load.
-template <int NR>
+template <int NR, bool PRE = false>   // PRE (few rows: latency-bound): the row's slab loads are all issued before the first add
 __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2, const SeqInfo* seq, const int32_t* off,
                                                              int n_seq, int n_rows, float scale, int ignore_self,
                                                              int aperture, Drop drop_in, unsigned short* P16,
@@ -437,7 +478,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
-  const int s = off[row];        // `off` = the row -> video table of the setup kernel (VasnetWs::row_seq)
+  const int s = n_seq == 1 ? 0 : off[row];        // `off` = the row -> video table of the setup kernel (VasnetWs::row_seq)
   const SeqInfo si = seq[s];
   const int i = row - si.row0, T = si.T;
   float* e = E + si.eoff + (int64_t)i * si.ldE;
@@ -451,10 +492,12 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
   if constexpr (NR > 0) {
     float v[NR];
     float m = -INFINITY;
+    if constexpr (PRE) row_gather<NR>(v, er, lane, T, n_slab, slab_stride);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int j = lane + 64 * r;
-      v[r] = j < T ? masked_logit(raw(j), scale, i, j, ignore_self, aperture) : -INFINITY;
+      if constexpr (PRE) v[r] = j < T ? masked_logit(v[r], scale, i, j, ignore_self, aperture) : -INFINITY;
+      else v[r] = j < T ? masked_logit(raw(j), scale, i, j, ignore_self, aperture) : -INFINITY;
       m = fmaxf(m, v[r]);
     }
     m = wave_max(m);
@@ -500,6 +543,9 @@ __global__ __launch_bounds__(256) void vasnet_softmax_kernel(float* E, float* E2
 }
 
 // dLogits(raw) = scale * alpha * (dAlpha - sum_j dAlpha_j alpha_j), dAlpha = dropout'(dAlphaDropped).  In place on E2.
+// NR > 0 (few rows, T <= 64 NR): the row's alpha and dAlpha are loaded up front and held in registers; same per-lane order of
+// operations as the streaming form (NR == 0), so the results are identical.
+template <int NR>
 __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E, float* E2, const SeqInfo* seq,
                                                                  const int32_t* off, int n_seq, int n_rows, float scale,
                                                                  Drop drop_in, unsigned short* S16,  // S16: bf16(dLogits), rows zero-padded to ld16
@@ -508,7 +554,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
-  const int s = off[row];        // `off` = the row -> video table of the setup kernel (VasnetWs::row_seq)
+  const int s = n_seq == 1 ? 0 : off[row];        // `off` = the row -> video table of the setup kernel (VasnetWs::row_seq)
   const SeqInfo si = seq[s];
   const int i = row - si.row0, T = si.T;
   const float* p = E + si.eoff + (int64_t)i * si.ldE;
@@ -516,6 +562,31 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
   const float* gr = Graw + si.eoff + (int64_t)i * si.ldE;
   auto gin = [&](int j) { return slab_sum(gr + j, n_slab, slab_stride); };
   float dot = 0.f;
+  if constexpr (NR > 0) {
+    float d[NR], pv[NR];
+    row_gather<NR>(d, gr, lane, T, n_slab, slab_stride);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pv[r] = p[min(lane + 64 * r, T - 1)];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = lane + 64 * r;
+      if (j < T) {
+        if (drop.thr) d[r] = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d[r]);
+        dot += d[r] * pv[r];
+      }
+    }
+    dot = wave_sum(dot);
+    const int ld16 = (T + 63) & ~63;
+    unsigned short* s16 = S16 ? S16 + si.e16off + (int64_t)i * ld16 : nullptr;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = lane + 64 * r;
+      const float v = j < T ? pv[r] * (d[r] - dot) * scale : 0.f;
+      if (j < si.ldE) g[j] = v;
+      if (s16 && j < ld16) s16[j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+    return;
+  }
   for (int j = lane; j < T; j += 64) {
     float d = gin(j);
     if (drop.thr) d = drop_apply(drop, 0, ((uint64_t)row << 20) | (uint64_t)j, d);
@@ -542,7 +613,7 @@ __global__ __launch_bounds__(256) void vasnet_softmax_bwd_kernel(const float* E,
 // scores[r] = sigmoid(y . w2 + b2)  (vasnet.py:144-145).
 // NQ > 0: the row (D <= 256 * NQ) is held in registers (NQ float4 per lane): ONE read of x instead of three.  NQ == 0: any D,
 // three passes.  The per-lane accumulation order is the same, so both forms give identical results.
-template <bool HEAD, int NQ>
+template <bool HEAD, int NQ, bool SLAB>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, float* __restrict__ Y,
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
@@ -573,9 +644,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   };
   constexpr int NR = NQ > 0 ? NQ : 1;
   float4 xr[NR];
-  if constexpr (NQ > 0) {
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  const float4* w4 = reinterpret_cast<const float4*>(w2);
+  float4 gq[NR], bq[NR], wq[NR];             // NQ > 0: the affine (and k2) rows, in flight with the row itself
+  if constexpr (NQ > 0 && SLAB) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; xr[q] = c < D4 ? ld(c) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int q = 0; q < NQ; ++q) {
+      const int c = min(lane + 64 * q, D4 - 1);
+      gq[q] = g4[c]; bq[q] = b4[c];
+      if constexpr (HEAD) wq[q] = w4[c];
+    }
+  }
+  if constexpr (NQ > 0) {
+    if constexpr (SLAB) {                    // SLAB == (sl.n > 1 || sl.add || sl.bias), chosen by the launcher
+      const float4* a4 = sl.add ? reinterpret_cast<const float4*>(sl.add + (int64_t)row * D) : nullptr;
+      const float4* bi4 = reinterpret_cast<const float4*>(sl.bias);
+      const int64_t st4 = sl.stride >> 2;
+      if (sl.n <= 1) ln_gather_n<NQ, 1>(xr, x4, a4, bi4, lane, D4, st4);
+      else if (sl.n == 2) ln_gather_n<NQ, 2>(xr, x4, a4, bi4, lane, D4, st4);
+      else if (sl.n == 4) ln_gather_n<NQ, 4>(xr, x4, a4, bi4, lane, D4, st4);
+      else ln_gather_n<NQ, 8>(xr, x4, a4, bi4, lane, D4, st4);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c = lane + 64 * q;
+        float4 v = xr[q];
+        if (sl.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }   // NaN-propagating, like torch.relu
+        if (sl.store && c < D4) reinterpret_cast<float4*>(sl.store + (int64_t)row * D)[c] = v;
+        if (drop.thr) {
+          uint64_t base = (uint64_t)row * D + 4 * c;
+          v.x = drop_apply(drop, site, base, v.x); v.y = drop_apply(drop, site, base + 1, v.y);
+          v.z = drop_apply(drop, site, base + 2, v.z); v.w = drop_apply(drop, site, base + 3, v.w);
+        }
+        xr[q] = c < D4 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; xr[q] = c < D4 ? ld(c) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
   }
   float s = 0.f;
   if constexpr (NQ > 0) {
@@ -597,12 +703,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int c = lane; c < D4; c += 64) sq(ld(c));
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + eps);
-  const float4* g4 = reinterpret_cast<const float4*>(g);
-  const float4* b4 = reinterpret_cast<const float4*>(b);
   if constexpr (!HEAD) {
     float4* y4 = reinterpret_cast<float4*>(Y + (int64_t)row * D);
-    auto emit = [&](int c, float4 v) {
-      float4 gg = g4[c], bv = b4[c], o;
+    auto emit = [&](int c, float4 v, float4 gg, float4 bv) {
+      float4 o;
       o.x = (v.x - mean) * rstd * gg.x + bv.x; o.y = (v.y - mean) * rstd * gg.y + bv.y;
       o.z = (v.z - mean) * rstd * gg.z + bv.z; o.w = (v.w - mean) * rstd * gg.w + bv.w;
       if (Y != nullptr) y4[c] = o;
@@ -610,23 +714,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     };
     if constexpr (NQ > 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) emit(c, xr[q]); }
+      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) { if constexpr (SLAB) emit(c, xr[q], gq[q], bq[q]); else emit(c, xr[q], g4[c], b4[c]); } }
     } else {
-      for (int c = lane; c < D4; c += 64) emit(c, ld(c));
+      for (int c = lane; c < D4; c += 64) emit(c, ld(c), g4[c], b4[c]);
     }
   } else {
-    const float4* w4 = reinterpret_cast<const float4*>(w2);
     float dot = 0.f;
-    auto acc = [&](int c, float4 v) {
-      float4 gg = g4[c], bv = b4[c], ww = w4[c];
+    auto acc = [&](float4 v, float4 gg, float4 bv, float4 ww) {
       dot += ((v.x - mean) * rstd * gg.x + bv.x) * ww.x + ((v.y - mean) * rstd * gg.y + bv.y) * ww.y +
              ((v.z - mean) * rstd * gg.z + bv.z) * ww.z + ((v.w - mean) * rstd * gg.w + bv.w) * ww.w;
     };
     if constexpr (NQ > 0) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) acc(c, xr[q]); }
+      for (int q = 0; q < NQ; ++q) { const int c = lane + 64 * q; if (c < D4) { if constexpr (SLAB) acc(xr[q], gq[q], bq[q], wq[q]); else acc(xr[q], g4[c], b4[c], w4[c]); } }
     } else {
-      for (int c = lane; c < D4; c += 64) acc(c, ld(c));
+      for (int c = lane; c < D4; c += 64) acc(ld(c), g4[c], b4[c], w4[c]);
     }
     dot = wave_sum(dot);
     if (lane == 0) scores[row] = 1.0f / (1.0f + expf(-(dot + b2[0])));
@@ -714,9 +816,12 @@ static void launch_ln_rows(const float* X, float* Y, const float* g, const float
                            unsigned short* y16 = nullptr, SlabIn sl = SlabIn()) {
   const dim3 grid((n_rows + 3) / 4), block(256);
   const int D4 = D >> 2;
-#define SUMK_LN(NQ) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site, y16, sl)
+  const bool slab = sl.n > 1 || sl.add || sl.bias;
+#define SUMK_LN_(NQ, SL) hipLaunchKernelGGL((layernorm_kernel<HEAD, NQ, SL>), grid, block, 0, stream, X, Y, g, b, w2, b2, scores, n_rows, D, eps, stats, drop, site, y16, sl)
+#define SUMK_LN(NQ) do { if (slab) SUMK_LN_(NQ, true); else SUMK_LN_(NQ, false); } while (0)
   if (D4 <= 64) SUMK_LN(1); else if (D4 <= 128) SUMK_LN(2); else if (D4 <= 256) SUMK_LN(4); else if (D4 <= 512) SUMK_LN(8); else SUMK_LN(0);
 #undef SUMK_LN
+#undef SUMK_LN_
 }
 
 // Backward of  y = LN(drop(x)) * g + b  for a strided set of rows per wave.
@@ -727,7 +832,7 @@ static void launch_ln_rows(const float* X, float* Y, const float* g, const float
 // of `part` ([n_blocks][4*D + 4], sumk_internal.h: ln_slot_floats); ln_bwd_reduce adds the slots into the gradients in one
 // launch (deterministic).  Round 1 wrote one slot per wave and reduced each vector with its own launch over ~1000 slots, and the
 // bias gradient took a separate pass over dX: 7 launches x 18 us + 45 us per training step.
-template <int NQ, bool HEAD>
+template <int NQ, bool HEAD, bool PRE = false>   // PRE (few rows: latency-bound): all of a row's loads issued before the first use
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ X, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             const float* __restrict__ dY, const float* __restrict__ w2,
@@ -755,6 +860,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float du = 0.f;
     if constexpr (HEAD) { float sc = scores[row]; du = dscores[row] * sc * (1.f - sc); ab2 += du; }
     float4 xh[NQ], dxh[NQ], keep[NQ];
+    float4 pxv[NQ], pgv[NQ], pwv[NQ], pbv[NQ], pdy[NQ];
+    if constexpr (PRE) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c = min(lane + 64 * q, D4 - 1);
+        pxv[q] = x4[c]; pgv[q] = g4[c];
+        if constexpr (HEAD) { pwv[q] = w4[c]; pbv[q] = b4[c]; }
+      }
+      if constexpr (!HEAD) {
+        const float4* dy4 = reinterpret_cast<const float4*>(dY + (int64_t)row * D);
+        const int64_t st4 = slab_stride >> 2;
+        row_gather<NQ>(pdy, dy4, lane, D4, n_slab, st4);
+      }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -762,7 +881,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       xh[q] = dxh[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       keep[q] = make_float4(1.f, 1.f, 1.f, 1.f);
       if (c < D4) {
-        float4 v = x4[c];
+        float4 v;
+        if constexpr (PRE) v = pxv[q]; else v = x4[c];
         if constexpr (HEAD) {  // ReLU mask on the stored post-ReLU value (vasnet.py:141)
           keep[q].x = v.x > 0.f ? 1.f : 0.f; keep[q].y = v.y > 0.f ? 1.f : 0.f;
           keep[q].z = v.z > 0.f ? 1.f : 0.f; keep[q].w = v.w > 0.f ? 1.f : 0.f;
@@ -779,15 +899,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         float4 h;
         h.x = (v.x - mean) * rstd; h.y = (v.y - mean) * rstd; h.z = (v.z - mean) * rstd; h.w = (v.w - mean) * rstd;
         xh[q] = h;
-        const float4 gg = g4[c];
+        float4 gg;
+        if constexpr (PRE) gg = pgv[q]; else gg = g4[c];
         float4 dy;
         if constexpr (HEAD) {
-          const float4 ww = w4[c], bv = b4[c];
+          float4 ww, bv;
+          if constexpr (PRE) { ww = pwv[q]; bv = pbv[q]; } else { ww = w4[c]; bv = b4[c]; }
           dy.x = du * ww.x; dy.y = du * ww.y; dy.z = du * ww.z; dy.w = du * ww.w;
           aw[q].x += du * (h.x * gg.x + bv.x); aw[q].y += du * (h.y * gg.y + bv.y);
           aw[q].z += du * (h.z * gg.z + bv.z); aw[q].w += du * (h.w * gg.w + bv.w);
         } else {
-          dy = slab_sum(reinterpret_cast<const float4*>(dY + (int64_t)row * D) + c, n_slab, slab_stride >> 2);
+          if constexpr (PRE) dy = pdy[q];
+          else dy = slab_sum(reinterpret_cast<const float4*>(dY + (int64_t)row * D) + c, n_slab, slab_stride >> 2);
         }
         ag[q].x += dy.x * h.x; ag[q].y += dy.y * h.y; ag[q].z += dy.z * h.z; ag[q].w += dy.w * h.w;
         ab[q].x += dy.x; ab[q].y += dy.y; ab[q].z += dy.z; ab[q].w += dy.w;
@@ -1218,7 +1341,7 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     float* e2p = use_e2 ? E2 : nullptr;
     const float* eraw = scratch;
     const int n_slab = G.P.seq[TB_S].S;
-#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(tb + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, (unsigned short*)nullptr, eraw, n_slab, (int64_t)L.e_elems)
+#define SUMK_SOFTMAX(NR) hipLaunchKernelGGL((vasnet_softmax_kernel<NR, true>), sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(tb + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, (unsigned short*)nullptr, eraw, n_slab, (int64_t)L.e_elems)
     if (G.t_max <= 256) SUMK_SOFTMAX(4); else if (G.t_max <= 512) SUMK_SOFTMAX(8); else if (G.t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
   }
@@ -1449,10 +1572,13 @@ static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const
   blocks = std::max(blocks, 1);
   *n_waves_out = blocks;              // slots written: one per block
   dim3 grid(blocks), block(256);
-#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16, n_slab, slab_stride)
+  const bool pre = (R + 3) / 4 <= blocks;     // one row per wave: the launch is one latency chain, not a stream
+#define LNB_(NQ, PRE) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD, PRE>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16, n_slab, slab_stride)
+#define LNB(NQ) do { if (pre) LNB_(NQ, true); else LNB_(NQ, false); } while (0)
   if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
   else { set_error("vasnet_backward: D=%d > 2048 is not supported by the LayerNorm backward kernel", D); return SUMK_ERR_ARG; }
 #undef LNB
+#undef LNB_
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -1561,8 +1687,10 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
       const SkCall c{dCTX, {QKV, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dAlphaD = dC V^T as slabs: the softmax backward kernel adds them
       SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, -1, TB_DP, c, stream));
     }
-    hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(tb + L.row_seq), n_seq, R,
-                       opts->scale, drop, (unsigned short*)nullptr, (const float*)scratch, G.P.seq[TB_DP].S, (int64_t)L.e_elems);
+#define SUMK_SOFTMAX_BWD(NR) hipLaunchKernelGGL(vasnet_softmax_bwd_kernel<NR>, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(tb + L.row_seq), n_seq, R, \
+                       opts->scale, drop, (unsigned short*)nullptr, (const float*)scratch, G.P.seq[TB_DP].S, (int64_t)L.e_elems)
+    if (G.t_max <= 256) SUMK_SOFTMAX_BWD(4); else if (G.t_max <= 512) SUMK_SOFTMAX_BWD(8); else if (G.t_max <= 1024) SUMK_SOFTMAX_BWD(16); else SUMK_SOFTMAX_BWD(0);
+#undef SUMK_SOFTMAX_BWD
     {
       const SkCall c{E2, {QKV, nullptr, nullptr, nullptr}, {dQKV, nullptr, nullptr, nullptr}, nullptr, nullptr, -1};        // dQ = dS K
       SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NN, EPI_NONE, -1, TB_DQ, c, stream));
@@ -1625,7 +1753,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   }
   // 3': softmax (+dropout, +scale) backward, in place on E2
   // (b16: bf16(dLogits) goes where bf16(alpha) was -- its last reader, the dV product, is queued before this kernel)
-  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(tb + L.row_seq), n_seq, R,
+  hipLaunchKernelGGL(vasnet_softmax_bwd_kernel<0>, dim3((R + 3) / 4), dim3(256), 0, stream, E, E2, seq, (const int32_t*)(tb + L.row_seq), n_seq, R,
                      opts->scale, drop, b16 ? (unsigned short*)(ws + L.p16) : nullptr, (const float*)E2, 0, (int64_t)0);
   // 2': dQ = dS K ; dK = dS^T Q
   {
