@@ -220,6 +220,45 @@ __host__ __device__ inline float drop_apply(const Drop& d, uint32_t site, uint64
   return dropout_keep(d.seed, site, idx, d.thr) ? v * d.scale : 0.f;
 }
 
+// One video of a packed batch as the attention kernels see it (built on device by vasnet_setup_kernel, csrc/vasnet.hip).
+struct SeqInfo {
+  int64_t eoff;  // element offset of this video's (T x ldE) logits block in E
+  int32_t row0, T, ldE, pad_;
+  int64_t e16off;  // element offset of its (T x ld16) bf16 attention block, ld16 = T rounded up to 64 (bf16-source training step)
+};
+
+// Masked, scaled logit exactly as vasnet.py:119-127 produces it.
+__device__ __forceinline__ float masked_logit(float raw, float scale, int i, int j, int ignore_self, int aperture) {
+  float e = raw * scale;
+  if (ignore_self && i == j) e = -INFINITY;
+  if (aperture >= 0) {
+    // scope = tril(e, w) * triu(e, -w);  e[scope == 0] = -inf   (also masks in-band logits whose square underflows)
+    float lo = (j - i <= aperture) ? e : 0.f;
+    float up = (j - i >= -aperture) ? e : 0.f;
+    if (lo * up == 0.f) e = -INFINITY;
+  }
+  return e;
+}
+
+// Fused attention strips of the bf16-source training step (attn_b16.hip): one workgroup per (video, 64 query rows), T <= 320 keys.
+//   forward : S = Q K^T (bf16 operands, fp32 accumulate) -> alpha = softmax(mask(S * scale)) (fp32, written to E) ->
+//             P = bf16(dropout(alpha)) (written to P16: the dV product reads it) -> CTX = P V (bf16, written to O16)
+//   backward: dP = dCTX V^T -> dS = scale * alpha * (dropout'(dP) - sum_j dropout'(dP)_j alpha_j) (alpha re-read from E) ->
+//             bf16(dS) (written over P16: the dK product reads it) -> dQ = dS K (bf16, written to O16)
+// The same rounding points as the separate launches (GEMM -> softmax kernel -> GEMM) they replace.
+struct AttnStripArgs {
+  const unsigned short* A16; int32_t lda;    // query-side rows of GEMM-1: Q (forward) / dCTX (backward)
+  const unsigned short* B16; int32_t ldb;    // key-side rows of GEMM-1: K (forward) / V (backward)
+  const unsigned short* C16; int32_t ldc;    // [key][column] operand of GEMM-2: V (forward) / K (backward)
+  unsigned short* O16; int32_t ldo;          // output rows: CTX (forward) / dQ (backward)
+  float* E;                                  // alpha, per-video (T x ldE) blocks (SeqInfo::eoff)
+  unsigned short* P16;                       // per-video (T x ld16) bf16 blocks (SeqInfo::e16off)
+  const SeqInfo* seq; int32_t n_seq, strips, D;
+  float scale; int32_t ignore_self, aperture; Drop drop;
+};
+bool attn_strip_ok(int t_max, int D, int64_t rows, int ld_max);
+int launch_attn_strip(bool backward, const AttnStripArgs& a, hipStream_t stream);
+
 // Optional pre-reduction of a row kernel's input (small-batch path: the producing GEMM was cut into K slices that each stored their
 // own slab with plain stores -- no in-launch reduction, no tickets -- and the row kernel that consumes the matrix anyway adds them):
 //   value(r, c) = sum_{s < n} X[s * stride + r * ld + c]  (slab order)  [+ add[r * ld + c]]  [+ bias[c]]  [relu]

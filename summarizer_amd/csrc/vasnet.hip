@@ -19,12 +19,6 @@
 
 namespace sumk {
 
-struct SeqInfo {
-  int64_t eoff;  // element offset of this video's (T x ldE) logits block in E
-  int32_t row0, T, ldE, pad_;
-  int64_t e16off;  // element offset of its (T x ld16) bf16 attention block, ld16 = T rounded up to 64 (bf16-source training step)
-};
-
 // per-video problem tables built on device by vasnet_setup_kernel (index = table id)
 enum { TB_S = 0, TB_PV = 1, TB_DV = 2, TB_DP = 3, TB_DQ = 4, TB_DK = 5, TB_COUNT = 6 };
 constexpr int ROW_PROBS = 8;
@@ -447,19 +441,6 @@ __device__ __forceinline__ void row_gather(V (&xr)[NQ], const V* p, int lane, in
   else if (n_slab == 2) ln_gather<NQ, 2, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
   else if (n_slab == 4) ln_gather<NQ, 4, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
   else ln_gather<NQ, 8, false, false, V>(xr, p, nullptr, nullptr, lane, n, stride);
-}
-
-// Masked, scaled logit exactly as vasnet.py:119-127 produces it.
-__device__ __forceinline__ float masked_logit(float raw, float scale, int i, int j, int ignore_self, int aperture) {
-  float e = raw * scale;
-  if (ignore_self && i == j) e = -INFINITY;
-  if (aperture >= 0) {
-    // scope = tril(e, w) * triu(e, -w);  e[scope == 0] = -inf   (also masks in-band logits whose square underflows)
-    float lo = (j - i <= aperture) ? e : 0.f;
-    float up = (j - i >= -aperture) ? e : 0.f;
-    if (lo * up == 0.f) e = -INFINITY;
-  }
-  return e;
 }
 
 // ------------------------------------------------------------------------------------------- softmax rows
@@ -996,6 +977,7 @@ struct Geometry {  // what both forward and backward derive from the batch
   VasnetWs L;
   int R, st_qkv, st_d, tiles_s, tiles_pv, cfg_s, cfg_pv, t_max;
   bool b16;          // the mixed-precision training step on the bf16-source kernels (use_b16)
+  bool attn_fused;   // ... with the per-video attention as fused strips (attn_b16.hip): t_max <= 320
   int sk;            // 1: the small-batch path (use_sk) -- every GEMM an in-launch split-K launch of gemm_lean.hip; P = its tables
   SkPlan P;
 };
@@ -1101,6 +1083,10 @@ static int geometry(int D, int n_seq, const int32_t* off, int training, int prec
   (void)workspace_bytes;
   G->b16 = use_b16(*G, D, precision, training);
   if (G->b16) G->cfg_s = G->cfg_pv = 0;       // the bf16-source kernel has 128x128 tiles
+  {  // SUMK_ATTN_FUSED=0 keeps the separate launches (GEMM -> softmax kernel -> GEMM): the A/B switch of tests/test_gpu_train_full.py
+    static const bool fused_on = !(getenv("SUMK_ATTN_FUSED") && getenv("SUMK_ATTN_FUSED")[0] == '0');
+    G->attn_fused = G->b16 && fused_on && attn_strip_ok(G->t_max, D, G->R, 3 * D);
+  }
   G->tiles_s = G->tiles_pv = 0;
   for (int s = 0; s < n_seq; ++s) {
     int T = off[s + 1] - off[s];
@@ -1441,6 +1427,15 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
+  if (G.attn_fused) {  // 2-4 in one launch per (video, 64-row strip): logits, softmax (+ dropout), context
+    AttnStripArgs at;
+    const unsigned short* qkv16 = (const unsigned short*)(ws + L.qkv16);
+    at.A16 = qkv16; at.lda = 3 * D; at.B16 = qkv16 + D; at.ldb = 3 * D; at.C16 = qkv16 + 2 * D; at.ldc = 3 * D;
+    at.O16 = (unsigned short*)(ws + L.ctx16); at.ldo = D; at.E = E; at.P16 = (unsigned short*)(ws + L.p16);
+    at.seq = seq; at.n_seq = n_seq; at.strips = (G.t_max + 63) / 64; at.D = D;
+    at.scale = opts->scale; at.ignore_self = opts->ignore_self; at.aperture = opts->aperture; at.drop = drop;
+    SUMK_TRY(launch_attn_strip(false, at, stream));
+  } else {
   {  // 2: logits per video
     GemmLaunch g; g.precision = opts->precision;
     g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + TB_S * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s;
@@ -1458,6 +1453,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
 #define SUMK_SOFTMAX(NR) hipLaunchKernelGGL(vasnet_softmax_kernel<NR>, sg, sb, 0, stream, E, e2p, seq, (const int32_t*)(tb + L.row_seq), n_seq, R, opts->scale, opts->ignore_self, opts->aperture, drop, p16, (const float*)E, 0, (int64_t)0)
     if (t_max <= 256) SUMK_SOFTMAX(4); else if (t_max <= 512) SUMK_SOFTMAX(8); else if (t_max <= 1024) SUMK_SOFTMAX(16); else SUMK_SOFTMAX(0);
 #undef SUMK_SOFTMAX
+  }
   }
   // Fused inference tail (128x128 tiles, no dropout; SUMK_FUSED_HEAD=0 / SUMK_FUSED_LN=0 are the A/B switches, training always
   // runs the separate kernels):
@@ -1478,7 +1474,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   float* ln_W1g = Y1 + ln_mom_f;
   float* ln_c1 = ln_W1g + ln_w_f;
   float* ln_stats = ln_c1 + ln_c_f;
-  {  // 4: context
+  if (!G.attn_fused) {  // 4: context
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
@@ -1745,6 +1741,15 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.dctx16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   }
+  if (G.attn_fused) {  // dAlphaD, softmax backward and dQ in one launch per (video, 64-row strip); bf16(dLogits) replaces bf16(alphaD) in place
+    AttnStripArgs at;
+    const unsigned short* qkv16 = (const unsigned short*)(ws + L.qkv16);
+    at.A16 = (const unsigned short*)(ws + L.dctx16); at.lda = D; at.B16 = qkv16 + 2 * D; at.ldb = 3 * D; at.C16 = qkv16 + D; at.ldc = 3 * D;
+    at.O16 = (unsigned short*)dQKV16; at.ldo = 3 * D; at.E = E; at.P16 = (unsigned short*)(ws + L.p16);
+    at.seq = seq; at.n_seq = n_seq; at.strips = (G.t_max + 63) / 64; at.D = D;
+    at.scale = opts->scale; at.ignore_self = opts->ignore_self; at.aperture = opts->aperture; at.drop = drop;
+    SUMK_TRY(launch_attn_strip(true, at, stream));
+  } else {
   {
     GemmLaunch g; g.precision = opts->precision;
     g.A = dCTX; g.B[0] = QKV; g.C = E2; g.probs = tabs + TB_DP * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_s; g.total_tiles = G.tiles_s;
@@ -1761,6 +1766,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DQ * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+  }
   }
   {
     GemmLaunch g; g.precision = opts->precision;
