@@ -30,43 +30,61 @@ namespace sumk {
 
 namespace {
 
-#ifndef AT_EXP
-#define AT_EXP 0
-#endif
 constexpr int AT_ROWS = 64, AT_TMAX = 320, AT_BK = 64;
-constexpr int AT_KCP = 2 * AT_BK + 16;         // K-contiguous image: bytes per row (144)
 constexpr int AT_PP = 2 * AT_TMAX + 16;        // P image: bytes per query row (656)
 constexpr int AT_NCH = 256;                    // GEMM-2: output columns per pass
-constexpr int AT_MCP = 2 * AT_NCH + 64;        // [key][col] image: bytes per key row (576)
-constexpr int AT_STAGE1 = (AT_TMAX + AT_ROWS) * AT_KCP;   // one GEMM-1 k-tile: key rows then query rows (55296)
-constexpr int AT_SP = 0;                                   // P
-constexpr int AT_ST = AT_ROWS * AT_PP;                     // two staging buffers (GEMM-1 k-tiles; GEMM-2 tiles of C)
-constexpr int AT_RED = AT_ST + 2 * AT_STAGE1;
-constexpr int AT_LDS = AT_RED + 4 * 64 * 4;
-constexpr int AT_R1 = 4, AT_R2 = 4;                        // register rings: k-tiles of GEMM-1 / tiles of C in flight
-static_assert(AT_BK * AT_MCP <= AT_STAGE1, "a C tile of phase 2 fits a GEMM-1 staging buffer");
-static_assert(AT_LDS <= 160 * 1024, "LDS");
+constexpr int AT_ROWB = 2 * AT_BK;             // GEMM-1 staged row: 64 bf16 = 128 B, no pad (LDS-DMA writes 1 KB runs): 16-byte chunks XOR-swizzled
+constexpr int AT_CROW = 2 * AT_NCH;            // GEMM-2 staged key row: 256 bf16 = 512 B, 64-byte pieces XOR-swizzled
+constexpr int AT_NST = 3;                      // LDS stages per GEMM: two tiles in flight behind the one being multiplied
+constexpr int AT_STAGE1 = (AT_TMAX + AT_ROWS) * AT_ROWB;      // 49152
+constexpr int AT_STAGE2 = AT_BK * AT_CROW;                    // 32768
+constexpr int AT_SP = 0;                                      // P (written after GEMM-1: overlays its first stage)
+constexpr int AT_ST2 = 43008;                                 // GEMM-2 stages, behind P
+constexpr int AT_RED = AT_NST * AT_STAGE1;                    // row-statistic exchange
+constexpr int AT_LDS = AT_RED + 8 * 64 * 4;
+static_assert(AT_ROWS * AT_PP <= AT_ST2 && AT_ST2 + AT_NST * AT_STAGE2 <= AT_RED && AT_LDS <= 160 * 1024, "LDS map");
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vptr;
 
 __device__ __forceinline__ u32x2 pack_bf16x4(float a, float b, float c, float d) {
   return __builtin_bit_cast(u32x2, __builtin_convertvector(f32x4v{a, b, c, d}, bf16x4v));
 }
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
+// workgroup barrier for LDS traffic alone: unlike __syncthreads() it does not drain the LDS-DMA requests in flight (vmcnt)
+__device__ __forceinline__ void lds_barrier() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
+template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
 
-// NJ = T64 / 64: key tiles of 32 per wave in GEMM-1 (a wave owns tiles kg, kg + 2, ...) and 64-key tiles of C in GEMM-2.  A template
-// parameter, not a run-time bound: with `if (j < nj)` around every fragment read and MFMA the compiler put a branch and a full
-// lgkmcnt(0) wait in front of each MFMA (74 us per launch); the workgroup picks its instance with one switch.
-__device__ unsigned long long attn_stamps[2][512][8];
-#define STAMP(k) do { if (threadIdx.x == 0) attn_stamps[BWD ? 1 : 0][blockIdx.x & 511][k] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// NJ = T64 / 64 (1 ... 5) is a template parameter, not a run-time bound: with `if (j < nj)` around every fragment read and MFMA the compiler
+// put a branch and a full lgkmcnt(0) wait in front of each MFMA; the workgroup picks its instance with one switch.
+//
+// EIGHT waves (two per SIMD).  GEMM-1: wave = (query tile qt, key group kg of 4), key tiles kg + 4 j, j < NTW = ceil(2 NJ / 4) -- tile
+// slots past 2 NJ are dummies (they multiply whatever rows follow in the stage; their logits are masked as key >= T and never stored).
+// GEMM-2: wave w owns output columns nc * 256 + 32 w + [0, 32) for both query tiles.
+//
+// Operands reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KB per wave instruction, no VGPRs, no ds_write), three stages per
+// product.  How this shape was arrived at (stamps + builds with one piece removed, 4 waves, T = 320):
+//   register staging, one tile in flight: 100 us per launch; four tiles in flight 74; branches out of the MFMA stream (NJ template) 68;
+//   of a k-tile's 2,300 cycles 1,200 were its 12 ds_write_b128 per wave (13 cycles of issue each, the waves' stores serialised on the
+//   store path, nothing hidden behind the 640 cycles of MFMA by a single wave per SIMD);
+//   LDS-DMA instead: no stores, but a DMA instruction holds its wave's issue ~100 cycles -- 1,200 cycles per wave and k-tile again,
+//   and the dropout hash moved into the k-loop simply added its cycles: with ONE wave per SIMD every stall of that wave idles the
+//   matrix pipe.  Hence two waves per SIMD that each issue half the DMAs and half the MFMAs.
+// A DMA writes lane-linear runs, so the images carry no pad; bank conflicts are avoided by an XOR swizzle applied on the SOURCE address
+// (which 16-byte chunk a lane fetches) and again by the fragment reads.  Rows past the video are CLAMPED to its last row (finite
+// data; their logits are masked / their P columns are zero), never out of range.
 template <bool BWD, int NJ>
 __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const SeqInfo& si, const int strip, char* const lds) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = si.T, i0 = strip * AT_ROWS;
   const Drop drop = drop_resolve(a.drop);
   constexpr int T64 = NJ * 64;
+  constexpr int NTW = (2 * NJ + 3) / 4;       // key-tile slots per wave
   const int D = a.D;
   const int rows = min(AT_ROWS, T - i0);
 
@@ -75,147 +93,146 @@ __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const Se
       const_cast<unsigned short*>(a.A16 + (int64_t)(si.row0 + i0) * a.lda), (short)0, ((rows - 1) * a.lda + D) * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned short*>(a.B16 + (int64_t)si.row0 * a.ldb), (short)0, ((T - 1) * a.ldb + D) * 2, 0x00020000);
-  const int lr = tid >> 3, lc = tid & 7;      // this thread's 16-byte chunks: rows lr + 32 p, k chunk lc (rows past the video read as zero)
-  const int voa = (lr * a.lda + lc * 8) * 2, vob = (lr * a.ldb + lc * 8) * 2;
-  const int sta = 32 * a.lda * 2, stb = 32 * a.ldb * 2;
-  const int KT1 = D / AT_BK;                  // a multiple of AT_R1 (D % 256 == 0)
-  // Register ring, AT_R1 k-tiles deep: with one workgroup per CU nothing else hides the L2 / HBM latency (one tile in flight: 100 us per
-  // launch), so a tile's loads are issued four tiles before its LDS write.
-  u32x4 rq[AT_R1][2], rk[AT_R1][2 * NJ];
-  // (requests past the last tile are ISSUED too, with a vector offset outside the descriptor -- they return zero without touching memory.
-  //  Under an `if` the compiler's wait counts assume the branch not taken: vmcnt(7..0) in front of a tile's LDS write with 32 newer
-  //  loads behind it, i.e. the whole ring drained at every tile.)
-  constexpr int AT_OOB = 0x40000000;
-  auto gload1 = [&](int kt, u32x4 (&q)[2], u32x4 (&k)[2 * NJ]) {
-    const int oob = kt < KT1 ? 0 : AT_OOB;
+  // DMA instruction p of this wave fills rows (8 p + wave) * 8 + [0, 8) of the stage, 8 chunks each: lane -> (row lane / 8, slot lane % 8);
+  // the slot holds chunk  slot ^ ((row >> 1) & 7)  of the row  (= slot ^ ((lane >> 4) + 4 (wave & 1)) & 7: the same for every p)
+  const int d_row = wave * 8 + (lane >> 3);
+  const int d_chunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  int vk[NJ];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) q[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rA, voa + p * sta + oob, kt * (AT_BK * 2), 0);
+  for (int p = 0; p < NJ; ++p) vk[p] = (min(d_row + 64 * p, T - 1) * a.ldb + d_chunk * 8) * 2;
+  const int vq = (min(d_row, rows - 1) * a.lda + d_chunk * 8) * 2;
+  constexpr int NI1 = NJ + 1;                 // DMA instructions per wave and k-tile
+  auto dma1 = [&](int kt, int stage) {
+    char* const dst = lds + stage * AT_STAGE1 + wave * 1024;
 #pragma unroll
-    for (int p = 0; p < 2 * NJ; ++p) k[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rB, vob + p * stb + oob, kt * (AT_BK * 2), 0);
+    for (int p = 0; p < NJ; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vptr)(dst + p * 8192), 16, vk[p], kt * (AT_BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(dst + T64 * AT_ROWB), 16, vq, kt * (AT_BK * 2), 0, 0);
   };
-  // LDS write of a staged k-tile, in four parts (chunks c = part mod 4) so that a tile's writes sit between the MFMA groups of the tile before it
-  auto swrite1_part = [&](char* buf, const u32x4 (&q)[2], const u32x4 (&k)[2 * NJ], int part) {
-#pragma unroll
-    for (int c = 0; c < 2 + 2 * NJ; ++c) {
-      if ((c & 3) != part) continue;
-      if (c < 2) *reinterpret_cast<u32x4*>(buf + (AT_TMAX + lr + 32 * c) * AT_KCP + lc * 16) = q[c];
-      else *reinterpret_cast<u32x4*>(buf + (lr + 32 * (c - 2)) * AT_KCP + lc * 16) = k[c - 2];
-    }
-  };
-  const int qt = wave & 1, kg = wave >> 1;    // this wave: query tile qt, key tiles kg + 2 j
-  const int fq = (AT_TMAX + qt * 32 + li) * AT_KCP + 16 * lh;     // fragment offsets inside a staging buffer
-  const int fk = (kg * 32 + li) * AT_KCP + 16 * lh;
-  struct Frag1 { bf16x8 bq, ak[NJ]; };
+  const int qt = wave & 1, kg = wave >> 1;    // this wave: query tile qt, key tiles kg + 4 j
+  const int sw = (li >> 1) & 7;               // fragment reads: chunk c of row r sits in slot c ^ ((r >> 1) & 7)
+  const int fq = (T64 + qt * 32 + li) * AT_ROWB, fk = (kg * 32 + li) * AT_ROWB;
+  struct Frag1 { bf16x8 bq, ak[NTW]; };
   auto read1 = [&](const char* buf, int ks, Frag1& f) {
-    f.bq = *reinterpret_cast<const bf16x8*>(buf + fq + 32 * ks);
+    const int so = ((2 * ks + lh) ^ sw) * 16;
+    f.bq = *reinterpret_cast<const bf16x8*>(buf + fq + so);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) f.ak[j] = *reinterpret_cast<const bf16x8*>(buf + fk + j * 64 * AT_KCP + 32 * ks);
+    for (int j = 0; j < NTW; ++j) f.ak[j] = *reinterpret_cast<const bf16x8*>(buf + fk + j * 128 * AT_ROWB + so);
   };
-  f32x16 acc[NJ];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j)
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // One wave per SIMD: nothing but the instruction order hides LDS latency, so the order is pinned (sched_barrier).  Iteration kt: the
-  // fragments of step ks + 1 and a quarter of tile kt + 1's LDS write are issued, THEN the MFMAs of step ks; tile kt + 5's loads follow
-  // the last step, one workgroup barrier closes the iteration (two staging buffers: tile kt + 1 is written while tile kt is read).
-  STAMP(0);
+  // Dropout keep bits of this lane's 16 NTW elements (a pure function of seed, row and key: sumk_internal.h dropout_keep), one accumulator
+  // register index r per k-tile, computed inside the k-loop where the partner wave's MFMAs cover the three 64-bit multiplies per element
+  const int qi = qt * 32 + li, i = i0 + qi;
+  const uint64_t drow = (uint64_t)(si.row0 + i) << 20;
+  uint32_t keepm[NTW];
 #pragma unroll
-  for (int st = 0; st < AT_R1; ++st) gload1(st, rq[st], rk[st]);
+  for (int j = 0; j < NTW; ++j) keepm[j] = 0u;
+  auto keep_step = [&](int r) {
 #pragma unroll
-  for (int part = 0; part < 4; ++part) swrite1_part(lds + AT_ST, rq[0], rk[0], part);
-  gload1(AT_R1, rq[0], rk[0]);
-  __syncthreads();
-  for (int kt0 = 0; kt0 < KT1; kt0 += AT_R1) {
-#pragma unroll
-    for (int st = 0; st < AT_R1; ++st) {
-      const char* const cur = lds + AT_ST + (st & 1) * AT_STAGE1;
-      char* const nxt = lds + AT_ST + ((st + 1) & 1) * AT_STAGE1;
-      constexpr int R1M = AT_R1 - 1;
-      const int ns = (st + 1) & R1M;
-      Frag1 f[2];
-      if (!(AT_EXP & 2) || kt0 + st == 0) read1(cur, 0, f[0]);
-#pragma unroll
-      for (int ks = 0; ks < AT_BK / 16; ++ks) {
-        if (!(AT_EXP & 2)) if (ks + 1 < AT_BK / 16) read1(cur, ks + 1, f[(ks + 1) & 1]);
-        if (!(AT_EXP & 4)) swrite1_part(nxt, rq[ns], rk[ns], ks);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(AT_EXP & 1)) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].ak[j], f[ks & 1].bq, acc[j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (!(AT_EXP & 8)) gload1(kt0 + st + 1 + AT_R1, rq[ns], rk[ns]);
-      if (!(AT_EXP & 16)) __syncthreads();
+    for (int j = 0; j < NTW; ++j) {
+      const int key = (kg + 4 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      keepm[j] |= (dropout_keep(drop.seed, 0, drow | (uint64_t)key, drop.thr) ? 1u : 0u) << r;
     }
+  };
+  const int KT1 = D / AT_BK;                  // >= 4
+  dma1(0, 0);
+  dma1(1, 1);
+  int stage = 0;
+  for (int kt = 0; kt < KT1; ++kt) {
+    // tile kt has landed (this wave's share: all but the NI1 younger requests; the barrier adds everyone else's), and every wave is
+    // past its reads of tile kt - 1, whose stage the requests for tile kt + 2 overwrite
+    if (kt + 1 < KT1) wait_vm<NI1>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    const int st2 = stage == 0 ? 2 : stage - 1;
+    if (kt + 2 < KT1) dma1(kt + 2, st2);
+    const char* const cur = lds + stage * AT_STAGE1;
+    if (drop.thr && kt < 16) keep_step(kt);
+    Frag1 f[2];
+    read1(cur, 0, f[0]);
+#pragma unroll
+    for (int ks = 0; ks < AT_BK / 16; ++ks) {
+      if (ks + 1 < AT_BK / 16) read1(cur, ks + 1, f[(ks + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].ak[j], f[ks & 1].bq, acc[j], 0, 0, 0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
   }
+  if (drop.thr)
+    for (int r = KT1; r < 16; ++r) keep_step(r);     // D < 1024: fewer k-tiles than accumulator registers
+  __syncthreads();                            // every wave is past its last GEMM-1 fragment read: the stages may be overwritten
 
-  STAMP(1);
-  // ---------------------------------------------------------------------------------------------- GEMM-2 operands: the first column pass in flight under the row op
+  // ---------------------------------------------------------------------------------------------- GEMM-2 operands: two tiles in flight under the row op
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned short*>(a.C16 + (int64_t)si.row0 * a.ldc), (short)0, ((T - 1) * a.ldc + D) * 2, 0x00020000);
-  const int cr = tid >> 5, cc = tid & 31;     // 16-byte chunks of the [64 keys][256 cols] tile: key rows cr + 8 p, column chunk cc
-  const int NC = D / AT_NCH;
-  u32x4 rc[NJ][8];                            // ring slot = key tile: tile (nc + 1, kt) is requested when tile (nc, kt) has gone to LDS
-  auto gload2 = [&](int nc, int kt, u32x4 (&c)[8]) {  // key rows in the VECTOR offset: rows past T are out of the descriptor's range and read as zero
-    const int oob = nc < NC ? 0 : AT_OOB;
+  // DMA instruction p of this wave fills key rows (8 p + wave) * 2 + [0, 2) of the [64 keys][256 cols] tile, 32 chunks of 16 B each:
+  // lane -> (row lane / 32, chunk lane % 32); the 64-byte piece q = chunk / 4 of a row is stored at piece position q ^ (row & 3)
+  const int c_row = wave * 2 + (lane >> 5);
+  const int c_chunk = ((((lane & 31) >> 2) ^ (c_row & 3)) << 2) | (lane & 3);
+  const int NC = D / AT_NCH, n_it = NC * NJ;
+  constexpr int NI2 = 4;
+  auto dma2 = [&](int nc, int kt, int stage) {
+    char* const dst = lds + AT_ST2 + stage * AT_STAGE2 + wave * 1024;
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
-      c[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rC, ((kt * 64 + cr + 8 * p) * a.ldc + nc * AT_NCH + cc * 8) * 2 + oob, 0, 0);
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (lds_vptr)(dst + p * 8192), 16,
+                                               (min(kt * 64 + c_row + 16 * p, T - 1) * a.ldc + nc * AT_NCH + c_chunk * 8) * 2, 0, 0, 0);
   };
-#pragma unroll
-  for (int kt = 0; kt < NJ; ++kt) gload2(0, kt, rc[kt]);
+  dma2(0, 0, 0);
+  if (n_it > 1) dma2(NJ > 1 ? 0 : 1, NJ > 1 ? 1 : 0, 1);
 
   // ---------------------------------------------------------------------------------------------- row op
-  // acc[j][r]: key = (kg + 2 j) * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = qt * 32 + li
-  const int qi = qt * 32 + li, i = i0 + qi;
+  // acc[j][r]: key = (kg + 4 j) * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = qt * 32 + li
   const bool row_ok = i < T;
-  float* const red = reinterpret_cast<float*>(lds + AT_RED);
-  const uint64_t drow = (uint64_t)(si.row0 + i) << 20;
+  float* const red = reinterpret_cast<float*>(lds + AT_RED);     // [4 key groups][64 queries], twice
   float* const erow = a.E + si.eoff + (int64_t)i * si.ldE;
   unsigned short* const prow = a.P16 + si.e16off + (int64_t)i * T64;
   char* const lrow = lds + AT_SP + qi * AT_PP;
   if constexpr (!BWD) {
     float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = (kg + 2 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        const int key = (kg + 4 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
         const float e = key < T ? masked_logit(acc[j][r], a.scale, i, key, a.ignore_self, a.aperture) : -INFINITY;
         acc[j][r] = e;
         m = fmaxf(m, e);
       }
     m = fmaxf(m, __shfl_xor(m, 32));
     if (lh == 0) red[kg * 64 + qi] = m;
-    __syncthreads();
-    m = fmaxf(red[qi], red[64 + qi]);
+    lds_barrier();
+    m = fmaxf(fmaxf(red[qi], red[64 + qi]), fmaxf(red[128 + qi], red[192 + qi]));
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = (kg + 2 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-        const float p = key < T ? expf(acc[j][r] - m) : 0.f;
+        const int key = (kg + 4 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        const float p = key < T ? __expf(acc[j][r] - m) : 0.f;
         acc[j][r] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32);
-    if (lh == 0) red[128 + kg * 64 + qi] = sum;
-    __syncthreads();
-    sum = red[128 + qi] + red[192 + qi];
+    if (lh == 0) red[256 + kg * 64 + qi] = sum;
+    lds_barrier();
+    sum = (red[256 + qi] + red[320 + qi]) + (red[384 + qi] + red[448 + qi]);
+    const float rsum = 1.0f / sum;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int k0 = (kg + 2 * j) * 32 + 8 * g + 4 * lh;
+        const int k0 = (kg + 4 * j) * 32 + 8 * g + 4 * lh;
+        if (k0 >= T64) continue;              // dummy tile slot
         float al[4], ad[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          al[c] = k0 + c < T ? acc[j][4 * g + c] / sum : 0.f;
-          ad[c] = (drop.thr && k0 + c < T) ? drop_apply(drop, 0, drow | (uint64_t)(k0 + c), al[c]) : al[c];
+          al[c] = k0 + c < T ? acc[j][4 * g + c] * rsum : 0.f;
+          ad[c] = drop.thr ? (((keepm[j] >> (4 * g + c)) & 1u) ? al[c] * drop.scale : 0.f) : al[c];
         }
         const u32x2 pk = pack_bf16x4(ad[0], ad[1], ad[2], ad[3]);
         if (row_ok) {
@@ -226,35 +243,35 @@ __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const Se
       }
   } else {
     float dot = 0.f;
-    float al[NJ][16];
+    float al[NTW][16];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int k0 = (kg + 2 * j) * 32 + 8 * g + 4 * lh;
+        const int k0 = (kg + 4 * j) * 32 + 8 * g + 4 * lh;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row_ok && k0 < si.ldE) t = *reinterpret_cast<const float4*>(erow + k0);
         al[j][4 * g] = t.x; al[j][4 * g + 1] = t.y; al[j][4 * g + 2] = t.z; al[j][4 * g + 3] = t.w;
       }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = (kg + 2 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
         float d = acc[j][r];
-        if (drop.thr) d = drop_apply(drop, 0, drow | (uint64_t)key, d);
+        if (drop.thr) d = ((keepm[j] >> r) & 1u) ? d * drop.scale : 0.f;
         acc[j][r] = d;
         dot += d * al[j][r];
       }
     dot += __shfl_xor(dot, 32);
     if (lh == 0) red[kg * 64 + qi] = dot;
-    __syncthreads();
-    dot = red[qi] + red[64 + qi];
+    lds_barrier();
+    dot = (red[qi] + red[64 + qi]) + (red[128 + qi] + red[192 + qi]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int k0 = (kg + 2 * j) * 32 + 8 * g + 4 * lh;
+        const int k0 = (kg + 4 * j) * 32 + 8 * g + 4 * lh;
+        if (k0 >= T64) continue;              // dummy tile slot
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = al[j][4 * g + c] * (acc[j][4 * g + c] - dot) * a.scale;
@@ -265,81 +282,61 @@ __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const Se
   }
 
   // ---------------------------------------------------------------------------------------------- GEMM-2
-  // wave w: output columns nc * 256 + w * 64 + [0, 64) (two M tiles), both query tiles
-  const int fc = (8 * lh + ((lane & 15) >> 2)) * AT_MCP + 2 * (wave * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+  // wave w: output columns nc * 256 + 32 w + [0, 32) (one M tile), both query tiles
+  const int rr = (lane >> 2) & 3;             // (key row & 3) of this lane's transposing reads
+  const int fct = (8 * lh + ((lane & 15) >> 2)) * AT_CROW + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + ((wave ^ rr) << 6);
   const char* const fp = lds + AT_SP + li * AT_PP + 16 * lh;
-  STAMP(2);
-  __syncthreads();                            // P complete
-  STAMP(3);
-  struct Frag2 { bf16x8 fa[2], fb[2]; };
+  struct Frag2 { bf16x8 fa, fb[2]; };
   auto read2 = [&](const char* buf, int kt, int ks, Frag2& f) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) f.fa[t] = tr_frag(buf + fc + 16 * ks * AT_MCP + 64 * t, AT_MCP);
+    f.fa = tr_frag(buf + fct + 16 * ks * AT_CROW, AT_CROW);
 #pragma unroll
     for (int u = 0; u < 2; ++u) f.fb[u] = *reinterpret_cast<const bf16x8*>(fp + u * 32 * AT_PP + (kt * 64 + ks * 16) * 2);
   };
-  auto swrite2_part = [&](char* buf, const u32x4 (&c)[8], int part) {
-#pragma unroll
-    for (int p = 2 * part; p < 2 * part + 2; ++p) *reinterpret_cast<u32x4*>(buf + (cr + 8 * p) * AT_MCP + cc * 16) = c[p];
-  };
-  // same schedule as GEMM-1: tile (nc, kt) is read from one staging buffer while the next tile of the (nc, kt) sequence goes into the other
-#pragma unroll
-  for (int part = 0; part < 4; ++part) swrite2_part(lds + AT_ST, rc[0], part);
-  gload2(1, 0, rc[0]);
-  __syncthreads();
-  int par = 0;
+  int stage2 = 0, it = 0;
+  int nc2 = NJ > 2 ? 0 : (NJ == 2 ? 1 : 2), kt2 = NJ > 2 ? 2 : 0;     // (nc, kt) of tile it + 2
   for (int nc = 0; nc < NC; ++nc) {
-    f32x16 o[2][2];
+    f32x16 o[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][u][r] = 0.f;
+      for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NJ; ++kt) {
-      const char* const cur = lds + AT_ST + par * AT_STAGE1;
-      char* const nxt = lds + AT_ST + (par ^ 1) * AT_STAGE1;
-      par ^= 1;
-      constexpr int NJ1 = NJ;
-      const int nk = (kt + 1) % NJ1;          // ring slot (= key tile) of the next tile; its column pass: nc + (kt + 1 == NJ)
+      // (the pass epilogue's global stores share the counter and complete out of order with loads: the first tile after them drains it)
+      if (it + 1 < n_it && !(kt == 0 && nc > 0)) wait_vm<NI2>(); else wait_vm<0>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): (first pass) this wave's P writes are in LDS before the barrier publishes them
+      __builtin_amdgcn_s_barrier();
+      const int st2 = stage2 == 0 ? 2 : stage2 - 1;
+      if (it + 2 < n_it) dma2(nc2, kt2, st2);
+      if (++kt2 == NJ) { kt2 = 0; ++nc2; }
+      const char* const cur = lds + AT_ST2 + stage2 * AT_STAGE2;
       Frag2 f[2];
       read2(cur, kt, 0, f[0]);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks + 1 < 4) read2(cur, kt, ks + 1, f[(ks + 1) & 1]);
-        swrite2_part(nxt, rc[nk], ks);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int u = 0; u < 2; ++u) o[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].fa[t], f[ks & 1].fb[u], o[t][u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 2; ++u) o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].fa, f[ks & 1].fb[u], o[u], 0, 0, 0);
       }
-      gload2(nc + (kt + 1 == NJ1 ? 2 : 1), nk, rc[nk]);
-      __syncthreads();
+      stage2 = stage2 == 2 ? 0 : stage2 + 1;
+      ++it;
     }
-    // o[t][u][r]: column = nc * 256 + wave * 64 + t * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = u * 32 + li
+    // o[u][r]: column = nc * 256 + wave * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = u * 32 + li
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int q = u * 32 + li;
-      unsigned short* const orow = a.O16 + (int64_t)(si.row0 + i0 + q) * a.ldo + nc * AT_NCH + wave * 64 + 4 * lh;
+      unsigned short* const orow = a.O16 + (int64_t)(si.row0 + i0 + q) * a.ldo + nc * AT_NCH + wave * 32 + 4 * lh;
       if (q < rows) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<u32x2*>(orow + t * 32 + 8 * g) = pack_bf16x4(o[t][u][4 * g], o[t][u][4 * g + 1], o[t][u][4 * g + 2], o[t][u][4 * g + 3]);
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(orow + 8 * g) = pack_bf16x4(o[u][4 * g], o[u][4 * g + 1], o[u][4 * g + 2], o[u][4 * g + 3]);
       }
     }
-    if (nc == 0) STAMP(4);
   }
-  STAMP(5);
-  if (threadIdx.x == 0) attn_stamps[BWD ? 1 : 0][blockIdx.x & 511][6] = NJ;
 }
 
 template <bool BWD>
-__global__ __launch_bounds__(256) void attn_strip_kernel(AttnStripArgs a) {
+__global__ __launch_bounds__(512) void attn_strip_kernel(AttnStripArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
@@ -372,13 +369,10 @@ int launch_attn_strip(bool backward, const AttnStripArgs& a_in, hipStream_t stre
     attr_set[backward ? 1 : 0] = true;
   }
   const unsigned grid = (unsigned)(8 * ((a.n_seq + 7) / 8) * a.strips);
-  if (backward) hipLaunchKernelGGL(attn_strip_kernel<true>, dim3(grid), dim3(256), AT_LDS, stream, a);
-  else hipLaunchKernelGGL(attn_strip_kernel<false>, dim3(grid), dim3(256), AT_LDS, stream, a);
+  if (backward) hipLaunchKernelGGL(attn_strip_kernel<true>, dim3(grid), dim3(512), AT_LDS, stream, a);
+  else hipLaunchKernelGGL(attn_strip_kernel<false>, dim3(grid), dim3(512), AT_LDS, stream, a);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
 
-extern "C" int sumk_attn_stamps_tmp(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(attn_stamps), sizeof(unsigned long long) * 2 * 512 * 8);
-}
 }  // namespace sumk

@@ -451,7 +451,9 @@ def test_bf16_source_step_equals_the_plane_kernel_step(tmp_path, D, lens):
     out = {}
     for tag, flag in (("src16", "1"), ("planes", "0")):
         f = tmp_path / f"{tag}.npz"
-        env = dict(os.environ, SUMK_BF16_SRC=flag)
+        # (SUMK_ATTN_FUSED=0: this test pins the bf16-source GEMM kernels; the fused attention strips that replace three of the launches for
+        #  T <= 320 re-associate the row statistics and have their own A/B test below)
+        env = dict(os.environ, SUMK_BF16_SRC=flag, SUMK_ATTN_FUSED="0")
         r = subprocess.run([sys.executable, "-c", _AB_CHILD, str(f), str(D), lens], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -471,3 +473,36 @@ def test_bf16_source_step_equals_the_plane_kernel_step(tmp_path, D, lens):
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert max(diffs) > 0, "bit-identical weight gradients: did SUMK_BF16_SRC select two different paths?"
+
+
+def test_fused_attention_strips_equal_separate_launches(tmp_path):
+    """csrc/attn_b16.hip (bf16 step, T <= 320: logits, softmax (+ dropout) and alpha.V in ONE launch per (video, 64-row strip); dC.V^T,
+    softmax backward and dS.K in another) against the separate launches it replaces (SUMK_ATTN_FUSED=0: GEMM -> softmax kernel -> GEMM),
+    each in its own process, through scripts/probes/attn_fused_equiv.py: fifty TVSum-sized videos; a ragged batch with T = 1, 2, 31 ... 320
+    (every NJ instance, strips that end inside a tile); local attention + ignore_self; no dropout.  Training-mode scores, every parameter
+    gradient, with and without dX.  Same dropout masks (a function of seed, row, key), same rounding points (bf16 operands, fp32
+    accumulate, fp32 row arithmetic, bf16 P / dS / CTX / dQ); the row statistics are added in a different order and exp is v_exp_f32, so a
+    P entry can land on the other side of a bf16 rounding boundary.  Measured: without dropout scores 6e-5, gradients <= 1.8e-4 relative
+    L2; with dropout (p = 0.5 doubles every kept entry) scores 4.5e-3 worst / 1e-4 L2, gradients <= 2.4e-3 L2."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    probe = os.path.join(ROOT, "scripts", "probes", "attn_fused_equiv.py")
+    outs = {}
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"fused{flag}.npz")
+        r = subprocess.run([sys.executable, probe, f], env=dict(os.environ, SUMK_ATTN_FUSED=flag), capture_output=True, text=True, cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs[flag] = np.load(f)
+    a, b = outs["1"], outs["0"]
+    assert set(a.files) == set(b.files) and len(a.files) > 80
+    differs = False
+    for k in a.files:
+        assert np.isfinite(a[k]).all(), k
+        differs = differs or not np.array_equal(a[k], b[k])
+        rel = float(np.linalg.norm((a[k] - b[k]).ravel()) / max(np.linalg.norm(b[k].ravel()), 1e-30))
+        nodrop = k.startswith("nodrop")
+        if "scores" in k:
+            assert np.abs(a[k] - b[k]).max() < (3e-4 if nodrop else 1.5e-2) and rel < (1e-4 if nodrop else 5e-4), (k, np.abs(a[k] - b[k]).max(), rel)
+        else:
+            assert rel < (6e-4 if nodrop else 6e-3), (k, rel)
+    assert differs, "bit-identical everywhere: did SUMK_ATTN_FUSED select two different paths?"
