@@ -15,13 +15,21 @@
 // then holds 4 consecutive keys (columns) of ONE query, so the row statistics reduce in registers (+ one cross-half shuffle + one LDS
 // exchange between the two waves that share a query tile), P goes to LDS and HBM in 8-byte pieces, and the outputs are 8-byte stores.
 //
-// LDS (96 KB, one workgroup per CU; 250 strips on the S-TVSum batch = one per CU):
-//   [0, 46080)      key-side k-tile of GEMM-1: 320 rows x (64 bf16 + 16 B)          | phase 2: the [64 keys][256 cols + 64 B] tile of C
-//   [46080, 55296)  query-side k-tile: 64 rows x (64 bf16 + 16 B)
-//   [55296, 97280)  P: 64 queries x (320 bf16 + 16 B)   (pitch 41 x 16 B: conflict-free ds_read_b128)
-//   [97280, 98304)  row-statistic exchange
+// LDS (148 KB, one workgroup of eight waves per CU; 250 strips on the S-TVSum batch = one per CU):
+//   [0, 147456)       GEMM-1: three stages of (320 key rows + 64 query rows) x 128 B (one 64-deep k-tile), filled by LDS-DMA
+//   [0, 41984)        after GEMM-1: P, 64 queries x (320 bf16 + 16 B)   (pitch 41 x 16 B: conflict-free ds_read_b128)
+//   [43008, 141312)   GEMM-2: three stages of [64 keys][256 cols] x 2 B
+//   [147456, 149504)  row-statistic exchange
 // Workgroup ids are dealt round-robin over the 8 XCDs, so id = xcd + 8 k: the strips of one video are given ids of the same residue and
 // its K / V rows (1.3 MB bf16) are fetched into ONE L2 instead of eight.
+//
+// Where the time goes (T = 320, in-kernel stamps, shader cycles per strip): GEMM-1 33 k, row op 14-18 k, GEMM-2 44 k against 12 k + 10 k of
+// MFMA: an iteration of either product costs ~2,000 cycles whatever the number of tiles in flight (one or two: equal), whichever of the
+// SIMD's two waves requests first, with or without an L2 prefetch of the tile four steps ahead by a ninth wave (tried, no effect, removed),
+// with or without the dropout hash in the loop (-4 us).  The LDS-DMA stream alone runs at 40 B/clk/CU (1,225 cycles per 48 KB k-tile),
+// the fragment reads + MFMAs alone at ~1,200, and the two add instead of overlapping: at 64 query rows per strip a k-tile carries
+// 54 FLOP per staged byte against the ~100 a CU needs to be matrix-bound.  Not tried: 2 x 3 register blocking per wave (-40 % fragment
+// reads), 128-row strips on half the CUs.
 #include "gemm_regstage.h"
 #include <math.h>
 #include <cstdlib>
@@ -40,9 +48,9 @@ constexpr int AT_STAGE1 = (AT_TMAX + AT_ROWS) * AT_ROWB;      // 49152
 constexpr int AT_STAGE2 = AT_BK * AT_CROW;                    // 32768
 constexpr int AT_SP = 0;                                      // P (written after GEMM-1: overlays its first stage)
 constexpr int AT_ST2 = 43008;                                 // GEMM-2 stages, behind P
-constexpr int AT_RED = AT_NST * AT_STAGE1;                    // row-statistic exchange
+constexpr int AT_RED = 3 * AT_STAGE1;                    // row-statistic exchange
 constexpr int AT_LDS = AT_RED + 8 * 64 * 4;
-static_assert(AT_ROWS * AT_PP <= AT_ST2 && AT_ST2 + AT_NST * AT_STAGE2 <= AT_RED && AT_LDS <= 160 * 1024, "LDS map");
+static_assert(AT_ROWS * AT_PP <= AT_ST2 && AT_ST2 + 3 * AT_STAGE2 <= AT_RED && AT_LDS <= 160 * 1024, "LDS map");
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -141,26 +149,37 @@ __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const Se
   };
   const int KT1 = D / AT_BK;                  // >= 4
   dma1(0, 0);
-  dma1(1, 1);
+  if (AT_NST > 2) dma1(1, 1);
   int stage = 0;
   for (int kt = 0; kt < KT1; ++kt) {
     // tile kt has landed (this wave's share: all but the NI1 younger requests; the barrier adds everyone else's), and every wave is
     // past its reads of tile kt - 1, whose stage the requests for tile kt + 2 overwrite
-    if (kt + 1 < KT1) wait_vm<NI1>(); else wait_vm<0>();
+    if (AT_NST > 2 && kt + 1 < KT1) wait_vm<NI1>(); else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    const int st2 = stage == 0 ? 2 : stage - 1;
-    if (kt + 2 < KT1) dma1(kt + 2, st2);
+    const int st2 = stage == 0 ? AT_NST - 1 : stage - 1;
     const char* const cur = lds + stage * AT_STAGE1;
-    if (drop.thr && kt < 16) keep_step(kt);
-    Frag1 f[2];
-    read1(cur, 0, f[0]);
+    auto compute1 = [&]() {
+      if (drop.thr && kt < 16) keep_step(kt);
+      Frag1 f[2];
+      read1(cur, 0, f[0]);
 #pragma unroll
-    for (int ks = 0; ks < AT_BK / 16; ++ks) {
-      if (ks + 1 < AT_BK / 16) read1(cur, ks + 1, f[(ks + 1) & 1]);
+      for (int ks = 0; ks < AT_BK / 16; ++ks) {
+        if (ks + 1 < AT_BK / 16) read1(cur, ks + 1, f[(ks + 1) & 1]);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].ak[j], f[ks & 1].bq, acc[j], 0, 0, 0);
+        for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].ak[j], f[ks & 1].bq, acc[j], 0, 0, 0);
+      }
+    };
+    // The two waves of a SIMD (w and w + 4) take the iteration in opposite orders: a DMA instruction holds its wave's issue for ~100-200
+    // cycles, and when both waves requested first and multiplied second the matrix pipe idled through every request phase (k-tile 2,000
+    // cycles = requests + MFMAs in series, the same with one or two tiles in flight).
+    if (wave < 4) {
+      if (kt + AT_NST - 1 < KT1) dma1(kt + AT_NST - 1, st2);
+      compute1();
+    } else {
+      compute1();
+      if (kt + AT_NST - 1 < KT1) dma1(kt + AT_NST - 1, st2);
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = stage == AT_NST - 1 ? 0 : stage + 1;
   }
   if (drop.thr)
     for (int r = KT1; r < 16; ++r) keep_step(r);     // D < 1024: fewer k-tiles than accumulator registers
@@ -307,17 +326,25 @@ __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const Se
       __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): (first pass) this wave's P writes are in LDS before the barrier publishes them
       __builtin_amdgcn_s_barrier();
       const int st2 = stage2 == 0 ? 2 : stage2 - 1;
-      if (it + 2 < n_it) dma2(nc2, kt2, st2);
-      if (++kt2 == NJ) { kt2 = 0; ++nc2; }
       const char* const cur = lds + AT_ST2 + stage2 * AT_STAGE2;
-      Frag2 f[2];
-      read2(cur, kt, 0, f[0]);
+      auto compute2 = [&]() {
+        Frag2 f[2];
+        read2(cur, kt, 0, f[0]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) read2(cur, kt, ks + 1, f[(ks + 1) & 1]);
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks + 1 < 4) read2(cur, kt, ks + 1, f[(ks + 1) & 1]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].fa, f[ks & 1].fb[u], o[u], 0, 0, 0);
+          for (int u = 0; u < 2; ++u) o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks & 1].fa, f[ks & 1].fb[u], o[u], 0, 0, 0);
+        }
+      };
+      if (wave < 4) {
+        if (it + 2 < n_it) dma2(nc2, kt2, st2);
+        compute2();
+      } else {
+        compute2();
+        if (it + 2 < n_it) dma2(nc2, kt2, st2);
       }
+      if (++kt2 == NJ) { kt2 = 0; ++nc2; }
       stage2 = stage2 == 2 ? 0 : stage2 + 1;
       ++it;
     }
