@@ -37,6 +37,7 @@ class VasnetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, sb, opts, table, rows, names, *params):
         p = dict(zip(names, params))
+        opts = dict(opts)            # the call adds what it derives (problem tables, the bf16 shadow of x) for the backward pass; the caller's dict stays as it was
         scores, ws = kernels.vasnet_forward_packed(xp, sb, p, opts, table, rows, training=True)
         ctx.sb, ctx.opts, ctx.names, ctx.ws, ctx.rows = sb, opts, names, ws, rows
         ctx.table_is_param = isinstance(table, torch.nn.Parameter) and table.requires_grad

@@ -1403,16 +1403,17 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   if (tb == ws) launch_setup(G, D, n_seq, seq_off_dev, tb, stream);
   // mixed-precision training: bf16 shadows of x and of the five weight matrices, then every row-wise GEMM reads bf16 from HBM
   const bool b16 = G.b16;
-  unsigned short* x16 = (unsigned short*)(ws + L.x16);
+  SUMK_ARG(!(b16 && opts->x16 && pos_table), "vasnet_forward: opts->x16 (a shadow of x) cannot be combined with pos_table (x changes in place)");
+  const unsigned short* x16 = (b16 && opts->x16) ? (const unsigned short*)opts->x16 : (const unsigned short*)(ws + L.x16);
   unsigned short* Wqkv16 = (unsigned short*)(ws + L.w16);
   unsigned short* Wo16 = Wqkv16 + (size_t)3 * D * D;
   unsigned short* W116 = Wo16 + (size_t)D * D;
-  if (b16) {   // one launch: x and the five matrices ([Wq; Wk; Wv] land stacked: one 3D x D operand)
-    const float* const src[6] = {x, w->Wq, w->Wk, w->Wv, w->Wo, w->W1};
-    void* const dst[6] = {x16, Wqkv16, Wqkv16 + (size_t)D * D, Wqkv16 + (size_t)2 * D * D, Wo16, W116};
+  if (b16) {   // one launch: the five matrices ([Wq; Wk; Wv] land stacked: one 3D x D operand) and, unless the caller keeps its shadow, x
+    const float* const src[6] = {w->Wq, w->Wk, w->Wv, w->Wo, w->W1, x};
+    void* const dst[6] = {Wqkv16, Wqkv16 + (size_t)D * D, Wqkv16 + (size_t)2 * D * D, Wo16, W116, ws + L.x16};
     const int64_t dd = (int64_t)D * D;
-    const int64_t ne[6] = {(int64_t)R * D, dd, dd, dd, dd, dd};
-    SUMK_TRY(cast_flat_b16(6, src, dst, ne, stream));
+    const int64_t ne[6] = {dd, dd, dd, dd, dd, (int64_t)R * D};
+    SUMK_TRY(cast_flat_b16(opts->x16 ? 5 : 6, src, dst, ne, stream));
   }
 
   // row-wise NT GEMMs with K = D: eligible for the buffer-load instances when D is a whole number of k-tiles and byte offsets fit 31 bits
@@ -1641,7 +1642,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   // bf16-source row-wise GEMMs (see the forward): dZ and dY0 are produced in bf16 by the LayerNorm backward kernels, dQKV by the
   // per-video GEMM epilogues; fp32 dZ is never needed, fp32 dY0 only for the residual branch of dx
   const bool b16 = G.b16;
-  const float* x16 = (const float*)(ws + L.x16);
+  const float* x16 = (G.b16 && opts->x16) ? (const float*)opts->x16 : (const float*)(ws + L.x16);
   const unsigned short* Wqkv16 = (const unsigned short*)(ws + L.w16);
   const float* Wo16 = (const float*)(Wqkv16 + (size_t)3 * D * D);
   const float* W116 = (const float*)(Wqkv16 + (size_t)4 * D * D);

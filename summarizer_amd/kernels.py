@@ -138,8 +138,23 @@ def _vasnet_structs(params, opts):
     o = _lib.VasnetOpts(float(opts["scale"]), float(opts["eps"]), int(bool(opts.get("ignore_self", False))),
                         -1 if opts.get("aperture") is None else int(opts["aperture"]),
                         float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)), precision_code(opts.get("precision")),
-                        opts["seed_dev"].data_ptr() if opts.get("seed_dev") is not None else None, opts.get("tables"))
+                        opts["seed_dev"].data_ptr() if opts.get("seed_dev") is not None else None, opts.get("tables"),
+                        opts["x16"].data_ptr() if opts.get("x16") is not None else None)
     return w, o
+
+
+def vasnet_x16(x, sb):
+    """bf16(x) for the mixed-precision training step (sumk_vasnet_opts.x16), kept with the SeqBatch and rebuilt only when x is another
+    tensor or was written to since (tensor version counter): features are constant over the epochs of a run."""
+    lib = _lib.load()
+    key = (x.data_ptr(), x._version, tuple(x.shape))
+    hit = getattr(sb, "_vasnet_x16", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    x16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.sumk_cast_bf16(_p(x), _p(x16), x.numel(), _stream()), "sumk_cast_bf16")
+    sb._vasnet_x16 = (key, x16)
+    return x16
 
 
 def fold_vo(w_o, w_v, out=None):
@@ -169,6 +184,9 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
         want = (int(D), int(bool(training)), precision_code(opts.get("precision")))
         hit = [v for k, v in getattr(sb, "_vasnet_tables", {}).items() if k[:3] == want]
         opts["tables"] = hit[-1][1] if hit else None
+    if (training and "x16" not in opts and precision_code(opts.get("precision")) == precision_code("bf16") and pos_table is None
+            and x.numel() % 4 == 0 and not x.requires_grad and not torch.cuda.is_current_stream_capturing()):
+        opts["x16"] = vasnet_x16(x, sb)        # (an input that asks for dX is an activation, not a dataset: cast per call)
     w, o = _vasnet_structs(params, opts)
     nbytes = lib.sumk_vasnet_workspace_bytes_for(D, sb.n_seq, sb.off_host_p, int(training), int(o.precision))
     if nbytes == 0:

@@ -506,3 +506,47 @@ def test_fused_attention_strips_equal_separate_launches(tmp_path):
         else:
             assert rel < (6e-4 if nodrop else 6e-3), (k, rel)
     assert differs, "bit-identical everywhere: did SUMK_ATTN_FUSED select two different paths?"
+
+
+def test_bf16_step_with_kept_x_shadow_equals_per_call_cast(dev):
+    """sumk_vasnet_opts::x16 (kernels.vasnet_x16: bf16(x) written once by sumk_cast_bf16 and kept with the SeqBatch) against the per-step
+    cast of x inside the call (opts["x16"] = None): the same rounding of the same values, so scores and every gradient are bit-identical;
+    the shadow is rebuilt when x is written to (tensor version) and reused otherwise."""
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import VasnetFunction
+    from summarizer_amd.models.vasnet import VASNet
+    D = 1024
+    lens = [int(t) for t in np.random.default_rng(3).integers(150, 321, size=45)]
+    w = R.vasnet_weights(D, 5)
+    m = VASNet(input_size=D, precision="bf16"); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 40 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    sb = kernels.SeqBatch.get(lens, dev)
+    names = [k for _, k in kernels.VASNET_FIELDS]
+    params = dict(m.named_parameters())
+
+    def step(extra):
+        for p in params.values():
+            p.grad = None
+        opts = dict(scale=float(m.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=0.5, seed=11, precision="bf16", **extra)
+        s = VasnetFunction.apply(x, sb, opts, None, None, names, *[params[n] for n in names])
+        (s * torch.linspace(-1, 1, s.numel(), device=dev)).sum().backward()
+        assert "x16" not in opts or opts["x16"] is None      # the caller's dict is not written to
+        return [s.detach().clone()] + [params[n].grad.clone() for n in names]
+
+    ref = step(dict(x16=None))
+    assert getattr(sb, "_vasnet_x16", None) is None
+    got = step({})
+    shadow = sb._vasnet_x16[1]
+    assert shadow.dtype == torch.bfloat16 and torch.equal(shadow, x.to(torch.bfloat16))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    again = step({})
+    assert sb._vasnet_x16[1] is shadow                        # reused
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+    x.mul_(1.5)                                               # written to: the shadow is rebuilt
+    ref2 = step(dict(x16=None)); got2 = step({})
+    assert sb._vasnet_x16[1] is not shadow
+    for a, b in zip(ref2, got2):
+        assert torch.equal(a, b)
+    assert not torch.equal(ref[0], ref2[0])
