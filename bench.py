@@ -215,7 +215,7 @@ def single_video_leg(dev, D=1024, T=300, iters=200):
     from their second epoch on: the step of a video captured once, replayed).  us per video and frames/s."""
     import recipes as R
     from summarizer_amd import kernels
-    from summarizer_amd.autograd import SegmentMseFunction
+    from summarizer_amd.autograd import SegmentMseMeanFunction
     from summarizer_amd.models.dsn import DSN
     from summarizer_amd.models.vasnet import VASNet
     from summarizer_amd.training import FlatAdam
@@ -265,7 +265,7 @@ def single_video_leg(dev, D=1024, T=300, iters=200):
             # (captured: the trainers' graph form -- the Adam kernel leaves the gradient bucket zero, so no fill kernel opens the step)
             if not captured:
                 opt.zero_grad()
-            loss = SegmentMseFunction.apply(m.score_packed(x2, [T]), target, sb).view(())      # one video (VASNetTrainer._single_video_step)
+            loss = SegmentMseMeanFunction.apply(m.score_packed(x2, [T]), target, sb, 1.0)      # one video (VASNetTrainer._single_video_step)
             loss.backward()
             opt.step(grad_scale=1.0, max_norm=5.0 if name == "dsn" else None, zero_grad=captured)
             seed.add_(1)
@@ -445,11 +445,11 @@ def main():
         opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5, comm_dtype=torch.bfloat16 if args.precision == "bf16" else None)
         target = torch.rand(frames, device=dev)
         from summarizer_amd import kernels as _k
-        from summarizer_amd.autograd import SegmentMseFunction
+        from summarizer_amd.autograd import SegmentMseMeanFunction
         sb_t = _k.SeqBatch.get(lens, dev)
         def run_step():
             opt.zero_grad()
-            loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()   # the trainers' loss: mean over videos of nn.MSELoss per video
+            loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))   # the trainers' loss: mean over videos of nn.MSELoss per video
             loss.backward()
             opt.step(grad_scale=opt.all_reduce_grads())
             return loss.detach()
@@ -609,7 +609,7 @@ def main():
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         from summarizer_amd.training import FlatAdam
         from summarizer_amd import kernels as _k
-        from summarizer_amd.autograd import SegmentMseFunction
+        from summarizer_amd.autograd import SegmentMseMeanFunction
         sb_t = _k.SeqBatch.get(lens, dev)
         target = torch.rand(frames, device=dev)
 
@@ -666,7 +666,7 @@ def main():
             model.tail_grads_ready_event = torch.cuda.Event() if dist is not None else None
             def train_step(reduce=True):
                 opt.zero_grad()
-                loss = SegmentMseFunction.apply(model.score_packed(x, lens), target, sb_t).mean()
+                loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))
                 loss.backward()
                 if reduce and tail_from is not None:
                     opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)

@@ -290,3 +290,34 @@ class SegmentMseFunction(torch.autograd.Function):
         _lib.check(_lib.load().sumk_segment_mse_backward(kernels._p(s), kernels._p(y), kernels._p(dmse.contiguous()), ctx.sb.n_seq,
                                                          ctx.sb.off_dev_p, kernels._p(ds), kernels._stream()), "sumk_segment_mse_backward")
         return ds, None, None
+
+
+class SegmentMseMeanFunction(torch.autograd.Function):
+    """scale * sum over the videos of a packed batch of nn.MSELoss per video, as ONE scalar in one HIP kernel each way
+    (sumk_segment_mse_mean_*): the trainers' step loss (vasnet.py:209-212; scale = 1 / videos of the step).  The same values and
+    gradients as `SegmentMseFunction.apply(...).sum() * scale` without torch's reduction / expand kernels around it."""
+
+    @staticmethod
+    def forward(ctx, scores, target, sb, scale):
+        from . import _lib
+        lib = _lib.load()
+        s, y = scores.contiguous(), target.detach().contiguous().float()
+        kernels._require_gpu(s, "segment_mse scores"); kernels._require_gpu(y, "segment_mse target")
+        if s.shape != (sb.n_rows,) or y.shape != (sb.n_rows,):
+            raise kernels.SumkError(f"segment_mse: scores {tuple(s.shape)} / target {tuple(y.shape)} do not fit {sb.n_rows} rows")
+        out = torch.empty(sb.n_seq + 1, dtype=torch.float32, device=s.device)       # [per-video ..., loss]
+        _lib.check(lib.sumk_segment_mse_mean_forward(kernels._p(s), kernels._p(y), sb.n_seq, sb.off_dev_p, float(scale), kernels._p(out),
+                                                     out.data_ptr() + 4 * sb.n_seq, kernels._stream()), "sumk_segment_mse_mean_forward")
+        ctx.save_for_backward(s, y)
+        ctx.sb, ctx.scale = sb, float(scale)
+        return out[sb.n_seq]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        from . import _lib
+        s, y = ctx.saved_tensors
+        ds = torch.empty_like(s)
+        g = dloss.contiguous().float()
+        _lib.check(_lib.load().sumk_segment_mse_mean_backward(kernels._p(s), kernels._p(y), kernels._p(g), ctx.scale, ctx.sb.n_seq,
+                                                              ctx.sb.off_dev_p, kernels._p(ds), kernels._stream()), "sumk_segment_mse_mean_backward")
+        return ds, None, None, None

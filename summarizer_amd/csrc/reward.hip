@@ -290,7 +290,53 @@ __global__ __launch_bounds__(256) void segment_mse_bwd_kernel(const float* __res
   const float c = 2.f * dmse[v] / (float)T;
   for (int t = threadIdx.x; t < T; t += 256) ds[r0 + t] = c * (s[r0 + t] - y[r0 + t]);
 }
+// The trainers' loss in one launch: loss = scale * sum_v mse[v] (scale = 1 / n_videos: the mean over the videos of a step).  One block, a
+// wave per video in turn; the per-video values are added in video order by one thread (deterministic).  Replaces the per-video kernel +
+// torch's mean and, in the backward pass, the expand / fill kernels of its autograd twin: five ~5 us launches per optimiser step become two.
+__global__ __launch_bounds__(1024) void segment_mse_mean_fwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
+                                                                    const int32_t* __restrict__ off, int n_seq, float scale,
+                                                                    float* __restrict__ mse, float* __restrict__ loss) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int v = wave; v < n_seq; v += 16) {
+    const int r0 = off[v], T = off[v + 1] - r0;
+    float acc = 0.f;
+    for (int t = lane; t < T; t += 64) { const float d = s[r0 + t] - y[r0 + t]; acc += d * d; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) mse[v] = acc / (float)T;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int v = 0; v < n_seq; ++v) a += mse[v];
+    loss[0] = a * scale;
+  }
+}
+__global__ __launch_bounds__(256) void segment_mse_mean_bwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
+                                                                   const float* __restrict__ dloss, float scale,
+                                                                   const int32_t* __restrict__ off, float* __restrict__ ds) {
+  const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
+  const float c = 2.f * (dloss[0] * scale) / (float)T;
+  for (int t = threadIdx.x; t < T; t += 256) ds[r0 + t] = c * (s[r0 + t] - y[r0 + t]);
+}
 }  // namespace sumk
+
+extern "C" int sumk_segment_mse_mean_forward(const float* scores, const float* target, int32_t n_seq, const int32_t* seq_off_dev,
+                                             float scale, float* mse_per_video, float* loss, void* stream) {
+  SUMK_ARG(scores && target && seq_off_dev && mse_per_video && loss && n_seq > 0, "segment_mse_mean_forward: bad argument");
+  hipLaunchKernelGGL(sumk::segment_mse_mean_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, target, seq_off_dev, n_seq, scale,
+                     mse_per_video, loss);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+extern "C" int sumk_segment_mse_mean_backward(const float* scores, const float* target, const float* dloss, float scale, int32_t n_seq,
+                                              const int32_t* seq_off_dev, float* dscores, void* stream) {
+  SUMK_ARG(scores && target && dloss && seq_off_dev && dscores && n_seq > 0, "segment_mse_mean_backward: bad argument");
+  hipLaunchKernelGGL(sumk::segment_mse_mean_bwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, scores, target, dloss, scale,
+                     seq_off_dev, dscores);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
 
 extern "C" int sumk_segment_mse_forward(const float* scores, const float* target, int32_t n_seq, const int32_t* seq_off_dev,
                                         float* mse_per_video, void* stream) {

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from .. import kernels
-from ..autograd import SegmentMseFunction
+from ..autograd import SegmentMseMeanFunction
 from . import Trainer
 from .vasnet import _sinusoid_table
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
@@ -161,8 +161,8 @@ class TransformerTrainer(Trainer):
                         x = vids[0][0] if len(vids) == 1 else torch.cat([v[0] for v in vids])
                         target = vids[0][1] if len(vids) == 1 else torch.cat([v[1] for v in vids])
                         scores = self.model.score_packed(x, lens_b)
-                        per_video = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev))   # MSE per video (transformer.py:161)
-                        loss = per_video.mean() if world == 1 else per_video.sum() / step_video_total(sizes, bv, step)
+                        n_total = len(lens_b) if world == 1 else step_video_total(sizes, bv, step)
+                        loss = SegmentMseMeanFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev), 1.0 / n_total)   # mean over videos of the MSE per video (transformer.py:161)
                         for k, piece in zip(keys, torch.split(scores.detach(), lens_b)):
                             dist_scores[k] = piece.view(-1, 1, 1)
                     else:

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from .. import kernels
-from ..autograd import SegmentMseFunction
+from ..autograd import SegmentMseMeanFunction
 from . import Trainer
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
@@ -273,10 +273,10 @@ class VASNetTrainer(Trainer):
                         off = np.concatenate([[0], np.cumsum(lens_b)])
                         # mean over videos of the per-video MSE (== nn.MSELoss per video, vasnet.py:209, when bv == 1)
                         target = torch.cat([v[1] for v in vids]) if len(vids) > 1 else vids[0][1]
-                        per_video = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev))
                         # world == 1: plain mean; data-parallel: every video of the GLOBAL step weighs 1/n_total (ranks whose
                         # shard has run out contribute nothing and the divisor shrinks with them)
-                        loss = per_video.mean() if world == 1 else per_video.sum() / step_video_total(sizes, bv, step)
+                        n_total = len(lens_b) if world == 1 else step_video_total(sizes, bv, step)
+                        loss = SegmentMseMeanFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev), 1.0 / n_total)
                         for i, k in enumerate(keys):
                             dist_scores[k] = scores[off[i]:off[i + 1]].detach().view(-1, 1, 1)
                     else:
@@ -322,7 +322,7 @@ class VASNetTrainer(Trainer):
         if not grads_are_zero:
             self.optimizer.zero_grad()
         scores = self.model.score_packed(seq, lens_b)
-        loss = SegmentMseFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev)).view(())    # one video: the mean over videos is the value itself
+        loss = SegmentMseMeanFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev), 1.0)    # one video: the mean over videos is the value itself
         loss.backward()
         self.optimizer.step(grad_scale=1.0, zero_grad=grads_are_zero)
         if self.model.graph_seed is not None:

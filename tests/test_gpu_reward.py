@@ -118,3 +118,32 @@ def test_segment_mse_kernels_match_torch():
     ref = sb.segment_mean((b - y) ** 2); (ref * w).sum().backward()
     torch.testing.assert_close(got.detach(), ref.detach(), rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_segment_mse_mean_equals_per_video_kernel_plus_torch_mean():
+    """SegmentMseMeanFunction (the trainers' step loss in one launch each way: sumk_segment_mse_mean_*) against what it replaced --
+    SegmentMseFunction + torch's mean / sum-and-divide and their autograd twins: the loss within one fp32 rounding of the sequential sum,
+    the gradient BIT-IDENTICAL (2 (s - y) / T_v * (dloss * scale), the same operations in the same order), for a plain mean, a
+    data-parallel divisor larger than the local video count, 2 000 videos (more than the block's 16 waves take in one round) and an
+    upstream gradient other than one."""
+    import torch
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import SegmentMseFunction, SegmentMseMeanFunction
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    for lens, n_total, up in (([70, 1, 300, 33, 129], 5, 1.0), ([240] * 50, 50, 1.0), ([17, 320, 5], 8, 1.0),
+                              ([int(t) for t in torch.randint(1, 40, (2000,), generator=g)], 2000, 0.37)):
+        sb = kernels.SeqBatch.get(lens, dev)
+        s0 = torch.rand(sum(lens), generator=g); y = torch.rand(sum(lens), generator=g).to(dev)
+        a = s0.clone().to(dev).requires_grad_(True); b = s0.clone().to(dev).requires_grad_(True)
+        got = SegmentMseMeanFunction.apply(a, y, sb, 1.0 / n_total)
+        assert got.shape == ()
+        (got * up).backward()
+        pv = SegmentMseFunction.apply(b, y, sb)
+        ref = pv.mean() if n_total == len(lens) else pv.sum() / n_total
+        (ref * up).backward()
+        torch.testing.assert_close(got.detach(), ref.detach(), rtol=2e-6, atol=0)
+        if n_total == len(lens) and up == 1.0:
+            assert torch.equal(a.grad, b.grad)
+        else:
+            torch.testing.assert_close(a.grad, b.grad, rtol=3e-7, atol=0)
