@@ -78,15 +78,13 @@ typedef struct sumk_vasnet_opts {
      may share them between forward, backward and any number of calls ON ONE STREAM AT A TIME (they hold the tickets of the
      in-launch split-K launches, which every launch leaves zero).  Wrong tables give wrong results, not errors: device memory. */
   void* tables;
-  /* NULL, or bf16(x) (n_rows, D) written by sumk_cast_bf16 from the SAME x this call (forward and backward) is given: the mixed-precision
+  /* NULL, or bf16(x) (n_rows, D) written by sumk_cast_f32_bf16 from the SAME x this call (forward and backward) is given: the mixed-precision
      training step (training != 0, SUMK_PRECISION_BF16 on the bf16-source kernels) then reads it instead of casting x again -- features
      are constant over the epochs of a run while the weights change every step, and x is 70 % of the elements the per-step cast kernel
      converts.  Ignored by every other mode.  Not allowed together with pos_table (which changes x in place). */
   const void* x16;
 } sumk_vasnet_opts;
 
-/* dst[i] = bf16(src[i]) (round to nearest even), i < n, n % 4 == 0; both 16-byte aligned device arrays (sumk_vasnet_opts::x16). */
-int sumk_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 
 /* Bytes of workspace sumk_vasnet_forward / _backward need for this batch (seq_off_host has n_seq+1 entries). */
 size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training);

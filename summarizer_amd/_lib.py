@@ -85,7 +85,6 @@ _SIGS = {
     "sumk_device_count": (C.c_int, []),
     "sumk_vasnet_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
     "sumk_vasnet_workspace_bytes_for": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32, C.c_int32]),
-    "sumk_cast_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sumk_vasnet_tables_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P]),
     "sumk_vasnet_build_tables": (C.c_int, [C.c_int32, C.c_int32, HOST_I32P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_vasnet_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),

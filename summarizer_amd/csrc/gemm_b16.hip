@@ -430,11 +430,3 @@ int cast_flat_b16(int n, const float* const src[], void* const dst[], const int6
 }
 
 }  // namespace sumk
-
-extern "C" int sumk_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
-  SUMK_ARG(src && dst && n > 0 && n % 4 == 0, "sumk_cast_bf16: n = %lld must be a positive multiple of 4", (long long)n);
-  const float* const s1[1] = {src};
-  void* const d1[1] = {dst};
-  const int64_t n1[1] = {n};
-  return sumk::cast_flat_b16(1, s1, d1, n1, (hipStream_t)stream);
-}

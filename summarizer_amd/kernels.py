@@ -152,7 +152,7 @@ def vasnet_x16(x, sb):
     if hit is not None and hit[0] == key:
         return hit[1]
     x16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.sumk_cast_bf16(_p(x), _p(x16), x.numel(), _stream()), "sumk_cast_bf16")
+    _lib.check(lib.sumk_cast_f32_bf16(_p(x), _p(x16), x.numel(), _stream()), "sumk_cast_f32_bf16")
     sb._vasnet_x16 = (key, x16)
     return x16
 

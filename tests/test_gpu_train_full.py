@@ -509,7 +509,7 @@ def test_fused_attention_strips_equal_separate_launches(tmp_path):
 
 
 def test_bf16_step_with_kept_x_shadow_equals_per_call_cast(dev):
-    """sumk_vasnet_opts::x16 (kernels.vasnet_x16: bf16(x) written once by sumk_cast_bf16 and kept with the SeqBatch) against the per-step
+    """sumk_vasnet_opts::x16 (kernels.vasnet_x16: bf16(x) written once by sumk_cast_f32_bf16 and kept with the SeqBatch) against the per-step
     cast of x inside the call (opts["x16"] = None): the same rounding of the same values, so scores and every gradient are bit-identical;
     the shadow is rebuilt when x is written to (tensor version) and reused otherwise."""
     from summarizer_amd import kernels
