@@ -409,6 +409,15 @@ typedef struct sumk_eval_dev_video {
 } sumk_eval_dev_video;
 int sumk_eval_device(const float* scores_dev, const sumk_eval_dev_video* videos_dev, int32_t n_videos, float* frame_scratch_dev,
                      float* seg_means_dev, double* corr_dev, void* stream);
+/* The same tail as two calls, so that the host's key-shot selection (which needs the segment means only) runs UNDER the correlation:
+ * _segments = upsample + segment means (a block per video); _spearman = the correlation spread over 8 blocks per video + a final kernel
+ * that adds their partial sums in order (scratch: sumk_eval_device_spearman_scratch_bytes(n_videos), 8-byte aligned).  The same
+ * descriptors; results equal sumk_eval_device's (segment means bit for bit, correlations to float64 re-association). */
+int sumk_eval_device_segments(const float* scores_dev, const sumk_eval_dev_video* videos_dev, int32_t n_videos, float* frame_scratch_dev,
+                              float* seg_means_dev, void* stream);
+size_t sumk_eval_device_spearman_scratch_bytes(int32_t n_videos);
+int sumk_eval_device_spearman(const float* scores_dev, const sumk_eval_dev_video* videos_dev, int32_t n_videos, double* scratch_dev,
+                              double* corr_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ data-parallel exchange (RCCL)
  * The gradient all-reduce of data-parallel training as a library call: SUM, in place, over one flat bucket, on the caller's

@@ -165,6 +165,9 @@ _SIGS = {
     "sumk_comm_destroy": (C.c_int, [C.c_void_p]),
     "sumk_gemm_nt": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_eval_device": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "sumk_eval_device_segments": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    "sumk_eval_device_spearman_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "sumk_eval_device_spearman": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sumk_pack_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), HOST_I32P, C.c_int32, C.c_int32, C.c_int32]),
     "sumk_pack_rows_bf16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), HOST_I32P, C.c_int32, C.c_int32, C.c_int32]),
     "sumk_gemm_prec": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

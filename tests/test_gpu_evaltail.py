@@ -36,6 +36,20 @@ def test_device_tail_equals_host_tail(method):
     np.testing.assert_array_equal(got[2], want[2])
     for a, b in zip(got[3], want[3]):
         np.testing.assert_array_equal(a, b)
+    # the batch's descriptors, device buffers and pinned buffers are kept between calls (Trainer.test asks for the same fold every time):
+    # other scores for the same videos, then a sub-batch of them, still give the host tail's numbers
+    scores2 = [rng.random(T).astype(np.float32) for T in lens]
+    want2 = eval_native.evaluate_batch(vids, scores2, 0.15, method, n_threads=3)
+    got2 = eval_native.evaluate_batch_device(vids, torch.from_numpy(np.concatenate(scores2)).to(dev), lens, 0.15, method, n_threads=3)
+    np.testing.assert_allclose(got2[0], want2[0], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(got2[1], want2[1]); np.testing.assert_array_equal(got2[2], want2[2])
+    assert not np.array_equal(got2[0], got[0])
+    sub = [0, 3, 5]
+    want3 = eval_native.evaluate_batch([vids[i] for i in sub], [scores2[i] for i in sub], 0.15, method, n_threads=3)
+    got3 = eval_native.evaluate_batch_device([vids[i] for i in sub], torch.from_numpy(np.concatenate([scores2[i] for i in sub])).to(dev),
+                                             [lens[i] for i in sub], 0.15, method, n_threads=3)
+    np.testing.assert_allclose(got3[0], want3[0], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(got3[1], want3[1]); np.testing.assert_array_equal(got3[2], want3[2])
 
 
 def test_device_tail_declines_what_it_does_not_cover():
