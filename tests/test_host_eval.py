@@ -105,6 +105,25 @@ def test_native_eval_tail_is_bit_identical_to_numpy():
             np.testing.assert_allclose(corr[i], c_ref, rtol=1e-12, atol=1e-14, equal_nan=True)
     with pytest.raises(KeyError):
         eval_native.evaluate_batch(vids, scores, 0.15, "greedy")
+    # default thread count = the library's persistent worker pool: same numbers as three fresh threads, call after call, and in a child
+    # process forked AFTER the pool exists (its workers do not survive the fork: the child builds its own)
+    want = eval_native.evaluate_batch(vids, scores, 0.15, "knapsack", n_threads=3)
+    for _ in range(3):
+        got = eval_native.evaluate_batch(vids, scores, 0.15, "knapsack")
+        for a, b in zip(got[:3], want[:3]):
+            np.testing.assert_array_equal(a, b)
+    import multiprocessing as mp
+    q = mp.get_context("fork").Queue()
+    def child():
+        g = eval_native.evaluate_batch(vids, scores, 0.15, "knapsack")
+        q.put([np.asarray(x).tolist() for x in g[:3]])
+    pr = mp.get_context("fork").Process(target=child)
+    pr.start()
+    res = q.get(timeout=120)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+    for a, b in zip(res, want[:3]):
+        np.testing.assert_array_equal(np.asarray(a), b)
 
 
 def test_pack_rows_native_threads():
