@@ -813,7 +813,7 @@ static void launch_ln_rows(const float* X, float* Y, const float* g, const float
 // of `part` ([n_blocks][4*D + 4], sumk_internal.h: ln_slot_floats); ln_bwd_reduce adds the slots into the gradients in one
 // launch (deterministic).  Round 1 wrote one slot per wave and reduced each vector with its own launch over ~1000 slots, and the
 // bias gradient took a separate pass over dX: 7 launches x 18 us + 45 us per training step.
-template <int NQ, bool HEAD, bool PRE = false>   // PRE (few rows: latency-bound): all of a row's loads issued before the first use
+template <int NQ, bool HEAD, bool PRE = true>   // PRE: all of a row's loads issued before the first use (what launch_ln_bwd instantiates; the per-chunk form is kept for A/B builds)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ X, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             const float* __restrict__ dY, const float* __restrict__ w2,
@@ -1565,13 +1565,16 @@ static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const
                          int n_slab = 0, int64_t slab_stride = 0) {
   const int D4 = D >> 2;
   const int nq = (D4 + 63) / 64;
-  int blocks = std::min((R + 3) / 4, LNB_MAX_WAVES / 4);
+  // 512 blocks of four waves: with every load of a row issued before its first use (PRE) a wave holds 200-240 VGPRs, two waves per SIMD =
+  // 2,048 resident, each walking ~6 rows of the 50-video batch.  Measured against the per-chunk form on 768 blocks (three waves per SIMD):
+  // 29.8 / 29.3 -> 27.9 / 27.7 us for the two LayerNorm backward launches of the step, and 256 fewer slots for the slot reduce (8.6 -> 6.7 us).
+  int blocks = std::min((R + 3) / 4, std::min(512, LNB_MAX_WAVES / 4));
   blocks = std::max(blocks, 1);
   *n_waves_out = blocks;              // slots written: one per block
   dim3 grid(blocks), block(256);
-  const bool pre = (R + 3) / 4 <= blocks;     // one row per wave: the launch is one latency chain, not a stream
+  constexpr bool pre = true;
 #define LNB_(NQ, PRE) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD, PRE>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16, n_slab, slab_stride)
-#define LNB(NQ) do { if (pre) LNB_(NQ, true); else LNB_(NQ, false); } while (0)
+#define LNB(NQ) LNB_(NQ, pre)
   if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
   else { set_error("vasnet_backward: D=%d > 2048 is not supported by the LayerNorm backward kernel", D); return SUMK_ERR_ARG; }
 #undef LNB
