@@ -813,7 +813,8 @@ static void launch_ln_rows(const float* X, float* Y, const float* g, const float
 // of `part` ([n_blocks][4*D + 4], sumk_internal.h: ln_slot_floats); ln_bwd_reduce adds the slots into the gradients in one
 // launch (deterministic).  Round 1 wrote one slot per wave and reduced each vector with its own launch over ~1000 slots, and the
 // bias gradient took a separate pass over dX: 7 launches x 18 us + 45 us per training step.
-template <int NQ, bool HEAD, bool PRE = true>   // PRE: all of a row's loads issued before the first use (what launch_ln_bwd instantiates; the per-chunk form is kept for A/B builds)
+// (all of a row's loads -- x, the affine vectors, dY or its K-slice slabs -- are issued before the first use: ln_gather)
+template <int NQ, bool HEAD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ X, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const float* __restrict__ b,
                                                             const float* __restrict__ dY, const float* __restrict__ w2,
@@ -842,18 +843,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     if constexpr (HEAD) { float sc = scores[row]; du = dscores[row] * sc * (1.f - sc); ab2 += du; }
     float4 xh[NQ], dxh[NQ], keep[NQ];
     float4 pxv[NQ], pgv[NQ], pwv[NQ], pbv[NQ], pdy[NQ];
-    if constexpr (PRE) {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int c = min(lane + 64 * q, D4 - 1);
-        pxv[q] = x4[c]; pgv[q] = g4[c];
-        if constexpr (HEAD) { pwv[q] = w4[c]; pbv[q] = b4[c]; }
-      }
-      if constexpr (!HEAD) {
-        const float4* dy4 = reinterpret_cast<const float4*>(dY + (int64_t)row * D);
-        const int64_t st4 = slab_stride >> 2;
-        row_gather<NQ>(pdy, dy4, lane, D4, n_slab, st4);
-      }
+    for (int q = 0; q < NQ; ++q) {
+      const int c = min(lane + 64 * q, D4 - 1);
+      pxv[q] = x4[c]; pgv[q] = g4[c];
+      if constexpr (HEAD) { pwv[q] = w4[c]; pbv[q] = b4[c]; }
+    }
+    if constexpr (!HEAD) {
+      const float4* dy4 = reinterpret_cast<const float4*>(dY + (int64_t)row * D);
+      const int64_t st4 = slab_stride >> 2;
+      row_gather<NQ>(pdy, dy4, lane, D4, n_slab, st4);
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -862,8 +861,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       xh[q] = dxh[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       keep[q] = make_float4(1.f, 1.f, 1.f, 1.f);
       if (c < D4) {
-        float4 v;
-        if constexpr (PRE) v = pxv[q]; else v = x4[c];
+        float4 v = pxv[q];
         if constexpr (HEAD) {  // ReLU mask on the stored post-ReLU value (vasnet.py:141)
           keep[q].x = v.x > 0.f ? 1.f : 0.f; keep[q].y = v.y > 0.f ? 1.f : 0.f;
           keep[q].z = v.z > 0.f ? 1.f : 0.f; keep[q].w = v.w > 0.f ? 1.f : 0.f;
@@ -880,18 +878,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         float4 h;
         h.x = (v.x - mean) * rstd; h.y = (v.y - mean) * rstd; h.z = (v.z - mean) * rstd; h.w = (v.w - mean) * rstd;
         xh[q] = h;
-        float4 gg;
-        if constexpr (PRE) gg = pgv[q]; else gg = g4[c];
+        const float4 gg = pgv[q];
         float4 dy;
         if constexpr (HEAD) {
-          float4 ww, bv;
-          if constexpr (PRE) { ww = pwv[q]; bv = pbv[q]; } else { ww = w4[c]; bv = b4[c]; }
+          const float4 ww = pwv[q], bv = pbv[q];
           dy.x = du * ww.x; dy.y = du * ww.y; dy.z = du * ww.z; dy.w = du * ww.w;
           aw[q].x += du * (h.x * gg.x + bv.x); aw[q].y += du * (h.y * gg.y + bv.y);
           aw[q].z += du * (h.z * gg.z + bv.z); aw[q].w += du * (h.w * gg.w + bv.w);
         } else {
-          if constexpr (PRE) dy = pdy[q];
-          else dy = slab_sum(reinterpret_cast<const float4*>(dY + (int64_t)row * D) + c, n_slab, slab_stride >> 2);
+          dy = pdy[q];
         }
         ag[q].x += dy.x * h.x; ag[q].y += dy.y * h.y; ag[q].z += dy.z * h.z; ag[q].w += dy.w * h.w;
         ab[q].x += dy.x; ab[q].y += dy.y; ab[q].z += dy.z; ab[q].w += dy.w;
@@ -1572,13 +1567,10 @@ static int launch_ln_bwd(int D, int R, const float* X, const float* stats, const
   blocks = std::max(blocks, 1);
   *n_waves_out = blocks;              // slots written: one per block
   dim3 grid(blocks), block(256);
-  constexpr bool pre = true;
-#define LNB_(NQ, PRE) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD, PRE>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16, n_slab, slab_stride)
-#define LNB(NQ) LNB_(NQ, pre)
+#define LNB(NQ) hipLaunchKernelGGL((layernorm_bwd_kernel<NQ, HEAD>), grid, block, 0, stream, X, stats, g, b, dY, w2, scores, dscores, dX, part, R, D, drop, site, dX16, n_slab, slab_stride)
   if (nq <= 1) LNB(1); else if (nq <= 2) LNB(2); else if (nq <= 4) LNB(4); else if (nq <= 8) LNB(8);
   else { set_error("vasnet_backward: D=%d > 2048 is not supported by the LayerNorm backward kernel", D); return SUMK_ERR_ARG; }
 #undef LNB
-#undef LNB_
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
