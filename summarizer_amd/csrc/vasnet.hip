@@ -27,12 +27,12 @@ constexpr int COLSUM_CHUNKS = 128;
 
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
-  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, stats, scores, row_seq, total;
+  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, prob_dvk, stats, scores, row_seq, total;
   size_t total_core;     // without the bf16 shadows at the end (all a step needs unless it runs on the bf16-source kernels)
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
   // bf16 shadows of the operands of the row-wise GEMMs (training; used when the step runs on the bf16-source kernels)
-  size_t x16, w16, ctx16, y116, dz16, dy016, dqkv16, qkv16, dctx16, p16;
+  size_t x16, w16, ctx16, y116, dz16, dy016, dqkv16, qkv16, dctx16, p16, s16;
   size_t slab_elems;
   int64_t e_elems;
   int32_t n_rows;
@@ -77,6 +77,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->seq = take((size_t)n_seq * sizeof(SeqInfo));
   w->prob_row = take(ROW_PROBS * sizeof(GemmProb));
   w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
+  w->prob_dvk = take((size_t)2 * n_seq * sizeof(GemmProb));      // dV and dK of the fused-attention bf16 step as ONE table (launch_setup)
   w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
   w->sk_cnt = w->sk_tabs = 0;
   if (sk_rows_ok((int64_t)R)) {
@@ -94,7 +95,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->scores = take(R * 4);
   w->e2 = w->dz = w->dy1 = w->dy0 = w->dctx = w->dqkv = w->lnpart = w->colpart = w->slab = w->prob_sk = 0;
   w->slab_elems = 0;
-  w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = w->qkv16 = w->dctx16 = w->p16 = 0;
+  w->x16 = w->w16 = w->ctx16 = w->y116 = w->dz16 = w->dy016 = w->dqkv16 = w->qkv16 = w->dctx16 = w->p16 = w->s16 = 0;
   w->sk_part = w->sk_part_bytes = 0;
   auto take_sk = [&]() {     // small-batch path: inside the core size (every arithmetic's workspace holds it)
     if (!sk_rows_ok((int64_t)R)) return;
@@ -128,6 +129,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
     w->qkv16 = take(R * 3 * D * 2);
     w->dctx16 = take(R * D * 2);
     w->p16 = take((size_t)e16 * 2);            // per video (T x ld16): alpha (dropped-out alpha) in the forward, dLogits in the backward
+    w->s16 = take((size_t)e16 * 2);            // fused attention strips: bf16(dLogits) beside P16 (dV and dK then run as ONE launch after the backward strip)
   }
   if (!training) take_sk();
   w->total = p;
@@ -148,6 +150,9 @@ struct SetupArgs {
   SeqInfo* seq; GemmProb* tabs;   // tabs[TB_COUNT][n_seq]
   int32_t s_tm, s_tn, pv_tm, pv_tn;  // block-tile dims of the (T x T) and (T x D) per-video products
   GemmProb* prow; RowProbSpec rows[ROW_PROBS]; int32_t n_rowprobs;
+  // fused-attention bf16 step: dV = P^T dC and dK = dS^T Q as ONE table of 2 n_seq problems for one launch (A base = P16, B base = dCTX16,
+  // C base = dQKV16); the dK entries reach dS (kept beside P, not over it) and Q through these element offsets between the buffers
+  GemmProb* dvk; int64_t dk_a_delta, dk_b_delta;
 };
 
 __device__ inline void put_prob(GemmProb* p, int64_t a_off, int64_t b_off, int64_t c_off, int M, int N, int K, int lda,
@@ -238,6 +243,13 @@ __global__ void vasnet_setup_kernel(SetupArgs a) {
   put_prob(a.tabs + TB_DP * n + s, c0, q0 + 2 * D, eoff, T, T, D, D, 3 * D, ldE, ts, tm);            // dAlpha = dC V^T  (NT)
   put_prob(a.tabs + TB_DQ * n + s, po, q0 + D, q0, T, D, T, ldp, 3 * D, 3 * D, tpv, tn);             // dQ = dS K        (NN)
   put_prob(a.tabs + TB_DK * n + s, po, q0, q0 + D, T, D, T, ldp, 3 * D, 3 * D, tpv, tn);             // dK = dS^T Q      (TN)
+  if (a.dvk != nullptr) {
+    int tpv_all = 0;                                    // tiles of the whole dV table: where the dK entries' tiles start
+    if (staged) { for (int q = 0; q < n; ++q) tpv_all += sTpv[q]; }
+    else { for (int q = 0; q < n; ++q) { const int Tq = a.off[q + 1] - a.off[q]; tpv_all += ((Tq + a.pv_tm - 1) / a.pv_tm) * tn; } }
+    put_prob(a.dvk + s, po, c0, q0 + 2 * D, T, D, T, ldp, D, 3 * D, tpv, tn);
+    put_prob(a.dvk + n + s, po + a.dk_a_delta, q0 + a.dk_b_delta, q0 + D, T, D, T, ldp, 3 * D, 3 * D, tpv_all + tpv, tn);
+  }
 }
 
 
@@ -1136,6 +1148,12 @@ static void launch_setup(const Geometry& G, int D, int n_seq, const int32_t* off
   a.rows[RP_DX_W] = a.rows[RP_DX]; a.rows[RP_DX_W].small = 3;
   a.n_rowprobs = 6;
   a.s_tm = gemm_tile_m(G.cfg_s); a.s_tn = gemm_tile_n(G.cfg_s); a.pv_tm = gemm_tile_m(G.cfg_pv); a.pv_tn = gemm_tile_n(G.cfg_pv);
+  a.dvk = nullptr; a.dk_a_delta = a.dk_b_delta = 0;
+  if (G.attn_fused) {   // (offsets between buffers of ONE workspace carve: the same for every workspace of this geometry)
+    a.dvk = (GemmProb*)(ws + G.L.prob_dvk);
+    a.dk_a_delta = ((int64_t)G.L.s16 - (int64_t)G.L.p16) / 2;
+    a.dk_b_delta = ((int64_t)G.L.qkv16 - (int64_t)G.L.dctx16) / 2;
+  }
   hipLaunchKernelGGL(vasnet_setup_kernel, dim3((n_seq + 63) / 64, 2 + 32), dim3(64), 0, stream, a);   // y: 0 per-video tables, 1 row problems, 2.. row -> video table
 }
 
@@ -1731,7 +1749,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   if (tail_grads_ready_event) SUMK_HIP(hipEventRecord((hipEvent_t)tail_grads_ready_event, stream));
   // 4': dV = alphaD^T dC ; dAlphaD = dC V^T
   const float* Pd = use_e2 ? E2 : E;
-  {
+  if (!G.attn_fused) {
     GemmLaunch g; g.precision = opts->precision;
     g.A = Pd; g.B[0] = dCTX; g.C = dQKV; g.probs = tabs + TB_DV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.dctx16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
@@ -1741,10 +1759,16 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     AttnStripArgs at;
     const unsigned short* qkv16 = (const unsigned short*)(ws + L.qkv16);
     at.A16 = (const unsigned short*)(ws + L.dctx16); at.lda = D; at.B16 = qkv16 + 2 * D; at.ldb = 3 * D; at.C16 = qkv16 + D; at.ldc = 3 * D;
-    at.O16 = (unsigned short*)dQKV16; at.ldo = 3 * D; at.E = E; at.P16 = (unsigned short*)(ws + L.p16);
+    at.O16 = (unsigned short*)dQKV16; at.ldo = 3 * D; at.E = E; at.P16 = (unsigned short*)(ws + L.s16);      // bf16(dLogits): beside P16, not over it
     at.seq = seq; at.n_seq = n_seq; at.strips = (G.t_max + 63) / 64; at.D = D;
     at.scale = opts->scale; at.ignore_self = opts->ignore_self; at.aperture = opts->aperture; at.drop = drop;
     SUMK_TRY(launch_attn_strip(true, at, stream));
+    // dV = P^T dC and dK = dS^T Q: the two products that contract over the query rows of ALL strips, as ONE launch of 2 n_seq problems
+    // (separately each was 800-960 tiles on 768 resident blocks -- one and a quarter rounds of latency-bound tiles, 25 us per launch)
+    GemmLaunch g; g.precision = opts->precision;
+    g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.dctx16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr;
+    g.probs = (GemmProb*)(tb + L.prob_dvk); g.nprob = 2 * n_seq; g.small_tile = G.cfg_pv; g.total_tiles = 2 * G.tiles_pv;
+    SUMK_TRY(launch_gemm(GEMM_TN, EPI_NONE, g, stream));
   } else {
   {
     GemmLaunch g; g.precision = opts->precision;
@@ -1764,7 +1788,7 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
   }
   }
-  {
+  if (!G.attn_fused) {
     GemmLaunch g; g.precision = opts->precision;
     g.A = E2; g.B[0] = QKV; g.C = dQKV; g.probs = tabs + TB_DK * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv; g.total_tiles = G.tiles_pv;
     if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = dQKV16; g.C = nullptr; }
