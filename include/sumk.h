@@ -311,9 +311,11 @@ int sumk_segment_mse_backward(const float* scores, const float* target, const fl
                               const int32_t* seq_off_dev, float* dscores, void* stream);
 /* The trainers' step loss in one launch each way (vasnet.py:209-212: mean over the videos of a step of nn.MSELoss per video):
  * loss[0] = scale * sum_v mse_per_video[v] (scale = 1 / videos of the step; the per-video values are written too and added in video order),
- * dscores_t = 2 (scores_t - target_t) / T_v * scale * dloss[0] (dloss: the device scalar autograd hands the backward). */
+ * dscores_t = 2 (scores_t - target_t) / T_v * scale * dloss[0] (dloss: the device scalar autograd hands the backward).
+ * `ticket`: one device word the caller zeroes ONCE and keeps for this batch; every launch leaves it zero (a block per video, the last
+ * arriver adds); one launch at a time per word. */
 int sumk_segment_mse_mean_forward(const float* scores, const float* target, int32_t n_seq, const int32_t* seq_off_dev, float scale,
-                                  float* mse_per_video, float* loss, void* stream);
+                                  float* mse_per_video, float* loss, uint32_t* ticket, void* stream);
 int sumk_segment_mse_mean_backward(const float* scores, const float* target, const float* dloss, float scale, int32_t n_seq,
                                    const int32_t* seq_off_dev, float* dscores, void* stream);
 

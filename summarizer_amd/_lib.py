@@ -144,7 +144,7 @@ _SIGS = {
                                                 C.c_int32, C.c_float, C.c_float, c_f32p, C.c_void_p]),
     "sumk_segment_mse_forward": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
     "sumk_segment_mse_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
-    "sumk_segment_mse_mean_forward": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_i32p, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    "sumk_segment_mse_mean_forward": (C.c_int, [c_f32p, c_f32p, C.c_int32, c_i32p, C.c_float, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "sumk_segment_mse_mean_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_float, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
     "sumk_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),

@@ -306,8 +306,12 @@ class SegmentMseMeanFunction(torch.autograd.Function):
         if s.shape != (sb.n_rows,) or y.shape != (sb.n_rows,):
             raise kernels.SumkError(f"segment_mse: scores {tuple(s.shape)} / target {tuple(y.shape)} do not fit {sb.n_rows} rows")
         out = torch.empty(sb.n_seq + 1, dtype=torch.float32, device=s.device)       # [per-video ..., loss]
+        ticket = getattr(sb, "_mse_ticket", None)                                   # one word per batch geometry, zeroed once; every launch leaves it zero
+        if ticket is None:
+            ticket = sb._mse_ticket = torch.zeros(1, dtype=torch.int32, device=s.device)
         _lib.check(lib.sumk_segment_mse_mean_forward(kernels._p(s), kernels._p(y), sb.n_seq, sb.off_dev_p, float(scale), kernels._p(out),
-                                                     out.data_ptr() + 4 * sb.n_seq, kernels._stream()), "sumk_segment_mse_mean_forward")
+                                                     out.data_ptr() + 4 * sb.n_seq, kernels._p(ticket), kernels._stream()),
+                   "sumk_segment_mse_mean_forward")
         ctx.save_for_backward(s, y)
         ctx.sb, ctx.scale = sb, float(scale)
         return out[sb.n_seq]

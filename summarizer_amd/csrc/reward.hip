@@ -290,26 +290,47 @@ __global__ __launch_bounds__(256) void segment_mse_bwd_kernel(const float* __res
   const float c = 2.f * dmse[v] / (float)T;
   for (int t = threadIdx.x; t < T; t += 256) ds[r0 + t] = c * (s[r0 + t] - y[r0 + t]);
 }
-// The trainers' loss in one launch: loss = scale * sum_v mse[v] (scale = 1 / n_videos: the mean over the videos of a step).  One block, a
-// wave per video in turn; the per-video values are added in video order by one thread (deterministic).  Replaces the per-video kernel +
-// torch's mean and, in the backward pass, the expand / fill kernels of its autograd twin: five ~5 us launches per optimiser step become two.
-__global__ __launch_bounds__(1024) void segment_mse_mean_fwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
-                                                                    const int32_t* __restrict__ off, int n_seq, float scale,
-                                                                    float* __restrict__ mse, float* __restrict__ loss) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int v = wave; v < n_seq; v += 16) {
-    const int r0 = off[v], T = off[v + 1] - r0;
-    float acc = 0.f;
-    for (int t = lane; t < T; t += 64) { const float d = s[r0 + t] - y[r0 + t]; acc += d * d; }
+// The trainers' loss in one launch: loss = scale * sum_v mse[v] (scale = 1 / n_videos: the mean over the videos of a step).  A block per
+// video (as segment_mse_fwd_kernel); the block that draws the last ticket adds the per-video values in video order (deterministic) and
+// leaves the ticket word zero for the next launch.  Replaces the per-video kernel + torch's mean and, in the backward pass, the expand /
+// fill kernels of its autograd twin: five ~5 us launches per optimiser step become two.  (First version: ONE block, a wave per video in
+// turn -- 50 videos were four dependent rounds of three round trips, 12.8-15 us.)
+__global__ __launch_bounds__(256) void segment_mse_mean_fwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
+                                                                   const int32_t* __restrict__ off, int n_seq, float scale,
+                                                                   float* __restrict__ mse, float* __restrict__ loss, unsigned* __restrict__ ticket) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const int v = blockIdx.x, r0 = off[v], T = off[v + 1] - r0;
+  float acc = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) { const float d = s[r0 + t] - y[r0 + t]; acc += d * d; }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (lane == 0) mse[v] = acc / (float)T;
-  }
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float a = 0.f;
-    for (int v = 0; v < n_seq; ++v) a += mse[v];
-    loss[0] = a * scale;
+    __hip_atomic_store(mse + v, ((red[0] + red[1]) + (red[2] + red[3])) / (float)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();                                           // the value is out before the ticket is drawn
+    last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_seq - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // the last arriver: every video's value is in memory; 256 loads in flight at a time (through LDS), added in video order by one thread
+  __shared__ float vals[256];
+  float part = 0.f;
+  for (int q0 = 0; q0 < n_seq; q0 += 256) {
+    const int q = q0 + threadIdx.x;
+    vals[threadIdx.x] = q < n_seq ? __hip_atomic_load(mse + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int n = min(256, n_seq - q0);
+      for (int i = 0; i < n; ++i) part += vals[i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = part * scale;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ __launch_bounds__(256) void segment_mse_mean_bwd_kernel(const float* __restrict__ s, const float* __restrict__ y,
@@ -322,10 +343,10 @@ __global__ __launch_bounds__(256) void segment_mse_mean_bwd_kernel(const float* 
 }  // namespace sumk
 
 extern "C" int sumk_segment_mse_mean_forward(const float* scores, const float* target, int32_t n_seq, const int32_t* seq_off_dev,
-                                             float scale, float* mse_per_video, float* loss, void* stream) {
-  SUMK_ARG(scores && target && seq_off_dev && mse_per_video && loss && n_seq > 0, "segment_mse_mean_forward: bad argument");
-  hipLaunchKernelGGL(sumk::segment_mse_mean_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, target, seq_off_dev, n_seq, scale,
-                     mse_per_video, loss);
+                                             float scale, float* mse_per_video, float* loss, uint32_t* ticket, void* stream) {
+  SUMK_ARG(scores && target && seq_off_dev && mse_per_video && loss && ticket && n_seq > 0, "segment_mse_mean_forward: bad argument");
+  hipLaunchKernelGGL(sumk::segment_mse_mean_fwd_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, scores, target, seq_off_dev, n_seq, scale,
+                     mse_per_video, loss, ticket);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
