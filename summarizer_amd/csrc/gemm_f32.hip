@@ -201,9 +201,12 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(SlabReduceArgs a) {
   *reinterpret_cast<float4*>(o) = c;
 }
 
+// mode 0 (default): build the K-slice table, multiply, reduce.  SPLITK_TABLE_READY: the table at probs_dev was built before for the same
+// shapes, capacities and operand distances (it depends on nothing else) -- no setup launch.  SPLITK_TABLE_ONLY: build the table, nothing else
+// (A / B are used for their DISTANCES only and may be offsets dressed as pointers).
 int gemm_tn_splitk_accum_multi(int np, const float* const A[], const float* const B[], int lda, int ldb, int M, int N, int K, float* slab,
                                size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                               int ldo, float alpha, hipStream_t stream, int precision, int src16) {
+                               int ldo, float alpha, hipStream_t stream, int precision, int src16, int mode) {
   SUMK_ARG(np >= 1 && np <= 4 && M > 0 && N > 0 && K > 0, "splitk: bad shape");
   SUMK_ARG(np == 1 || rows_per_out == M, "splitk: several products take one output each");
   SUMK_ARG(slab_elems >= (size_t)np * M * N, "splitk: slab too small");
@@ -230,7 +233,8 @@ int gemm_tn_splitk_accum_multi(int np, const float* const A[], const float* cons
     su.rel_a[p] = p < np ? ((const char*)A[p] - (const char*)A[0]) / esz : 0;
     su.rel_b[p] = p < np ? ((const char*)B[p] - (const char*)B[0]) / esz : 0;
   }
-  hipLaunchKernelGGL(splitk_setup_kernel, dim3((np * S + 63) / 64), dim3(64), 0, stream, su);
+  if (mode != SPLITK_TABLE_READY) hipLaunchKernelGGL(splitk_setup_kernel, dim3((np * S + 63) / 64), dim3(64), 0, stream, su);
+  if (mode == SPLITK_TABLE_ONLY) { SUMK_HIP(hipGetLastError()); return SUMK_OK; }
   GemmLaunch g;
   g.A = A[0]; g.B[0] = B[0]; g.C = slab; g.probs = probs_dev; g.nprob = np * S; g.small_tile = small; g.total_tiles = S * tiles;
   g.precision = precision; g.src16 = src16; g.wide16 = wide;
@@ -252,11 +256,11 @@ int gemm_tn_splitk_accum_multi(int np, const float* const A[], const float* cons
 
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream, int precision, int src16) {
+                         int ldo, float alpha, hipStream_t stream, int precision, int src16, int mode) {
   const float* const As[1] = {A};
   const float* const Bs[1] = {B};
   return gemm_tn_splitk_accum_multi(1, As, Bs, lda, ldb, M, N, K, slab, slab_elems, probs_dev, probs_cap, out, rows_per_out, ldo, alpha,
-                                    stream, precision, src16);
+                                    stream, precision, src16, mode);
 }
 
 // ------------------------------------------------------------------------------------------- column sums

@@ -166,14 +166,15 @@ int fill_single_prob(GemmProb* dev_prob, int M, int N, int K, int lda, int ldb, 
 
 // C(M,N) = A(K,M)^T B(K,N) contracted over a long K with deterministic split-K; out[g][rl*ldo+col] += alpha*C[row][col]
 // for row = g*rows_per_out + rl.  probs_dev must hold probs_cap entries; slab holds slab_elems floats.
+enum { SPLITK_BUILD_AND_RUN = 0, SPLITK_TABLE_READY = 1, SPLITK_TABLE_ONLY = 2 };   // `mode` of the two entries below (csrc/gemm_f32.hip)
 int gemm_tn_splitk_accum(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* slab,
                          size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                         int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0);   // src16: A and B are bf16 arrays (GemmLaunch::src16)
+                         int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0, int mode = 0);   // src16: A and B are bf16 arrays (GemmLaunch::src16)
 // np (<= 4) same-shaped products C_p = A_p^T B_p in ONE split-K launch + ONE reduce: out[p] += alpha * C_p (rows_per_out == M when np > 1).
 // Every A_p (B_p) must lie in the same allocation as A_0 (B_0): the kernel addresses them as offsets from it.
 int gemm_tn_splitk_accum_multi(int np, const float* const A[], const float* const B[], int lda, int ldb, int M, int N, int K, float* slab,
                                size_t slab_elems, GemmProb* probs_dev, int probs_cap, float* const out[4], int rows_per_out,
-                               int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0);
+                               int ldo, float alpha, hipStream_t stream, int precision = 0, int src16 = 0, int mode = 0);
 // out[c] += sum_r X[r*ld + c]; partial must hold max_chunks*N floats.
 int colsum_accum(const float* X, int ld, int R, int N, float* partial, int max_chunks, float* out, hipStream_t stream);
 // out[c] += sum_p partial[p*stride + c]

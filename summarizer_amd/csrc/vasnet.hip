@@ -27,7 +27,7 @@ constexpr int COLSUM_CHUNKS = 128;
 
 // Workspace carve-up, computed identically by the size query and by forward/backward.
 struct VasnetWs {
-  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, prob_dvk, stats, scores, row_seq, total;
+  size_t qkv, e, ctx, y0, y1, z, seq, prob_row, prob_seq, prob_dvk, prob_skw, stats, scores, row_seq, total;
   size_t total_core;     // without the bf16 shadows at the end (all a step needs unless it runs on the bf16-source kernels)
   // training-only buffers
   size_t e2, dz, dy1, dy0, dctx, dqkv, lnpart, colpart, slab, prob_sk;
@@ -79,6 +79,7 @@ static int carve(int D, int n_seq, const int32_t* off, int training, VasnetWs* w
   w->prob_seq = take((size_t)TB_COUNT * n_seq * sizeof(GemmProb));
   w->prob_dvk = take((size_t)2 * n_seq * sizeof(GemmProb));      // dV and dK of the fused-attention bf16 step as ONE table (launch_setup)
   w->row_seq = take(R * 4);          // video of every packed row (vasnet_setup_kernel): one load instead of a binary search per row
+  w->prob_skw = take((size_t)2 * SPLITK_PROBS * sizeof(GemmProb));   // K-slice tables of the two weight-gradient launches (dWo + dW1, dWqkv): built with the rest
   w->sk_cnt = w->sk_tabs = 0;
   if (sk_rows_ok((int64_t)R)) {
     w->sk_cnt = take((size_t)SK_TICKETS * 4);
@@ -1274,6 +1275,23 @@ extern "C" size_t sumk_vasnet_tables_bytes(int32_t D, int32_t n_seq, const int32
   if (carve(D, n_seq, seq_off_host, 0, &w) != SUMK_OK) return 0;
   return w.tab_bytes;
 }
+// The K-slice tables of the backward pass's two weight-gradient launches (d[Wo, W1] in one launch, d[Wq; Wk; Wv] in another), as
+// sumk_vasnet_backward would build them per call: they depend on the shapes, the slab / table capacities and the DISTANCES between the
+// operands inside the workspace -- all functions of the geometry -- so they are built once with the other tables.
+static int build_skw_tables(const Geometry& G, int D, GemmProb* pskw, int precision, hipStream_t stream) {
+  const VasnetWs& L = G.L;
+  const int R = G.R;
+  const bool b16 = G.b16;
+  const char* const base = reinterpret_cast<const char*>((uintptr_t)1 << 40);       // never dereferenced: only differences are taken
+  const float* const As[2] = {(const float*)(base + (b16 ? L.dy016 : L.dy0)), (const float*)(base + (b16 ? L.dz16 : L.dz))};
+  const float* const Bs[2] = {(const float*)(base + (b16 ? L.ctx16 : L.ctx)), (const float*)(base + (b16 ? L.y116 : L.y1))};
+  float* none[4] = {nullptr, nullptr, nullptr, nullptr};
+  SUMK_TRY(gemm_tn_splitk_accum_multi(2, As, Bs, D, D, D, D, R, nullptr, L.slab_elems, pskw, SPLITK_PROBS, none, D, D, 1.f, stream, precision, b16, SPLITK_TABLE_ONLY));
+  SUMK_TRY(gemm_tn_splitk_accum((const float*)base, 3 * D, (const float*)base, D, 3 * D, D, R, nullptr, L.slab_elems, pskw + SPLITK_PROBS, SPLITK_PROBS, none, D, D, 1.f,
+                                stream, precision, b16, SPLITK_TABLE_ONLY));
+  return SUMK_OK;
+}
+
 extern "C" int sumk_vasnet_build_tables(int32_t D, int32_t n_seq, const int32_t* seq_off_host, const int32_t* seq_off_dev, int32_t training,
                                         int32_t precision, void* tables, size_t tables_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1284,6 +1302,7 @@ extern "C" int sumk_vasnet_build_tables(int32_t D, int32_t n_seq, const int32_t*
   if (tables_bytes < G.L.tab_bytes) { set_error("vasnet_build_tables: %zu bytes < required %zu", tables_bytes, G.L.tab_bytes); return SUMK_ERR_WORKSPACE; }
   launch_setup(G, D, n_seq, seq_off_dev, (char*)tables, stream);                 // the large-batch tables (also what a dX-producing backward uses)
   if (G.sk) SUMK_TRY(launch_sk_setup(G, D, n_seq, seq_off_dev, (char*)tables, stream));   // the small-batch tables + zeroed tickets
+  if (training) SUMK_TRY(build_skw_tables(G, D, (GemmProb*)((char*)tables + G.L.prob_skw), precision, stream));
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -1649,6 +1668,9 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   GemmProb* prow = (GemmProb*)(tb + L.prob_row);
   GemmProb* tabs = (GemmProb*)(tb + L.prob_seq);
   GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
+  // K-slice tables of the two weight-gradient launches: in the table block; prebuilt when the caller keeps the block (opts->tables)
+  GemmProb* pskw = (GemmProb*)(tb + L.prob_skw);
+  const bool skw_ready = tb != ws;
   const Drop drop = make_drop(opts);
   const bool use_e2 = drop.thr != 0;
   int nw = 0;
@@ -1738,7 +1760,8 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
     const float* const As[2] = {b16 ? (const float*)dY016 : dY0, b16 ? (const float*)dZ16 : dZ};
     const float* const Bs[2] = {b16 ? CTX16 : CTX, b16 ? Y116 : Y1};
     float* out[4] = {gr->Wo, gr->W1, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum_multi(2, As, Bs, D, D, D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision, b16));
+    SUMK_TRY(gemm_tn_splitk_accum_multi(2, As, Bs, D, D, D, D, R, slab, L.slab_elems, pskw, SPLITK_PROBS, out, D, D, 1.f, stream, opts->precision, b16,
+                                        skw_ready ? SPLITK_TABLE_READY : SPLITK_BUILD_AND_RUN));
     GemmLaunch g; g.precision = opts->precision;  // dCTX = dY0 . Wo
     g.A = dY0; g.B[0] = w->Wo; g.C = dCTX; g.probs = prow + RP_DD; g.small_tile = G.st_d; g.total_tiles = gemm_tiles(R, D, G.st_d); g.xcd_M = R; g.xcd_N = D;
     if (b16) { to_b16(g, dY016, Wo16, R, D, prow, RP_DD_W); g.C16 = ws + L.dctx16; g.C = nullptr; }
@@ -1797,8 +1820,8 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   // 1': projection weights  d[Wq;Wk;Wv] += dQKV^T X
   {
     float* out[4] = {gr->Wq, gr->Wk, gr->Wv, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dQKV16 : dQKV, 3 * D, b16 ? x16 : x, D, 3 * D, D, R, slab, L.slab_elems, psk, SPLITK_PROBS, out, D, D, 1.f,
-                                  stream, opts->precision, b16));
+    SUMK_TRY(gemm_tn_splitk_accum(b16 ? (const float*)dQKV16 : dQKV, 3 * D, b16 ? x16 : x, D, 3 * D, D, R, slab, L.slab_elems, pskw + SPLITK_PROBS, SPLITK_PROBS, out, D, D, 1.f,
+                                  stream, opts->precision, b16, skw_ready ? SPLITK_TABLE_READY : SPLITK_BUILD_AND_RUN));
   }
   if (dx) {  // dX = dY0 (residual) + dQ Wq + dK Wk + dV Wv
     SUMK_HIP(hipMemcpyAsync(dx, dY0, (size_t)R * D * 4, hipMemcpyDeviceToDevice, stream));
