@@ -328,8 +328,7 @@ int sumk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
 /* The same step with NOTHING on the host: `state` is a 16-byte device block the caller zeroes once -- state[0] (int32) counts
- * the optimiser steps and is incremented by the call (by the last block of the launch to finish), state[1] is that launch's arrival ticket
- * (zero between calls), state[2..3] are unused -- so the bias correction follows a counter that
+ * the optimiser steps and is incremented by the call, state[1..3] are scratch -- so the bias correction follows a counter that
  * lives on the device, and when `sumsq` (device scalar from sumk_sumsq: the squared L2 norm of the UNscaled gradient) is
  * given, torch.nn.utils.clip_grad_norm_(params, max_norm) (dsn.py:145) is folded in without reading the norm back.  No host
  * synchronisation, captures into a HIP graph and replays with the right step count.  Same arithmetic as sumk_adam_step. */

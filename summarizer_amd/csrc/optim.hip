@@ -9,37 +9,17 @@ namespace sumk {
 
 // torch (non-amsgrad, maximize=False):  g = grad*grad_scale + wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-// dyn.state != nullptr: step size, bias correction and gradient scale are derived on the device (AdamDyn below: the sync-free /
-// graph-capturable form -- the step counter and the clip coefficient never visit the host).
+// dyn != nullptr: step size, bias correction and gradient scale come from the device block adam_prep_kernel wrote (the
+// sync-free / graph-capturable form: the step counter and the clip coefficient never visit the host).
 // zero_grad: the gradient is set to zero once it has been read -- the next step's zero_grad() folded into this pass (21 MB written
 // here instead of a 21 MB fill kernel plus its launch boundary ahead of every step; the reference's order zero_grad -> backward -> step,
 // vasnet.py:210-212, leaves the same state).
-// Device-side step bookkeeping of the sync-free form: state[0] (int32) = optimiser steps taken so far, state[1] (uint32) = arrival
-// ticket of the running launch (zero between launches).  Every block READS the counter when it starts and derives lr / (1 - b1^t),
-// 1 / sqrt(1 - b2^t) and the effective gradient scale = grad_scale * min(1, max_norm / (sqrt(sumsq) * grad_scale + 1e-6)) (torch's
-// clip_grad_norm_), all in double like the host path; the block that draws the LAST ticket -- every block has read the counter by then --
-// writes counter + 1 and zeroes the ticket.  (Until round 4 a one-thread kernel in front of this one did that: 4.8 us of launch boundary
-// per optimiser step.)
-struct AdamDyn { int32_t* state; const float* sumsq; float max_norm; };
-
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                    float wd, float step_size, float inv_sqrt_bc2, float grad_scale,
-                                                   AdamDyn dyn) {
-  if (dyn.state != nullptr) {
-    const int step = __hip_atomic_load(dyn.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
-    step_size = (float)((double)lr / bc1);
-    inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    double gs = (double)grad_scale;
-    if (dyn.sumsq != nullptr) {
-      const double norm = sqrt((double)dyn.sumsq[0]) * (double)grad_scale;
-      gs = (double)grad_scale * fmin(1.0, (double)dyn.max_norm / (norm + 1e-6));
-    }
-    grad_scale = (float)gs;
-  }
+                                                   const float* __restrict__ dyn) {
+  if (dyn != nullptr) { step_size = dyn[1]; inv_sqrt_bc2 = dyn[2]; grad_scale = dyn[3]; }
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -64,16 +44,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
     if constexpr (ZERO) g[i] = 0.f;
   }
-  if (dyn.state != nullptr) {
-    __syncthreads();                            // (the block read the counter at its start: every thread is past that)
-    if (threadIdx.x == 0) {
-      unsigned* const ticket = reinterpret_cast<unsigned*>(dyn.state + 1);
-      if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-        __hip_atomic_store(dyn.state, __hip_atomic_load(dyn.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+}
+
+// state[0] (int32): optimiser steps taken so far, incremented here; state[1..3] (float): lr / (1 - b1^t), 1 / sqrt(1 - b2^t) and
+// the effective gradient scale = grad_scale * min(1, max_norm / (sqrt(sumsq) * grad_scale + 1e-6)) -- torch's clip_grad_norm_ --
+// all in double like the host path of sumk_adam_step.
+__global__ void adam_prep_kernel(int32_t* state, float lr, float b1, float b2, float grad_scale, const float* sumsq, float max_norm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int step = state[0] + 1;
+  state[0] = step;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  float* f = reinterpret_cast<float*>(state);
+  f[1] = (float)((double)lr / bc1);
+  f[2] = (float)(1.0 / sqrt(bc2));
+  double gs = (double)grad_scale;
+  if (sumsq != nullptr) {
+    const double norm = sqrt((double)sumsq[0]) * (double)grad_scale;
+    const double coef = fmin(1.0, (double)max_norm / (norm + 1e-6));
+    gs = (double)grad_scale * coef;
   }
+  f[3] = (float)gs;
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
@@ -145,7 +136,7 @@ extern "C" int sumk_adam_step(float* param, const float* grad, float* exp_avg, f
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
   hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n, lr,
-                     beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale, AdamDyn{nullptr, nullptr, 0.f});
+                     beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale, (const float*)nullptr);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -156,12 +147,12 @@ static int adam_step_dev_impl(float* param, float* grad, float* exp_avg, float* 
   SUMK_ARG(param && grad && exp_avg && exp_avg_sq && state, "adam_dev: null pointer");
   SUMK_ARG(n > 0, "adam_dev: n=%lld", (long long)n);
   SUMK_ARG(sumsq == nullptr || max_norm > 0.f, "adam_dev: max_norm=%g with a norm given", (double)max_norm);
-  const AdamDyn dyn{state, sumsq, max_norm};
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2, grad_scale, sumsq, max_norm);
   int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
   if (zero_grad) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                                    beta1, beta2, eps, weight_decay, 0.f, 0.f, grad_scale, dyn);
+                                    beta1, beta2, eps, weight_decay, 0.f, 0.f, 0.f, (const float*)state);
   else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                          beta1, beta2, eps, weight_decay, 0.f, 0.f, grad_scale, dyn);
+                          beta1, beta2, eps, weight_decay, 0.f, 0.f, 0.f, (const float*)state);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
