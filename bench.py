@@ -309,7 +309,7 @@ def trainer_test_leg(dev, D=1024, n_videos=50):
                      "means, Spearman) + host knapsack / F-scores; features resident in HBM after the first call")
 
 
-def stream_leg(model, x, lens, dev, steps=30):
+def stream_leg(model, x, lens, dev, steps=60):
     """SURVEY 8d's PCIe-inclusive variant (never `value`): features start in pageable host memory and scores end in host memory every
     step -- native threaded pack into pinned staging, one H2D, packed scoring, one D2H, three slots in flight (ingest.StreamingScorer)."""
     from summarizer_amd.ingest import StreamingScorer
