@@ -208,7 +208,7 @@ def make_reinforce_step(model, x, lens, dev):
     return run_step, opt
 
 
-def single_video_leg(dev, D=1024, T=300, iters=200):
+def single_video_leg(dev, D=1024, T=300, iters=400):
     """The reference's OWN calling pattern, driver-timed: ONE TVSum-sized video per forward (models/__init__.py:45-54) and ONE
     optimiser step per video (vasnet.py:193-212, dsn.py:96-156) -- what `main.py` unchanged runs with the default batch_videos = 1.
     VASNet and DSN, scoring and training step, each eager (the Python call per video) and as a HIP-graph replay (what the trainers do
@@ -224,7 +224,7 @@ def single_video_leg(dev, D=1024, T=300, iters=200):
     target = torch.rand(T, device=dev)
     sb = kernels.SeqBatch.get([T], dev)
 
-    def timed(fn, n=iters, warm=20):
+    def timed(fn, n=iters, warm=200):     # (a ~100 us call: 20 warm-up calls were 2 ms -- the clock had not settled when timing began)
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
@@ -269,9 +269,9 @@ def single_video_leg(dev, D=1024, T=300, iters=200):
             loss.backward()
             opt.step(grad_scale=1.0, max_norm=5.0 if name == "dsn" else None, zero_grad=captured)
             seed.add_(1)
-        tt_eager = timed(step, n=iters // 2, warm=10)
+        tt_eager = timed(step, n=iters // 2, warm=50)
         opt.zero_grad()
-        tt_graph = timed(graphed(lambda: step(True)), n=iters // 2, warm=10)
+        tt_graph = timed(graphed(lambda: step(True)), n=iters // 2, warm=50)
         kernels.health_check()
         rec = lambda t: dict(us_per_video=round(t * 1e6, 1), frames_per_s=round(T / t, 1))
         out[name] = dict(score_eager=rec(t_eager), score_graph=rec(t_graph), train_step_eager=rec(tt_eager), train_step_graph=rec(tt_graph))
@@ -294,10 +294,10 @@ def trainer_test_leg(dev, D=1024, n_videos=50):
     torch.manual_seed(1234)
     tr = VASNetTrainer(hps, hps.splits_files[0]).reset()
     frames = int(sum(ds[k]["features"].shape[0] for k in keys))
-    for _ in range(3):
+    for _ in range(10):
         res = tr.test(0)
     torch.cuda.synchronize()
-    n = 20
+    n = 30
     t0 = time.perf_counter()
     for _ in range(n):
         res = tr.test(0)
