@@ -29,7 +29,28 @@ done
 # one video per call: kernel trace of the probe (score x 220, train step x 110; VASNet then DSN) -> per-kernel stats + one step's timeline
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_single -o p -- python3 scripts/single_video_probe.py > $OUT/single_video_probe.log 2>&1
 T=$(ls $OUT/prof_single/*/p_kernel_trace.csv $OUT/prof_single/p_kernel_trace.csv 2>/dev/null | head -1)
-python3 scripts/trace_timeline.py $T vasnet_sk_setup_kernel 100 260 > $OUT/single_video_timeline.txt 2>&1
+python3 - "$T" > $OUT/single_video_timeline.txt 2>&1 <<'PY'
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(n):
+    n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*", "", n)
+    return n.replace("sumk::", "")[:70]
+names = [short(r["Kernel_Name"]) for r in rows]
+# a scoring call = [QKV lean NT (grid 240 blocks)] ... [layernorm_kernel<true, 4, true>]; a training step ends with adam_kernel
+def grid(i): return int(rows[i]["Grid_Size_X"]) // int(rows[i]["Workgroup_Size_X"])
+starts = [i for i, n in enumerate(names) if n.startswith("gemm_lean_kernel<true, true, true>") and grid(i) == 240]
+def show(a, b, title):
+    t0 = int(rows[a]["Start_Timestamp"])
+    print(title)
+    for i in range(a, b):
+        s, e = int(rows[i]["Start_Timestamp"]), int(rows[i]["End_Timestamp"])
+        print(f"{(s-t0)/1e3:8.1f} +{(e-s)/1e3:7.1f}  {names[i]}  grid={grid(i)}x{rows[i]['Workgroup_Size_X']}")
+    print("period us", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3, "\n")
+show(starts[100], starts[101], "== VASNet, one video per call (T = 300, D = 1024): one scoring call")
+tr = [i for i in starts if any(names[j].startswith("adam_kernel") for j in range(i, min(i + 60, len(names))))]
+show(tr[50], tr[51], "== one eager training step (zero_grad + forward + MSE + backward + Adam)")
+PY
 cp $(dirname $T)/p_kernel_stats.csv $OUT/single_video_kernel_stats.csv
 rm -rf $OUT/prof_single
 python3 scripts/single_video_probe.py > $OUT/single_video_probe_unprofiled.log 2>&1
