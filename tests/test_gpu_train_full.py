@@ -495,6 +495,14 @@ def test_fused_attention_strips_equal_separate_launches(tmp_path):
         outs[flag] = np.load(f)
     a, b = outs["1"], outs["0"]
     assert set(a.files) == set(b.files) and len(a.files) > 150
+    # a second process on the fused path: bit-identical (the strips exchange statistics, accumulators and tiles through LDS, barriers and
+    # hand-counted DMA waits -- a race would show up as run-to-run differences)
+    f2 = str(tmp_path / "fused1_again.npz")
+    r = subprocess.run([sys.executable, probe, f2], env=dict(os.environ, SUMK_ATTN_FUSED="1"), capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    again = np.load(f2)
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], again[k], err_msg=k)
     differs = False
     for k in a.files:
         assert np.isfinite(a[k]).all(), k
