@@ -69,6 +69,13 @@ def test_status_codes_and_messages():
                                           lv.data_ptr(), mp.data_ptr(), st)
     assert rc == -1 and b"episodes=0" in lib.sumk_last_error()
     assert lib.sumk_segment_mse_forward(pr.data_ptr(), None, 1, sb.off_dev_p, lv.data_ptr(), st) == -1
+    # round-4 entries: the fused step loss needs its ticket word, the two-stage device tail its scratch; zero videos is a no-op
+    assert lib.sumk_segment_mse_mean_forward(pr.data_ptr(), pr.data_ptr(), 1, sb.off_dev_p, 1.0, lv.data_ptr(), mp.data_ptr(), None, st) == -1
+    assert lib.sumk_segment_mse_mean_backward(pr.data_ptr(), pr.data_ptr(), None, 1.0, 1, sb.off_dev_p, pr.data_ptr(), st) == -1
+    assert lib.sumk_eval_device_segments(pr.data_ptr(), None, 1, pr.data_ptr(), pr.data_ptr(), st) == -1
+    assert lib.sumk_eval_device_spearman(pr.data_ptr(), pr.data_ptr(), 1, None, pr.data_ptr(), st) == -1
+    assert lib.sumk_eval_device_segments(None, None, 0, None, None, st) == 0 and lib.sumk_eval_device_spearman(None, None, 0, None, None, st) == 0
+    assert lib.sumk_eval_device_spearman_scratch_bytes(50) == 50 * 8 * 33 * 8 and lib.sumk_eval_device_spearman_scratch_bytes(-3) == 0
     assert lib.sumk_adam_step_dev(pr.data_ptr(), pr.data_ptr(), pr.data_ptr(), pr.data_ptr(), 9, 1e-3, 0.9, 0.999, 1e-8, 0.0, None, 1.0,
                                   None, 0.0, st) == -1
     from summarizer_amd.models.dsn import DSN
