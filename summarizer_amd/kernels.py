@@ -143,17 +143,23 @@ def _vasnet_structs(params, opts):
     return w, o
 
 
-def vasnet_x16(x, sb):
-    """bf16(x) for the mixed-precision training step (sumk_vasnet_opts.x16), kept with the SeqBatch and rebuilt only when x is another
-    tensor or was written to since (tensor version counter): features are constant over the epochs of a run."""
+_X16_CACHE = {}     # (data_ptr, version, shape, device) -> bf16(x); at most two entries (a training set and a validation set packed once each)
+
+
+def vasnet_x16(x, sb=None):
+    """bf16(x) for the mixed-precision training step (sumk_vasnet_opts.x16): kept while x is the same tensor with the same contents
+    (address + tensor version counter) -- features packed once are constant over the epochs of a run.  Two entries at most: a loop that
+    packs a fresh batch every step (shuffled mini-batches) converts per call as before and holds no more than two shadows."""
     lib = _lib.load()
-    key = (x.data_ptr(), x._version, tuple(x.shape))
-    hit = getattr(sb, "_vasnet_x16", None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device))
+    hit = _X16_CACHE.get(key)
+    if hit is not None:
+        return hit
     x16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     _lib.check(lib.sumk_cast_f32_bf16(_p(x), _p(x16), x.numel(), _stream()), "sumk_cast_f32_bf16")
-    sb._vasnet_x16 = (key, x16)
+    while len(_X16_CACHE) >= 2:
+        _X16_CACHE.pop(next(iter(_X16_CACHE)))
+    _X16_CACHE[key] = x16
     return x16
 
 

@@ -517,7 +517,7 @@ def test_fused_attention_strips_equal_separate_launches(tmp_path):
 
 
 def test_bf16_step_with_kept_x_shadow_equals_per_call_cast(dev):
-    """sumk_vasnet_opts::x16 (kernels.vasnet_x16: bf16(x) written once by sumk_cast_f32_bf16 and kept with the SeqBatch) against the per-step
+    """sumk_vasnet_opts::x16 (kernels.vasnet_x16: bf16(x) written once by sumk_cast_f32_bf16 and kept while x is unchanged) against the per-step
     cast of x inside the call (opts["x16"] = None): the same rounding of the same values, so scores and every gradient are bit-identical;
     the shadow is rebuilt when x is written to (tensor version) and reused otherwise."""
     from summarizer_amd import kernels
@@ -541,20 +541,21 @@ def test_bf16_step_with_kept_x_shadow_equals_per_call_cast(dev):
         assert "x16" not in opts or opts["x16"] is None      # the caller's dict is not written to
         return [s.detach().clone()] + [params[n].grad.clone() for n in names]
 
+    kernels._X16_CACHE.clear()
     ref = step(dict(x16=None))
-    assert getattr(sb, "_vasnet_x16", None) is None
+    assert len(kernels._X16_CACHE) == 0
     got = step({})
-    shadow = sb._vasnet_x16[1]
+    (shadow,) = kernels._X16_CACHE.values()
     assert shadow.dtype == torch.bfloat16 and torch.equal(shadow, x.to(torch.bfloat16))
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
     again = step({})
-    assert sb._vasnet_x16[1] is shadow                        # reused
+    assert list(kernels._X16_CACHE.values())[0] is shadow and len(kernels._X16_CACHE) == 1       # reused
     for a, b in zip(ref, again):
         assert torch.equal(a, b)
     x.mul_(1.5)                                               # written to: the shadow is rebuilt
     ref2 = step(dict(x16=None)); got2 = step({})
-    assert sb._vasnet_x16[1] is not shadow
+    assert len(kernels._X16_CACHE) == 2 and list(kernels._X16_CACHE.values())[-1] is not shadow      # (the stale entry leaves when a third comes)
     for a, b in zip(ref2, got2):
         assert torch.equal(a, b)
     assert not torch.equal(ref[0], ref2[0])
