@@ -143,24 +143,44 @@ def _vasnet_structs(params, opts):
     return w, o
 
 
-_X16_CACHE = {}     # (data_ptr, version, shape, device) -> bf16(x); at most two entries (a training set and a validation set packed once each)
+def tensor_shadow(x, name, build):
+    """A value derived from the CONTENTS of tensor x (a bf16 copy, bf16 planes ...), kept ON the tensor object: `build()` runs again when
+    x was written to through torch (tensor version counter) and the entry dies with x.  Nothing is keyed by address: a fresh tensor that
+    the caching allocator places where an earlier one lived (torch.cat of a new mini-batch every step) has no shadow and gets its own
+    (the address-keyed cache handed such a tensor the previous batch's copy).  Writes torch cannot see (a C-ABI kernel
+    writing into x) must be followed by `drop_shadows(x)`."""
+    d = getattr(x, "_sumk_shadows", None)
+    if d is None:
+        d = {}
+        try:
+            x._sumk_shadows = d
+        except AttributeError:          # (an object that takes no attributes: no caching)
+            return build()
+    hit = d.get(name)
+    if hit is not None and hit[0] == x._version:
+        return hit[1]
+    val = build()
+    d[name] = (x._version, val)
+    return val
+
+
+def drop_shadows(x):
+    """Forget every shadow of x (after a write torch's version counter does not see)."""
+    if getattr(x, "_sumk_shadows", None):
+        x._sumk_shadows.clear()
 
 
 def vasnet_x16(x, sb=None):
-    """bf16(x) for the mixed-precision training step (sumk_vasnet_opts.x16): kept while x is the same tensor with the same contents
-    (address + tensor version counter) -- features packed once are constant over the epochs of a run.  Two entries at most: a loop that
-    packs a fresh batch every step (shuffled mini-batches) converts per call as before and holds no more than two shadows."""
+    """bf16(x) for the mixed-precision training step (sumk_vasnet_opts.x16): kept with the tensor OBJECT while its contents are unchanged
+    (tensor_shadow) -- features packed once are constant over the epochs of a run; a loop that packs a fresh batch every step converts per
+    call as before."""
     lib = _lib.load()
-    key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device))
-    hit = _X16_CACHE.get(key)
-    if hit is not None:
-        return hit
-    x16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.sumk_cast_f32_bf16(_p(x), _p(x16), x.numel(), _stream()), "sumk_cast_f32_bf16")
-    while len(_X16_CACHE) >= 2:
-        _X16_CACHE.pop(next(iter(_X16_CACHE)))
-    _X16_CACHE[key] = x16
-    return x16
+
+    def build():
+        x16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.sumk_cast_f32_bf16(_p(x), _p(x16), x.numel(), _stream()), "sumk_cast_f32_bf16")
+        return x16
+    return tensor_shadow(x, "x16", build)
 
 
 def fold_vo(w_o, w_v, out=None):

@@ -258,6 +258,7 @@ class VASNetTrainer(Trainer):
                         except Exception as e:      # noqa: BLE001  (a configuration that does not capture keeps the eager loop)
                             self.log.warning(f"HIP graph capture failed ({type(e).__name__}: {e}); training continues eagerly")
                             use_graph, self.model.graph_seed = False, None
+                            torch.cuda.synchronize(dev)      # leave no half-finished capture work behind the eager steps
                     if use_graph:
                         if not graphs_zeroed:          # the captured steps keep the gradient bucket zero between them (Adam kernel); the
                             self.optimizer.zero_grad(); graphs_zeroed = True      # first replay after eager steps starts from an explicit one
@@ -314,10 +315,11 @@ class VASNetTrainer(Trainer):
         self.model.graph_seed = None
         return best_corr, best_avg_f_score, best_max_f_score
 
-    def _single_video_step(self, key, dev, grads_are_zero=False):
+    def _single_video_step(self, key, dev, grads_are_zero=False, video=None):
         """One optimiser step on one video (vasnet.py:193-212): (loss, scores) as detached tensors.  grads_are_zero: the captured
-        form -- the previous step's Adam kernel left the gradient bucket zero and this one does the same, so no fill kernel runs."""
-        seq, target = self._load_video(key, dev)
+        form -- the previous step's Adam kernel left the gradient bucket zero and this one does the same, so no fill kernel runs.
+        video: the (features, target) device tensors to use instead of loading `key` (a capture passes the tensors it keeps alive)."""
+        seq, target = video if video is not None else self._load_video(key, dev)
         lens_b = [seq.shape[0]]
         if not grads_are_zero:
             self.optimizer.zero_grad()
@@ -326,13 +328,24 @@ class VASNetTrainer(Trainer):
         loss.backward()
         self.optimizer.step(grad_scale=1.0, zero_grad=grads_are_zero)
         if self.model.graph_seed is not None:
-            self.model.graph_seed.add_(1)            # next replay: other dropout masks
+            # next replay: other dropout masks.  The kernels add this word to the seed captured with the step, and the captured seeds of
+            # the per-video graphs are consecutive integers: a stride of 1 made video A's replay g draw the masks of video B's replay
+            # g - 1.  A large odd stride keeps (captured seed + word) distinct over videos and replays.
+            self.model.graph_seed.add_(0x9E3779B97F4A7C15 - (1 << 64))
         return loss.detach(), scores.detach().view(-1, 1, 1)
 
     def _capture_step(self, key, dev, pool):
         """(graph, loss, scores): the step of `key` captured into a HIP graph; loss / scores are the graph's static outputs (rewritten
         by every replay).  All captured steps share one memory pool -- they never run concurrently."""
-        seq, _ = self._load_video(key, dev)          # (uploaded and cached before capture: no H2D copy inside the graph)
+        # The graph records raw addresses of the features and the target: they must be the HBM-cached tensors (alive as long as the
+        # trainer) and are ALSO kept in the graph entry -- a video the cache declined (over its byte limit) would be re-uploaded from a
+        # pinned buffer INSIDE the capture and every replay would copy from recycled host memory (ADVICE r4): such a video stays eager.
+        if (key, str(dev)) not in self._hbm:
+            self._load_video(key, dev)
+        if (key, str(dev)) not in self._hbm:
+            raise RuntimeError(f"video {key} is not resident in the HBM cache")
+        video = self._hbm[(key, str(dev))]
+        seq = video[0]
         # the outputs live OUTSIDE the shared graph pool (allocated before the capture, written by a copy inside it): tensors a capture
         # leaves in the pool were seen to alias those of later captures into the same pool -- the epoch's mean loss then read eight
         # copies of the last step's loss while the weights were exactly right
@@ -341,8 +354,8 @@ class VASNetTrainer(Trainer):
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool):
-            loss, scores = self._single_video_step(key, dev, grads_are_zero=True)
+            loss, scores = self._single_video_step(key, dev, grads_are_zero=True, video=video)
             loss_out.copy_(loss); scores_out.copy_(scores)
         # (the graph holds raw addresses of the batch descriptor's device arrays -- sequence offsets, prebuilt problem tables: keep the
         #  SeqBatch alive beside it, whatever happens to kernels.SeqBatch's cache)
-        return g, loss_out, scores_out, kernels.SeqBatch.get([seq.shape[0]], dev)
+        return g, loss_out, scores_out, kernels.SeqBatch.get([seq.shape[0]], dev), video

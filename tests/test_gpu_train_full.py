@@ -541,21 +541,60 @@ def test_bf16_step_with_kept_x_shadow_equals_per_call_cast(dev):
         assert "x16" not in opts or opts["x16"] is None      # the caller's dict is not written to
         return [s.detach().clone()] + [params[n].grad.clone() for n in names]
 
-    kernels._X16_CACHE.clear()
+    kernels.drop_shadows(x)
     ref = step(dict(x16=None))
-    assert len(kernels._X16_CACHE) == 0
+    assert not getattr(x, "_sumk_shadows", None)
     got = step({})
-    (shadow,) = kernels._X16_CACHE.values()
+    shadow = x._sumk_shadows["x16"][1]
     assert shadow.dtype == torch.bfloat16 and torch.equal(shadow, x.to(torch.bfloat16))
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
     again = step({})
-    assert list(kernels._X16_CACHE.values())[0] is shadow and len(kernels._X16_CACHE) == 1       # reused
+    assert x._sumk_shadows["x16"][1] is shadow       # reused
     for a, b in zip(ref, again):
         assert torch.equal(a, b)
     x.mul_(1.5)                                               # written to: the shadow is rebuilt
     ref2 = step(dict(x16=None)); got2 = step({})
-    assert len(kernels._X16_CACHE) == 2 and list(kernels._X16_CACHE.values())[-1] is not shadow      # (the stale entry leaves when a third comes)
+    assert x._sumk_shadows["x16"][1] is not shadow
     for a, b in zip(ref2, got2):
         assert torch.equal(a, b)
     assert not torch.equal(ref[0], ref2[0])
+
+
+def test_bf16_step_fresh_batches_at_recycled_addresses_get_their_own_shadow(dev):
+    """two DIFFERENT mini-batches of equal shape built by torch.cat every step alternate between the same two allocator
+    addresses with tensor version 0 -- an address-keyed shadow cache handed step k the bf16 copy of step k - 2's batch.  The shadow now lives
+    on the tensor object: every step's scores and gradients equal those of the per-call cast, over four alternating steps."""
+    from summarizer_amd import kernels
+    from summarizer_amd.autograd import VasnetFunction
+    from summarizer_amd.models.vasnet import VASNet
+    D = 256
+    lens = [40, 72, 55]
+    w = R.vasnet_weights(D, 5)
+    m = VASNet(input_size=D, precision="bf16"); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    vids = [[torch.from_numpy(R.features(T, 1, D, 100 * b + i)[:, 0, :]).to(dev) for i, T in enumerate(lens)] for b in range(2)]
+    sb = kernels.SeqBatch.get(lens, dev)
+    names = [k for _, k in kernels.VASNET_FIELDS]
+    params = dict(m.named_parameters())
+
+    def step(x, extra):
+        for p in params.values():
+            p.grad = None
+        opts = dict(scale=float(m.scale), eps=1e-6, ignore_self=False, aperture=None, dropout_p=0.0, seed=3, precision="bf16", **extra)
+        s = VasnetFunction.apply(x, sb, opts, None, None, names, *[params[n] for n in names])
+        (s * torch.linspace(-1, 1, s.numel(), device=dev)).sum().backward()
+        return [s.detach().clone()] + [params[n].grad.clone() for n in names]
+
+    refs = [step(torch.cat(vids[b]), dict(x16=None)) for b in range(2)]
+    assert not torch.equal(refs[0][0], refs[1][0])
+    ptrs = set()
+    scores = None
+    for k in range(4):
+        x = torch.cat(vids[k & 1])                    # a fresh tensor every step; the previous one is released below
+        ptrs.add(x.data_ptr())
+        got = step(x, {})
+        for a, b in zip(refs[k & 1], got):
+            assert torch.equal(a, b), k
+        scores = got[0]
+        del x, got
+    assert scores is not None and len(ptrs) <= 4

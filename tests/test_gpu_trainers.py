@@ -342,12 +342,13 @@ def test_vasnet_trainer_hip_graph_steps_equal_eager_steps(data):
     dev = tr._device()
     tr.model.graph_seed = torch.zeros(1, dtype=torch.int64, device=dev)
     tr._single_video_step(keys[5], dev)                                  # eager warm-up
-    g, loss, scores, _sb = tr._capture_step(keys[5], dev, None)
+    g, loss, scores, _sb, _vid = tr._capture_step(keys[5], dev, None)
     seen = []
     for _ in range(3):
         g.replay()
         torch.cuda.synchronize()
         seen.append((float(loss), scores.clone()))
-    assert int(tr.model.graph_seed.item()) == 4                          # 1 eager + 3 replays
+    stride = 0x9E3779B97F4A7C15                                           # the per-step advance of the device seed word (odd, large)
+    assert int(tr.model.graph_seed.item()) % (1 << 64) == (4 * stride) % (1 << 64)      # 1 eager + 3 replays
     assert all(np.isfinite(v[0]) for v in seen)
     assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1])
