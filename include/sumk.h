@@ -364,6 +364,18 @@ int sumk_gemm_prec(int32_t layout, const float* A, const float* B, float* C, int
  * bytes): deterministic split-K over a long K and C += product -- the weight-gradient form of vasnet.py:193-212's backward. */
 int sumk_gemm_bf16src(int32_t layout, const void* A_bf16, const void* B_bf16, float* C, int32_t M, int32_t N, int32_t K,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* ---- "KB planes": the operand format of the plane-aware wide GEMM behind SUMK_PRECISION_BF16X6 / BF16X3 scoring (csrc/gemm_pw.hip).
+ * An fp32 matrix (rows x K, K % 16 == 0) as n_planes = 3 (x = x1 + x2 + x3 exactly) or 2 (hi + lo) bf16 planes, k-blocked:
+ *   byte offset of (row, k, plane p) = (((k / 16) * n_planes + p) * 2 + (k / 8) % 2) * 16 * pitch + row * 16 + (k % 8) * 2,
+ *   pitch = rows rounded up to 64.   Written once per dataset (x), per weight change (weights) or by the producing kernel's epilogue;
+ * no reference counterpart (the reference multiplies fp32 tensors with torch.matmul, vasnet.py:114-131).
+ * sumk_planes_bytes: device bytes of one plane array (0 = bad arguments).  sumk_split_planes: fp32 (rows x K, leading dimension ld)
+ * -> planes.  sumk_gemm_planes (tests / bench probe): C(M,N) fp32 = A . B^T from two plane arrays built for a_rows / b_rows rows
+ * (N % 256 == 0, K % 32 == 0, K >= 128); variant selects a schedule variant of the probe (0 = the product's). */
+size_t sumk_planes_bytes(int64_t rows, int32_t K, int32_t n_planes);
+int sumk_split_planes(const float* src, int64_t rows, int32_t K, int32_t ld, int32_t n_planes, void* planes, void* stream);
+int sumk_gemm_planes(const void* A_planes, int64_t a_rows, const void* B_planes, int64_t b_rows, float* C, int32_t M, int32_t N, int32_t K,
+                     int32_t n_planes, int32_t variant, void* stream);
 /* C(M,N) = A(M,K) * B(K,N) */
 int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 /* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */

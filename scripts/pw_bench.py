@@ -1,0 +1,44 @@
+"""Probe: the plane-aware wide GEMM (csrc/gemm_pw.hip) against the in-loop split kernels on the headline shapes.
+usage: python scripts/pw_bench.py [reps]"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from summarizer_amd import kernels, _lib
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+lib = _lib.load()
+dev = torch.device("cuda:0")
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn(); ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(reps))
+    return ts[len(ts) // 2], ts[0]
+
+
+for (M, N, K) in [(12003, 3072, 1024), (12003, 1024, 1024), (12003, 2048, 1024)]:
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(N, K, device=dev) * 0.03
+    c = torch.empty(M, N, device=dev)
+    fl = 2.0 * M * N * K
+    for npl, prec, peak in ((3, 2, 2500.0 / 6), (2, 1, 2500.0 / 3)):
+        ap, bp = kernels.split_planes(a, npl), kernels.split_planes(b, npl)
+        med, best = timeit(lambda: lib.sumk_gemm_prec(0, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, prec, st))
+        print(f"M={M} N={N} K={K} planes={npl}  in-loop split: {med:8.1f} us (best {best:8.1f})  {fl / med / 1e6:7.1f} TF = {fl / med / 1e6 / peak:.3f} of {peak:.0f}")
+        for variant in (0, 1, 2):
+            med, best = timeit(lambda: kernels.gemm_planes(ap, M, bp, N, M, N, K, npl, variant=variant, out=c))
+            print(f"M={M} N={N} K={K} planes={npl}  gemm_pw var {variant}: {med:8.1f} us (best {best:8.1f})  {fl / med / 1e6:7.1f} TF = {fl / med / 1e6 / peak:.3f} of {peak:.0f}")
+        med, best = timeit(lambda: kernels.split_planes(a, npl))
+        print(f"   split_planes({M} x {K}, {npl}): {med:.1f} us")

@@ -1,0 +1,435 @@
+// Plane-aware wide GEMM for the split-bf16 arithmetics (SUMK_PRECISION_BF16X6 / BF16X3) of the packed scoring path
+// (reference: summarizer/models/vasnet.py:114-145 -- the K/Q/V projections, the output projection and k1).
+//
+// C(M, N) = A(M, K) . B(N, K)^T with BOTH operands already split into bf16 planes in HBM ("KB planes", sumk_internal.h): x once per
+// dataset, weights once per weight change, activations by the epilogue of the kernel that produced them.  The in-loop split kernels
+// (gemm_regstage.h, NS = 2 / 3) convert every k-tile of both operands on the vector ALU of every block that touches it and read
+// 0.8 LDS fragments per MFMA: matrix pipe busy 0.31-0.53 (profiles/r03_pmc_clock_mfma_by_mode.json).  Here
+//   * a (192 x 256) block tile, 512 threads = 2 x 4 waves of 96 x 64 (3 x 2 MFMA tiles of 32 x 32), one block per CU;
+//   * one k16 step = NP (A planes) x 3 + NP (B planes) x 2 fragment reads (ds_read_b128, conflict-free, no padding) feeding
+//     6 x NT MFMAs (NT = 6 products for three planes, 3 for two): 15 reads per 36 MFMAs at bf16x6, 10 per 18 at bf16x3;
+//   * operands reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds): 1 KiB = 64 rows x 16 B per wave instruction, contiguous in HBM AND
+//     in LDS by construction of the plane format -- no VGPR staging, no ds_write, no VALU, no address arithmetic in the loop (the
+//     per-lane offset is lane * 16 for every piece; everything else is a scalar offset);
+//   * a ring of NS k16 stages (bf16x6: 3 x 42 KB; bf16x3: 4 x 28 KB), ONE barrier per k16 step placed after two thirds of the step's
+//     MFMAs: the fragments of step s + 1 are requested right behind the barrier and land under the last third, so neither the
+//     barrier nor the LDS latency is exposed; the two waves of a SIMD (w, w + 4) issue their DMA pieces at different points of the
+//     step (a piece holds its wave's instruction issue for ~100 cycles; the partner's MFMAs fill the pipe meanwhile).
+// Term order per accumulator and k16 step is that of the in-loop kernels (smallest products first), the planes are the same roundings,
+// so on the same operand values the results are bit-identical to precision = bf16x6 / bf16x3 of gemm_regstage.h (tested).
+//
+// Epilogues (PwEpi).  PW_F32 keeps the usual orientation (lane = output column: 128-byte row segments of fp32).  The others run the
+// MFMA TRANSPOSED (B rows on the M axis): a lane then owns ONE output row and 4 consecutive columns per register quad, which is
+// exactly an 8-byte piece of a KB-plane chunk -- the result is split into planes in registers and leaves as 512-byte contiguous runs.
+#include "gemm_regstage.h"
+#include <atomic>
+#include <type_traits>
+
+namespace sumk {
+
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+struct PwArgs {
+  const char* A; const char* B;
+  uint32_t a_rp16, b_rp16;             // bytes of one (k16 block, plane, half) sub-array
+  int32_t M, N, K;
+  int32_t tiles_m, tiles_n, total_tiles, xcd_map;
+  float* C; int32_t ldc;
+  char* O; int64_t o_rp16;
+  const float* R; int32_t ldr;
+  float* moments;
+  const float* bias; const float* gw; const float* ln_c1; const float* ln_stats; float* head_part;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
+__device__ __forceinline__ void lds_barrier() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
+
+// x -> NP bf16 planes of 4 values (each subtraction exact): the roundings of gemm_regstage.h's split_planes
+template <int NP>
+__device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NP]) {
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const bf16x4 b = __builtin_convertvector(r, bf16x4);
+    pl[q] = __builtin_bit_cast(u32x2, b);
+    if (q + 1 < NP) r = r - __builtin_convertvector(b, f32x4);
+  }
+}
+
+constexpr int PW_CONST_BYTES = 4096;   // PW_HEAD: the tile's 256 columns of c1 / bias / gw
+
+template <int NP, int BM, int EPI, int NS, int VAR>
+__global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
+  constexpr int BN = 256, WTM = BM / 2, TM = WTM / 32, TN = 2, NSUB = 2 * NP;
+  constexpr bool SWAP = EPI != PW_F32;
+  constexpr int A_BYTES = NSUB * BM * 16, B_BYTES = NSUB * BN * 16, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = BM / 64, PB = BN / 64, PPS = PA + PB;
+  static_assert(NS * STAGE + PW_CONST_BYTES <= 160 * 1024, "the stage ring must fit the CU's LDS");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool early = VAR == 1 ? true : VAR == 2 ? false : wave < 4;      // when this wave issues its DMA pieces inside a step
+
+  // DMA pieces: a stage is NSUB sub-arrays x (PA + PB) blocks of 64 rows; wave w < PA + PB owns row block w of EVERY sub-array (waves
+  // 0 .. PA - 1: blocks of A, the next PB: blocks of B; wave 7 issues none) -- one descriptor, one row offset and one LDS offset per
+  // wave, the sub-array a compile-time multiple: no per-piece tables (a first version kept three scalar arrays per wave and spilled
+  // 150 SGPRs into the k-loop).
+  static_assert(PPS <= 8, "one 64-row block per wave");
+  const bool dma_wave = wave < PPS, dma_a = wave < PA;
+  const int blk = dma_a ? wave : wave - PA;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dma_a ? a.A : a.B), (short)0, 0x80000000u, 0x00020000);
+  const int rp16 = (int)(dma_a ? a.a_rp16 : a.b_rp16);
+  const int lds_blk = dma_a ? blk * 1024 : A_BYTES + blk * 1024;
+  constexpr int LSUB_A = BM * 16, LSUB_B = BN * 16;
+  const int lsub = dma_a ? LSUB_A : LSUB_B;
+  const int vlane = lane * 16;
+  const int k_step = NSUB * rp16;                                       // bytes per k16 block
+  auto dma = [&](int m0, int n0, int kb, int slot) {
+    if (!dma_wave) return;
+    char* const st = lds + slot * STAGE + lds_blk;
+    const int g0 = kb * k_step + ((dma_a ? m0 : n0) + blk * 64) * 16;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + sub * lsub), 16, vlane, g0 + sub * rp16, 0, 0);
+  };
+  constexpr int IN_FLIGHT = (NS - 2) * NSUB;                            // DMA instructions of this wave that may stay in flight across a step's barrier
+
+  // fragments: plane p, MFMA tile t of this wave -> 16 bytes per lane
+  const int fa = (lh * BM + wm * WTM + li) * 16, fb = A_BYTES + (lh * BN + wn * 64 + li) * 16;
+  struct Frags { bf16x8 a[NP][TM], b[NP][TN]; };
+  auto read_frags = [&](int slot, Frags& f) {
+    const char* const st = lds + slot * STAGE;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t) f.b[p][t] = *reinterpret_cast<const bf16x8*>(st + fb + p * 2 * BN * 16 + t * 512);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) f.a[p][t] = *reinterpret_cast<const bf16x8*>(st + fa + p * 2 * BM * 16 + t * 512);
+    }
+  };
+  auto mfma_rows = [&](const Frags& f, f32x16 (&acc)[TM][TN], int tm_lo, int tm_hi) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if (tm < tm_lo || tm >= tm_hi) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int sum = NP - 1; sum >= 0; --sum)          // planes (i, j) with i + j descending: smallest products first
+#pragma unroll
+          for (int i = NP - 1; i >= 0; --i) {
+            const int j = sum - i;
+            if (j < 0 || j >= NP) continue;
+            if constexpr (SWAP) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[j][tn], f.a[i][tm], acc[tm][tn], 0, 0, 0);
+            else acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][tm], f.b[j][tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  // tile walk: the XCD-aware map of gemm_device.h (tile % 8 labels the XCD: each XCD owns a (tiles_m / 2) x (tiles_n / 4) rectangle)
+  auto decode = [&](int t, int& m0, int& n0) -> bool {
+    int mt, nt;
+    if (a.xcd_map) {
+      const int x = t & 7, j = t >> 3, sm = (a.tiles_m + 1) >> 1, sn = a.tiles_n >> 2;
+      const int jm = j / sn;
+      mt = (x >> 2) * sm + jm; nt = (x & 3) * sn + (j - jm * sn);
+      if (jm >= sm || mt >= a.tiles_m) return false;
+    } else {
+      if (t >= a.total_tiles) return false;
+      mt = t / a.tiles_n; nt = t - mt * a.tiles_n;
+    }
+    m0 = mt * BM; n0 = nt * BN;
+    return true;
+  };
+
+  const int nk = a.K >> 4;
+  int tile = blockIdx.x, m0 = 0, n0 = 0;
+  if (tile >= a.total_tiles || !decode(tile, m0, n0)) return;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) dma(m0, n0, s, s);
+
+  while (true) {
+    f32x16 acc[TM][TN];
+    if constexpr (EPI == PW_RES_MOM_PLANES) {
+      // lane = row m, registers 4 g .. 4 g + 3 = columns n0w + 32 tn + 8 g + 4 lh + (0..3)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + wm * WTM + tm * 32 + li;
+        const float* const rp = a.R + (int64_t)min(m, a.M - 1) * a.ldr + n0 + wn * 64 + 4 * lh;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(rp + tn * 32 + 8 * g);
+            acc[tm][tn][4 * g] = v.x; acc[tm][tn][4 * g + 1] = v.y; acc[tm][tn][4 * g + 2] = v.z; acc[tm][tn][4 * g + 3] = v.w;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+
+    // ---- k loop: stage s lives in slot s % NS; Frags[s & 1]
+    wait_vm<0>();                      // (start of a tile: the previous epilogue's stores share the counter: drain; stages 1.. are mostly there by now)
+    __builtin_amdgcn_s_barrier();
+    Frags F0, F1;
+    read_frags(0, F0);
+    int slot = 0;
+    // MAIN: steady state (stage s + NS exists: refill the slot of stage s; stages s + 2 .. s + NS - 1 stay in flight across the barrier).
+    // !MAIN: the last steps of a tile (run-time conditions, full drain before the barrier).
+    auto kstep = [&](auto main_, const Frags& cur, Frags& nxt, int s) {
+      constexpr bool MAIN = decltype(main_)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_rows(cur, acc, 0, TM - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = MAIN || s + 1 < nk, fill = MAIN || s + NS < nk;
+      const int nslot = slot + 1 == NS ? 0 : slot + 1;
+      if (more) {
+        if constexpr (MAIN) wait_vm<IN_FLIGHT>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                         // stage s + 1 has landed; every wave is past its reads of stage s
+        read_frags(nslot, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (fill && early) dma(m0, n0, s + NS, slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_rows(cur, acc, TM - 1, TM);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more && fill && !early) dma(m0, n0, s + NS, slot);
+      slot = nslot;
+    };
+    int s = 0;
+    for (; s + NS + 1 < nk; s += 2) {
+      kstep(std::true_type{}, F0, F1, s);
+      kstep(std::true_type{}, F1, F0, s + 1);
+    }
+    for (; s < nk; s += 2) {
+      kstep(std::false_type{}, F0, F1, s);
+      kstep(std::false_type{}, F1, F0, s + 1);
+    }
+
+    // ---- next tile's first stages go out under this tile's epilogue
+    lds_barrier();                     // every wave is past its last fragment read
+    const int next_tile = tile + gridDim.x;
+    int m1 = 0, n1 = 0;
+    const bool has_next = next_tile < a.total_tiles && decode(next_tile, m1, n1);
+    if (has_next) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) dma(m1, n1, s, s);
+    }
+
+    // ---- epilogue
+    const int row_w = m0 + wm * WTM, col_w = n0 + wn * 64;
+    if constexpr (EPI == PW_F32) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = col_w + tn * 32 + li;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row_w + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[tm][tn][r];
+          }
+      }
+    } else if constexpr (EPI == PW_PLANES || EPI == PW_RES_MOM_PLANES) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = row_w + tm * 32 + li;
+        if constexpr (EPI == PW_RES_MOM_PLANES) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; s1 += v; s2 += v * v; }
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          if (lh == 0 && m < a.M) reinterpret_cast<float2*>(a.moments)[(int64_t)m * (a.N >> 6) + (col_w >> 6)] = make_float2(s1, s2);
+        }
+        if (m < a.M) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              u32x2 pl[NP];
+              split4<NP>(f32x4{acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]}, pl);
+              const int kb = (col_w >> 4) + tn * 2 + (g >> 1), h = g & 1;
+              char* const op = a.O + ((int64_t)(kb * NP) * 2 + h) * a.o_rp16 + (int64_t)m * 16 + 8 * lh;
+#pragma unroll
+              for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.o_rp16) = pl[p];
+            }
+        }
+      }
+    } else {   // PW_HEAD
+      float* const cst = reinterpret_cast<float*>(lds + NS * STAGE);     // [c1 | bias | gw] x 256 columns of this tile
+      if (tid < 256) {
+        cst[tid] = a.ln_c1[n0 + tid]; cst[256 + tid] = a.bias[n0 + tid]; cst[512 + tid] = a.gw[n0 + tid];
+      }
+      lds_barrier();
+      // one 32-row tile at a time (its accumulators die with it); the column constants are re-read from LDS per tile
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = row_w + tm * 32 + li;
+        const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[min(m, a.M - 1)];
+        const float mean = st.x, rstd = st.y;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = wn * 64 + tn * 32 + 8 * g + 4 * lh;
+            const float4 c1 = *reinterpret_cast<const float4*>(cst + cl), bi = *reinterpret_cast<const float4*>(cst + 256 + cl),
+                         gw = *reinterpret_cast<const float4*>(cst + 512 + cl);
+            const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, biv[4] = {bi.x, bi.y, bi.z, bi.w}, gwv[4] = {gw.x, gw.y, gw.z, gw.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              float v = rstd * (acc[tm][tn][4 * g + c] - mean * c1v[c]) + biv[c];
+              v = (v < 0.f) ? 0.f : v;            // NaN-propagating like torch.relu
+              s1 += v; s2 += v * v; s3 += v * gwv[c];
+            }
+          }
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+        if (lh == 0 && m < a.M) reinterpret_cast<float4*>(a.head_part)[(int64_t)m * (a.N >> 6) + (col_w >> 6)] = make_float4(s1, s2, s3, 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!has_next) break;
+    tile = next_tile; m0 = m1; n0 = n1;
+  }
+}
+
+std::atomic<uint64_t> g_attr_done[64];      // per kernel instance (index below): bit d = device d has the dynamic-LDS opt-in
+
+template <int NP, int BM, int EPI, int NS, int VAR>
+int launch_one(const PwArgs& a, int inst, hipStream_t s) {
+  constexpr int LDS = NS * (2 * NP * (BM + 256) * 16) + PW_CONST_BYTES;
+  const void* fn = (const void*)gemm_pw_kernel<NP, BM, EPI, NS, VAR>;
+  int dev = 0;
+  SUMK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(g_attr_done[inst].load(std::memory_order_acquire) & bit)) {
+    SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    g_attr_done[inst].fetch_or(bit, std::memory_order_release);
+  }
+  const int grid = a.xcd_map ? 256 : std::min(a.total_tiles, 256);
+  hipLaunchKernelGGL((gemm_pw_kernel<NP, BM, EPI, NS, VAR>), dim3(grid), dim3(512), LDS, s, a);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+template <int NP, int NS>
+int launch_np(PwEpi epi, const PwArgs& a, int variant, hipStream_t s) {
+  constexpr int base = NP == 3 ? 0 : 16;
+  switch (epi) {
+    case PW_F32:
+      if (variant == 1) return launch_one<NP, 192, PW_F32, NS, 1>(a, base + 4, s);
+      if (variant == 2) return launch_one<NP, 192, PW_F32, NS, 2>(a, base + 5, s);
+      return launch_one<NP, 192, PW_F32, NS, 0>(a, base + 0, s);
+    case PW_PLANES: return launch_one<NP, 192, PW_PLANES, NS, 0>(a, base + 1, s);
+    case PW_RES_MOM_PLANES: return launch_one<NP, 192, PW_RES_MOM_PLANES, NS, 0>(a, base + 2, s);
+    case PW_HEAD: return launch_one<NP, 192, PW_HEAD, NS, 0>(a, base + 3, s);
+  }
+  set_error("gemm_pw: bad epilogue %d", (int)epi);
+  return SUMK_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------- fp32 -> KB planes
+// One block: 64 rows x 128 columns.  Rows are read coalesced (512-byte row segments) into LDS, then lane = row writes, per 8-column chunk
+// and plane, the 16-byte chunk of its row: 64 lanes = 1 KiB contiguous of one sub-array.  Rows in [rows, pitch) are written as zeros.
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t rows, int K, int ld, char* __restrict__ dst, int64_t rp16) {
+  __shared__ float tile[64][132];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 128;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = tid + 256 * j, r = i >> 5, c4 = (i & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows && c0 + c4 < K) v = *reinterpret_cast<const float4*>(src + (r0 + r) * ld + c0 + c4);
+    *reinterpret_cast<float4*>(&tile[r][c4]) = v;
+  }
+  __syncthreads();
+  const int r = tid & 63, cg = tid >> 6;            // 4 chunk groups x 4 chunks of 8 columns
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ch = cg * 4 + q, k = c0 + ch * 8;
+    if (k >= K) continue;
+    const float4 lo = *reinterpret_cast<const float4*>(&tile[r][ch * 8]), hi = *reinterpret_cast<const float4*>(&tile[r][ch * 8 + 4]);
+    u32x2 pa[NP], pb[NP];
+    split4<NP>(f32x4{lo.x, lo.y, lo.z, lo.w}, pa);
+    split4<NP>(f32x4{hi.x, hi.y, hi.z, hi.w}, pb);
+    char* const op = dst + ((int64_t)((k >> 4) * NP) * 2 + ((k >> 3) & 1)) * rp16 + (r0 + r) * 16;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<u32x4*>(op + (int64_t)p * 2 * rp16) = u32x4{pa[p].x, pa[p].y, pb[p].x, pb[p].y};
+    }
+  }
+}
+
+}  // namespace
+
+int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* planes, hipStream_t stream) {
+  SUMK_ARG(src && planes && rows >= 1 && K >= 16 && K % 16 == 0 && ld >= K && ld % 4 == 0 && (np == 2 || np == 3), "split_planes: bad arguments (K %% 16, ld %% 4, 2 or 3 planes)");
+  SUMK_ARG(((uintptr_t)planes & 15) == 0 && ((uintptr_t)src & 15) == 0, "split_planes: 16-byte aligned buffers");
+  const int64_t rp = pw_rows_pitch(rows);
+  const dim3 grid((unsigned)(rp / 64), (unsigned)((K + 127) / 128));
+  if (np == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, stream, src, rows, K, ld, (char*)planes, rp * 16);
+  else hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, stream, src, rows, K, ld, (char*)planes, rp * 16);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {
+  SUMK_ARG(g.A && g.B && pw_ok(g.M, g.N, g.K, g.a_rows, g.b_rows, g.np), "gemm_pw: M=%d N=%d K=%d planes=%d is not eligible (N %% 256, K %% 32, K >= 128, plane arrays < 2 GiB)", g.M, g.N, g.K, g.np);
+  SUMK_ARG(g.a_rows >= g.M && g.b_rows >= g.N, "gemm_pw: operand planes have fewer rows than the product reads");
+  PwArgs a;
+  a.A = (const char*)g.A; a.B = (const char*)g.B;
+  a.a_rp16 = (uint32_t)(pw_rows_pitch(g.a_rows) * 16); a.b_rp16 = (uint32_t)(pw_rows_pitch(g.b_rows) * 16);
+  a.M = g.M; a.N = g.N; a.K = g.K;
+  a.tiles_m = (g.M + 191) / 192; a.tiles_n = g.N / 256;
+  a.xcd_map = (a.tiles_n % 4 == 0 && a.tiles_m >= 16) ? 1 : 0;
+  a.total_tiles = a.xcd_map ? 8 * ((a.tiles_m + 1) / 2) * (a.tiles_n / 4) : a.tiles_m * a.tiles_n;
+  a.C = g.C; a.ldc = g.ldc; a.O = (char*)g.O; a.o_rp16 = pw_rows_pitch(g.o_rows) * 16; a.R = g.R; a.ldr = g.ldr; a.moments = g.moments;
+  a.bias = g.bias; a.gw = g.gw; a.ln_c1 = g.ln_c1; a.ln_stats = g.ln_stats; a.head_part = g.head_part;
+  switch (epi) {
+    case PW_F32: SUMK_ARG(g.C && g.ldc >= g.N, "gemm_pw: fp32 output missing"); break;
+    case PW_PLANES: SUMK_ARG(g.O && g.o_rows >= g.M, "gemm_pw: plane output missing"); break;
+    case PW_RES_MOM_PLANES: SUMK_ARG(g.O && g.o_rows >= g.M && g.R && g.ldr >= g.N && g.ldr % 4 == 0 && g.moments, "gemm_pw: residual / moments / plane output missing"); break;
+    case PW_HEAD: SUMK_ARG(g.bias && g.gw && g.ln_c1 && g.ln_stats && g.head_part, "gemm_pw: head epilogue operands missing"); break;
+  }
+  if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
+  prof_begin(SUMK_PROF_GEMM_ALL, stream);
+  const int rc = g.np == 3 ? launch_np<3, 3>(epi, a, g.variant, stream) : launch_np<2, 4>(epi, a, g.variant, stream);
+  prof_end(SUMK_PROF_GEMM_ALL, stream);
+  if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
+  return rc;
+}
+
+}  // namespace sumk
+
+// ------------------------------------------------------------------------------------------- C ABI (tests, probes, host-side caches)
+extern "C" size_t sumk_planes_bytes(int64_t rows, int32_t K, int32_t n_planes) {
+  if (rows < 1 || K < 16 || K % 16 != 0 || (n_planes != 2 && n_planes != 3)) return 0;
+  return sumk::pw_planes_bytes(rows, K, n_planes);
+}
+
+extern "C" int sumk_split_planes(const float* src, int64_t rows, int32_t K, int32_t ld, int32_t n_planes, void* planes, void* stream) {
+  return sumk::split_planes(src, rows, K, ld, n_planes, planes, (hipStream_t)stream);
+}
+
+extern "C" int sumk_gemm_planes(const void* A_planes, int64_t a_rows, const void* B_planes, int64_t b_rows, float* C, int32_t M, int32_t N,
+                                int32_t K, int32_t n_planes, int32_t variant, void* stream) {
+  using namespace sumk;
+  PwLaunch g;
+  g.A = A_planes; g.B = B_planes; g.a_rows = a_rows; g.b_rows = b_rows; g.M = M; g.N = N; g.K = K; g.np = n_planes; g.C = C; g.ldc = N;
+  g.variant = variant;
+  return launch_gemm_pw(PW_F32, g, (hipStream_t)stream);
+}

@@ -272,6 +272,45 @@ struct SlabIn {
   float* store = nullptr;
 };
 
+// ------------------------------------------------------------------------------------------- plane-aware wide GEMM (gemm_pw.hip)
+// "KB planes": an fp32 matrix X (rows x K, K % 16 == 0) held as NP = 2 (hi + lo: bf16x3) or 3 (x1 + x2 + x3 = x EXACTLY: bf16x6)
+// bf16 planes, k-blocked so that the GEMM's LDS-DMA reads and the producers' stores are whole contiguous runs:
+//   byte offset of element (row, k) of plane p = (((k / 16) * NP + p) * 2 + (k / 8) % 2) * rp16 + row * 16 + (k % 8) * 2,
+//   rp16 = 16 * rows_pitch (rows rounded up to 64): [k16 block][plane][k half][row][8 bf16].
+// One (k16 block, plane, half) sub-array is `rows` 16-byte chunks -- exactly the lane fragment of v_mfma_f32_32x32x16_bf16 -- so 64
+// consecutive rows of it are one 1-KiB LDS-DMA instruction, and the LDS image [plane][half][row] is read by ds_read_b128 without bank
+// conflicts and without padding.  Planes are written ONCE: x per dataset, weights per weight change, activations by the epilogue of
+// the kernel that produced them -- no fp32 -> bf16 split inside any k-loop (the in-loop split of gemm_regstage.h kept the matrix
+// pipe at 0.3-0.5 busy).  pw_planes_bytes includes the slack a row tile may read past the last sub-array.
+inline int64_t pw_rows_pitch(int64_t rows) { return (rows + 63) / 64 * 64; }
+inline size_t pw_planes_bytes(int64_t rows, int K, int np) { return (size_t)pw_rows_pitch(rows) * K * np * 2 + 8192; }
+int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* planes, hipStream_t stream);
+enum PwEpi {
+  PW_F32 = 0,             // C (fp32, row-major, ldc) = product
+  PW_PLANES = 1,          // O (KB planes of the (M, N) result: the K-contiguous operand of a later product over N) = product
+  PW_RES_MOM_PLANES = 2,  // v = product + R; moments float2[M][N / 64] {sum v, sum v^2} per 64-column slot; O = planes of v
+  PW_HEAD = 3,            // v = relu(rstd_m (product - mean_m c1[n]) + bias[n]) is NOT stored: head_part float4[M][N / 64] {sum v, sum v^2, sum v gw[n], 0}
+};
+struct PwLaunch {
+  const void* A = nullptr; const void* B = nullptr;    // KB planes of A (M x K) and B (N x K): C = A B^T
+  int64_t a_rows = 0, b_rows = 0;                      // rows the plane arrays were built for (their pitch = pw_rows_pitch)
+  int32_t M = 0, N = 0, K = 0, np = 3;
+  float* C = nullptr; int32_t ldc = 0;
+  void* O = nullptr; int64_t o_rows = 0;
+  const float* R = nullptr; int32_t ldr = 0;
+  float* moments = nullptr;
+  const float* bias = nullptr; const float* gw = nullptr; const float* ln_c1 = nullptr; const float* ln_stats = nullptr; float* head_part = nullptr;
+  int32_t prof_tag = -1;
+  int32_t variant = 0;                                  // schedule variant (probes; 0 = the product's)
+};
+// M >= 1, N % 256 == 0, K % 32 == 0, K >= 128, plane arrays below 2^31 bytes
+inline int pw_ok(int64_t M, int64_t N, int64_t K, int64_t a_rows, int64_t b_rows, int np) {
+  const int64_t lim = ((int64_t)1 << 31) - 65536;
+  return (M >= 1 && N % 256 == 0 && K % 32 == 0 && K >= 128 && (np == 2 || np == 3) &&
+          (int64_t)pw_planes_bytes(a_rows, (int)K, np) < lim && (int64_t)pw_planes_bytes(b_rows, (int)K, np) < lim) ? 1 : 0;
+}
+int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
 // Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.
 int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int n_rows, int D, float eps, float* stats,

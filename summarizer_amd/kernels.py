@@ -183,6 +183,34 @@ def vasnet_x16(x, sb=None):
     return tensor_shadow(x, "x16", build)
 
 
+# ------------------------------------------------------------------------------------------------ KB planes (csrc/gemm_pw.hip)
+PLANES_OF = {"bf16x6": 3, "bf16x3": 2}      # planes per operand of the split-bf16 arithmetics
+
+
+def split_planes(x, n_planes):
+    """fp32 (rows, K) row-major GPU tensor -> its KB-plane array (uint8 tensor; layout: include/sumk.h "KB planes")."""
+    lib = _lib.load()
+    _require_gpu(x, "split_planes")
+    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) % 4 != 0:
+        raise SumkError("split_planes: a 2-D row-major tensor with a leading dimension that is a multiple of 4")
+    rows, K = x.shape
+    nb = lib.sumk_planes_bytes(rows, K, n_planes)
+    if nb == 0:
+        raise SumkError(f"split_planes: rows={rows} K={K} planes={n_planes} is not representable (K % 16, 2 or 3 planes)")
+    out = torch.zeros(nb, dtype=torch.uint8, device=x.device)      # (zeros: the slack behind the last sub-array is read by row tiles)
+    _lib.check(lib.sumk_split_planes(_p(x), rows, K, x.stride(0), n_planes, _p(out), _stream()), "sumk_split_planes")
+    return out
+
+
+def gemm_planes(a_planes, a_rows, b_planes, b_rows, M, N, K, n_planes, variant=0, out=None):
+    """C (M, N) fp32 = A . B^T from two KB-plane arrays (tests / bench probe of the plane-aware wide GEMM)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
+    _lib.check(lib.sumk_gemm_planes(_p(a_planes), a_rows, _p(b_planes), b_rows, _p(out), M, N, K, n_planes, variant, _stream()), "sumk_gemm_planes")
+    return out
+
+
 def fold_vo(w_o, w_v, out=None):
     """Wvo = Wo . Wv (D, D) for the folded inference path (sumk_vasnet_forward_folded); one fp32 MFMA GEMM."""
     lib = _lib.load()
