@@ -83,6 +83,14 @@ typedef struct sumk_vasnet_opts {
      are constant over the epochs of a run while the weights change every step, and x is 70 % of the elements the per-step cast kernel
      converts.  Ignored by every other mode.  Not allowed together with pos_table (which changes x in place). */
   const void* x16;
+  /* NULL, or -- for inference in SUMK_PRECISION_BF16X6 / BF16X3 -- the "KB planes" (below) of the SAME x (n_rows x D; 3 resp. 2 planes)
+     written by sumk_split_planes, and the weight-plane block written by sumk_vasnet_wplanes_build for the SAME weights and plane count.
+     With both given (and D % 256 == 0, n_rows >= 256, no pos_table) the three row-wise GEMMs of the call -- K/Q/V projection, output
+     projection, k1 (vasnet.py:114-116,132,138) -- run on the plane-aware wide kernel (csrc/gemm_pw.hip): no fp32 -> bf16 split inside any
+     k-loop.  Same arithmetic as without them (the planes are the roundings the in-loop kernels make), faster.  x planes are constant per
+     dataset, weight planes per weight change; stale planes give wrong results, not errors. */
+  const void* xplanes;
+  const void* wplanes;
 } sumk_vasnet_opts;
 
 
@@ -93,6 +101,14 @@ size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_
  * runs on never depends on the workspace it is handed: a bf16 training step given the smaller workspace is refused
  * (SUMK_ERR_WORKSPACE), so a forward and a backward pass cannot end up on different paths. */
 size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training, int32_t precision);
+
+/* Weight-plane block of sumk_vasnet_opts::wplanes: bytes (0 = D or n_planes not eligible: D % 256, n_planes 2 or 3), and the build --
+ * planes of [Wq; Wk; Wv] (Wvo != NULL: [Wq; Wk; Wvo], the folded path of sumk_vasnet_forward_folded), of Wo, of k1's weight with the
+ * LayerNorm gain folded in (W1 diag(ln_w)), and the three per-column vectors of the fused tail.  256-byte aligned device buffer; redo
+ * after every weight change. */
+size_t sumk_vasnet_wplanes_bytes(int32_t D, int32_t n_planes);
+int sumk_vasnet_wplanes_build(int32_t D, const sumk_vasnet_weights* w, const float* Wvo, int32_t n_planes, void* out, size_t out_bytes,
+                              void* stream);
 
 /* Problem tables of a batch, separately (sumk_vasnet_opts::tables): size, and the one-time build (the setup kernels of a call, run into
  * `tables` instead of the workspace).  256-byte aligned device buffer. */

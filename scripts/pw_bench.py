@@ -10,6 +10,8 @@ import torch
 from summarizer_amd import kernels, _lib
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+VARIANTS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 0, 1, 4, 5, 6]
+STAMPS = "libsumk_diag" in os.environ.get("SUMK_LIB_PATH", "")
 lib = _lib.load()
 dev = torch.device("cuda:0")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -37,8 +39,20 @@ for (M, N, K) in [(12003, 3072, 1024), (12003, 1024, 1024), (12003, 2048, 1024)]
         ap, bp = kernels.split_planes(a, npl), kernels.split_planes(b, npl)
         med, best = timeit(lambda: lib.sumk_gemm_prec(0, a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, prec, st))
         print(f"M={M} N={N} K={K} planes={npl}  in-loop split: {med:8.1f} us (best {best:8.1f})  {fl / med / 1e6:7.1f} TF = {fl / med / 1e6 / peak:.3f} of {peak:.0f}")
-        for variant in (0, 1, 2):
+        for variant in VARIANTS:
             med, best = timeit(lambda: kernels.gemm_planes(ap, M, bp, N, M, N, K, npl, variant=variant, out=c))
             print(f"M={M} N={N} K={K} planes={npl}  gemm_pw var {variant}: {med:8.1f} us (best {best:8.1f})  {fl / med / 1e6:7.1f} TF = {fl / med / 1e6 / peak:.3f} of {peak:.0f}")
+        if STAMPS:       # diagnostic build: variant 3 leaves per-block cycle stamps in the front of C
+            import numpy as np
+            for _ in range(30):
+                kernels.gemm_planes(ap, M, bp, N, M, N, K, npl, variant=3, out=c)
+            torch.cuda.synchronize()
+            st_ = c.view(-1)[:256 * 16].cpu().numpy().view(np.uint64).reshape(256, 8)
+            tot, loop, epi, nt, rt = (st_[:, i].astype(np.float64) for i in range(5))
+            clk = tot / rt * 100.0          # MHz: shader cycles per 100 MHz tick
+            steps = nt * (K // 16)
+            print(f"   stamps planes={npl}: block total {np.median(tot):.0f} cyc (max {tot.max():.0f}), k-loop {np.median(loop / tot):.3f}, epilogue {np.median(epi / tot):.3f} of it, "
+                  f"tiles/block {nt.min():.0f}-{nt.max():.0f}, cycles per k16 step {np.median(loop / steps):.0f} (MFMA floor {36 * 32 * 2 if npl == 3 else 18 * 32 * 2}), "
+                  f"epilogue per tile {np.median(epi / nt):.0f} cyc, clock {np.median(clk):.0f} MHz (min {clk.min():.0f}), wall {np.median(rt) / 100:.1f} us")
         med, best = timeit(lambda: kernels.split_planes(a, npl))
         print(f"   split_planes({M} x {K}, {npl}): {med:.1f} us")

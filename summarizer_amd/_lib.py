@@ -31,7 +31,8 @@ class VasnetGrads(C.Structure):
 
 class VasnetOpts(C.Structure):
     _fields_ = [("scale", C.c_float), ("eps", C.c_float), ("ignore_self", C.c_int32), ("aperture", C.c_int32),
-                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32), ("seed_dev", C.c_void_p), ("tables", C.c_void_p), ("x16", C.c_void_p)]
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32), ("seed_dev", C.c_void_p), ("tables", C.c_void_p), ("x16", C.c_void_p),
+                ("xplanes", C.c_void_p), ("wplanes", C.c_void_p)]
 
 
 class LstmDirWeights(C.Structure):
@@ -87,6 +88,8 @@ _SIGS = {
     "sumk_vasnet_workspace_bytes_for": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P, C.c_int32, C.c_int32]),
     "sumk_vasnet_tables_bytes": (C.c_size_t, [C.c_int32, C.c_int32, HOST_I32P]),
     "sumk_vasnet_build_tables": (C.c_int, [C.c_int32, C.c_int32, HOST_I32P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sumk_vasnet_wplanes_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sumk_vasnet_wplanes_build": (C.c_int, [C.c_int32, C.POINTER(VasnetWeights), c_f32p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_vasnet_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, HOST_I32P, c_i32p, C.POINTER(VasnetWeights),
                                       C.POINTER(VasnetOpts), c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
                                       C.c_int32, C.c_void_p]),

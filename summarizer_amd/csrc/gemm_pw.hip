@@ -72,7 +72,13 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const bool early = VAR == 1 ? true : VAR == 2 ? false : wave < 4;      // when this wave issues its DMA pieces inside a step
+  // Schedule variants (probes; the product runs VAR = 2).  When does a wave issue the DMA pieces that refill the slot a barrier freed?
+  //   0: waves 0-3 right behind the barrier, waves 4-7 after the step's last MFMAs;  1: every wave right behind the barrier;
+  //   2, 3, 5, 6: every wave after the step's last MFMAs (3: + cycle stamps, diagnostic build; 5: barrier after one third of the MFMAs
+  //   instead of two thirds; 6: + s_setprio around the MFMA groups);  4: spread between the MFMA groups of the NEXT step's first part.
+  const bool early = VAR == 1 ? true : (VAR == 0 ? wave < 4 : false);
+  constexpr bool SPREAD = VAR == 4, PRIO = VAR == 6;
+  constexpr int P1 = (VAR == 5 && TM > 2) ? TM - 2 : TM - 1;             // MFMA row tiles in front of the barrier
 
   // DMA pieces: a stage is NSUB sub-arrays x (PA + PB) blocks of 64 rows; wave w < PA + PB owns row block w of EVERY sub-array (waves
   // 0 .. PA - 1: blocks of A, the next PB: blocks of B; wave 7 issues none) -- one descriptor, one row offset and one LDS offset per
@@ -88,14 +94,16 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
   const int lsub = dma_a ? LSUB_A : LSUB_B;
   const int vlane = lane * 16;
   const int k_step = NSUB * rp16;                                       // bytes per k16 block
-  auto dma = [&](int m0, int n0, int kb, int slot) {
+  auto dma_some = [&](int m0, int n0, int kb, int slot, int first, int stride) {      // sub-arrays first, first + stride, ...
     if (!dma_wave) return;
     char* const st = lds + slot * STAGE + lds_blk;
     const int g0 = kb * k_step + ((dma_a ? m0 : n0) + blk * 64) * 16;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + sub * lsub), 16, vlane, g0 + sub * rp16, 0, 0);
+      if (sub >= first && (sub - first) % stride == 0)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + sub * lsub), 16, vlane, g0 + sub * rp16, 0, 0);
   };
+  auto dma = [&](int m0, int n0, int kb, int slot) { dma_some(m0, n0, kb, slot, 0, 1); };
   constexpr int IN_FLIGHT = (NS - 2) * NSUB;                            // DMA instructions of this wave that may stay in flight across a step's barrier
 
   // fragments: plane p, MFMA tile t of this wave -> 16 bytes per lane
@@ -111,12 +119,13 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
       for (int t = 0; t < TM; ++t) f.a[p][t] = *reinterpret_cast<const bf16x8*>(st + fa + p * 2 * BM * 16 + t * 512);
     }
   };
-  auto mfma_rows = [&](const Frags& f, f32x16 (&acc)[TM][TN], int tm_lo, int tm_hi) {
+  auto mfma_rows = [&](const Frags& f, f32x16 (&acc)[TM][TN], int tm_lo, int tm_hi, int tn_only) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       if (tm < tm_lo || tm >= tm_hi) continue;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
+        if (tn_only >= 0 && tn != tn_only) continue;
 #pragma unroll
         for (int sum = NP - 1; sum >= 0; --sum)          // planes (i, j) with i + j descending: smallest products first
 #pragma unroll
@@ -147,6 +156,10 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
   };
 
   const int nk = a.K >> 4;
+#ifdef SUMK_DIAG
+  unsigned long long t_start = 0, t_loop = 0, t_epi = 0, rt_start = 0, n_tiles = 0;
+  if constexpr (VAR == 3) { t_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
+#endif
   int tile = blockIdx.x, m0 = 0, n0 = 0;
   if (tile >= a.total_tiles || !decode(tile, m0, n0)) return;
 #pragma unroll
@@ -180,15 +193,34 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
     // ---- k loop: stage s lives in slot s % NS; Frags[s & 1]
     wait_vm<0>();                      // (start of a tile: the previous epilogue's stores share the counter: drain; stages 1.. are mostly there by now)
     __builtin_amdgcn_s_barrier();
+#ifdef SUMK_DIAG
+    unsigned long long t0 = 0;
+    if constexpr (VAR == 3) t0 = __builtin_amdgcn_s_memtime();
+#endif
     Frags F0, F1;
     read_frags(0, F0);
     int slot = 0;
     // MAIN: steady state (stage s + NS exists: refill the slot of stage s; stages s + 2 .. s + NS - 1 stay in flight across the barrier).
     // !MAIN: the last steps of a tile (run-time conditions, full drain before the barrier).
+    int pslot = 0;                      // SPREAD: the slot the previous step's barrier freed
     auto kstep = [&](auto main_, const Frags& cur, Frags& nxt, int s) {
       constexpr bool MAIN = decltype(main_)::value;
       __builtin_amdgcn_sched_barrier(0);
-      mfma_rows(cur, acc, 0, TM - 1);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+      if constexpr (SPREAD) {
+        const bool pend = s >= 1 && s - 1 + NS < nk;
+        constexpr int G = P1 * TN;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          mfma_rows(cur, acc, g / TN, g / TN + 1, g % TN);
+          __builtin_amdgcn_sched_barrier(0);
+          if (pend && g < NSUB) dma_some(m0, n0, s - 1 + NS, pslot, g, G);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        mfma_rows(cur, acc, 0, P1, -1);
+      }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       const bool more = MAIN || s + 1 < nk, fill = MAIN || s + NS < nk;
       const int nslot = slot + 1 == NS ? 0 : slot + 1;
@@ -197,12 +229,15 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
         __builtin_amdgcn_s_barrier();                         // stage s + 1 has landed; every wave is past its reads of stage s
         read_frags(nslot, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        if (fill && early) dma(m0, n0, s + NS, slot);
+        if (!SPREAD && fill && early) dma(m0, n0, s + NS, slot);
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_rows(cur, acc, TM - 1, TM);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+      mfma_rows(cur, acc, P1, TM, -1);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (more && fill && !early) dma(m0, n0, s + NS, slot);
+      if (!SPREAD && more && fill && !early) dma(m0, n0, s + NS, slot);
+      pslot = slot;
       slot = nslot;
     };
     int s = 0;
@@ -217,6 +252,10 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
 
     // ---- next tile's first stages go out under this tile's epilogue
     lds_barrier();                     // every wave is past its last fragment read
+#ifdef SUMK_DIAG
+    unsigned long long t1 = 0;
+    if constexpr (VAR == 3) t1 = __builtin_amdgcn_s_memtime();
+#endif
     const int next_tile = tile + gridDim.x;
     int m1 = 0, n1 = 0;
     const bool has_next = next_tile < a.total_tiles && decode(next_tile, m1, n1);
@@ -299,9 +338,22 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef SUMK_DIAG
+    if constexpr (VAR == 3) { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_loop += t1 - t0; t_epi += t2 - t1; n_tiles += 1; }
+#endif
     if (!has_next) break;
     tile = next_tile; m0 = m1; n0 = n1;
   }
+#ifdef SUMK_DIAG
+  if constexpr (VAR == 3 && EPI == PW_F32) {     // diagnostic build only: the stamps OVERWRITE the first floats of C (scripts/pw_bench.py reads them)
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(a.C) + (size_t)blockIdx.x * 8;
+      o[0] = __builtin_amdgcn_s_memtime() - t_start; o[1] = t_loop; o[2] = t_epi; o[3] = n_tiles;
+      o[4] = __builtin_amdgcn_s_memrealtime() - rt_start; o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20 /* XCC_ID */);
+    }
+  }
+#endif
 }
 
 std::atomic<uint64_t> g_attr_done[64];      // per kernel instance (index below): bit d = device d has the dynamic-LDS opt-in
@@ -328,12 +380,18 @@ int launch_np(PwEpi epi, const PwArgs& a, int variant, hipStream_t s) {
   constexpr int base = NP == 3 ? 0 : 16;
   switch (epi) {
     case PW_F32:
-      if (variant == 1) return launch_one<NP, 192, PW_F32, NS, 1>(a, base + 4, s);
-      if (variant == 2) return launch_one<NP, 192, PW_F32, NS, 2>(a, base + 5, s);
-      return launch_one<NP, 192, PW_F32, NS, 0>(a, base + 0, s);
-    case PW_PLANES: return launch_one<NP, 192, PW_PLANES, NS, 0>(a, base + 1, s);
-    case PW_RES_MOM_PLANES: return launch_one<NP, 192, PW_RES_MOM_PLANES, NS, 0>(a, base + 2, s);
-    case PW_HEAD: return launch_one<NP, 192, PW_HEAD, NS, 0>(a, base + 3, s);
+      switch (variant) {
+        case 0: return launch_one<NP, 192, PW_F32, NS, 0>(a, base + 4, s);
+        case 1: return launch_one<NP, 192, PW_F32, NS, 1>(a, base + 5, s);
+        case 3: return launch_one<NP, 192, PW_F32, NS, 3>(a, base + 6, s);
+        case 4: return launch_one<NP, 192, PW_F32, NS, 4>(a, base + 7, s);
+        case 5: return launch_one<NP, 192, PW_F32, NS, 5>(a, base + 8, s);
+        case 6: return launch_one<NP, 192, PW_F32, NS, 6>(a, base + 9, s);
+        default: return launch_one<NP, 192, PW_F32, NS, 2>(a, base + 0, s);
+      }
+    case PW_PLANES: return launch_one<NP, 192, PW_PLANES, NS, 2>(a, base + 1, s);
+    case PW_RES_MOM_PLANES: return launch_one<NP, 192, PW_RES_MOM_PLANES, NS, 2>(a, base + 2, s);
+    case PW_HEAD: return launch_one<NP, 192, PW_HEAD, NS, 2>(a, base + 3, s);
   }
   set_error("gemm_pw: bad epilogue %d", (int)epi);
   return SUMK_ERR_ARG;
@@ -376,15 +434,20 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 }  // namespace
 
-int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* planes, hipStream_t stream) {
+int split_planes_at(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t row0, int64_t total_rows, hipStream_t stream) {
   SUMK_ARG(src && planes && rows >= 1 && K >= 16 && K % 16 == 0 && ld >= K && ld % 4 == 0 && (np == 2 || np == 3), "split_planes: bad arguments (K %% 16, ld %% 4, 2 or 3 planes)");
   SUMK_ARG(((uintptr_t)planes & 15) == 0 && ((uintptr_t)src & 15) == 0, "split_planes: 16-byte aligned buffers");
-  const int64_t rp = pw_rows_pitch(rows);
-  const dim3 grid((unsigned)(rp / 64), (unsigned)((K + 127) / 128));
-  if (np == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, stream, src, rows, K, ld, (char*)planes, rp * 16);
-  else hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, stream, src, rows, K, ld, (char*)planes, rp * 16);
+  SUMK_ARG(row0 >= 0 && row0 % 64 == 0 && row0 + rows <= total_rows && (row0 + rows == total_rows || rows % 64 == 0), "split_planes: a stacked part starts and ends on a 64-row boundary");
+  const int64_t rp = pw_rows_pitch(total_rows);
+  const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((K + 127) / 128));
+  char* const dst = (char*)planes + row0 * 16;
+  if (np == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, stream, src, rows, K, ld, dst, rp * 16);
+  else hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, stream, src, rows, K, ld, dst, rp * 16);
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
+}
+int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* planes, hipStream_t stream) {
+  return split_planes_at(src, rows, K, ld, np, planes, 0, rows, stream);
 }
 
 int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {

@@ -285,6 +285,9 @@ struct SlabIn {
 inline int64_t pw_rows_pitch(int64_t rows) { return (rows + 63) / 64 * 64; }
 inline size_t pw_planes_bytes(int64_t rows, int K, int np) { return (size_t)pw_rows_pitch(rows) * K * np * 2 + 8192; }
 int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* planes, hipStream_t stream);
+// the same into rows [row0, row0 + rows) of a plane array built for `total_rows` rows (row0 % 64 == 0; pad rows are written only behind the
+// LAST row of the array): stacking several matrices into one operand ([Wq; Wk; Wv])
+int split_planes_at(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t row0, int64_t total_rows, hipStream_t stream);
 enum PwEpi {
   PW_F32 = 0,             // C (fp32, row-major, ldc) = product
   PW_PLANES = 1,          // O (KB planes of the (M, N) result: the K-contiguous operand of a later product over N) = product

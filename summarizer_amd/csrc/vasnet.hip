@@ -803,6 +803,40 @@ __global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restr
   stats[row] = make_float2((float)mean, (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps)));
 }
 
+// {mean, rstd} per row from the slot moments of a GEMM epilogue (the second half of ln_fold_stats_kernel by itself: the plane path keeps
+// the weight fold in its per-weight-change block, sumk_vasnet_wplanes_build)
+__global__ __launch_bounds__(256) void ln_row_stats_kernel(const float2* __restrict__ moments, int slots, int n_rows, int D, float eps,
+                                                           float2* __restrict__ stats) {
+  const int row = (int)blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double s1 = 0.0, s2 = 0.0;
+  if (row < n_rows)
+    for (int k = sub; k < slots; k += 8) { const float2 p = moments[(int64_t)row * slots + k]; s1 += p.x; s2 += p.y; }
+#pragma unroll
+  for (int m = 1; m <= 4; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (row >= n_rows || sub != 0) return;
+  const double mean = s1 / D, var = s2 / D - mean * mean;
+  stats[row] = make_float2((float)mean, (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps)));
+}
+// biasc = b1 + c2 (k1's bias + the LayerNorm shift seen through W1), gw = ln_w * w2: the per-column vectors of the PW_HEAD epilogue
+__global__ void head_vectors_kernel(const float* __restrict__ b1, const float* __restrict__ c2, const float* __restrict__ ln_w,
+                                    const float* __restrict__ w2, int D, float* __restrict__ biasc, float* __restrict__ gw) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < D) { biasc[n] = b1[n] + c2[n]; gw[n] = ln_w[n] * w2[n]; }
+}
+
+// Weight-plane block of the plane path (sumk_vasnet_opts::wplanes): everything that depends on the weights only.
+struct WPlanes { size_t wqkv, wo, w1g, c1, biasc, gw, tmp, total; };
+static WPlanes wplanes_layout(int D, int np) {
+  WPlanes l; size_t p = 0;
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  l.wqkv = take(pw_planes_bytes(3 * (int64_t)D, D, np)); l.wo = take(pw_planes_bytes(D, D, np)); l.w1g = take(pw_planes_bytes(D, D, np));
+  l.c1 = take((size_t)D * 4); l.biasc = take((size_t)D * 4); l.gw = take((size_t)D * 4);
+  l.tmp = take((size_t)D * D * 4 + (size_t)D * 4);        // build scratch: fp32 W1 diag(ln_w), c2
+  l.total = p;
+  return l;
+}
+static bool wplanes_ok(int D, int np) { return D >= 256 && D % 256 == 0 && (np == 2 || np == 3) && pw_ok(256, 3 * (int64_t)D, D, 256, 3 * (int64_t)D, np); }
+
 // one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
 template <bool HEAD>
 static void launch_ln_rows(const float* X, float* Y, const float* g, const float* b, const float* w2, const float* b2, float* scores,
@@ -1307,6 +1341,32 @@ extern "C" int sumk_vasnet_build_tables(int32_t D, int32_t n_seq, const int32_t*
   return SUMK_OK;
 }
 
+extern "C" size_t sumk_vasnet_wplanes_bytes(int32_t D, int32_t n_planes) {
+  return wplanes_ok(D, n_planes) ? wplanes_layout(D, n_planes).total : 0;
+}
+
+extern "C" int sumk_vasnet_wplanes_build(int32_t D, const sumk_vasnet_weights* w, const float* Wvo, int32_t n_planes, void* out, size_t out_bytes,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(wplanes_ok(D, n_planes), "vasnet_wplanes_build: D=%d planes=%d is not eligible (D %% 256, 2 or 3 planes)", D, n_planes);
+  SUMK_ARG(w && w->Wk && w->Wq && w->Wv && w->Wo && w->W1 && w->b1 && w->w2 && w->ln_w && w->ln_b && out, "vasnet_wplanes_build: null pointer");
+  const WPlanes l = wplanes_layout(D, n_planes);
+  SUMK_ARG(out_bytes >= l.total && ((uintptr_t)out & 255) == 0, "vasnet_wplanes_build: buffer of %zu bytes (256-byte aligned) needed, got %zu", l.total, out_bytes);
+  char* o = (char*)out;
+  SUMK_HIP(hipMemsetAsync(o, 0, l.c1, stream));           // (the slack behind each plane array is read by row tiles: keep it finite)
+  const float* parts[3] = {w->Wq, w->Wk, Wvo ? Wvo : w->Wv};
+  for (int i = 0; i < 3; ++i) SUMK_TRY(split_planes_at(parts[i], D, D, D, n_planes, o + l.wqkv, (int64_t)i * D, 3 * (int64_t)D, stream));
+  SUMK_TRY(split_planes(w->Wo, D, D, D, n_planes, o + l.wo, stream));
+  float* W1g = (float*)(o + l.tmp); float* c2 = W1g + (size_t)D * D;
+  hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, W1g, (float*)(o + l.c1), c2,
+                     (const float2*)nullptr, 0, 0, 0.f, (float2*)nullptr);
+  SUMK_HIP(hipGetLastError());
+  SUMK_TRY(split_planes(W1g, D, D, D, n_planes, o + l.w1g, stream));
+  hipLaunchKernelGGL(head_vectors_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, w->b1, c2, w->ln_w, w->w2, D, (float*)(o + l.biasc), (float*)(o + l.gw));
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
 extern "C" size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training) {
   VasnetWs w;
   if (carve(D, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
@@ -1450,6 +1510,18 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
 
   // row-wise NT GEMMs with K = D: eligible for the buffer-load instances when D is a whole number of k-tiles and byte offsets fit 31 bits
   const int lean_rows = (D % 32 == 0 && (int64_t)R * 3 * D * 4 < ((int64_t)1 << 31)) ? 1 : 0;
+  // Plane path (inference in bf16x6 / bf16x3 with the caller's x planes and weight-plane block): the three row-wise GEMMs on gemm_pw.hip.
+  // (A/B: a call without the plane pointers runs the in-loop split kernels; tests/test_gpu_planes.py compares the two.)
+  const int np = opts->precision == SUMK_PRECISION_BF16X6 ? 3 : opts->precision == SUMK_PRECISION_BF16X3 ? 2 : 0;
+  const bool pw = np && !training && opts->xplanes && opts->wplanes && !pos_table && wplanes_ok(D, np) && R >= 256 && G.st_qkv == 0 &&
+                  G.st_d == 0 && pw_ok(R, 3 * (int64_t)D, D, R, 3 * (int64_t)D, np) && (Wvo == nullptr || G.cfg_pv == 1);
+  const WPlanes wl = pw ? wplanes_layout(D, np) : WPlanes();
+  const char* const wp = (const char*)opts->wplanes;
+  if (pw) {  // 1: QKV projection from planes (fp32 output: the per-video products below read it)
+    PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
+    g.C = QKV; g.ldc = 3 * D; g.prof_tag = SUMK_PROF_GEMM_QKV;
+    SUMK_TRY(launch_gemm_pw(PW_F32, g, stream));
+  } else
   {  // 1: QKV projection
     GemmLaunch g; g.precision = opts->precision;
     g.A = x; g.B[0] = w->Wq; g.B[1] = w->Wk; g.B[2] = Wvo ? Wvo : w->Wv; g.n_group = D; g.C = QKV; g.probs = prow + RP_QKV;
@@ -1502,8 +1574,14 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   // alpha.(X Wvo) product with the residual (64x64 tiles, D / 16 slots)
   const int ln_slots = Wvo ? D / 16 : D / 32;
   const size_t ln_mom_f = align_up((size_t)R * ln_slots * 2, 64), ln_w_f = (size_t)D * D, ln_c_f = align_up((size_t)2 * D, 64);
-  const bool fused_ln = fused_tail && fused_ln_on && (!Wvo || G.cfg_pv == 1) && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D;
-  float* ln_moments = Y1;
+  const bool fused_ln = pw || (fused_tail && fused_ln_on && (!Wvo || G.cfg_pv == 1) && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D);
+  // plane path: CTX planes span the Y0 / Y1 regions, Y0's planes take the (by then dead) fp32 Q/K/V region, the small per-row arrays live in Z
+  char* const pw_ctxp = ws + L.y0;
+  char* const pw_y0p = ws + L.qkv;
+  float* const pw_mom = Z;                                                        // float2[R][slots]
+  float* const pw_stats = Z + align_up((size_t)R * (D / 16) * 2, 64);             // float2[R]
+  float* const pw_part = pw_stats + align_up((size_t)R * 2, 64);                  // float4[R][D / 64]
+  float* ln_moments = pw ? pw_mom : Y1;
   float* ln_W1g = Y1 + ln_mom_f;
   float* ln_c1 = ln_W1g + ln_w_f;
   float* ln_stats = ln_c1 + ln_c_f;
@@ -1514,12 +1592,25 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     if (Wvo && fused_ln) g.moments = ln_moments;
     if (b16) { g.A = (const float*)(ws + L.p16); g.B[0] = (const float*)(ws + L.qkv16); g.src16 = 1; g.C16 = ws + L.ctx16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NN, Wvo ? (fused_ln ? EPI_RESIDUAL_MOMENTS : EPI_RESIDUAL) : EPI_NONE, g, stream));
+    if (Wvo && pw) {        // folded plane path: Y0 (fp32, with its moments) -> {mean, rstd}, and its planes for k1
+      hipLaunchKernelGGL(ln_row_stats_kernel, dim3((R + 31) / 32), dim3(256), 0, stream, (const float2*)pw_mom, ln_slots, R, D, opts->eps, (float2*)pw_stats);
+      SUMK_HIP(hipGetLastError());
+      SUMK_TRY(split_planes(Y0, R, D, D, np, pw_y0p, stream));
+    } else
     if (Wvo && fused_ln) {
       hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(D + (R + 31) / 32), dim3(256), 0, stream, w->W1, w->ln_w, w->ln_b, D, ln_W1g, ln_c1,
                          ln_c1 + D, (const float2*)ln_moments, ln_slots, R, opts->eps, (float2*)ln_stats);
       SUMK_HIP(hipGetLastError());
     }
   }
+  if (pw && !Wvo) {  // 5: output projection + residual from planes: CTX is split once, Y0 leaves as planes + per-row moments only
+    SUMK_TRY(split_planes(CTX, R, D, D, np, pw_ctxp, stream));
+    PwLaunch g; g.A = pw_ctxp; g.a_rows = R; g.B = wp + wl.wo; g.b_rows = D; g.M = R; g.N = D; g.K = D; g.np = np;
+    g.R = x; g.ldr = D; g.moments = pw_mom; g.O = pw_y0p; g.o_rows = R; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
+    SUMK_TRY(launch_gemm_pw(PW_RES_MOM_PLANES, g, stream));
+    hipLaunchKernelGGL(ln_row_stats_kernel, dim3((R + 31) / 32), dim3(256), 0, stream, (const float2*)pw_mom, D / 64, R, D, opts->eps, (float2*)pw_stats);
+    SUMK_HIP(hipGetLastError());
+  } else
   if (!Wvo) {  // 5: output projection + residual
     GemmLaunch g; g.precision = opts->precision;
     g.A = CTX; g.B[0] = w->Wo; g.C = Y0; g.R = x; g.probs = prow + RP_DD; g.small_tile = G.st_d;
@@ -1543,6 +1634,16 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   // 7 + 8 fused (inference, 128x128 tiles): k1 + bias + ReLU with the LayerNorm + k2 moments taken in the GEMM epilogue -- the
   // (R, D) activation matrix is neither written (49 MB in the lock-stepped store burst of this single-round launch) nor read
   // back by a LayerNorm kernel.
+  if (pw) {   // 7 + 8: k1 on the RAW Y0 planes with the LayerNorm applied to the product, moments of relu(.) per 64-column slot, then the head
+    PwLaunch g; g.A = pw_y0p; g.a_rows = R; g.B = wp + wl.w1g; g.b_rows = D; g.M = R; g.N = D; g.K = D; g.np = np;
+    g.bias = (const float*)(wp + wl.biasc); g.gw = (const float*)(wp + wl.gw); g.ln_c1 = (const float*)(wp + wl.c1); g.ln_stats = pw_stats;
+    g.head_part = pw_part; g.prof_tag = SUMK_PROF_GEMM_K1;
+    SUMK_TRY(launch_gemm_pw(PW_HEAD, g, stream));
+    hipLaunchKernelGGL(head_finalize_kernel, dim3((R + 31) / 32), dim3(256), 0, stream, (const float4*)pw_part, D / 64, R, D, w->ln_w,
+                       w->ln_b, w->w2, w->b2, opts->eps, scores);
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
   if (fused_tail) {
     GemmLaunch g; g.precision = opts->precision;
     g.A = Y1; g.B[0] = w->W1; g.bias0[0] = w->b1; g.bias1[0] = w->ln_w; g.bias1[1] = w->w2;

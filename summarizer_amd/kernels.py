@@ -139,8 +139,30 @@ def _vasnet_structs(params, opts):
                         -1 if opts.get("aperture") is None else int(opts["aperture"]),
                         float(opts.get("dropout_p", 0.0)), int(opts.get("seed", 0)), precision_code(opts.get("precision")),
                         opts["seed_dev"].data_ptr() if opts.get("seed_dev") is not None else None, opts.get("tables"),
-                        opts["x16"].data_ptr() if opts.get("x16") is not None else None)
+                        opts["x16"].data_ptr() if opts.get("x16") is not None else None,
+                        opts["xplanes"].data_ptr() if opts.get("xplanes") is not None else None,
+                        opts["wplanes"].data_ptr() if opts.get("wplanes") is not None else None)
     return w, o
+
+
+def vasnet_wplanes(params, D, n_planes, wvo=None, out=None):
+    """The weight-plane block of the plane path (sumk_vasnet_opts.wplanes) for the current weights: planes of [Wq; Wk; Wv] (or Wvo),
+    Wo, W1 diag(ln_w) and the fused tail's column vectors.  Returns a 256-byte aligned uint8 tensor, or None when D is not eligible."""
+    lib = _lib.load()
+    nb = lib.sumk_vasnet_wplanes_bytes(int(D), int(n_planes))
+    if nb == 0:
+        return None
+    w = _lib.VasnetWeights()
+    for f, k in VASNET_FIELDS:
+        setattr(w, f, params[k].data_ptr())
+    dev = params[VASNET_FIELDS[0][1]].device
+    if out is None or out.numel() < nb + 256 or out.device != dev:
+        out = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+    base = (out.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.sumk_vasnet_wplanes_build(int(D), C.byref(w), _p(wvo), int(n_planes), C.c_void_p(base), nb, _stream()), "sumk_vasnet_wplanes_build")
+    view = out[base - out.data_ptr():]
+    view._sumk_keep = out
+    return view
 
 
 def tensor_shadow(x, name, build):
@@ -241,6 +263,11 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
     if (training and "x16" not in opts and precision_code(opts.get("precision")) == precision_code("bf16") and pos_table is None
             and x.numel() % 4 == 0 and not x.requires_grad and not torch.cuda.is_current_stream_capturing()):
         opts["x16"] = vasnet_x16(x, sb)        # (an input that asks for dX is an activation, not a dataset: cast per call)
+    n_planes = PLANES_OF.get(opts.get("precision"))
+    if (n_planes and not training and "xplanes" not in opts and opts.get("wplanes") is not None and pos_table is None
+            and D % 256 == 0 and sb.n_rows >= 256 and not torch.cuda.is_current_stream_capturing()):
+        # plane path (csrc/gemm_pw.hip): the operand planes of x are kept with the tensor object (constant per dataset)
+        opts["xplanes"] = tensor_shadow(x, f"planes{n_planes}", lambda: split_planes(x, n_planes))
     w, o = _vasnet_structs(params, opts)
     nbytes = lib.sumk_vasnet_workspace_bytes_for(D, sb.n_seq, sb.off_host_p, int(training), int(o.precision))
     if nbytes == 0:

@@ -139,9 +139,30 @@ class VASNet(nn.Module):
             names = [k for _, k in kernels.VASNET_FIELDS]
             p = self._params()
             return VasnetFunction.apply(xp, sb, self._opts(self.training), table, rows, names, *[p[n] for n in names])
-        scores, _ = kernels.vasnet_forward_packed(xp, sb, self._params(), self._opts(False), table, rows, training=False,
-                                                  wvo=self._folded() if self.fold_vo else None)
+        opts = self._opts(False)
+        wvo = self._folded() if self.fold_vo else None
+        if self.precision in kernels.PLANES_OF and table is None and self.input_size % 256 == 0 and sb.n_rows >= 256:
+            opts["wplanes"] = self._wplanes(wvo)          # split-bf16 scoring on operand planes (csrc/gemm_pw.hip)
+        scores, _ = kernels.vasnet_forward_packed(xp, sb, self._params(), opts, table, rows, training=False, wvo=wvo)
         return scores
+
+    def _weights_key(self):
+        """What a cache derived from the weights must be keyed by: storage addresses and tensor versions (what torch can see) plus
+        kernels.WEIGHTS_EPOCH (bumped by every optimiser step through the C ABI, invisible to torch)."""
+        ps = [p for _, p in sorted(self._params().items())]
+        return tuple(p.data_ptr() for p in ps) + tuple(p._version for p in ps) + (kernels.WEIGHTS_EPOCH[0], self.precision, bool(self.fold_vo))
+
+    def _wplanes(self, wvo):
+        """Cached weight-plane block (kernels.vasnet_wplanes) of the current weights; rebuilt on any weight change (same rules as
+        _folded; invalidate_folded() drops it too)."""
+        key = self._weights_key()
+        if getattr(self, "_wpl", None) is None or self._wpl_key != key:
+            with torch.no_grad():
+                self._wpl = kernels.vasnet_wplanes({k: v.detach() for k, v in self._params().items()}, self.input_size,
+                                                   kernels.PLANES_OF[self.precision], wvo=wvo, out=getattr(self, "_wpl_buf", None))
+            self._wpl_buf = getattr(self._wpl, "_sumk_keep", None) if self._wpl is not None else None
+            self._wpl_key = key
+        return self._wpl
 
     def _folded(self):
         """Cached Wvo = Wo.Wv.  The key holds what torch can see (storage addresses and tensor versions) plus
@@ -159,13 +180,16 @@ class VASNet(nn.Module):
 
     def invalidate_folded(self):
         self._wvo_key = None
+        self._wpl_key = None
 
     def train(self, mode=True):
         self._wvo_key = None
+        self._wpl_key = None
         return super().train(mode)
 
     def load_state_dict(self, *args, **kwargs):
         self._wvo_key = None
+        self._wpl_key = None
         return super().load_state_dict(*args, **kwargs)
 
 

@@ -89,3 +89,88 @@ def test_gemm_planes_rejects_ineligible_shapes(dev):
         kernels.gemm_planes(xp, 300, wp, 200, 300, 200, 128, 3)
     with pytest.raises(SumkError):
         kernels.split_planes(torch.randn(10, 24, device=dev), 3)      # K % 16
+
+
+# ------------------------------------------------------------------------------------------------ VASNet scoring on the plane path
+def _batch(D, n, seed):
+    sys_path_golden()
+    import recipes as Rc
+    lens = [int(t) for t in np.random.default_rng(seed).integers(150, 321, size=n)]
+    x = np.concatenate([Rc.features(T, 1, D, 300 + i)[:, 0, :] for i, T in enumerate(lens)])
+    return lens, x, Rc.vasnet_weights(D, seed + 1)
+
+
+def sys_path_golden():
+    import os, sys
+    from conftest import GOLDEN
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+
+
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("D", [256, 1024])
+def test_vasnet_plane_path_vs_inloop_split_and_port(dev, D, precision, fold):
+    """VASNet.score_packed in bf16x6 / bf16x3 runs its three row-wise GEMMs on operand planes (vasnet.hip `pw`): scores against (a) the
+    SAME arithmetic on the in-loop split kernels (a call without the plane pointers; the only difference is the summation order of the
+    LayerNorm moments: 2e-6), (b) the fp32 oracle port of vasnet.py:101-148 at the 1e-4 gate."""
+    from summarizer_amd import kernels
+    from summarizer_amd.models.vasnet import VASNet
+    from oracle import torch_port
+    lens, x, w = _batch(D, 9, 21 + D)
+    m = VASNet(input_size=D, precision=precision, fold_vo=fold).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    xt = torch.from_numpy(x).to(dev)
+    with torch.no_grad():
+        got = m.score_packed(xt, lens)
+    assert f"planes{kernels.PLANES_OF[precision]}" in xt._sumk_shadows and m._wpl is not None      # the plane path ran
+    sb = kernels.SeqBatch.get(lens, dev)
+    old, _ = kernels.vasnet_forward_packed(xt, sb, m._params(), m._opts(False), None, None, training=False, wvo=m._folded() if fold else None)
+    assert float((got - old).abs().max()) < 2e-6, float((got - old).abs().max())
+    ref = torch_port.vasnet_scores_packed(x, lens, w) if hasattr(torch_port, "vasnet_scores_packed") else None
+    if ref is None:
+        from oracle import vasnet_np
+        off = np.concatenate([[0], np.cumsum(lens)])
+        ref = np.concatenate([vasnet_np.vasnet_forward(x[off[i]:off[i + 1], None, :], w)[:, 0, 0] for i in range(len(lens))])
+    d = float(np.abs(got.cpu().numpy() - ref).max())
+    assert d < 1e-4, d
+    with torch.no_grad():
+        again = m.score_packed(xt, lens)
+    assert torch.equal(again, got)                              # cached planes, same launch sequence: bit-repeatable
+
+
+def test_weight_planes_follow_the_weights(dev):
+    """The weight-plane block is rebuilt when the weights change -- through torch (tensor versions), through load_state_dict, and
+    through the optimiser kernels of the C ABI (kernels.WEIGHTS_EPOCH) -- and reused otherwise."""
+    from summarizer_amd import kernels
+    from summarizer_amd.models.vasnet import VASNet
+    D = 256
+    lens, x, w = _batch(D, 4, 77)
+    m = VASNet(input_size=D, precision="bf16x6").eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to(dev)
+    xt = torch.from_numpy(x).to(dev)
+    sb = kernels.SeqBatch.get(lens, dev)
+
+    def both():
+        with torch.no_grad():
+            got = m.score_packed(xt, lens)
+        old, _ = kernels.vasnet_forward_packed(xt, sb, m._params(), m._opts(False), None, None, training=False)
+        assert float((got - old).abs().max()) < 2e-6
+        return got
+    s0 = both()
+    key0, blk0 = m._wpl_key, m._wpl.data_ptr()
+    both()
+    assert m._wpl_key == key0 and m._wpl.data_ptr() == blk0                      # reused
+    with torch.no_grad():
+        m.k1.weight.mul_(1.25)                                                  # torch-visible write
+    s1 = both()
+    assert m._wpl_key != key0 and not torch.equal(s0, s1)
+    key1 = m._wpl_key
+    g = torch.zeros_like(m.Q.weight); g.fill_(0.01)
+    kernels.adam_step(m.Q.weight.data, g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-2)      # C-ABI write: WEIGHTS_EPOCH
+    s2 = both()
+    assert m._wpl_key != key1 and not torch.equal(s1, s2)
+    x2 = xt.clone(); x2[5] += 1.0                                               # another input tensor: its own planes
+    with torch.no_grad():
+        s3 = m.score_packed(x2, lens)
+    assert not torch.equal(s3, s2)
