@@ -87,7 +87,10 @@ def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None, seed_ba
 
 def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16x3"):
     """Opt-in split-bf16 arithmetic on the same batch, reported NEXT TO the fp32 headline (never as `value`): this rank's
-    frames/s and the largest score difference from the fp32 path (gate: 1e-4)."""
+    frames/s, the largest score difference from the fp32 path (gate: 1e-4) and a roofline record of ITS dominant kernel -- the
+    plane-aware wide GEMM of the QKV projection (csrc/gemm_pw.hip), timed with the library's HIP event pairs in a separate short pass."""
+    from summarizer_amd import _lib
+    lib = _lib.load()
     model.precision = precision
     try:
         with torch.no_grad():
@@ -99,13 +102,35 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16
                 s = model.score_packed(x, lens)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
+            lib.sumk_prof_read(_lib.PROF_GEMM_QKV, None, None, 1)
+            lib.sumk_prof_enable(1 << _lib.PROF_GEMM_QKV)
+            for _ in range(10):
+                model.score_packed(x, lens)
+            torch.cuda.synchronize()
+            lib.sumk_prof_enable(0)
+            ms = C.c_double(0); n = C.c_int64(0)
+            lib.sumk_prof_read(_lib.PROF_GEMM_QKV, C.byref(ms), C.byref(n), 1)
     finally:
         model.precision = "fp32"
-    return dict(frames_per_s_this_gpu=round(frames / dt, 1), ms_per_step=round(dt * 1e3, 4),
-                max_abs_score_diff_vs_fp32=float((s - ref_scores).abs().max()),
-                note=("products as bf16 hi/lo splits (3 bf16 MFMAs), fp32 accumulate; select with --precision bf16x3" if precision == "bf16x3"
-                      else "operands split EXACTLY into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-grade "
-                           "(same error bound vs float64 as the fp32 MFMA path); select with --precision bf16x6"))
+    D = x.shape[1]
+    rec = dict(frames_per_s_this_gpu=round(frames / dt, 1), ms_per_step=round(dt * 1e3, 4),
+               max_abs_score_diff_vs_fp32=float((s - ref_scores).abs().max()),
+               note=("products as bf16 hi/lo splits (3 bf16 MFMAs), fp32 accumulate; select with --precision bf16x3" if precision == "bf16x3"
+                     else "operands split EXACTLY into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-grade "
+                          "(same error bound vs float64 as the fp32 MFMA path); select with --precision bf16x6"))
+    if n.value > 0:
+        us = ms.value / n.value * 1e3
+        fl = 2.0 * frames * 3 * D * D
+        mf = {"bf16x3": 3.0, "bf16x6": 6.0}[precision]
+        peak = BF16_MFMA_PEAK_TFLOPS / mf
+        rec["roofline"] = dict(bound="mfma", kernel=f"gemm_pw_kernel<{2 if precision == 'bf16x3' else 3} planes, 192x256> (QKV projection on operand planes)",
+                               achieved=round(fl / us / 1e6, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(fl / us / 1e6 / peak, 4),
+                               avg_launch_us=round(us, 2), launches=int(n.value), flops_per_launch=fl, mfma_flops_per_launch=fl * mf,
+                               traffic=None,
+                               note=f"algorithmic fp32 FLOP of the product; the kernel issues {int(mf)} dense bf16 MFMA FLOP per algorithmic FLOP, so the "
+                                    f"ceiling is the 2.5 PFLOP/s bf16 peak / {int(mf)}.  The chip holds ~1.7 GHz (not 2.4) under this load (in-kernel "
+                                    "s_memtime / s_memrealtime stamps, profiles/r05_pw_stamps.txt): PMC passes under profiles/r05_pmc_pw_*")
+    return rec
 
 
 def folded_leg(model, x, lens, ref_scores, steps, frames, precision="fp32"):
@@ -330,6 +355,89 @@ def stream_leg(model, x, lens, dev, steps=60):
     dt = (time.perf_counter() - t0) / steps
     return dict(ms_per_step=round(dt * 1e3, 3), frames_per_s=round(frames / dt, 1), h2d_bytes_per_step=int(frames * x.shape[1] * 4),
                 note="host -> host: fp32 features from pageable host memory, scores back to host memory, every step")
+
+
+def recurrent_legs(x, lens, dev, frames):
+    """BASELINE config 3 on the headline batch: DSN (BiLSTM 1024 -> 2 x 256, dsn.py:38-47) scoring and MSE training step, sLSTM
+    (2-layer BiLSTM, H = 1024, sumgan.py:23-46) scoring.  A recurrence has no roofline worth quoting (T dependent steps): the legs report
+    time per recurrence step of the longest video beside frames/s."""
+    from summarizer_amd import kernels as _k
+    from summarizer_amd.models.dsn import DSN
+    from summarizer_amd.models.sumgan import sLSTM
+    from summarizer_amd.training import FlatAdam
+    from summarizer_amd.autograd import SegmentMseMeanFunction
+    t_max = max(lens)
+    out = {}
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(r).all())
+        return (time.perf_counter() - t0) / n
+
+    torch.manual_seed(1234)
+    dsn = DSN(input_size=x.shape[1]).to(dev).eval()
+    with torch.no_grad():
+        dt = timed(lambda: dsn.score_packed(x, lens), 20)
+    out["dsn_score_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / t_max, 2),
+                                 note=f"DSN scoring, 50 videos packed: input projection GEMM + one persistent bidirectional recurrence of {t_max} dependent steps + head")
+    dsn.train()
+    opt = FlatAdam(dsn.parameters(), lr=1e-5, weight_decay=1e-5)
+    target = torch.rand(frames, device=dev)
+    sb = _k.SeqBatch.get(lens, dev)
+
+    def train_step():
+        opt.zero_grad()
+        loss = SegmentMseMeanFunction.apply(dsn.score_packed(x, lens), target, sb, 1.0 / len(lens))
+        loss.backward()
+        opt.step(grad_scale=1.0)
+        return loss.detach()
+    dt = timed(train_step, 10)
+    out["dsn_train_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
+                                 note="DSN MSE training step (forward + per-video MSE + BPTT + fused Adam); recurrence steps = forward + backward")
+    del dsn, opt
+    sl = sLSTM(input_size=x.shape[1]).to(dev).eval()
+    with torch.no_grad():
+        dt = timed(lambda: sl.score_packed(x, lens), 5)
+    out["slstm_score_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
+                                   note=f"sLSTM scoring (2 layers x {t_max} dependent steps, H = 1024, wide persistent recurrence) + 4 input projections")
+    _k.health_check()
+    return out
+
+
+def stress_leg(dev, steps=3):
+    """BASELINE config 5 at one GPU's share: 8 sequences of T = 10 000 frames, D = 2048, exact fp32 (the attention matrix of one sequence is
+    400 MB: E is materialised, 3.2 GB).  Reports the whole-path fraction of the fp32 MFMA peak (the path is matrix-bound, not HBM-bound:
+    ~10 D^2 + 4 T D FLOP per frame against ~30 KB of HBM traffic per frame)."""
+    from summarizer_amd.models.vasnet import VASNet
+    D, lens = 2048, [10000] * 8
+    frames = sum(lens)
+    torch.manual_seed(1234)
+    model = VASNet(input_size=D).to(dev).eval()
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    x = torch.randn(frames, D, device=dev, generator=g) * 0.05
+    with torch.no_grad():
+        s = model.score_packed(x, lens)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s = model.score_packed(x, lens)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(s).all())
+    flops = frames * (10.0 * D * D + 2.0 * D) + 4.0 * sum(t * t for t in lens) * D
+    tf = flops / dt / 1e12
+    del x, model, s
+    torch.cuda.empty_cache()
+    return dict(ms_per_step=round(dt * 1e3, 3), frames_per_s=round(frames / dt, 1), steps=steps, whole_path_tflops=round(tf, 2),
+                roofline=dict(bound="mfma", achieved=round(tf, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                              traffic=None, note="whole step (all kernels) against the fp32 MFMA peak; 45 % of the FLOP are the (T x T) attention products"),
+                workload="vasnet score, S-stress (BASELINE config 5): 8 sequences/GPU, T=10000, D=2048, packed batch, exact fp32")
 
 
 def spawn_ranks(args):
@@ -734,7 +842,7 @@ def main():
             single = single_video_leg(dev)
         except Exception as e:          # noqa: BLE001
             single = dict(error=f"{type(e).__name__}: {e}"[:300])
-    e2e = stream = None
+    e2e = stream = recurrent = stress = None
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only and rank == 0:
         def _side(fn, *a):
             try:
@@ -744,6 +852,8 @@ def main():
         model.eval(); model.precision = "fp32"
         e2e = _side(trainer_test_leg, dev)
         stream = _side(stream_leg, model, x, lens, dev)
+        recurrent = _side(recurrent_legs, x, lens, dev, frames)
+        stress = _side(stress_leg, dev)
     if dist is not None and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         barrier()          # the rank-0-only legs above take a few seconds: the other ranks wait here, not inside destroy_process_group
     if rank == 0:
@@ -787,6 +897,13 @@ def main():
             out["trainer_test_mode"] = e2e
         if stream is not None:
             out["stream_mode"] = stream
+        if recurrent is not None:
+            if "error" in recurrent:
+                out["dsn_score_mode"] = recurrent
+            else:
+                out.update(recurrent)
+        if stress is not None:
+            out["stress_mode"] = stress
         if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
             try:
                 out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None, seed_base=1000 * rank)

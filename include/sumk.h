@@ -392,6 +392,14 @@ size_t sumk_planes_bytes(int64_t rows, int32_t K, int32_t n_planes);
 int sumk_split_planes(const float* src, int64_t rows, int32_t K, int32_t ld, int32_t n_planes, void* planes, void* stream);
 int sumk_gemm_planes(const void* A_planes, int64_t a_rows, const void* B_planes, int64_t b_rows, float* C, int32_t M, int32_t N, int32_t K,
                      int32_t n_planes, int32_t variant, void* stream);
+/* Per-video attention on planes (csrc/attn_pw.hip; tests / probes -- sumk_vasnet_forward runs the same two launches): from the KB planes
+ * of the (rows x 3 D) matrix [Q | K | V], per video s (frames seq_off[s] .. seq_off[s + 1], at most 320):
+ *   alpha = softmax(mask(Q K^T * scale)) (vasnet.py:118-129) -> alpha_planes (rows = frames, k = key index inside the video, row pitch of
+ *   the input planes; sumk_attn_planes_alpha_bytes) and, when E != NULL, fp32 alpha as (T x roundup4(T)) blocks back to back;
+ *   ctx_planes != NULL: context = alpha V (vasnet.py:131) as KB planes of the (rows x D) matrix.  Synchronises the stream (test entry). */
+size_t sumk_attn_planes_alpha_bytes(int64_t rows, int32_t t_max, int32_t n_planes);
+int sumk_attn_planes(const void* qkv_planes, int64_t rows, int32_t D, int32_t n_planes, int32_t n_seq, const int32_t* seq_off_host,
+                     float scale, int32_t ignore_self, int32_t aperture, float* E, void* alpha_planes, void* ctx_planes, void* stream);
 /* C(M,N) = A(M,K) * B(K,N) */
 int sumk_gemm_nn(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, void* stream);
 /* C(M,N) = A^T * B with A given as (K,M), B as (K,N) */

@@ -178,6 +178,9 @@ _SIGS = {
     "sumk_planes_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "sumk_split_planes": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sumk_gemm_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sumk_attn_planes_alpha_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "sumk_attn_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_float, C.c_int32, C.c_int32, c_f32p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "sumk_gemm_nn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_gemm_tn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sumk_knapsack_dp": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.c_int64,

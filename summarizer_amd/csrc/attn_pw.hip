@@ -1,0 +1,452 @@
+// Per-video attention of the split-bf16 scoring path on operand planes (SUMK_PRECISION_BF16X6 / BF16X3 inference, T <= 320 keys):
+// reference summarizer/models/vasnet.py:118-131 (logits = Q K^T * scale, masks, softmax over keys, context = alpha V).
+//
+// Two launches, both one workgroup per (video, 64 query rows), both reading the K / Q / V PLANES the projection GEMM's epilogue wrote
+// (gemm_pw.hip, PW_PLANES: "KB planes" of the (R x 3D) matrix [Q | K | V]) -- nothing is split on the vector ALU inside a k-loop:
+//   A  attn_pw_logits_kernel : S^T[key][query] = K . Q^T over D (NT, both operands K-contiguous planes), masked softmax in registers (the
+//      transposed product leaves 4 consecutive keys of ONE query per lane register quad), alpha split into planes in registers and
+//      stored as 512-byte runs (alpha planes: rows = packed query rows, k = key index inside the video); optionally alpha in fp32 (E).
+//   B  attn_pw_context_kernel: CTX^T[col][query] = V^T . alpha^T over the keys; alpha planes are K-contiguous, V is not ([key][col]
+//      chunks of 8 columns): its fragments come out of LDS with ds_read_b64_tr_b16, from an image whose DMA pieces interleave the four
+//      sub-arrays a transposing read touches (conflict-free without padding).  CTX leaves as planes: the operand of the output projection.
+// The in-loop split kernels these replace (64 x 64 tiles, two barriers per k-tile, both operands split per block) ran the two products at
+// 0.2 of the split-bf16 ceiling (69 + 13 + 65 us at bf16x6 on S-TVSum) and CTX needed a separate fp32 -> planes pass (30 us).
+#include "pw_common.h"
+#include <math.h>
+#include <atomic>
+#include <vector>
+#include <algorithm>
+
+namespace sumk {
+
+namespace {
+
+constexpr int AP_ROWS = 64, AP_TMAX = 320;
+
+struct AttnPwArgs {
+  const char* QKV; uint32_t rp16;          // KB planes of [Q | K | V] (rows = packed frames, k = 3 D columns)
+  int32_t D;
+  float* E;                                // null, or alpha in fp32: per-video (T x ldE) blocks (SeqInfo::eoff)
+  char* AP; uint32_t ap_rp16;              // alpha planes: rows = packed frames, k = key index inside the video (< T rounded up to 16)
+  char* CP; uint32_t cp_rp16;              // context planes (kernel B): rows = packed frames, k = D columns
+  const SeqInfo* seq; int32_t n_seq, strips;
+  float scale; int32_t ignore_self, aperture;
+};
+
+// ------------------------------------------------------------------------------------------------ A: logits + softmax
+// EIGHT waves (two per SIMD): wave = (query tile qt of 32, key group kg of 4); key tiles kg + 4 j, j < NTW = ceil(2 NJ / 4), NJ = ceil(T / 64)
+// (tile slots past 2 NJ multiply whatever rows follow in the stage -- the query rows, finite -- and are masked as key >= T).
+// One k16 step of D per stage: NSUB sub-arrays (plane, k half) x (64 NJ key rows + 64 query rows) x 16 B, filled by LDS-DMA pieces of 64
+// rows; NS stages in a ring, ONE barrier per step behind all but the last key tile's MFMAs (gemm_pw.hip's loop).
+template <int NP, int NJ>
+__device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqInfo& si, const int strip, char* const lds) {
+  constexpr int NSUB = 2 * NP, T64 = NJ * 64, ROWS = T64 + 64, STAGE = NSUB * ROWS * 16;
+  constexpr int NS = NP == 3 ? 3 : 4;
+  constexpr int NTW = (2 * NJ + 3) / 4;
+  constexpr int NPIECE = NSUB * (NJ + 1), MAXP = (NPIECE + 7) / 8;
+  static_assert(NS * STAGE + 4096 <= 160 * 1024, "LDS map");
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = si.T, i0 = strip * AP_ROWS, D = a.D;
+  const int qt = wave & 1, kg = wave >> 1;
+
+  // this wave's DMA pieces of a stage: piece idx = wave + 8 i -> (sub-array, 64-row block: NJ key blocks, then the query block)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.QKV), (short)0, 0x80000000u, 0x00020000);
+  int pg[MAXP], pl[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    int idx = wave + 8 * i;
+    idx = idx < NPIECE ? idx : NPIECE - 1;
+    const int sub = idx / (NJ + 1), blk = idx - sub * (NJ + 1);
+    const bool key = blk < NJ;
+    // K columns are k-blocks D / 16 ... 2 D / 16 - 1 of the [Q | K | V] planes, Q columns the first D / 16
+    pg[i] = ((key ? (D >> 4) * NSUB : 0) + sub) * (int)a.rp16 + (si.row0 + (key ? blk * 64 : i0)) * 16;
+    pl[i] = (sub * ROWS + (key ? blk * 64 : T64)) * 16;
+  }
+  const bool full = (NPIECE % 8 == 0) || wave < NPIECE % 8;          // this wave issues MAXP pieces (else MAXP - 1)
+  const int vlane = lane * 16, k_step = NSUB * (int)a.rp16;
+  auto dma = [&](int kb, int slot) {
+    char* const st = lds + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (i == MAXP - 1 && !full) break;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + pl[i]), 16, vlane, kb * k_step + pg[i], 0, 0);
+    }
+  };
+  const int fk = (lh * ROWS + kg * 32 + li) * 16, fq = (lh * ROWS + T64 + qt * 32 + li) * 16;
+  struct Frags { bf16x8 k[NP][NTW], q[NP]; };
+  auto read_frags = [&](int slot, Frags& f) {
+    const char* const st = lds + slot * STAGE;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f.q[p] = *reinterpret_cast<const bf16x8*>(st + fq + p * 2 * ROWS * 16);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) f.k[p][j] = *reinterpret_cast<const bf16x8*>(st + fk + p * 2 * ROWS * 16 + j * 128 * 16);
+    }
+  };
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  auto mfma_tiles = [&](const Frags& f, int j_lo, int j_hi) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (j < j_lo || j >= j_hi) continue;
+#pragma unroll
+      for (int sum = NP - 1; sum >= 0; --sum)            // (Q plane i, K plane j2), smallest products first: the order of the NT GEMM Q . K^T
+#pragma unroll
+        for (int i = NP - 1; i >= 0; --i) {
+          const int j2 = sum - i;
+          if (j2 < 0 || j2 >= NP) continue;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[j2][j], f.q[i], acc[j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = D >> 4;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) dma(s, s);
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  Frags F0, F1;
+  read_frags(0, F0);
+  int slot = 0;
+  constexpr int P1 = NTW > 1 ? NTW - 1 : 0;
+  auto kstep = [&](const Frags& cur, Frags& nxt, int s) {
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tiles(cur, 0, P1);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = s + 1 < nk, fill = s + NS < nk;
+    const int nslot = slot + 1 == NS ? 0 : slot + 1;
+    if (more) {
+      if (s + NS - 1 < nk) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      read_frags(nslot, nxt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tiles(cur, P1, NTW);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && fill) dma(s + NS, slot);
+    slot = nslot;
+  };
+  for (int s = 0; s < nk; s += 2) {
+    kstep(F0, F1, s);
+    kstep(F1, F0, s + 1);
+  }
+
+  // ---- row op: acc[j][r]: key = (kg + 4 j) * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = qt * 32 + li
+  lds_barrier();                                  // every wave is past its last fragment read: the stages are free
+  float* const red = reinterpret_cast<float*>(lds);        // [4 key groups][64 queries], twice
+  const int qi = qt * 32 + li, i = i0 + qi;
+  const bool row_ok = i < T;
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (kg + 4 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      const float e = key < T ? masked_logit(acc[j][r], a.scale, i, key, a.ignore_self, a.aperture) : -INFINITY;
+      acc[j][r] = e;
+      m = fmaxf(m, e);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (lh == 0) red[kg * 64 + qi] = m;
+  lds_barrier();
+  m = fmaxf(fmaxf(red[qi], red[64 + qi]), fmaxf(red[128 + qi], red[192 + qi]));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (kg + 4 * j) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      const float p = key < T ? __expf(acc[j][r] - m) : 0.f;
+      acc[j][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32);
+  if (lh == 0) red[256 + kg * 64 + qi] = sum;
+  lds_barrier();
+  sum = (red[256 + qi] + red[320 + qi]) + (red[384 + qi] + red[448 + qi]);
+  const float rsum = 1.0f / sum;
+  const int T32 = (T + 31) & ~31;                 // alpha planes are written (zeros past T) up to the k32 step the context kernel ends on
+  float* const erow = a.E ? a.E + si.eoff + (int64_t)i * si.ldE : nullptr;
+  char* const arow = a.AP + (int64_t)(si.row0 + i) * 16 + 8 * lh;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k0 = (kg + 4 * j) * 32 + 8 * g + 4 * lh;
+      if (k0 >= T32 || !row_ok) continue;
+      float al[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) al[c] = k0 + c < T ? acc[j][4 * g + c] * rsum : 0.f;
+      if (erow && k0 < si.ldE) *reinterpret_cast<float4*>(erow + k0) = make_float4(al[0], al[1], al[2], al[3]);
+      u32x2 pl2[NP];
+      split4<NP>(f32x4{al[0], al[1], al[2], al[3]}, pl2);
+      char* const op = arow + (int64_t)(((k0 >> 4) * NP) * 2 + ((k0 >> 3) & 1)) * a.ap_rp16;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.ap_rp16) = pl2[p];
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
+  if (s >= a.n_seq) return;
+  const SeqInfo si = a.seq[s];
+  if (strip * AP_ROWS >= si.T) return;
+  switch ((si.T + 63) >> 6) {
+    case 1: attn_logits_body<NP, 1>(a, si, strip, lds); break;
+    case 2: attn_logits_body<NP, 2>(a, si, strip, lds); break;
+    case 3: attn_logits_body<NP, 3>(a, si, strip, lds); break;
+    case 4: attn_logits_body<NP, 4>(a, si, strip, lds); break;
+    default: attn_logits_body<NP, 5>(a, si, strip, lds); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ B: context = alpha . V
+// EIGHT waves; per pass of 256 output columns wave w owns columns 32 w + [0, 32) for both 32-query tiles.  One k32 step of keys per stage:
+//   alpha: 2 k16 blocks x NSUB sub-arrays x 64 query rows x 16 B (plain 1-KiB pieces);
+//   V    : per (32-column pair of k-blocks fbp, plane, k16 half) ONE 1-KiB piece = 16 keys x the 4 sub-arrays {fb, fb + 1} x {h 0, 1} a
+//          transposing read touches, ordered [key / 4][sub-array c][key % 4][16 B] by the per-lane SOURCE offset of the DMA -- the 32 lanes
+//          of one ds_read_b64_tr_b16 half then cover 256 contiguous bytes: no bank conflict, no padding.
+// MFMA A operand = V^T (columns on the M axis), B operand = alpha (queries on the N axis): a lane ends with ONE query row and 4 consecutive
+// columns per register quad -- the 8-byte piece of a context-plane chunk.
+template <int NP>
+__device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
+  constexpr int NSUB = 2 * NP, A_BYTES = 2 * NSUB * 1024, V_BYTES = 16 * NP * 1024, STAGE = A_BYTES + V_BYTES;
+  constexpr int NS = NP == 3 ? 2 : 3;
+  constexpr int NA = 2 * NSUB, NV = 16 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
+  static_assert(NS * STAGE <= 160 * 1024, "LDS map");
+  const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+  const int sv = (bslot / a.strips) * 8 + xcd, strip = bslot - (bslot / a.strips) * a.strips;
+  if (sv >= a.n_seq) return;
+  const SeqInfo si = a.seq[sv];
+  if (strip * AP_ROWS >= si.T) return;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = si.T, i0 = strip * AP_ROWS, D = a.D;
+  const int nks = (T + 31) >> 5, NC = D >> 8, n_it = NC * nks;
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(a.AP, (short)0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.QKV), (short)0, 0x80000000u, 0x00020000);
+  // pieces of a stage: idx < NA: alpha (k16 half kbh = idx / NSUB, sub-array idx % NSUB); else V (fbp, plane, kbh)
+  bool pa[MAXP]; int pg[MAXP], pl[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    int idx = wave + 8 * i;
+    idx = idx < NPIECE ? idx : NPIECE - 1;
+    pa[i] = idx < NA;
+    if (pa[i]) {
+      pg[i] = idx * (int)a.ap_rp16 + (si.row0 + i0) * 16;                       // + ks * 2 NSUB ap_rp16
+      pl[i] = idx * 1024;
+    } else {
+      const int v = idx - NA, fbp = v / (2 * NP), rem = v - fbp * 2 * NP, p = rem >> 1, kbh = rem & 1;
+      pg[i] = (((2 * D) >> 4) + 2 * fbp) * NSUB * (int)a.rp16 + p * 2 * (int)a.rp16 + (si.row0 + 16 * kbh) * 16;      // + nc * 16 NSUB rp16 + ks * 32 rows
+      pl[i] = A_BYTES + ((kbh * 8 + fbp) * NP + p) * 1024;
+    }
+  }
+  const bool full = (NPIECE % 8 == 0) || wave < NPIECE % 8;
+  const int vlane = lane * 16;
+  const int vperm = ((lane >> 3) & 1) * NSUB * (int)a.rp16 + ((lane >> 2) & 1) * (int)a.rp16 + (4 * (lane >> 4) + (lane & 3)) * 16;
+  auto dma = [&](int it, int slot) {
+    const int nc = it / nks, ks = it - nc * nks;
+    char* const st = lds + slot * STAGE;
+    const int ga = ks * 2 * NSUB * (int)a.ap_rp16, gv = nc * 16 * NSUB * (int)a.rp16 + ks * 512;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (i == MAXP - 1 && !full) break;
+      if (pa[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(st + pl[i]), 16, vlane, ga + pg[i], 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_vptr)(st + pl[i]), 16, vperm, gv + pg[i], 0, 0);
+    }
+  };
+  // fragments of one k16 half kbh: V plane p (tr reads), alpha plane p of query tile u
+  const int fv = A_BYTES + wave * NP * 1024 + (2 * lh) * 256 + ((((lane >> 4) & 1) << 1) | ((lane & 3) >> 1)) * 64 + ((lane & 15) >> 2) * 16 + (lane & 1) * 8;
+  const int fa = (lh * 64 + li) * 16;
+  struct Frags { bf16x8 v[NP], al[NP][2]; };
+  auto read_frags = [&](int slot, int kbh, Frags& f) {
+    const char* const st = lds + slot * STAGE;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f.v[p] = tr_frag(st + fv + (kbh * 8 * NP + p) * 1024, 64);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) f.al[p][u] = *reinterpret_cast<const bf16x8*>(st + fa + ((kbh * NSUB + p * 2) * 64 + u * 32) * 16);
+    }
+  };
+  f32x16 o[2];
+  auto mfma_half = [&](const Frags& f) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int sum = NP - 1; sum >= 0; --sum)            // (alpha plane i, V plane j), smallest products first: the order of the NN GEMM alpha . V
+#pragma unroll
+        for (int i = NP - 1; i >= 0; --i) {
+          const int j = sum - i;
+          if (j < 0 || j >= NP) continue;
+          o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[j], f.al[i][u], o[u], 0, 0, 0);
+        }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS; ++s) if (s < n_it) dma(s, s);
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  Frags H0, H1, G0, G1;                       // halves 0 / 1 of the current stage, of the next one
+  read_frags(0, 0, H0); read_frags(0, 1, H1);
+  int slot = 0, ks = 0, nc = 0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+  auto step = [&](const Frags& c0, const Frags& c1, Frags& n0, Frags& n1, int it) {
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(c0);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = it + 1 < n_it, fill = it + NS < n_it;
+    const int nslot = slot + 1 == NS ? 0 : slot + 1;
+    if (more) {
+      // (NS == 2, the tail, and the step right behind a pass epilogue -- its stores share the counter and retire out of order with the
+      //  loads -- drain fully)
+      if (NS > 2 && it + NS - 1 < n_it && !(ks == 0 && nc > 0)) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      read_frags(nslot, 0, n0); read_frags(nslot, 1, n1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(c1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more && fill) dma(it + NS, slot);
+    slot = nslot;
+    if (++ks == nks) {                        // end of a 256-column pass: o[u][4 g + c] = CTX[query u * 32 + li][nc * 256 + 32 wave + 8 g + 4 lh + c]
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = i0 + u * 32 + li;
+        if (q < T) {
+          char* const orow = a.CP + (int64_t)(si.row0 + q) * 16 + 8 * lh;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x2 pl2[NP];
+            split4<NP>(f32x4{o[u][4 * g], o[u][4 * g + 1], o[u][4 * g + 2], o[u][4 * g + 3]}, pl2);
+            const int kb = nc * 16 + wave * 2 + (g >> 1), h = g & 1;
+            char* const op = orow + (int64_t)((kb * NP) * 2 + h) * a.cp_rp16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.cp_rp16) = pl2[p];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+      }
+      ks = 0; ++nc;
+    }
+  };
+  for (int it = 0; it < n_it; it += 2) {
+    step(H0, H1, G0, G1, it);
+    if (it + 1 < n_it) step(G0, G1, H0, H1, it + 1);
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  attn_context_body<NP>(a, lds);
+}
+
+std::atomic<uint64_t> g_attr[4];
+
+template <typename K>
+int set_lds_once(K kernel, int inst, int bytes) {
+  int dev = 0;
+  SUMK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(g_attr[inst].load(std::memory_order_acquire) & bit)) {
+    SUMK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_attr[inst].fetch_or(bit, std::memory_order_release);
+  }
+  return SUMK_OK;
+}
+
+}  // namespace
+
+// T <= 320 keys per video, D a multiple of 256, every plane offset inside 31 bits
+bool attn_pw_ok(int t_max, int D, int64_t rows, int np) {
+  const int64_t lim = ((int64_t)1 << 31) - 65536;
+  return t_max >= 1 && t_max <= AP_TMAX && D % 256 == 0 && D >= 256 && (np == 2 || np == 3) && (int64_t)pw_planes_bytes(rows, 3 * D, np) < lim;
+}
+
+int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, float* E, void* alpha_planes, const SeqInfo* seq, int n_seq,
+                          int t_max, float scale, int ignore_self, int aperture, hipStream_t stream) {
+  SUMK_ARG(qkv_planes && alpha_planes && seq && attn_pw_ok(t_max, D, rows, np), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes)");
+  AttnPwArgs a;
+  a.QKV = (const char*)qkv_planes; a.rp16 = (uint32_t)(pw_rows_pitch(rows) * 16); a.D = D; a.E = E;
+  a.AP = (char*)alpha_planes; a.ap_rp16 = a.rp16; a.CP = nullptr; a.cp_rp16 = 0;
+  a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = scale; a.ignore_self = ignore_self; a.aperture = aperture;
+  const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
+  if (np == 3) {
+    constexpr int LDS = 3 * (6 * 384 * 16) + 4096;
+    SUMK_TRY(set_lds_once(attn_pw_logits_kernel<3>, 0, LDS));
+    hipLaunchKernelGGL(attn_pw_logits_kernel<3>, dim3(grid), dim3(512), LDS, stream, a);
+  } else {
+    constexpr int LDS = 4 * (4 * 384 * 16) + 4096;
+    SUMK_TRY(set_lds_once(attn_pw_logits_kernel<2>, 1, LDS));
+    hipLaunchKernelGGL(attn_pw_logits_kernel<2>, dim3(grid), dim3(512), LDS, stream, a);
+  }
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, const void* alpha_planes, void* ctx_planes, const SeqInfo* seq,
+                           int n_seq, int t_max, hipStream_t stream) {
+  SUMK_ARG(qkv_planes && alpha_planes && ctx_planes && seq && attn_pw_ok(t_max, D, rows, np), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes)");
+  AttnPwArgs a;
+  a.QKV = (const char*)qkv_planes; a.rp16 = (uint32_t)(pw_rows_pitch(rows) * 16); a.D = D; a.E = nullptr;
+  a.AP = (char*)const_cast<void*>(alpha_planes); a.ap_rp16 = a.rp16; a.CP = (char*)ctx_planes; a.cp_rp16 = a.rp16;
+  a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = 0.f; a.ignore_self = 0; a.aperture = -1;
+  const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
+  if (np == 3) {
+    constexpr int LDS = 2 * (12 + 48) * 1024;
+    SUMK_TRY(set_lds_once(attn_pw_context_kernel<3>, 2, LDS));
+    hipLaunchKernelGGL(attn_pw_context_kernel<3>, dim3(grid), dim3(512), LDS, stream, a);
+  } else {
+    constexpr int LDS = 3 * (8 + 32) * 1024;
+    SUMK_TRY(set_lds_once(attn_pw_context_kernel<2>, 3, LDS));
+    hipLaunchKernelGGL(attn_pw_context_kernel<2>, dim3(grid), dim3(512), LDS, stream, a);
+  }
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+}  // namespace sumk
+
+// ------------------------------------------------------------------------------------------------ C ABI (tests / probes)
+extern "C" size_t sumk_attn_planes_alpha_bytes(int64_t rows, int32_t t_max, int32_t n_planes) {
+  if (rows < 1 || t_max < 1 || (n_planes != 2 && n_planes != 3)) return 0;
+  return sumk::pw_alpha_bytes(rows, t_max, n_planes);
+}
+
+extern "C" int sumk_attn_planes(const void* qkv_planes, int64_t rows, int32_t D, int32_t n_planes, int32_t n_seq, const int32_t* seq_off_host,
+                                float scale, int32_t ignore_self, int32_t aperture, float* E, void* alpha_planes, void* ctx_planes, void* stream_) {
+  using namespace sumk;
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(qkv_planes && seq_off_host && alpha_planes && n_seq >= 1 && seq_off_host[0] == 0 && seq_off_host[n_seq] == rows, "attn_planes: bad arguments");
+  std::vector<SeqInfo> h(n_seq);
+  int64_t eoff = 0; int t_max = 0;
+  for (int s = 0; s < n_seq; ++s) {
+    const int T = seq_off_host[s + 1] - seq_off_host[s];
+    SUMK_ARG(T >= 1, "attn_planes: empty video %d", s);
+    h[s].eoff = eoff; h[s].row0 = seq_off_host[s]; h[s].T = T; h[s].ldE = (T + 3) & ~3; h[s].pad_ = 0; h[s].e16off = 0;
+    eoff += (int64_t)T * h[s].ldE; t_max = std::max(t_max, T);
+  }
+  SUMK_ARG(attn_pw_ok(t_max, D, rows, n_planes), "attn_planes: not eligible (T <= 320, D %% 256, 2 or 3 planes)");
+  SeqInfo* d = nullptr;
+  SUMK_HIP(hipMalloc(&d, sizeof(SeqInfo) * n_seq));
+  SUMK_HIP(hipMemcpyAsync(d, h.data(), sizeof(SeqInfo) * n_seq, hipMemcpyHostToDevice, stream));
+  int rc = launch_attn_pw_logits(n_planes, qkv_planes, rows, D, E, alpha_planes, d, n_seq, t_max, scale, ignore_self, aperture, stream);
+  if (rc == SUMK_OK && ctx_planes) rc = launch_attn_pw_context(n_planes, qkv_planes, rows, D, alpha_planes, ctx_planes, d, n_seq, t_max, stream);
+  (void)hipStreamSynchronize(stream);    // (test entry: the table is freed here)
+  (void)hipFree(d);
+  return rc;
+}

@@ -21,7 +21,7 @@
 // Epilogues (PwEpi).  PW_F32 keeps the usual orientation (lane = output column: 128-byte row segments of fp32).  The others run the
 // MFMA TRANSPOSED (B rows on the M axis): a lane then owns ONE output row and 4 consecutive columns per register quad, which is
 // exactly an 8-byte piece of a KB-plane chunk -- the result is split into planes in registers and leaves as 512-byte contiguous runs.
-#include "gemm_regstage.h"
+#include "pw_common.h"
 #include <atomic>
 #include <type_traits>
 
@@ -29,34 +29,17 @@ namespace sumk {
 
 namespace {
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_vptr;
-
 struct PwArgs {
   const char* A; const char* B;
   uint32_t a_rp16, b_rp16;             // bytes of one (k16 block, plane, half) sub-array
   int32_t M, N, K;
   int32_t tiles_m, tiles_n, total_tiles, xcd_map;
   float* C; int32_t ldc;
-  char* O; int64_t o_rp16;
+  char* O; int64_t o_rp16; int32_t o_store_rows;
   const float* R; int32_t ldr;
   float* moments;
   const float* bias; const float* gw; const float* ln_c1; const float* ln_stats; float* head_part;
 };
-
-template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
-__device__ __forceinline__ void lds_barrier() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
-
-// x -> NP bf16 planes of 4 values (each subtraction exact): the roundings of gemm_regstage.h's split_planes
-template <int NP>
-__device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NP]) {
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const bf16x4 b = __builtin_convertvector(r, bf16x4);
-    pl[q] = __builtin_bit_cast(u32x2, b);
-    if (q + 1 < NP) r = r - __builtin_convertvector(b, f32x4);
-  }
-}
 
 constexpr int PW_CONST_BYTES = 4096;   // PW_HEAD: the tile's 256 columns of c1 / bias / gw
 
@@ -74,11 +57,13 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   // Schedule variants (probes; the product runs VAR = 2).  When does a wave issue the DMA pieces that refill the slot a barrier freed?
   //   0: waves 0-3 right behind the barrier, waves 4-7 after the step's last MFMAs;  1: every wave right behind the barrier;
-  //   2, 3, 5, 6: every wave after the step's last MFMAs (3: + cycle stamps, diagnostic build; 5: barrier after one third of the MFMAs
-  //   instead of two thirds; 6: + s_setprio around the MFMA groups);  4: spread between the MFMA groups of the NEXT step's first part.
+  //   2: every wave after the step's last MFMAs;  3: as 2, with cycle stamps (diagnostic build only).
+  // Measured (profiles/r05_pw_gemm_variants.txt, QKV shape): 2 is the fastest at two planes and ties the rest at three; also tried and
+  // within +-2 % of it: the barrier after one third of the step's MFMAs instead of two thirds, s_setprio(1) around the MFMA groups,
+  // both, and the refill spread between the MFMA groups of the next step -- the loop runs at 83 % of its MFMA floor whatever the
+  // placement, and the chip holds ~1.7 GHz under it (stamps: profiles/r05_pw_stamps.txt).
   const bool early = VAR == 1 ? true : (VAR == 0 ? wave < 4 : false);
-  constexpr bool SPREAD = VAR == 4, PRIO = VAR == 6;
-  constexpr int P1 = (VAR == 5 && TM > 2) ? TM - 2 : TM - 1;             // MFMA row tiles in front of the barrier
+  constexpr int P1 = TM - 1;                                             // MFMA row tiles in front of the barrier
 
   // DMA pieces: a stage is NSUB sub-arrays x (PA + PB) blocks of 64 rows; wave w < PA + PB owns row block w of EVERY sub-array (waves
   // 0 .. PA - 1: blocks of A, the next PB: blocks of B; wave 7 issues none) -- one descriptor, one row offset and one LDS offset per
@@ -94,16 +79,14 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
   const int lsub = dma_a ? LSUB_A : LSUB_B;
   const int vlane = lane * 16;
   const int k_step = NSUB * rp16;                                       // bytes per k16 block
-  auto dma_some = [&](int m0, int n0, int kb, int slot, int first, int stride) {      // sub-arrays first, first + stride, ...
+  auto dma = [&](int m0, int n0, int kb, int slot) {
     if (!dma_wave) return;
     char* const st = lds + slot * STAGE + lds_blk;
     const int g0 = kb * k_step + ((dma_a ? m0 : n0) + blk * 64) * 16;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
-      if (sub >= first && (sub - first) % stride == 0)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + sub * lsub), 16, vlane, g0 + sub * rp16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + sub * lsub), 16, vlane, g0 + sub * rp16, 0, 0);
   };
-  auto dma = [&](int m0, int n0, int kb, int slot) { dma_some(m0, n0, kb, slot, 0, 1); };
   constexpr int IN_FLIGHT = (NS - 2) * NSUB;                            // DMA instructions of this wave that may stay in flight across a step's barrier
 
   // fragments: plane p, MFMA tile t of this wave -> 16 bytes per lane
@@ -119,13 +102,12 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
       for (int t = 0; t < TM; ++t) f.a[p][t] = *reinterpret_cast<const bf16x8*>(st + fa + p * 2 * BM * 16 + t * 512);
     }
   };
-  auto mfma_rows = [&](const Frags& f, f32x16 (&acc)[TM][TN], int tm_lo, int tm_hi, int tn_only) {
+  auto mfma_rows = [&](const Frags& f, f32x16 (&acc)[TM][TN], int tm_lo, int tm_hi) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       if (tm < tm_lo || tm >= tm_hi) continue;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        if (tn_only >= 0 && tn != tn_only) continue;
 #pragma unroll
         for (int sum = NP - 1; sum >= 0; --sum)          // planes (i, j) with i + j descending: smallest products first
 #pragma unroll
@@ -202,25 +184,10 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
     int slot = 0;
     // MAIN: steady state (stage s + NS exists: refill the slot of stage s; stages s + 2 .. s + NS - 1 stay in flight across the barrier).
     // !MAIN: the last steps of a tile (run-time conditions, full drain before the barrier).
-    int pslot = 0;                      // SPREAD: the slot the previous step's barrier freed
     auto kstep = [&](auto main_, const Frags& cur, Frags& nxt, int s) {
       constexpr bool MAIN = decltype(main_)::value;
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-      if constexpr (SPREAD) {
-        const bool pend = s >= 1 && s - 1 + NS < nk;
-        constexpr int G = P1 * TN;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          mfma_rows(cur, acc, g / TN, g / TN + 1, g % TN);
-          __builtin_amdgcn_sched_barrier(0);
-          if (pend && g < NSUB) dma_some(m0, n0, s - 1 + NS, pslot, g, G);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        mfma_rows(cur, acc, 0, P1, -1);
-      }
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+      mfma_rows(cur, acc, 0, P1);
       __builtin_amdgcn_sched_barrier(0);
       const bool more = MAIN || s + 1 < nk, fill = MAIN || s + NS < nk;
       const int nslot = slot + 1 == NS ? 0 : slot + 1;
@@ -229,15 +196,12 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
         __builtin_amdgcn_s_barrier();                         // stage s + 1 has landed; every wave is past its reads of stage s
         read_frags(nslot, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        if (!SPREAD && fill && early) dma(m0, n0, s + NS, slot);
+        if (fill && early) dma(m0, n0, s + NS, slot);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-      mfma_rows(cur, acc, P1, TM, -1);
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+      mfma_rows(cur, acc, P1, TM);
       __builtin_amdgcn_sched_barrier(0);
-      if (!SPREAD && more && fill && !early) dma(m0, n0, s + NS, slot);
-      pslot = slot;
+      if (more && fill && !early) dma(m0, n0, s + NS, slot);
       slot = nslot;
     };
     int s = 0;
@@ -291,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
           if (lh == 0 && m < a.M) reinterpret_cast<float2*>(a.moments)[(int64_t)m * (a.N >> 6) + (col_w >> 6)] = make_float2(s1, s2);
         }
-        if (m < a.M) {
+        if (m < (EPI == PW_PLANES ? a.o_store_rows : a.M)) {
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -384,9 +348,6 @@ int launch_np(PwEpi epi, const PwArgs& a, int variant, hipStream_t s) {
         case 0: return launch_one<NP, 192, PW_F32, NS, 0>(a, base + 4, s);
         case 1: return launch_one<NP, 192, PW_F32, NS, 1>(a, base + 5, s);
         case 3: return launch_one<NP, 192, PW_F32, NS, 3>(a, base + 6, s);
-        case 4: return launch_one<NP, 192, PW_F32, NS, 4>(a, base + 7, s);
-        case 5: return launch_one<NP, 192, PW_F32, NS, 5>(a, base + 8, s);
-        case 6: return launch_one<NP, 192, PW_F32, NS, 6>(a, base + 9, s);
         default: return launch_one<NP, 192, PW_F32, NS, 2>(a, base + 0, s);
       }
     case PW_PLANES: return launch_one<NP, 192, PW_PLANES, NS, 2>(a, base + 1, s);
@@ -460,7 +421,8 @@ int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {
   a.tiles_m = (g.M + 191) / 192; a.tiles_n = g.N / 256;
   a.xcd_map = (a.tiles_n % 4 == 0 && a.tiles_m >= 16) ? 1 : 0;
   a.total_tiles = a.xcd_map ? 8 * ((a.tiles_m + 1) / 2) * (a.tiles_n / 4) : a.tiles_m * a.tiles_n;
-  a.C = g.C; a.ldc = g.ldc; a.O = (char*)g.O; a.o_rp16 = pw_rows_pitch(g.o_rows) * 16; a.R = g.R; a.ldr = g.ldr; a.moments = g.moments;
+  a.C = g.C; a.ldc = g.ldc; a.O = (char*)g.O; a.o_rp16 = pw_rows_pitch(g.o_rows) * 16;
+  a.o_store_rows = (int32_t)std::max<int64_t>(g.M, std::min<int64_t>(g.o_store_rows, std::min<int64_t>(pw_rows_pitch(g.o_rows), pw_rows_pitch(g.a_rows)))); a.R = g.R; a.ldr = g.ldr; a.moments = g.moments;
   a.bias = g.bias; a.gw = g.gw; a.ln_c1 = g.ln_c1; a.ln_stats = g.ln_stats; a.head_part = g.head_part;
   switch (epi) {
     case PW_F32: SUMK_ARG(g.C && g.ldc >= g.N, "gemm_pw: fp32 output missing"); break;

@@ -300,6 +300,8 @@ struct PwLaunch {
   int32_t M = 0, N = 0, K = 0, np = 3;
   float* C = nullptr; int32_t ldc = 0;
   void* O = nullptr; int64_t o_rows = 0;
+  int64_t o_store_rows = 0;                             // PW_PLANES: rows [M, o_store_rows) are stored too (0: none) -- zeros when A's pad rows are zero: readers
+                                                        // that run a few rows past the last video (attn_pw.hip) then multiply finite data
   const float* R = nullptr; int32_t ldr = 0;
   float* moments = nullptr;
   const float* bias = nullptr; const float* gw = nullptr; const float* ln_c1 = nullptr; const float* ln_stats = nullptr; float* head_part = nullptr;
@@ -313,6 +315,15 @@ inline int pw_ok(int64_t M, int64_t N, int64_t K, int64_t a_rows, int64_t b_rows
           (int64_t)pw_planes_bytes(a_rows, (int)K, np) < lim && (int64_t)pw_planes_bytes(b_rows, (int)K, np) < lim) ? 1 : 0;
 }
 int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream);
+// Per-video attention on planes (attn_pw.hip; T <= 320): logits + softmax -> alpha planes (rows = packed frames, k = key index inside the
+// video, written up to T rounded up to 32) [+ fp32 alpha in E], then context = alpha . V -> planes of the (rows x D) context matrix.
+// alpha / context planes use the row pitch of the [Q | K | V] planes (pw_rows_pitch(rows)).
+bool attn_pw_ok(int t_max, int D, int64_t rows, int np);
+inline size_t pw_alpha_bytes(int64_t rows, int t_max, int np) { return (size_t)pw_rows_pitch(rows) * ((t_max + 31) / 32 * 32) * np * 2 + 8192; }
+int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, float* E, void* alpha_planes, const SeqInfo* seq, int n_seq,
+                          int t_max, float scale, int ignore_self, int aperture, hipStream_t stream);
+int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, const void* alpha_planes, void* ctx_planes, const SeqInfo* seq,
+                           int n_seq, int t_max, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
 // Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.

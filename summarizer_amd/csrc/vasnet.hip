@@ -835,6 +835,17 @@ static WPlanes wplanes_layout(int D, int np) {
   l.total = p;
   return l;
 }
+// Extra workspace of the plane path when the per-video attention runs on planes too (attn_pw.hip): [Q | K | V] planes (later re-used for
+// Y0's planes), alpha planes, context planes -- appended behind the regular carve-up (sumk_vasnet_workspace_bytes_for adds it for
+// inference in bf16x6 / bf16x3 when the batch is eligible).
+struct PwExtra { size_t qkv, ap, ctx, total; };
+static PwExtra pw_extra(int D, int64_t R, int t_max, int np, size_t base) {
+  PwExtra e; size_t p = align_up(base, 256);
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  e.qkv = take(pw_planes_bytes(R, 3 * D, np)); e.ap = take(pw_alpha_bytes(R, t_max, np)); e.ctx = take(pw_planes_bytes(R, D, np));
+  e.total = p;
+  return e;
+}
 static bool wplanes_ok(int D, int np) { return D >= 256 && D % 256 == 0 && (np == 2 || np == 3) && pw_ok(256, 3 * (int64_t)D, D, 256, 3 * (int64_t)D, np); }
 
 // one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
@@ -1375,6 +1386,12 @@ extern "C" size_t sumk_vasnet_workspace_bytes(int32_t D, int32_t n_seq, const in
 extern "C" size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, const int32_t* seq_off_host, int32_t training, int32_t precision) {
   VasnetWs w;
   if (carve(D, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
+  const int np = precision == SUMK_PRECISION_BF16X6 ? 3 : precision == SUMK_PRECISION_BF16X3 ? 2 : 0;
+  if (!training && np && wplanes_ok(D, np)) {
+    int t_max = 0;
+    for (int s = 0; s < n_seq; ++s) t_max = std::max(t_max, seq_off_host[s + 1] - seq_off_host[s]);
+    if (w.n_rows >= 256 && attn_pw_ok(t_max, D, w.n_rows, np)) return pw_extra(D, w.n_rows, t_max, np, w.total_core).total;
+  }
   return (training && precision == SUMK_PRECISION_BF16) ? w.total : w.total_core;
 }
 
@@ -1517,6 +1534,20 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
                   G.st_d == 0 && pw_ok(R, 3 * (int64_t)D, D, R, 3 * (int64_t)D, np) && (Wvo == nullptr || G.cfg_pv == 1);
   const WPlanes wl = pw ? wplanes_layout(D, np) : WPlanes();
   const char* const wp = (const char*)opts->wplanes;
+  // ... and the per-video attention on planes as well (attn_pw.hip): T <= 320, not the folded path, the extra workspace present
+  const PwExtra px = pw ? pw_extra(D, R, G.t_max, np, L.total_core) : PwExtra();
+  const bool pw_attn = pw && !Wvo && attn_pw_ok(G.t_max, D, R, np) && workspace_bytes >= px.total;
+  if (pw_attn) {  // 1-4: projection -> planes of [Q | K | V]; logits + softmax -> alpha planes; alpha . V -> context planes
+    PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
+    g.O = ws + px.qkv; g.o_rows = R; g.o_store_rows = (R + 31) & ~31; g.prof_tag = SUMK_PROF_GEMM_QKV;
+    SUMK_TRY(launch_gemm_pw(PW_PLANES, g, stream));
+    prof_begin(SUMK_PROF_GEMM_QKT, stream);
+    SUMK_TRY(launch_attn_pw_logits(np, ws + px.qkv, R, D, nullptr, ws + px.ap, seq, n_seq, G.t_max, opts->scale, opts->ignore_self, opts->aperture, stream));
+    prof_end(SUMK_PROF_GEMM_QKT, stream);
+    prof_begin(SUMK_PROF_GEMM_PV, stream);
+    SUMK_TRY(launch_attn_pw_context(np, ws + px.qkv, R, D, ws + px.ap, ws + px.ctx, seq, n_seq, G.t_max, stream));
+    prof_end(SUMK_PROF_GEMM_PV, stream);
+  } else
   if (pw) {  // 1: QKV projection from planes (fp32 output: the per-video products below read it)
     PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
     g.C = QKV; g.ldc = 3 * D; g.prof_tag = SUMK_PROF_GEMM_QKV;
@@ -1532,6 +1563,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
+  if (pw_attn) {
+  } else
   if (G.attn_fused) {  // 2-4 in one launch per (video, 64-row strip): logits, softmax (+ dropout), context
     AttnStripArgs at;
     const unsigned short* qkv16 = (const unsigned short*)(ws + L.qkv16);
@@ -1576,8 +1609,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   const size_t ln_mom_f = align_up((size_t)R * ln_slots * 2, 64), ln_w_f = (size_t)D * D, ln_c_f = align_up((size_t)2 * D, 64);
   const bool fused_ln = pw || (fused_tail && fused_ln_on && (!Wvo || G.cfg_pv == 1) && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D);
   // plane path: CTX planes span the Y0 / Y1 regions, Y0's planes take the (by then dead) fp32 Q/K/V region, the small per-row arrays live in Z
-  char* const pw_ctxp = ws + L.y0;
-  char* const pw_y0p = ws + L.qkv;
+  char* const pw_ctxp = pw_attn ? ws + px.ctx : ws + L.y0;
+  char* const pw_y0p = pw_attn ? ws + px.qkv : ws + L.qkv;          // ([Q | K | V]'s planes are dead once the context exists)
   float* const pw_mom = Z;                                                        // float2[R][slots]
   float* const pw_stats = Z + align_up((size_t)R * (D / 16) * 2, 64);             // float2[R]
   float* const pw_part = pw_stats + align_up((size_t)R * 2, 64);                  // float4[R][D / 64]
@@ -1585,7 +1618,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   float* ln_W1g = Y1 + ln_mom_f;
   float* ln_c1 = ln_W1g + ln_w_f;
   float* ln_stats = ln_c1 + ln_c_f;
-  if (!G.attn_fused) {  // 4: context
+  if (!G.attn_fused && !pw_attn) {  // 4: context
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
@@ -1604,7 +1637,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     }
   }
   if (pw && !Wvo) {  // 5: output projection + residual from planes: CTX is split once, Y0 leaves as planes + per-row moments only
-    SUMK_TRY(split_planes(CTX, R, D, D, np, pw_ctxp, stream));
+    if (!pw_attn) SUMK_TRY(split_planes(CTX, R, D, D, np, pw_ctxp, stream));
     PwLaunch g; g.A = pw_ctxp; g.a_rows = R; g.B = wp + wl.wo; g.b_rows = D; g.M = R; g.N = D; g.K = D; g.np = np;
     g.R = x; g.ldr = D; g.moments = pw_mom; g.O = pw_y0p; g.o_rows = R; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
     SUMK_TRY(launch_gemm_pw(PW_RES_MOM_PLANES, g, stream));

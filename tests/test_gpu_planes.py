@@ -126,7 +126,8 @@ def test_vasnet_plane_path_vs_inloop_split_and_port(dev, D, precision, fold):
     assert f"planes{kernels.PLANES_OF[precision]}" in xt._sumk_shadows and m._wpl is not None      # the plane path ran
     sb = kernels.SeqBatch.get(lens, dev)
     old, _ = kernels.vasnet_forward_packed(xt, sb, m._params(), m._opts(False), None, None, training=False, wvo=m._folded() if fold else None)
-    assert float((got - old).abs().max()) < 2e-6, float((got - old).abs().max())
+    # (with T <= 320 the per-video attention runs on planes as well, csrc/attn_pw.hip: other tile shapes and summation orders of the same arithmetic)
+    assert float((got - old).abs().max()) < (5e-6 if precision == "bf16x6" else 5e-5), float((got - old).abs().max())
     ref = torch_port.vasnet_scores_packed(x, lens, w) if hasattr(torch_port, "vasnet_scores_packed") else None
     if ref is None:
         from oracle import vasnet_np
@@ -155,7 +156,7 @@ def test_weight_planes_follow_the_weights(dev):
         with torch.no_grad():
             got = m.score_packed(xt, lens)
         old, _ = kernels.vasnet_forward_packed(xt, sb, m._params(), m._opts(False), None, None, training=False)
-        assert float((got - old).abs().max()) < 2e-6
+        assert float((got - old).abs().max()) < 5e-6
         return got
     s0 = both()
     key0, blk0 = m._wpl_key, m._wpl.data_ptr()
@@ -174,3 +175,67 @@ def test_weight_planes_follow_the_weights(dev):
     with torch.no_grad():
         s3 = m.score_packed(x2, lens)
     assert not torch.equal(s3, s2)
+
+
+# ------------------------------------------------------------------------------------------------ per-video attention on planes
+@pytest.mark.parametrize("mask", [dict(), dict(ignore_self=1), dict(aperture=20)])
+@pytest.mark.parametrize("n_planes", [3, 2])
+def test_attention_on_planes_vs_float64(dev, n_planes, mask):
+    """csrc/attn_pw.hip through sumk_attn_planes: alpha = softmax(mask(Q K^T scale)) and context = alpha V per video (vasnet.py:118-131) from
+    the planes of [Q | K | V], against float64 on the same fp32 inputs -- ragged lengths from 1 to 320 frames (1 to 5 strips, every key-tile
+    count), both mask options.  The alpha planes are exactly the split of the fp32 alpha the kernel also writes (and zero from T up to the
+    k32 step the context kernel ends on); the context planes sum to the fp32-grade product."""
+    from summarizer_amd import kernels, _lib
+    lib = _lib.load()
+    D = 256
+    lens = [37, 64, 150, 320, 1, 200, 257, 96]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    R = int(off[-1])
+    rng = np.random.default_rng(11 + n_planes)
+    qkv = rng.standard_normal((R, 3 * D)).astype(np.float32)
+    qkv[:, :2 * D] *= 1.5
+    scale = 0.06
+    qt = torch.from_numpy(qkv).to(dev)
+    qp = kernels.split_planes(qt, n_planes)
+    ldes = [(t + 3) // 4 * 4 for t in lens]
+    E = torch.zeros(int(sum(t * l for t, l in zip(lens, ldes))), dtype=torch.float32, device=dev)
+    tmax = max(lens)
+    AP = torch.zeros(lib.sumk_attn_planes_alpha_bytes(R, tmax, n_planes), dtype=torch.uint8, device=dev)
+    CP = torch.zeros(lib.sumk_planes_bytes(R, D, n_planes), dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.sumk_attn_planes(qp.data_ptr(), R, D, n_planes, len(lens), _lib.host_i32(off), scale, mask.get("ignore_self", 0),
+                                    mask.get("aperture", -1), E.data_ptr(), AP.data_ptr(), CP.data_ptr(), st), "sumk_attn_planes")
+    Eh = E.cpu().numpy()
+    K32 = (tmax + 31) // 32 * 32
+    ap, _ = decode_planes(AP, R, K32, n_planes)
+    cp, _ = decode_planes(CP, R, D, n_planes)
+    tol_a, tol_c = (2e-6, 2e-5) if n_planes == 3 else (6e-5, 4e-4)
+    eo = 0
+    for s, T in enumerate(lens):
+        r0 = int(off[s])
+        q, k, v = (qkv[r0:r0 + T, i * D:(i + 1) * D].astype(np.float64) for i in range(3))
+        lg = q @ k.T * np.float64(np.float32(scale))
+        i, j = np.meshgrid(np.arange(T), np.arange(T), indexing="ij")
+        if mask.get("ignore_self"):
+            lg[i == j] = -np.inf
+        if "aperture" in mask:
+            lg[np.abs(i - j) > mask["aperture"]] = -np.inf
+        if T == 1 and mask.get("ignore_self"):
+            eo += T * ldes[s]
+            continue                                          # a single self-masked frame: softmax of an empty row (NaN in the reference too)
+        al = np.exp(lg - lg.max(1, keepdims=True)); al /= al.sum(1, keepdims=True)
+        got = Eh[eo:eo + T * ldes[s]].reshape(T, ldes[s])[:, :T]
+        eo += T * ldes[s]
+        assert np.abs(got - al).max() < tol_a, (s, T, np.abs(got - al).max())
+        # planes of alpha: plane 0 = bf16(alpha), the sum reproduces alpha (exactly with three planes), zeros behind T
+        T32 = (T + 31) // 32 * 32
+        rec = ap[:, r0:r0 + T, :T32].sum(0)
+        if n_planes == 3:
+            np.testing.assert_array_equal(rec[:, :T].astype(np.float32), got)
+        else:
+            assert (np.abs(rec[:, :T] - got) <= 2.0 ** -16 * got + 1e-38).all()
+        assert not rec[:, T:].any()
+        np.testing.assert_array_equal(ap[0, r0:r0 + T, :T].astype(np.float32), torch.from_numpy(got.copy()).to(torch.bfloat16).float().numpy())
+        ctx = cp[:, r0:r0 + T].sum(0)
+        ref = al @ v
+        assert np.abs(ctx - ref).max() < tol_c, (s, T, np.abs(ctx - ref).max())
