@@ -713,7 +713,7 @@ def main():
         barrier()
     # data-parallel TRAINING leg on the same batch (every rank): forward + MSE + backward + the flat-bucket gradient all-reduce +
     # fused Adam.  Scoring has no data-path collective, so this is what makes a multi-GPU run of this script exercise RCCL.
-    train_leg = train_leg_bf16 = reinforce_leg = None
+    train_leg = train_leg_bf16 = reinforce_leg = one_video_leg = None
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         from summarizer_amd.training import FlatAdam
         from summarizer_amd import kernels as _k
@@ -811,6 +811,39 @@ def main():
         train_leg = collective_leg(run_train_leg, "fp32")
         train_leg_bf16 = collective_leg(run_train_leg, "bf16")
 
+        def run_one_video_leg():
+            """The trainers' DEFAULT schedule under data parallelism: batch_videos = 1 -- every rank steps on ONE video (vasnet.py:193-212
+            scaled out by video), the 21 MB bucket all-reduced in two pieces every step.  The step is ~0.3 ms of compute, so this is the leg
+            on which the exchange shows (predicted 0.55-0.85 at 8 GPUs); `training.choose_batch_videos` is what a
+            caller who wants >= 0.9 uses (extra_params batch_videos=auto)."""
+            from summarizer_amd.training import predicted_dp_efficiency
+            model.train(); model.precision = "fp32"
+            opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
+            opt.broadcast()
+            tail_from = opt.tail_offset(model.attention_head_projection.weight) if dist is not None else None
+            model.tail_grads_ready_event = torch.cuda.Event() if dist is not None else None
+            T1 = lens[0]
+            x1, t1, sb1 = x[:T1].contiguous(), target[:T1].contiguous(), _k.SeqBatch.get([T1], dev)
+            def step1(reduce=True):
+                opt.zero_grad()
+                loss = SegmentMseMeanFunction.apply(model.score_packed(x1, [T1]), t1, sb1, 1.0 / world)
+                loss.backward()
+                if reduce and tail_from is not None:
+                    opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
+                opt.step(grad_scale=opt.all_reduce_grads(average=False) if reduce else 1.0)
+                return loss.detach()
+            n_train = 40
+            sec = timed_steps(step1, n_train)
+            sec_local = timed_steps(lambda: step1(False), n_train) if dist is not None else sec
+            model.tail_grads_ready_event = None
+            model.eval()
+            rec = dict(frames_per_s=round(T1 * world / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=n_train, videos_per_rank_per_step=1, frames_per_video=T1,
+                       allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0, collectives_per_step=2 if world > 1 else 0,
+                       predicted_efficiency_at_this_world=predicted_dp_efficiency("vasnet", "fp32", max(world, 2), 1),
+                       note="eager steps (the per-video HIP graphs of VASNetTrainer are single-process only); fp32; the all-reduce in two pieces as the trainer issues it")
+            return decompose(rec, sec * 1e3, sec_local * 1e3, allreduce_alone_us(opt.flat_grad.numel(), torch.float32))
+        one_video_leg = collective_leg(run_one_video_leg)
+
         def run_reinforce_leg():
             """BASELINE config 4: the DSN REINFORCE step, data-parallel by video (every rank its own 50 videos, one all-reduce of the
             10.5 MB flat gradient bucket per step, clip after the reduction, per-video baselines rank-local)."""
@@ -881,6 +914,7 @@ def main():
             out["train_step_mode"] = train_leg
             out["train_step_bf16_mode"] = train_leg_bf16
             out["dsn_reinforce_step_mode"] = reinforce_leg
+            out["dp_one_video_per_rank_mode"] = one_video_leg
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
         if args.mode == "stream":

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <vector>
 #include <algorithm>
+#include <cstdlib>
 
 namespace sumk {
 
@@ -31,6 +32,7 @@ struct AttnPwArgs {
   char* CP; uint32_t cp_rp16;              // context planes (kernel B): rows = packed frames, k = D columns
   const SeqInfo* seq; int32_t n_seq, strips;
   float scale; int32_t ignore_self, aperture;
+  unsigned long long* stamps;              // diagnostic build: per block {T, prologue, k-loop, row op, total} shader cycles + realtime
 };
 
 // ------------------------------------------------------------------------------------------------ A: logits + softmax
@@ -38,7 +40,9 @@ struct AttnPwArgs {
 // (tile slots past 2 NJ multiply whatever rows follow in the stage -- the query rows, finite -- and are masked as key >= T).
 // One k16 step of D per stage: NSUB sub-arrays (plane, k half) x (64 NJ key rows + 64 query rows) x 16 B, filled by LDS-DMA pieces of 64
 // rows; NS stages in a ring, ONE barrier per step behind all but the last key tile's MFMAs (gemm_pw.hip's loop).
-template <int NP, int NJ>
+// VAR (when a wave issues the DMA pieces that refill the slot a barrier freed): 0 = after the step's last MFMAs, 1 = right behind the
+// barrier, 2 = spread: a share behind every key tile's MFMAs, from the step's last tile through the next step's tiles in front of the barrier.
+template <int NP, int NJ, int VAR>
 __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqInfo& si, const int strip, char* const lds) {
   constexpr int NSUB = 2 * NP, T64 = NJ * 64, ROWS = T64 + 64, STAGE = NSUB * ROWS * 16;
   constexpr int NS = NP == 3 ? 3 : 4;
@@ -65,14 +69,19 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   }
   const bool full = (NPIECE % 8 == 0) || wave < NPIECE % 8;          // this wave issues MAXP pieces (else MAXP - 1)
   const int vlane = lane * 16, k_step = NSUB * (int)a.rp16;
-  auto dma = [&](int kb, int slot) {
+  auto dma_share = [&](int kb, int slot, int share, int n_shares) {      // pieces i with i % n_shares == share
+#ifdef SUMK_DIAG
+    if (VAR == 4 && kb >= NS) return;                                     // timing probe: MFMAs + reads + barriers only (stale stages)
+#endif
     char* const st = lds + slot * STAGE;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
+      if (i % n_shares != share) continue;
       if (i == MAXP - 1 && !full) break;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + pl[i]), 16, vlane, kb * k_step + pg[i], 0, 0);
     }
   };
+  auto dma = [&](int kb, int slot) { dma_share(kb, slot, 0, 1); };
   const int fk = (lh * ROWS + kg * 32 + li) * 16, fq = (lh * ROWS + T64 + qt * 32 + li) * 16;
   struct Frags { bf16x8 k[NP][NTW], q[NP]; };
   auto read_frags = [&](int slot, Frags& f) {
@@ -99,23 +108,43 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
         for (int i = NP - 1; i >= 0; --i) {
           const int j2 = sum - i;
           if (j2 < 0 || j2 >= NP) continue;
+#ifdef SUMK_DIAG
+          if constexpr (VAR == 3) { asm volatile("" :: "v"(f.k[j2][j]), "v"(f.q[i])); continue; }      // timing probe: DMA + reads + barriers only
+#endif
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[j2][j], f.q[i], acc[j], 0, 0, 0);
         }
     }
   };
 
   const int nk = D >> 4;
+#ifdef SUMK_DIAG
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
   for (int s = 0; s < NS; ++s) dma(s, s);
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
+#ifdef SUMK_DIAG
+  const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
   Frags F0, F1;
   read_frags(0, F0);
   int slot = 0;
   constexpr int P1 = NTW > 1 ? NTW - 1 : 0;
+  int pend_kb = -1, pend_slot = 0;               // VAR 2: the refill in progress (stage, slot)
   auto kstep = [&](const Frags& cur, Frags& nxt, int s) {
     __builtin_amdgcn_sched_barrier(0);
-    mfma_tiles(cur, 0, P1);
+    if constexpr (VAR == 2 && NTW > 1) {
+#pragma unroll
+      for (int j = 0; j < P1; ++j) {
+        mfma_tiles(cur, j, j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pend_kb >= 0) dma_share(pend_kb, pend_slot, j, NTW);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      mfma_tiles(cur, 0, P1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const bool more = s + 1 < nk, fill = s + NS < nk;
     const int nslot = slot + 1 == NS ? 0 : slot + 1;
@@ -124,11 +153,18 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
       else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       read_frags(nslot, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (VAR == 1 && fill) dma(s + NS, slot);
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_tiles(cur, P1, NTW);
     __builtin_amdgcn_sched_barrier(0);
-    if (more && fill) dma(s + NS, slot);
+    if constexpr (VAR == 2 && NTW > 1) {
+      pend_kb = (more && fill) ? s + NS : -1; pend_slot = slot;
+      if (pend_kb >= 0) dma_share(pend_kb, pend_slot, NTW - 1, NTW);
+    } else if (VAR != 1) {
+      if (more && fill) dma(s + NS, slot);
+    }
     slot = nslot;
   };
   for (int s = 0; s < nk; s += 2) {
@@ -138,6 +174,9 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
 
   // ---- row op: acc[j][r]: key = (kg + 4 j) * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = qt * 32 + li
   lds_barrier();                                  // every wave is past its last fragment read: the stages are free
+#ifdef SUMK_DIAG
+  const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
   float* const red = reinterpret_cast<float*>(lds);        // [4 key groups][64 queries], twice
   const int qi = qt * 32 + li, i = i0 + qi;
   const bool row_ok = i < T;
@@ -189,9 +228,18 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
 #pragma unroll
       for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.ap_rp16) = pl2[p];
     }
+#ifdef SUMK_DIAG
+  if (a.stamps && tid == 0) {
+    wait_vm<0>();
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    o[0] = T; o[1] = st1 - st0; o[2] = st2 - st1; o[3] = st3 - st2; o[4] = st3 - st0; o[5] = __builtin_amdgcn_s_memrealtime() - rt0; o[6] = rt0;
+    o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+  }
+#endif
 }
 
-template <int NP>
+template <int NP, int VAR>
 __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -200,27 +248,29 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
   const SeqInfo si = a.seq[s];
   if (strip * AP_ROWS >= si.T) return;
   switch ((si.T + 63) >> 6) {
-    case 1: attn_logits_body<NP, 1>(a, si, strip, lds); break;
-    case 2: attn_logits_body<NP, 2>(a, si, strip, lds); break;
-    case 3: attn_logits_body<NP, 3>(a, si, strip, lds); break;
-    case 4: attn_logits_body<NP, 4>(a, si, strip, lds); break;
-    default: attn_logits_body<NP, 5>(a, si, strip, lds); break;
+    case 1: attn_logits_body<NP, 1, VAR>(a, si, strip, lds); break;
+    case 2: attn_logits_body<NP, 2, VAR>(a, si, strip, lds); break;
+    case 3: attn_logits_body<NP, 3, VAR>(a, si, strip, lds); break;
+    case 4: attn_logits_body<NP, 4, VAR>(a, si, strip, lds); break;
+    default: attn_logits_body<NP, 5, VAR>(a, si, strip, lds); break;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ B: context = alpha . V
-// EIGHT waves; per pass of 256 output columns wave w owns columns 32 w + [0, 32) for both 32-query tiles.  One k32 step of keys per stage:
-//   alpha: 2 k16 blocks x NSUB sub-arrays x 64 query rows x 16 B (plain 1-KiB pieces);
-//   V    : per (32-column pair of k-blocks fbp, plane, k16 half) ONE 1-KiB piece = 16 keys x the 4 sub-arrays {fb, fb + 1} x {h 0, 1} a
+// EIGHT waves; per pass of 256 output columns wave w owns columns 32 w + [0, 32) for both 32-query tiles.  A stage holds KH k16 blocks of keys
+// (three planes: one block, a ring of four 30-KB stages; two planes: two blocks, a ring of three 40-KB stages -- with 60-KB stages only two
+// fit and every step waited for its own refill: 107 us instead of ~70 at bf16x6):
+//   alpha: KH k16 blocks x NSUB sub-arrays x 64 query rows x 16 B (plain 1-KiB pieces);
+//   V    : per (32-column pair of k-blocks fbp, plane, k16 block) ONE 1-KiB piece = 16 keys x the 4 sub-arrays {fb, fb + 1} x {h 0, 1} a
 //          transposing read touches, ordered [key / 4][sub-array c][key % 4][16 B] by the per-lane SOURCE offset of the DMA -- the 32 lanes
 //          of one ds_read_b64_tr_b16 half then cover 256 contiguous bytes: no bank conflict, no padding.
 // MFMA A operand = V^T (columns on the M axis), B operand = alpha (queries on the N axis): a lane ends with ONE query row and 4 consecutive
 // columns per register quad -- the 8-byte piece of a context-plane chunk.
 template <int NP>
 __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
-  constexpr int NSUB = 2 * NP, A_BYTES = 2 * NSUB * 1024, V_BYTES = 16 * NP * 1024, STAGE = A_BYTES + V_BYTES;
-  constexpr int NS = NP == 3 ? 2 : 3;
-  constexpr int NA = 2 * NSUB, NV = 16 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
+  constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;
+  constexpr int NSUB = 2 * NP, A_BYTES = KH * NSUB * 1024, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
+  constexpr int NA = KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
   const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
   const int sv = (bslot / a.strips) * 8 + xcd, strip = bslot - (bslot / a.strips) * a.strips;
@@ -230,11 +280,11 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = si.T, i0 = strip * AP_ROWS, D = a.D;
-  const int nks = (T + 31) >> 5, NC = D >> 8, n_it = NC * nks;
+  const int nks = (T + 16 * KH - 1) / (16 * KH), NC = D >> 8, n_it = NC * nks;       // (alpha planes hold zeros from T up to T rounded up to 32)
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(a.AP, (short)0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.QKV), (short)0, 0x80000000u, 0x00020000);
-  // pieces of a stage: idx < NA: alpha (k16 half kbh = idx / NSUB, sub-array idx % NSUB); else V (fbp, plane, kbh)
+  // pieces of a stage: idx < NA: alpha (k16 block kbh = idx / NSUB of the stage, sub-array idx % NSUB); else V (fbp, plane, kbh)
   bool pa[MAXP]; int pg[MAXP], pl[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
@@ -242,11 +292,11 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
     idx = idx < NPIECE ? idx : NPIECE - 1;
     pa[i] = idx < NA;
     if (pa[i]) {
-      pg[i] = idx * (int)a.ap_rp16 + (si.row0 + i0) * 16;                       // + ks * 2 NSUB ap_rp16
+      pg[i] = idx * (int)a.ap_rp16 + (si.row0 + i0) * 16;                       // + ks * KH NSUB ap_rp16
       pl[i] = idx * 1024;
     } else {
-      const int v = idx - NA, fbp = v / (2 * NP), rem = v - fbp * 2 * NP, p = rem >> 1, kbh = rem & 1;
-      pg[i] = (((2 * D) >> 4) + 2 * fbp) * NSUB * (int)a.rp16 + p * 2 * (int)a.rp16 + (si.row0 + 16 * kbh) * 16;      // + nc * 16 NSUB rp16 + ks * 32 rows
+      const int v = idx - NA, fbp = v / (KH * NP), rem = v - fbp * KH * NP, p = rem / KH, kbh = rem - p * KH;
+      pg[i] = (((2 * D) >> 4) + 2 * fbp) * NSUB * (int)a.rp16 + p * 2 * (int)a.rp16 + (si.row0 + 16 * kbh) * 16;      // + nc * 16 NSUB rp16 + ks * 16 KH rows
       pl[i] = A_BYTES + ((kbh * 8 + fbp) * NP + p) * 1024;
     }
   }
@@ -256,7 +306,7 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   auto dma = [&](int it, int slot) {
     const int nc = it / nks, ks = it - nc * nks;
     char* const st = lds + slot * STAGE;
-    const int ga = ks * 2 * NSUB * (int)a.ap_rp16, gv = nc * 16 * NSUB * (int)a.rp16 + ks * 512;
+    const int ga = ks * KH * NSUB * (int)a.ap_rp16, gv = nc * 16 * NSUB * (int)a.rp16 + ks * KH * 256;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       if (i == MAXP - 1 && !full) break;
@@ -264,60 +314,67 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_vptr)(st + pl[i]), 16, vperm, gv + pg[i], 0, 0);
     }
   };
-  // fragments of one k16 half kbh: V plane p (tr reads), alpha plane p of query tile u
+  // fragments of the k16 block kbh of a stage: V plane p (tr reads), alpha plane p of query tile u
   const int fv = A_BYTES + wave * NP * 1024 + (2 * lh) * 256 + ((((lane >> 4) & 1) << 1) | ((lane & 3) >> 1)) * 64 + ((lane & 15) >> 2) * 16 + (lane & 1) * 8;
   const int fa = (lh * 64 + li) * 16;
-  struct Frags { bf16x8 v[NP], al[NP][2]; };
-  auto read_frags = [&](int slot, int kbh, Frags& f) {
+  struct Frags { bf16x8 v[KH][NP], al[KH][NP][2]; };
+  auto read_frags = [&](int slot, Frags& f) {
     const char* const st = lds + slot * STAGE;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      f.v[p] = tr_frag(st + fv + (kbh * 8 * NP + p) * 1024, 64);
+    for (int kbh = 0; kbh < KH; ++kbh)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) f.al[p][u] = *reinterpret_cast<const bf16x8*>(st + fa + ((kbh * NSUB + p * 2) * 64 + u * 32) * 16);
-    }
+      for (int p = 0; p < NP; ++p) {
+        f.v[kbh][p] = tr_frag(st + fv + (kbh * 8 * NP + p) * 1024, 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) f.al[kbh][p][u] = *reinterpret_cast<const bf16x8*>(st + fa + ((kbh * NSUB + p * 2) * 64 + u * 32) * 16);
+      }
   };
   f32x16 o[2];
-  auto mfma_half = [&](const Frags& f) {
+  // the step's MFMAs in two parts around its barrier: part 0 = the first k16 block (KH = 2) or query tile 0 (KH = 1), part 1 = the rest
+  auto mfma_part = [&](const Frags& f, int part) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int kbh = 0; kbh < KH; ++kbh)
 #pragma unroll
-      for (int sum = NP - 1; sum >= 0; --sum)            // (alpha plane i, V plane j), smallest products first: the order of the NN GEMM alpha . V
+      for (int u = 0; u < 2; ++u) {
+        if ((KH == 2 ? kbh : u) != part) continue;
 #pragma unroll
-        for (int i = NP - 1; i >= 0; --i) {
-          const int j = sum - i;
-          if (j < 0 || j >= NP) continue;
-          o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[j], f.al[i][u], o[u], 0, 0, 0);
-        }
+        for (int sum = NP - 1; sum >= 0; --sum)            // (alpha plane i, V plane j), smallest products first: the order of the NN GEMM alpha . V
+#pragma unroll
+          for (int i = NP - 1; i >= 0; --i) {
+            const int j = sum - i;
+            if (j < 0 || j >= NP) continue;
+            o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[kbh][j], f.al[kbh][i][u], o[u], 0, 0, 0);
+          }
+      }
   };
 
 #pragma unroll
   for (int s = 0; s < NS; ++s) if (s < n_it) dma(s, s);
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
-  Frags H0, H1, G0, G1;                       // halves 0 / 1 of the current stage, of the next one
-  read_frags(0, 0, H0); read_frags(0, 1, H1);
+  Frags F0, F1;
+  read_frags(0, F0);
   int slot = 0, ks = 0, nc = 0;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
-  auto step = [&](const Frags& c0, const Frags& c1, Frags& n0, Frags& n1, int it) {
+  auto step = [&](const Frags& cur, Frags& nxt, int it) {
     __builtin_amdgcn_sched_barrier(0);
-    mfma_half(c0);
+    mfma_part(cur, 0);
     __builtin_amdgcn_sched_barrier(0);
     const bool more = it + 1 < n_it, fill = it + NS < n_it;
     const int nslot = slot + 1 == NS ? 0 : slot + 1;
     if (more) {
-      // (NS == 2, the tail, and the step right behind a pass epilogue -- its stores share the counter and retire out of order with the
-      //  loads -- drain fully)
-      if (NS > 2 && it + NS - 1 < n_it && !(ks == 0 && nc > 0)) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
+      // (the tail, and the step right behind a pass epilogue -- its stores share the counter and retire out of order with the loads --
+      //  drain fully)
+      if (it + NS - 1 < n_it && !(ks == 0 && nc > 0)) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
       else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
-      read_frags(nslot, 0, n0); read_frags(nslot, 1, n1);
+      read_frags(nslot, nxt);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfma_half(c1);
+    mfma_part(cur, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (more && fill) dma(it + NS, slot);
     slot = nslot;
@@ -344,8 +401,8 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
     }
   };
   for (int it = 0; it < n_it; it += 2) {
-    step(H0, H1, G0, G1, it);
-    if (it + 1 < n_it) step(G0, G1, H0, H1, it + 1);
+    step(F0, F1, it);
+    if (it + 1 < n_it) step(F1, F0, it + 1);
   }
 }
 
@@ -355,7 +412,8 @@ __global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
   attn_context_body<NP>(a, lds);
 }
 
-std::atomic<uint64_t> g_attr[4];
+std::atomic<uint64_t> g_attr[12];
+constexpr int ATTN_VAR_A = 0;      // the product's schedule variant of the logits kernel (measured: profiles/r05_attn_pw_dma_variants.txt)
 
 template <typename K>
 int set_lds_once(K kernel, int inst, int bytes) {
@@ -385,15 +443,41 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
   a.AP = (char*)alpha_planes; a.ap_rp16 = a.rp16; a.CP = nullptr; a.cp_rp16 = 0;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = scale; a.ignore_self = ignore_self; a.aperture = aperture;
   const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
-  if (np == 3) {
-    constexpr int LDS = 3 * (6 * 384 * 16) + 4096;
-    SUMK_TRY(set_lds_once(attn_pw_logits_kernel<3>, 0, LDS));
-    hipLaunchKernelGGL(attn_pw_logits_kernel<3>, dim3(grid), dim3(512), LDS, stream, a);
-  } else {
-    constexpr int LDS = 4 * (4 * 384 * 16) + 4096;
-    SUMK_TRY(set_lds_once(attn_pw_logits_kernel<2>, 1, LDS));
-    hipLaunchKernelGGL(attn_pw_logits_kernel<2>, dim3(grid), dim3(512), LDS, stream, a);
+  a.stamps = nullptr;
+#ifdef SUMK_DIAG
+  static unsigned long long* stamp_buf = nullptr;
+  static int stamp_calls = 0;
+  if (getenv("SUMK_ATTN_STAMPS")) {
+    if (!stamp_buf) SUMK_HIP(hipMalloc(&stamp_buf, 4096 * 8 * sizeof(unsigned long long)));
+    SUMK_HIP(hipMemsetAsync(stamp_buf, 0, 4096 * 8 * sizeof(unsigned long long), stream));
+    a.stamps = grid <= 4096 ? stamp_buf : nullptr;
   }
+#endif
+  static const int var = SUMK_TUNE_ENV("SUMK_ATTN_VAR_A") ? atoi(SUMK_TUNE_ENV("SUMK_ATTN_VAR_A")) : ATTN_VAR_A;      // (diagnostic build only)
+  constexpr int LDS3 = 3 * (6 * 384 * 16) + 4096, LDS2 = 4 * (4 * 384 * 16) + 4096;
+#define SUMK_A_CASE(NP_, V_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_logits_kernel<NP_, V_>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_logits_kernel<NP_, V_>), dim3(grid), dim3(512), LDS_, stream, a); }
+#ifdef SUMK_DIAG
+  if (np == 3 && var == 3) { SUMK_A_CASE(3, 3, LDS3, 10) } else if (np == 3 && var == 4) { SUMK_A_CASE(3, 4, LDS3, 11) } else
+#endif
+  if (np == 3) { if (var == 1) SUMK_A_CASE(3, 1, LDS3, 0) else if (var == 2) SUMK_A_CASE(3, 2, LDS3, 1) else SUMK_A_CASE(3, 0, LDS3, 2) }
+  else { if (var == 1) SUMK_A_CASE(2, 1, LDS2, 3) else if (var == 2) SUMK_A_CASE(2, 2, LDS2, 4) else SUMK_A_CASE(2, 0, LDS2, 5) }
+#undef SUMK_A_CASE
+#ifdef SUMK_DIAG
+  if (a.stamps && ++stamp_calls == 40) {       // one report, from a warm call
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    SUMK_HIP(hipStreamSynchronize(stream));
+    SUMK_HIP(hipMemcpy(h.data(), stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long rmin = ~0ull, rmax = 0;
+    for (unsigned b = 0; b < grid; ++b) if (h[b * 8]) { rmin = std::min(rmin, h[b * 8 + 6]); rmax = std::max(rmax, h[b * 8 + 6] + h[b * 8 + 5]); }
+    fprintf(stderr, "[attn logits stamps] grid %u, kernel window %.1f us (first block start to last block end)\n", grid, (rmax - rmin) / 100.0);
+    for (unsigned b = 0; b < grid; ++b) {
+      const unsigned long long* e = &h[b * 8];
+      if (!e[0] || (b % 9 != 0 && e[0] < 300)) continue;
+      fprintf(stderr, "  block %3u T %3llu start +%.1f us: prologue %6llu  k-loop %7llu (%.0f / k16 step)  row op + stores %6llu  total %7llu cycles = %.1f us, clock %.0f MHz, xcc %llu cu-id %llx\n",
+              b, e[0], (e[6] - rmin) / 100.0, e[1], e[2], e[2] / (double)(a.D / 16), e[3], e[4], e[5] / 100.0, e[4] / (e[5] / 100.0), e[7] & 0xf, e[7] >> 32);
+    }
+  }
+#endif
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }
@@ -406,15 +490,9 @@ int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, 
   a.AP = (char*)const_cast<void*>(alpha_planes); a.ap_rp16 = a.rp16; a.CP = (char*)ctx_planes; a.cp_rp16 = a.rp16;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = 0.f; a.ignore_self = 0; a.aperture = -1;
   const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
-  if (np == 3) {
-    constexpr int LDS = 2 * (12 + 48) * 1024;
-    SUMK_TRY(set_lds_once(attn_pw_context_kernel<3>, 2, LDS));
-    hipLaunchKernelGGL(attn_pw_context_kernel<3>, dim3(grid), dim3(512), LDS, stream, a);
-  } else {
-    constexpr int LDS = 3 * (8 + 32) * 1024;
-    SUMK_TRY(set_lds_once(attn_pw_context_kernel<2>, 3, LDS));
-    hipLaunchKernelGGL(attn_pw_context_kernel<2>, dim3(grid), dim3(512), LDS, stream, a);
-  }
+  constexpr int LDS3 = 4 * (6 + 24) * 1024, LDS2 = 3 * (8 + 32) * 1024;
+  if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3>, 6, LDS3)); hipLaunchKernelGGL(attn_pw_context_kernel<3>, dim3(grid), dim3(512), LDS3, stream, a); }
+  else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2>, 7, LDS2)); hipLaunchKernelGGL(attn_pw_context_kernel<2>, dim3(grid), dim3(512), LDS2, stream, a); }
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

@@ -23,6 +23,7 @@
 // exactly an 8-byte piece of a KB-plane chunk -- the result is split into planes in registers and leaves as 512-byte contiguous runs.
 #include "pw_common.h"
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace sumk {
@@ -121,10 +122,20 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
     }
   };
 
-  // tile walk: the XCD-aware map of gemm_device.h (tile % 8 labels the XCD: each XCD owns a (tiles_m / 2) x (tiles_n / 4) rectangle)
+  // Tile walk (speed only; block b runs on XCD b % 8 under round-robin dispatch and the persistent stride keeps tile % 8 = b % 8).
+  // xcd_map 2: XCD x owns a BAND of ceil(tiles_m / 8) row tiles and every column tile; inside the band the tiles are dealt in groups of 4
+  // column tiles, rows fastest across groups of 4 columns -- the 32 blocks an XCD runs at a time are 8 row tiles x 4 column tiles: each A
+  // panel is fetched into ONE L2 and hit by the other three blocks that need it, each B panel by the other seven.  (The 2 x 4 rectangles
+  // of gemm_device.h, xcd_map 1, give an XCD with N = 1024 a single column tile: every A panel was fetched by four L2s and never re-used
+  // inside one -- PMC: L2 hit 0.52, 343 MB fetched for 74 MB of A; profiles/r05_pmc_pw_x6_tail.json.)
   auto decode = [&](int t, int& m0, int& n0) -> bool {
     int mt, nt;
-    if (a.xcd_map) {
+    if (a.xcd_map == 2) {
+      const int x = t & 7, j = t >> 3, rx = (a.tiles_m + 7) >> 3, per = rx * 4;
+      const int grp = j / per, jj = j - grp * per, r = jj >> 2;
+      mt = x * rx + r; nt = grp * 4 + (jj & 3);
+      if (grp >= (a.tiles_n >> 2) || mt >= a.tiles_m) return false;
+    } else if (a.xcd_map == 1) {
       const int x = t & 7, j = t >> 3, sm = (a.tiles_m + 1) >> 1, sn = a.tiles_n >> 2;
       const int jm = j / sn;
       mt = (x >> 2) * sm + jm; nt = (x & 3) * sn + (j - jm * sn);
@@ -142,8 +153,15 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
   unsigned long long t_start = 0, t_loop = 0, t_epi = 0, rt_start = 0, n_tiles = 0;
   if constexpr (VAR == 3) { t_start = __builtin_amdgcn_s_memtime(); rt_start = __builtin_amdgcn_s_memrealtime(); }
 #endif
-  int tile = blockIdx.x, m0 = 0, n0 = 0;
-  if (tile >= a.total_tiles || !decode(tile, m0, n0)) return;
+  // (a virtual tile id of an XCD map may name no tile: walk on to this block's next one)
+  auto next_valid = [&](int t, int& m, int& n) -> int {
+    for (; t < a.total_tiles; t += gridDim.x)
+      if (decode(t, m, n)) return t;
+    return -1;
+  };
+  int m0 = 0, n0 = 0;
+  int tile = next_valid(blockIdx.x, m0, n0);
+  if (tile < 0) return;
 #pragma unroll
   for (int s = 0; s < NS; ++s) dma(m0, n0, s, s);
 
@@ -220,9 +238,9 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
     unsigned long long t1 = 0;
     if constexpr (VAR == 3) t1 = __builtin_amdgcn_s_memtime();
 #endif
-    const int next_tile = tile + gridDim.x;
     int m1 = 0, n1 = 0;
-    const bool has_next = next_tile < a.total_tiles && decode(next_tile, m1, n1);
+    const int next_tile = next_valid(tile + gridDim.x, m1, n1);
+    const bool has_next = next_tile >= 0;
     if (has_next) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) dma(m1, n1, s, s);
@@ -419,8 +437,9 @@ int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {
   a.a_rp16 = (uint32_t)(pw_rows_pitch(g.a_rows) * 16); a.b_rp16 = (uint32_t)(pw_rows_pitch(g.b_rows) * 16);
   a.M = g.M; a.N = g.N; a.K = g.K;
   a.tiles_m = (g.M + 191) / 192; a.tiles_n = g.N / 256;
-  a.xcd_map = (a.tiles_n % 4 == 0 && a.tiles_m >= 16) ? 1 : 0;
-  a.total_tiles = a.xcd_map ? 8 * ((a.tiles_m + 1) / 2) * (a.tiles_n / 4) : a.tiles_m * a.tiles_n;
+  static const int map_env = SUMK_TUNE_ENV("SUMK_PW_XCD_MAP") ? atoi(SUMK_TUNE_ENV("SUMK_PW_XCD_MAP")) : 2;      // (diagnostic build only)
+  a.xcd_map = (a.tiles_n % 4 == 0 && a.tiles_m >= 16) ? map_env : 0;
+  a.total_tiles = a.xcd_map == 2 ? 8 * ((a.tiles_m + 7) / 8) * a.tiles_n : a.xcd_map == 1 ? 8 * ((a.tiles_m + 1) / 2) * (a.tiles_n / 4) : a.tiles_m * a.tiles_n;
   a.C = g.C; a.ldc = g.ldc; a.O = (char*)g.O; a.o_rp16 = pw_rows_pitch(g.o_rows) * 16;
   a.o_store_rows = (int32_t)std::max<int64_t>(g.M, std::min<int64_t>(g.o_store_rows, std::min<int64_t>(pw_rows_pitch(g.o_rows), pw_rows_pitch(g.a_rows)))); a.R = g.R; a.ldr = g.ldr; a.moments = g.moments;
   a.bias = g.bias; a.gw = g.gw; a.ln_c1 = g.ln_c1; a.ln_stats = g.ln_stats; a.head_part = g.head_part;

@@ -102,7 +102,8 @@ class DSNTrainer(Trainer):
         self.log.debug("Parameters: {}".format(sum([_.numel() for _ in self.model.parameters()])))
         dev = self._device()
         rank, world = dist_info()
-        bv = int(self.hps.extra_params.get("batch_videos", 1))
+        from ..training import resolve_batch_videos
+        bv = resolve_batch_videos(self.hps.extra_params, "dsn", "fp32", train_keys, self.log)
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.hps.lr, weight_decay=self.hps.weight_decay,
                                   comm_dtype=torch.bfloat16 if getattr(self.model, "precision", "fp32") == "bf16" else None)
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket

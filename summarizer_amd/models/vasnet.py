@@ -247,7 +247,8 @@ class VASNetTrainer(Trainer):
         self.draw_gtscores(fold, train_keys)
         dev = self._device()
         rank, world = dist_info()
-        bv = int(self.hps.extra_params.get("batch_videos", 1))
+        from ..training import resolve_batch_videos
+        bv = resolve_batch_videos(self.hps.extra_params, "vasnet", "bf16" if self.model.precision == "bf16" else "fp32", train_keys, self.log)
         # precision "bf16" = mixed-precision training (BASELINE config 2): bf16 matrix arithmetic with fp32 accumulation, fp32
         # master weights / moments in the flat bucket, and the gradient bucket crossing the all-reduce as bf16
         self.optimizer = FlatAdam(filter(lambda p: p.requires_grad, self.model.parameters()), lr=self.hps.lr,

@@ -70,6 +70,61 @@ def step_video_total(sizes, bv, step):
     return sum(max(0, min(bv, n - step * bv)) for n in sizes)
 
 
+# ---- what a data-parallel step is expected to cost (NOT measured on more than one GPU yet) -------------------------
+# Per-GPU step time of the trainers as a function of the videos per rank per step (TVSum-shaped videos, ~240 frames, D = 1024; fitted to the
+# 1-GPU measurements of bench.py: 1 video and 50 videos per step), the bucket a step all-reduces, and the fraction of the exchange the step
+# hides (VASNet: the tail piece, 40 % of the bucket, runs under the attention backward; DSN: the reverse direction's half runs under the
+# forward direction's weight gradients).  All-reduce time: SURVEY section 5's link model -- a ring is per-link bound (2 (N - 1) / N bytes
+# over ~153 GB/s), a direct reduce-scatter + all-gather moves bytes / N per link and phase.
+_DP_MODEL = {            # (us per step at 1 video, extra us per further video, bucket bytes, hidden fraction)
+    ("vasnet", "fp32"): (300.0, 55.0, 21.0e6, 0.4),
+    ("vasnet", "bf16"): (260.0, 10.0, 10.5e6, 0.4),
+    ("dsn", "fp32"): (1700.0, 40.0, 10.5e6, 0.5),
+}
+
+
+def predicted_allreduce_us(nbytes, world):
+    """(ring, direct) estimate of one SUM all-reduce of nbytes over `world` GPUs of one xGMI node, microseconds."""
+    link = 153.0e9
+    ring = 2.0 * (world - 1) / world * nbytes / link * 1e6 + 15.0
+    direct = 2.0 * nbytes / world / link * 1e6 + 15.0
+    return ring, direct
+
+
+def predicted_dp_efficiency(kind, precision, world, batch_videos):
+    """[pessimistic (ring), optimistic (direct)] predicted weak-scaling efficiency step / (step + exposed exchange) of a trainer's step
+    with `batch_videos` videos per rank.  A prediction to compare the first multi-GPU measurement with, nothing more."""
+    t1, dt, nbytes, hidden = _DP_MODEL.get((kind, precision), _DP_MODEL[(kind, "fp32")])
+    step = t1 + dt * (batch_videos - 1)
+    return [round(step / (step + (1.0 - hidden) * ar), 3) for ar in predicted_allreduce_us(nbytes, world)]
+
+
+def choose_batch_videos(kind, precision, world, shard_videos, target=0.9):
+    """Smallest number of videos per rank per step whose PESSIMISTIC predicted efficiency reaches `target`, capped by the rank's shard
+    (extra_params batch_videos=auto).  The default of the trainers stays 1 -- the reference's optimisation schedule scaled out by video,
+    global batch = world -- because the videos per step change the training dynamics, not only the speed."""
+    if world <= 1:
+        return 1
+    for bv in range(1, max(1, shard_videos) + 1):
+        if predicted_dp_efficiency(kind, precision, world, bv)[0] >= target:
+            return bv
+    return max(1, shard_videos)
+
+
+def resolve_batch_videos(extra_params, kind, precision, train_keys, log=None):
+    """batch_videos of a trainer run: extra_params["batch_videos"] (an integer, default 1; "auto" = choose_batch_videos).  Under
+    torch.distributed the choice and the predicted efficiency of the step are logged, so that a slow multi-GPU run explains itself."""
+    rank, world = dist_info()
+    raw = str(extra_params.get("batch_videos", 1))
+    shard = max(1, -(-len(train_keys) // world))
+    bv = choose_batch_videos(kind, precision, world, shard) if raw == "auto" else int(raw)
+    if world > 1 and log is not None:
+        lo, hi = predicted_dp_efficiency(kind, precision, world, bv)
+        log.info(f"data parallel over {world} ranks: batch_videos={bv} per rank (global batch {bv * world} videos), predicted weak-scaling "
+                 f"efficiency {lo}-{hi} (ring - direct all-reduce; extra_params batch_videos=auto picks the smallest value predicted >= 0.9)")
+    return bv
+
+
 class RcclDirect:
     """The flat-bucket all-reduce through libsumk's own RCCL entry point (`sumk_allreduce_flat`) instead of torch.distributed:
     the collective is enqueued on the CURRENT HIP stream like any other kernel of the step (no process-group stream hop).

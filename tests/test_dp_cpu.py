@@ -52,3 +52,28 @@ def test_flat_bucket_allreduce_gloo_world2():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_dp_schedule_prediction_and_auto_batch_videos():
+    """training.predicted_dp_efficiency / choose_batch_videos / resolve_batch_videos: the trainers keep the reference's
+    one-video-per-step schedule by default (global batch = world), say what it is predicted to cost, and `batch_videos=auto` picks the
+    smallest batch predicted >= 0.9 under the pessimistic (ring) all-reduce estimate, capped by the rank's shard."""
+    from summarizer_amd import training as T
+    for kind, prec in (("vasnet", "fp32"), ("vasnet", "bf16"), ("dsn", "fp32")):
+        prev = 0.0
+        for bv in (1, 2, 8, 32, 128):
+            lo, hi = T.predicted_dp_efficiency(kind, prec, 8, bv)
+            assert 0.0 < lo <= hi <= 1.0 and lo >= prev
+            prev = lo
+        bv = T.choose_batch_videos(kind, prec, 8, 1000)
+        assert T.predicted_dp_efficiency(kind, prec, 8, bv)[0] >= 0.9
+        assert bv == 1 or T.predicted_dp_efficiency(kind, prec, 8, bv - 1)[0] < 0.9
+        assert T.choose_batch_videos(kind, prec, 1, 1000) == 1
+        assert T.choose_batch_videos(kind, prec, 8, 3) <= 3                 # capped by the shard
+    lo1, _ = T.predicted_dp_efficiency("vasnet", "fp32", 8, 1)
+    assert lo1 < 0.9                                                        # the default schedule is NOT predicted to scale at 0.9: said, not hidden
+    ring, direct = T.predicted_allreduce_us(21.0e6, 8)
+    assert 200 < ring < 300 and 30 < direct < 80
+    assert T.resolve_batch_videos({}, "vasnet", "fp32", list(range(40))) == 1
+    assert T.resolve_batch_videos({"batch_videos": "4"}, "vasnet", "fp32", list(range(40))) == 4
+    assert T.resolve_batch_videos({"batch_videos": "auto"}, "vasnet", "fp32", list(range(40))) == 1      # single process: nothing to hide
