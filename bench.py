@@ -385,7 +385,13 @@ def recurrent_legs(x, lens, dev, frames):
     with torch.no_grad():
         dt = timed(lambda: dsn.score_packed(x, lens), 20)
     out["dsn_score_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / t_max, 2),
-                                 note=f"DSN scoring, 50 videos packed: input projection GEMM + one persistent bidirectional recurrence of {t_max} dependent steps + head")
+                                 note=f"DSN scoring, 50 videos packed: input projection GEMM + one persistent bidirectional recurrence of {t_max} dependent steps + head (the per-step figure is the whole call / {t_max})")
+    dsn.precision = "bf16x6"
+    with torch.no_grad():
+        dt = timed(lambda: dsn.score_packed(x, lens), 20)
+    dsn.precision = "fp32"
+    out["dsn_score_bf16x6_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / t_max, 2),
+                                        note="the same with the input projection in the fp32-grade bf16x6 arithmetic on operand planes (csrc/gemm_pw.hip); the recurrence stays fp32")
     dsn.train()
     opt = FlatAdam(dsn.parameters(), lr=1e-5, weight_decay=1e-5)
     target = torch.rand(frames, device=dev)
@@ -406,6 +412,11 @@ def recurrent_legs(x, lens, dev, frames):
         dt = timed(lambda: sl.score_packed(x, lens), 5)
     out["slstm_score_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
                                    note=f"sLSTM scoring (2 layers x {t_max} dependent steps, H = 1024, wide persistent recurrence) + 4 input projections")
+    sl.precision = "bf16x6"
+    with torch.no_grad():
+        dt = timed(lambda: sl.score_packed(x, lens), 5)
+    out["slstm_score_bf16x6_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
+                                          note="the same with both layers' input projections in the fp32-grade bf16x6 arithmetic on operand planes; the recurrences stay fp32")
     _k.health_check()
     return out
 

@@ -144,7 +144,17 @@ typedef struct sumk_lstm_layer_weights {
   const float* w_hh[2]; /* (4H, H)   weight_hh_l{k}[_reverse] */
   const float* b_ih[2]; /* (4H)      bias_ih_l{k}[_reverse]   */
   const float* b_hh[2]; /* (4H)      bias_hh_l{k}[_reverse]   */
+  /* Optional, all three or none (zero-initialise the struct otherwise): inference in SUMK_PRECISION_BF16X6 / BF16X3 then runs the
+     input projection of dsn.py:45 / sumgan.py:43 on the plane-aware wide GEMM (csrc/gemm_pw.hip) -- x_planes: the "KB planes" of x
+     (n_rows x In, sumk_split_planes); w_planes: the block sumk_bilstm_wplanes_build wrote for THESE weights (planes of
+     [w_ih[0]; w_ih[1]] and the summed biases).  Needs 8 H % 256 == 0, In % 32 == 0, In >= 128, n_rows >= 1024. */
+  const void* x_planes;
+  const void* w_planes;
 } sumk_lstm_layer_weights;
+
+/* Weight-plane block of sumk_lstm_layer_weights::w_planes: bytes (0 = not eligible) and the build (redo after a weight change). */
+size_t sumk_bilstm_wplanes_bytes(int32_t In, int32_t H, int32_t n_planes);
+int sumk_bilstm_wplanes_build(int32_t In, int32_t H, const sumk_lstm_layer_weights* w, int32_t n_planes, void* out, size_t out_bytes, void* stream);
 
 size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
 /* precision: SUMK_PRECISION_FP32, or SUMK_PRECISION_BF16X3 for the input projection (and, for 256 < H <= 1024, the

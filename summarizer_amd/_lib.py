@@ -72,7 +72,8 @@ class EvalDevVideo(C.Structure):      # sumk_eval_dev_video: every pointer is a 
 
 
 class LstmLayerWeights(C.Structure):
-    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2)]
+    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2),
+                ("x_planes", C.c_void_p), ("w_planes", C.c_void_p)]
 
 
 class LstmLayerGrads(C.Structure):
@@ -99,6 +100,8 @@ _SIGS = {
                                        C.POINTER(VasnetOpts), c_f32p, C.POINTER(VasnetGrads), c_f32p, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_void_p]),
     "sumk_bilstm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_bilstm_wplanes_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "sumk_bilstm_wplanes_build": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(LstmLayerWeights), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_bilstm_layer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
                                             C.POINTER(LstmLayerWeights), c_f32p, C.c_void_p, C.c_size_t, C.c_int32,
                                             C.c_int32, C.c_void_p]),

@@ -252,12 +252,13 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int col = col_w + tn * 32 + li;
+        const float bv = a.bias ? a.bias[col] : 0.f;            // (kernel-uniform: the input projection of the LSTM scorers adds its summed biases)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = row_w + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[tm][tn][r];
+            if (row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[tm][tn][r] + bv;
           }
       }
     } else if constexpr (EPI == PW_PLANES || EPI == PW_RES_MOM_PLANES) {

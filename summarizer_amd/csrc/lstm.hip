@@ -1812,6 +1812,32 @@ extern "C" size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_s
   return w.total;
 }
 
+// weight-plane block of the input projection (sumk_lstm_layer_weights::w_planes): planes of [w_ih[0]; w_ih[1]] (8H x In), then b_ih + b_hh (8H)
+static bool bilstm_wplanes_ok(int In, int H, int np) {
+  return H > 0 && (8 * H) % 256 == 0 && In % 32 == 0 && In >= 128 && (np == 2 || np == 3) && pw_ok(1024, 8 * (int64_t)H, In, 1024, 8 * (int64_t)H, np);
+}
+__global__ void bilstm_bias_sum_kernel(const float* b0, const float* b1, const float* b2, const float* b3, int H4, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < H4) { out[i] = b0[i] + b1[i]; out[H4 + i] = b2[i] + b3[i]; }
+}
+extern "C" size_t sumk_bilstm_wplanes_bytes(int32_t In, int32_t H, int32_t n_planes) {
+  if (!bilstm_wplanes_ok(In, H, n_planes)) return 0;
+  return align_up(pw_planes_bytes(8 * (int64_t)H, In, n_planes), 256) + (size_t)8 * H * 4;
+}
+extern "C" int sumk_bilstm_wplanes_build(int32_t In, int32_t H, const sumk_lstm_layer_weights* w, int32_t n_planes, void* out, size_t out_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(bilstm_wplanes_ok(In, H, n_planes), "bilstm_wplanes_build: In=%d H=%d planes=%d is not eligible (8H %% 256, In %% 32, In >= 128)", In, H, n_planes);
+  SUMK_ARG(w && out && w->w_ih[0] && w->w_ih[1] && w->b_ih[0] && w->b_ih[1] && w->b_hh[0] && w->b_hh[1], "bilstm_wplanes_build: null pointer");
+  const size_t pb = align_up(pw_planes_bytes(8 * (int64_t)H, In, n_planes), 256);
+  SUMK_ARG(out_bytes >= pb + (size_t)8 * H * 4 && ((uintptr_t)out & 255) == 0, "bilstm_wplanes_build: buffer too small or misaligned");
+  SUMK_HIP(hipMemsetAsync(out, 0, pb, stream));
+  for (int d = 0; d < 2; ++d) SUMK_TRY(split_planes_at(w->w_ih[d], 4 * H, In, In, n_planes, out, (int64_t)d * 4 * H, 8 * (int64_t)H, stream));
+  hipLaunchKernelGGL(bilstm_bias_sum_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, stream, w->b_ih[0], w->b_hh[0], w->b_ih[1], w->b_hh[1], 4 * H,
+                     (float*)((char*)out + pb));
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
 extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq,
                                          const int32_t* seq_off_host, const int32_t* seq_off_dev,
                                          const sumk_lstm_layer_weights* w, float* h_out, void* workspace,
@@ -1834,6 +1860,13 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
 
   // 1: input projection for both directions, biases fused
   const int small = gemm_tiles(R, 8 * H, 0) >= 512 ? 0 : 1;
+  const int np_in = precision == SUMK_PRECISION_BF16X6 ? 3 : precision == SUMK_PRECISION_BF16X3 ? 2 : 0;
+  if (!training && np_in && w->x_planes && w->w_planes && bilstm_wplanes_ok(In, H, np_in) && R >= 1024 && pw_ok(R, 8 * (int64_t)H, In, R, 8 * (int64_t)H, np_in)) {
+    // operand planes (x per dataset / per call, weights per weight change): the plane-aware wide GEMM, no split in the k-loop
+    PwLaunch g; g.A = w->x_planes; g.a_rows = R; g.B = w->w_planes; g.b_rows = 8 * (int64_t)H; g.M = R; g.N = 8 * H; g.K = In; g.np = np_in;
+    g.C = G; g.ldc = 8 * H; g.bias = (const float*)((const char*)w->w_planes + align_up(pw_planes_bytes(8 * (int64_t)H, In, np_in), 256));
+    SUMK_TRY(launch_gemm_pw(PW_F32, g, stream));
+  } else {
   SUMK_TRY(fill_single_prob(prob, R, 8 * H, In, In, In, 8 * H, 0, small, stream));
   {
     GemmLaunch g;
@@ -1842,6 +1875,7 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     g.C = G; g.probs = prob; g.small_tile = small; g.total_tiles = gemm_tiles(R, 8 * H, small);
     g.precision = precision; g.lean = gemm_lean_ok(R, 4 * H, In, In, In);
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
+  }
   }
   // 2: recurrence.  The health word is cleared on BOTH paths so sumk_bilstm_check never reads stale workspace bytes.
   // (the flag-in-data hand-off buffer lies directly behind the state words: one launch clears both -- a tag of 0 matches no step)

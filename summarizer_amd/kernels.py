@@ -305,14 +305,39 @@ def _lstm_layer_struct(params, prefix, layer):
     return w
 
 
-def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False, precision=None):
-    """x: (n_rows, In) packed -> h (n_rows, 2H) = [h_fwd || h_rev].  Returns (h, workspace or None)."""
+def bilstm_wplanes(params, prefix, layer, In, H, n_planes, out=None):
+    """Weight-plane block of one BiLSTM layer's input projection (sumk_lstm_layer_weights.w_planes), or None when the shape is not eligible."""
+    lib = _lib.load()
+    nb = lib.sumk_bilstm_wplanes_bytes(int(In), int(H), int(n_planes))
+    if nb == 0:
+        return None
+    w = _lstm_layer_struct(params, prefix, layer)
+    dev = params[f"{prefix}weight_ih_l{layer}"].device
+    if out is None or out.numel() < nb + 256 or out.device != dev:
+        out = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+    base = (out.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.sumk_bilstm_wplanes_build(int(In), int(H), C.byref(w), int(n_planes), C.c_void_p(base), nb, _stream()), "sumk_bilstm_wplanes_build")
+    view = out[base - out.data_ptr():]
+    view._sumk_keep = out
+    return view
+
+
+def bilstm_layer_forward(x, sb, params, prefix, layer, H, training=False, precision=None, wplanes=None, dataset_input=False):
+    """x: (n_rows, In) packed -> h (n_rows, 2H) = [h_fwd || h_rev].  Returns (h, workspace or None).
+    wplanes (inference in bf16x6 / bf16x3): the layer's weight-plane block -- the input projection then runs on operand planes
+    (csrc/gemm_pw.hip); x's planes are kept with the tensor object when dataset_input (layer 0: features), split per call otherwise."""
     lib = _lib.load()
     _require_gpu(x, "bilstm input")
     if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
         raise SumkError(f"bilstm input must be contiguous (n_rows={sb.n_rows}, In), got {tuple(x.shape)}")
     In = x.shape[1]
     w = _lstm_layer_struct(params, prefix, layer)
+    n_planes = PLANES_OF.get(precision)
+    xplanes = None
+    if wplanes is not None and n_planes and not training and sb.n_rows >= 1024:
+        xplanes = (tensor_shadow(x, f"planes{n_planes}", lambda: split_planes(x, n_planes)) if dataset_input and not torch.cuda.is_current_stream_capturing()
+                   else split_planes(x, n_planes))
+        w.x_planes, w.w_planes = xplanes.data_ptr(), wplanes.data_ptr()
     nbytes = lib.sumk_bilstm_workspace_bytes(In, H, sb.n_seq, sb.off_host_p, int(training))
     if nbytes == 0:
         _lib.check(-1, "sumk_bilstm_workspace_bytes")

@@ -15,7 +15,7 @@ def pack_time_major(x):
 
 
 def bilstm_scores(model, xp, sb, prefix, num_layers, H, head_w, head_b):
-    precision = getattr(model, "precision", "fp32")     # "fp32" | "bf16x3" (kernels.precision_code)
+    precision = getattr(model, "precision", "fp32")     # "fp32" | "bf16x3" | "bf16x6" (kernels.precision_code)
     training = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if training:
         from ..autograd import BiLstmScorerFunction
@@ -24,9 +24,30 @@ def bilstm_scores(model, xp, sb, prefix, num_layers, H, head_w, head_b):
         return BiLstmScorerFunction.apply(xp, sb, prefix, num_layers, H, head_w, head_b, precision, names, *[p[n] for n in names])
     p = dict(model.named_parameters())
     h = xp
+    wpl = _layer_wplanes(model, p, prefix, num_layers, xp.shape[1], H, precision) if sb.n_rows >= 1024 else None
     for layer in range(num_layers):
-        h, _ = kernels.bilstm_layer_forward(h, sb, p, prefix, layer, H, training=False, precision=precision)
+        h, _ = kernels.bilstm_layer_forward(h, sb, p, prefix, layer, H, training=False, precision=precision,
+                                            wplanes=None if wpl is None else wpl[layer], dataset_input=(layer == 0))
     return kernels.frame_head_forward(h, p[head_w], p[head_b])
+
+
+def _layer_wplanes(model, p, prefix, num_layers, In, H, precision):
+    """Per-layer weight-plane blocks of the input projections for the split-bf16 arithmetics (kernels.bilstm_wplanes), cached on the
+    model and rebuilt when a weight changes (storage addresses, tensor versions, kernels.WEIGHTS_EPOCH: the rules of VASNet._wplanes)."""
+    n_planes = kernels.PLANES_OF.get(precision)
+    if not n_planes:
+        return None
+    ps = [v for k, v in sorted(p.items()) if k.startswith(prefix)]
+    key = tuple(t.data_ptr() for t in ps) + tuple(t._version for t in ps) + (kernels.WEIGHTS_EPOCH[0], precision)
+    cache = model.__dict__.get("_sumk_wpl")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            old = cache[2] if cache is not None else [None] * num_layers
+            blocks = [kernels.bilstm_wplanes({k: v.detach() for k, v in p.items()}, prefix, layer, In if layer == 0 else 2 * H, H, n_planes,
+                                             out=old[layer]) for layer in range(num_layers)]
+        cache = (key, blocks, [getattr(b, "_sumk_keep", None) if b is not None else None for b in blocks])
+        model.__dict__["_sumk_wpl"] = cache
+    return cache[1]
 
 
 def lstm_stack(lstm, xp, sb, h0=None, c0=None, precision="fp32"):

@@ -239,3 +239,45 @@ def test_attention_on_planes_vs_float64(dev, n_planes, mask):
         ctx = cp[:, r0:r0 + T].sum(0)
         ref = al @ v
         assert np.abs(ctx - ref).max() < tol_c, (s, T, np.abs(ctx - ref).max())
+
+
+# ------------------------------------------------------------------------------------------------ BiLSTM scorers: input projection on planes
+@pytest.mark.parametrize("kind", ["dsn", "slstm"])
+def test_lstm_scorers_input_projection_on_planes(dev, kind):
+    """DSN (dsn.py:38-47) and sLSTM (sumgan.py:23-46) with precision = bf16x6 / bf16x3: the input projection X W_ih^T + b_ih + b_hh of every
+    layer runs on operand planes (csrc/gemm_pw.hip; x planes kept with the feature tensor, weight planes per weight change).  The layer output
+    is BIT-IDENTICAL to the same arithmetic on the in-loop split kernels (a call without the weight-plane block), and the scores stay within
+    2e-6 (bf16x6: fp32-grade) / 5e-5 (bf16x3) of the exact-fp32 path; the planes follow a weight change."""
+    from summarizer_amd import kernels
+    sys_path_golden()
+    import recipes as Rc
+    D = 1024
+    lens = [int(t) for t in np.random.default_rng(9).integers(150, 321, size=7)]
+    x = torch.from_numpy(np.concatenate([Rc.features(T, 1, D, 700 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    torch.manual_seed(3)
+    if kind == "dsn":
+        from summarizer_amd.models.dsn import DSN
+        m = DSN(input_size=D).to(dev).eval(); prefix, H, layers = "rnn.", 256, 1
+    else:
+        from summarizer_amd.models.sumgan import sLSTM
+        m = sLSTM(input_size=D).to(dev).eval(); prefix, H, layers = "lstm.", 1024, 2
+    with torch.no_grad():
+        ref = m.score_packed(x, lens)
+        for prec, tol in (("bf16x6", 2e-6), ("bf16x3", 5e-5)):
+            m.precision = prec
+            got = m.score_packed(x, lens)
+            assert m.__dict__["_sumk_wpl"][1][0] is not None and f"planes{kernels.PLANES_OF[prec]}" in x._sumk_shadows      # the plane path ran
+            assert float((got - ref).abs().max()) < tol, (prec, float((got - ref).abs().max()))
+            sb = kernels.SeqBatch.get(lens, dev)
+            p = dict(m.named_parameters())
+            wpl = m.__dict__["_sumk_wpl"][1]
+            h_pl, _ = kernels.bilstm_layer_forward(x, sb, p, prefix, 0, H, precision=prec, wplanes=wpl[0], dataset_input=True)
+            h_old, _ = kernels.bilstm_layer_forward(x, sb, p, prefix, 0, H, precision=prec)
+            assert torch.equal(h_pl, h_old)
+        key0 = m.__dict__["_sumk_wpl"][0]
+        dict(m.named_parameters())[prefix + "weight_ih_l0"].mul_(1.1)
+        got2 = m.score_packed(x, lens)
+        assert m.__dict__["_sumk_wpl"][0] != key0 and not torch.equal(got2, got)
+        m.precision = "fp32"
+        assert float((m.score_packed(x, lens) - got2).abs().max()) < 5e-5
+    kernels.health_check()
