@@ -215,11 +215,18 @@ def make_reinforce_step(model, x, lens, dev):
     from summarizer_amd import kernels
     from summarizer_amd.training import FlatAdam
     from summarizer_amd.autograd import PolicyLossFunction
+    from summarizer_amd.training import dist_info
     opt = FlatAdam(model.parameters(), lr=5e-5, weight_decay=1e-5)
     sb = kernels.SeqBatch.get(lens, dev)
     base = torch.zeros(len(lens), device=dev)
+    # data parallel: the bucket's tail [reverse direction | head] goes out on a side stream under the forward direction's weight-gradient
+    # GEMMs, as DSNTrainer issues it (sumk_lstm_layer_grads::tail_ready_event)
+    tail_from = None
+    if dist_info()[1] > 1:
+        tail_from = opt.tail_offset(dict(model.named_parameters())["rnn.weight_ih_l0_reverse"])
+        model.tail_grads_ready_event = torch.cuda.Event()
 
-    def run_step():
+    def run_step(reduce=True):
         opt.zero_grad()
         probs = model.score_packed(x, lens)
         dist_ = Bernoulli(probs, validate_args=False)          # (validation is a D2H sync per step)
@@ -227,7 +234,9 @@ def make_reinforce_step(model, x, lens, dev):
         rewards = kernels.dsn_reward(x, sb, actions.contiguous())
         loss = PolicyLossFunction.apply(probs, sb, actions, rewards, base, 0.01, 0.5).mean()    # dsn.py:113-140 in two HIP kernels
         loss.backward()
-        opt.step(grad_scale=opt.all_reduce_grads(), max_norm=5.0)
+        if reduce and tail_from is not None:
+            opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
+        opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / dist_info()[1], max_norm=5.0)
         base.mul_(0.9).add_(rewards.mean(dim=0), alpha=0.1)        # in place: also valid under --graph replays
         return loss.detach()
     return run_step, opt
@@ -867,17 +876,15 @@ def main():
             sec = timed_steps(step, n_train)
             sec_local = sec
             if dist is not None:          # the same step with the exchange left out (every rank then steps on its own gradient)
-                real = opt.all_reduce_grads
-                opt.all_reduce_grads = lambda average=True: 1.0 / world
-                sec_local = timed_steps(step, n_train)
-                opt.all_reduce_grads = real
+                sec_local = timed_steps(lambda: step(False), n_train)
             from summarizer_amd import kernels as _kk
             _kk.health_check()                                            # persistent recurrences: no hand-off timed out
             rec = dict(frames_per_s=round(frames * world / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=n_train,
                        allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0,
-                       collectives_per_step=1 if world > 1 else 0,
+                       collectives_per_step=2 if world > 1 else 0,
                        note="DSN (BiLSTM 1024 -> 2 x 256) REINFORCE step: scores, 5 Bernoulli episodes, reward kernel, policy loss, "
-                            "backward, one all-reduce of the flat gradient bucket (RCCL when world > 1; no overlap: it needs the whole BPTT), clip + fused Adam")
+                            "backward, the all-reduce of the flat gradient bucket in two pieces (RCCL when world > 1: [reverse direction | head] early on a side "
+                            "stream under the forward direction's weight-gradient GEMMs, the rest after the backward), clip + fused Adam")
             return decompose(rec, sec * 1e3, sec_local * 1e3, allreduce_alone_us(opt.flat_grad.numel(), torch.float32))
         reinforce_leg = collective_leg(run_reinforce_leg)
     single = None

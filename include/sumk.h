@@ -196,6 +196,12 @@ int sumk_health_check(void* stream);
 
 typedef struct sumk_lstm_layer_grads {
   float* w_ih[2]; float* w_hh[2]; float* b_ih[2]; float* b_hh[2];
+  /* NULL (zero-initialise the struct), or a hipEvent_t the call RECORDS on `stream` once both bias gradients and the REVERSE direction's
+     weight gradients (w_ih[1], w_hh[1]) are final -- before the forward direction's weight-gradient GEMMs run.  A data-parallel caller whose
+     gradient bucket ends with [reverse direction | head] (the parameter order of DSN, dsn.py:23-36) can all-reduce that half on a side stream
+     under the remaining GEMMs (training.FlatAdam.reduce_tail_async).  With the event set the two directions' dW_ih run as two launches
+     (reverse first) instead of one. */
+  void* tail_ready_event;
 } sumk_lstm_layer_grads;
 /* dh_out (n_rows,2H) -> accumulates weight grads; dx (n_rows,In) written if non-NULL.  Needs the workspace of
  * a training-mode sumk_bilstm_layer_forward and that call's h_out. */

@@ -77,7 +77,8 @@ class LstmLayerWeights(C.Structure):
 
 
 class LstmLayerGrads(C.Structure):
-    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2)]
+    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2),
+                ("tail_ready_event", C.c_void_p)]
 
 
 _SIGS = {

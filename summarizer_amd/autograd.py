@@ -66,9 +66,10 @@ class BiLstmScorerFunction(torch.autograd.Function):
     """scores = sigmoid(Linear(BiLSTM_stack(x))) for a packed batch (DSN: dsn.py:45-46, sLSTM: sumgan.py:43-45)."""
 
     @staticmethod
-    def forward(ctx, xp, sb, prefix, num_layers, H, head_w, head_b, precision, names, *params):
+    def forward(ctx, xp, sb, prefix, num_layers, H, head_w, head_b, precision, tail_event, names, *params):
         p = dict(zip(names, params))
         acts, wss = [xp], []
+        ctx.tail_event = tail_event
         for layer in range(num_layers):
             h, ws = kernels.bilstm_layer_forward(acts[-1], sb, p, prefix, layer, H, training=True, precision=precision)
             acts.append(h); wss.append(ws)
@@ -89,12 +90,14 @@ class BiLstmScorerFunction(torch.autograd.Function):
         dh = kernels.frame_head_backward(acts[-1], scores, dscores, p[head_w], grads[head_w], grads[head_b])
         for layer in range(num_layers - 1, -1, -1):
             want_dx = layer > 0 or ctx.needs_input_grad[0]
+            # (the event goes with the LAST layer processed, layer 0: by then every other gradient of the bucket's tail is final)
             dh = kernels.bilstm_layer_backward(acts[layer], acts[layer + 1], dh, sb, p, grads, prefix, layer, H,
-                                               ctx.wss[layer], want_dx, precision=precision)
+                                               ctx.wss[layer], want_dx, precision=precision,
+                                               tail_event=ctx.tail_event if (layer == 0 and num_layers == 1) else None)
         ctx.wss = None
         gx = dh if ctx.needs_input_grad[0] else None
         ctx.params = None
-        return (gx, None, None, None, None, None, None, None, None) + tuple(ret)
+        return (gx, None, None, None, None, None, None, None, None, None) + tuple(ret)
 
 
 class TransformerFunction(torch.autograd.Function):

@@ -2126,18 +2126,32 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     SUMK_HIP(hipGetLastError());
   }
   // weight gradients: dW_ih[d] += dG_d^T X (both directions in one split-K launch), dW_hh[d] += dG_d^T h_prev_d
-  {
-    float* out[4] = {gr->w_ih[0], gr->w_ih[1], nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dG, 8 * H, x, In, 8 * H, In, R, slab, L.slab_elems, psk, 64, out, 4 * H, In, 1.f, stream, precision));
-  }
-  for (int d = 0; d < 2; ++d) {
+  auto dw_hh = [&](int d) -> int {
     float* out[4] = {gr->w_hh[d], nullptr, nullptr, nullptr};
-    SUMK_TRY(gemm_tn_splitk_accum(dG + (size_t)d * 4 * H, 8 * H, hprev + (size_t)d * H, 2 * H, 4 * H, H, R, slab, L.slab_elems,
-                                  psk, 64, out, 4 * H, H, 1.f, stream, precision));
-  }
-  {   // b_ih and b_hh of a direction both receive the column sums of its half of dG: one pass over dG for all four
+    return gemm_tn_splitk_accum(dG + (size_t)d * 4 * H, 8 * H, hprev + (size_t)d * H, 2 * H, 4 * H, H, R, slab, L.slab_elems,
+                                psk, 64, out, 4 * H, H, 1.f, stream, precision);
+  };
+  auto bias_grads = [&]() -> int {   // b_ih and b_hh of a direction both receive the column sums of its half of dG: one pass over dG for all four
     const ReduceSeg segs[4] = {{0, 4 * H, gr->b_ih[0]}, {0, 4 * H, gr->b_hh[0]}, {4 * H, 4 * H, gr->b_ih[1]}, {4 * H, 4 * H, gr->b_hh[1]}};
-    SUMK_TRY(colsum_multi(dG, 8 * H, R, 8 * H, colpart, 128, segs, 4, stream));
+    return colsum_multi(dG, 8 * H, R, 8 * H, colpart, 128, segs, 4, stream);
+  };
+  if (gr->tail_ready_event) {
+    // data-parallel overlap: the biases and the REVERSE direction first, then the event -- the caller's all-reduce of [reverse | head] runs
+    // on a side stream under the forward direction's GEMMs (sumk.h: sumk_lstm_layer_grads::tail_ready_event)
+    SUMK_TRY(bias_grads());
+    for (int d = 1; d >= 0; --d) {
+      float* out[4] = {gr->w_ih[d], nullptr, nullptr, nullptr};
+      SUMK_TRY(gemm_tn_splitk_accum(dG + (size_t)d * 4 * H, 8 * H, x, In, 4 * H, In, R, slab, L.slab_elems, psk, 64, out, 4 * H, In, 1.f, stream, precision));
+      SUMK_TRY(dw_hh(d));
+      if (d == 1) SUMK_HIP(hipEventRecord((hipEvent_t)gr->tail_ready_event, stream));
+    }
+  } else {
+    {
+      float* out[4] = {gr->w_ih[0], gr->w_ih[1], nullptr, nullptr};
+      SUMK_TRY(gemm_tn_splitk_accum(dG, 8 * H, x, In, 8 * H, In, R, slab, L.slab_elems, psk, 64, out, 4 * H, In, 1.f, stream, precision));
+    }
+    for (int d = 0; d < 2; ++d) SUMK_TRY(dw_hh(d));
+    SUMK_TRY(bias_grads());
   }
   if (dx) {  // dX = dG_fwd W_ih_fwd + dG_rev W_ih_rev
     const int small = gemm_tiles(R, In, 0) >= 512 ? 0 : 1;

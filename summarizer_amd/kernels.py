@@ -461,8 +461,10 @@ def sumsq(v, out=None):
     return out
 
 
-def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, want_dx, precision=None):
-    """BPTT of one bidirectional layer; accumulates into grads[<prefix>{weight,bias}_{ih,hh}_l{layer}[_reverse]]."""
+def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, want_dx, precision=None, tail_event=None):
+    """BPTT of one bidirectional layer; accumulates into grads[<prefix>{weight,bias}_{ih,hh}_l{layer}[_reverse]].
+    tail_event (torch.cuda.Event, data-parallel trainers): recorded by the library once the biases' and the reverse direction's gradients
+    are final, before the forward direction's weight-gradient GEMMs (sumk_lstm_layer_grads.tail_ready_event)."""
     lib = _lib.load()
     In = x.shape[1]
     w = _lstm_layer_struct(params, prefix, layer)
@@ -470,6 +472,9 @@ def bilstm_layer_backward(x, h, dh, sb, params, grads, prefix, layer, H, ws, wan
     for d, suf in enumerate(("", "_reverse")):
         for f, n in (("w_ih", "weight_ih"), ("w_hh", "weight_hh"), ("b_ih", "bias_ih"), ("b_hh", "bias_hh")):
             getattr(g, f)[d] = grads[f"{prefix}{n}_l{layer}{suf}"].data_ptr()
+    if tail_event is not None:
+        tail_event.record()                          # materialise the lazy hipEvent_t handle (re-recorded by the library)
+        g.tail_ready_event = tail_event.cuda_event
     dx = torch.empty_like(x) if want_dx else None
     if not dh.is_contiguous():
         dh = dh.contiguous()

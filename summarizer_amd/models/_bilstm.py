@@ -21,7 +21,8 @@ def bilstm_scores(model, xp, sb, prefix, num_layers, H, head_w, head_b):
         from ..autograd import BiLstmScorerFunction
         names = [n for n, _ in model.named_parameters()]
         p = dict(model.named_parameters())
-        return BiLstmScorerFunction.apply(xp, sb, prefix, num_layers, H, head_w, head_b, precision, names, *[p[n] for n in names])
+        return BiLstmScorerFunction.apply(xp, sb, prefix, num_layers, H, head_w, head_b, precision,
+                                          getattr(model, "tail_grads_ready_event", None), names, *[p[n] for n in names])
     p = dict(model.named_parameters())
     h = xp
     wpl = _layer_wplanes(model, p, prefix, num_layers, xp.shape[1], H, precision) if sb.n_rows >= 1024 else None

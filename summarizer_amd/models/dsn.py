@@ -108,6 +108,14 @@ class DSNTrainer(Trainer):
                                   comm_dtype=torch.bfloat16 if getattr(self.model, "precision", "fp32") == "bf16" else None)
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
         my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
+        # data-parallel overlap (one BiLSTM layer): the library records this event once the biases' and the reverse direction's gradients are
+        # final; the tail of the bucket [reverse direction | head] is then all-reduced on a side stream under the forward direction's
+        # weight-gradient GEMMs (sumk_lstm_layer_grads::tail_ready_event)
+        tail_from = None
+        self.model.tail_grads_ready_event = None
+        if world > 1 and getattr(self.model, "num_layers", 1) == 1 and getattr(self.model, "cell", "lstm") == "lstm":
+            tail_from = self.optimizer.tail_offset(dict(self.model.named_parameters())["rnn.weight_ih_l0_reverse"])
+            self.model.tail_grads_ready_event = torch.cuda.Event()
 
         # dsn.py:81,84: per-video moving-average baselines and the last reward of every video -- kept ON THE DEVICE (float64 like the
         # reference's Python floats) so that a training step never synchronises with the host: the reference reads E rewards
@@ -155,6 +163,10 @@ class DSNTrainer(Trainer):
                     mean_r = rewards.detach().mean(dim=0).double()
                     baselines.index_copy_(0, idx, 0.9 * baselines[idx] + 0.1 * mean_r)     # dsn.py:149
                     last_reward.index_copy_(0, idx, mean_r)
+                if tail_from is not None:            # every rank issues the same two collectives, videos or not
+                    if not keys:
+                        self.model.tail_grads_ready_event.record()
+                    self.optimizer.reduce_tail_async(tail_from, self.model.tail_grads_ready_event)
                 scale = self.optimizer.all_reduce_grads(average=False)
                 self.optimizer.step(grad_scale=scale, max_norm=5.0)       # clip_grad_norm_(…, 5.0) dsn.py:145, post all-reduce
 
@@ -178,4 +190,5 @@ class DSNTrainer(Trainer):
                     self.best_weights = self.model.state_dict()
 
         self.draw_scores(fold, dist_scores)
+        self.model.tail_grads_ready_event = None
         return best_corr, best_avg_f_score, best_max_f_score
