@@ -236,7 +236,7 @@ def make_reinforce_step(model, x, lens, dev):
         loss.backward()
         if reduce and tail_from is not None:
             opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
-        opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / dist_info()[1], max_norm=5.0)
+        opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / dist_info()[1], max_norm=5.0, zero_grad=True)
         base.mul_(0.9).add_(rewards.mean(dim=0), alpha=0.1)        # in place: also valid under --graph replays
         return loss.detach()
     return run_step, opt
@@ -288,9 +288,8 @@ def single_video_leg(dev, D=1024, T=300, iters=400):
         def score():
             with torch.no_grad():
                 return m(x3)
-        t_eager = timed(score)
-        t_graph = timed(graphed(score))
-        m.train()
+        t_eager = timed(score)          # (a captured-graph replay of the scoring call was measured SLOWER than the eager call, 98.7 vs 93.8 us
+        m.train()                       #  in round 4 -- nine short launches are not host-bound -- and is no longer reported)
         opt = FlatAdam(m.parameters(), lr=5e-5, weight_decay=1e-5)
         seed = torch.zeros(1, dtype=torch.int64, device=dev)
         if name == "vasnet":
@@ -308,10 +307,10 @@ def single_video_leg(dev, D=1024, T=300, iters=400):
         tt_graph = timed(graphed(lambda: step(True)), n=iters // 2, warm=50)
         kernels.health_check()
         rec = lambda t: dict(us_per_video=round(t * 1e6, 1), frames_per_s=round(T / t, 1))
-        out[name] = dict(score_eager=rec(t_eager), score_graph=rec(t_graph), train_step_eager=rec(tt_eager), train_step_graph=rec(tt_graph))
+        out[name] = dict(score_eager=rec(t_eager), train_step_eager=rec(tt_eager), train_step_graph=rec(tt_graph))
     out["note"] = (f"one video per call (T={T}, D={D}, fp32), features resident in HBM; score = model.forward((T,1,D)); train step = zero_grad + "
-                   "forward + per-video MSE + backward + fused Adam (DSN: + grad-norm clip), dropout on; graph = the same call captured once "
-                   "into a HIP graph and replayed")
+                   "forward + per-video MSE + backward + fused Adam (DSN: + grad-norm clip), dropout on; train_step_graph = the step captured once "
+                   "into a HIP graph and replayed (what VASNetTrainer does from its second epoch on)")
     return out
 
 
@@ -410,7 +409,7 @@ def recurrent_legs(x, lens, dev, frames):
         opt.zero_grad()
         loss = SegmentMseMeanFunction.apply(dsn.score_packed(x, lens), target, sb, 1.0 / len(lens))
         loss.backward()
-        opt.step(grad_scale=1.0)
+        opt.step(grad_scale=1.0, zero_grad=True)
         return loss.detach()
     dt = timed(train_step, 10)
     out["dsn_train_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
@@ -579,7 +578,7 @@ def main():
             opt.zero_grad()
             loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))   # the trainers' loss: mean over videos of nn.MSELoss per video
             loss.backward()
-            opt.step(grad_scale=opt.all_reduce_grads())
+            opt.step(grad_scale=opt.all_reduce_grads(), zero_grad=True)      # (the Adam kernel leaves the bucket zero: the next zero_grad() is free)
             return loss.detach()
     elif args.mode == "reinforce":
         assert args.model == "dsn", "--mode reinforce is the DSN trainer step"
@@ -798,7 +797,7 @@ def main():
                 loss.backward()
                 if reduce and tail_from is not None:
                     opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
-                opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / world)
+                opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / world, zero_grad=True)
                 return loss.detach()
             n_train = 10
             sec = timed_steps(train_step, n_train)
@@ -850,7 +849,7 @@ def main():
                 loss.backward()
                 if reduce and tail_from is not None:
                     opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
-                opt.step(grad_scale=opt.all_reduce_grads(average=False) if reduce else 1.0)
+                opt.step(grad_scale=opt.all_reduce_grads(average=False) if reduce else 1.0, zero_grad=True)
                 return loss.detach()
             n_train = 40
             sec = timed_steps(step1, n_train)
@@ -964,7 +963,7 @@ def main():
                 out["parity_gate"] = 1e-4
                 if single is not None and "vasnet" in single and args.model == "vasnet":      # the same one-video-per-call pattern on the host cores
                     cpu = out["cpu_baseline"]["value"]
-                    single["vasnet"]["score_vs_cpu_port"] = {k: round(single["vasnet"][k]["frames_per_s"] / cpu, 1) for k in ("score_eager", "score_graph")}
+                    single["vasnet"]["score_vs_cpu_port"] = {k: round(single["vasnet"][k]["frames_per_s"] / cpu, 1) for k in ("score_eager",)}
             except Exception as e:          # noqa: BLE001
                 out["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
         print(json.dumps(out), flush=True)

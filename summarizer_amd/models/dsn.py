@@ -168,7 +168,7 @@ class DSNTrainer(Trainer):
                         self.model.tail_grads_ready_event.record()
                     self.optimizer.reduce_tail_async(tail_from, self.model.tail_grads_ready_event)
                 scale = self.optimizer.all_reduce_grads(average=False)
-                self.optimizer.step(grad_scale=scale, max_norm=5.0)       # clip_grad_norm_(…, 5.0) dsn.py:145, post all-reduce
+                self.optimizer.step(grad_scale=scale, max_norm=5.0, zero_grad=True)       # clip_grad_norm_(…, 5.0) dsn.py:145, post all-reduce
 
             epoch_avg_reward = float(torch.nanmean(last_reward)) if my_keys else float("nan")      # the epoch's host sync
             epoch_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")

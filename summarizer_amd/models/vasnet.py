@@ -318,7 +318,7 @@ class VASNetTrainer(Trainer):
                         self.model.tail_grads_ready_event.record()
                     self.optimizer.reduce_tail_async(tail_from, self.model.tail_grads_ready_event)
                 scale = self.optimizer.all_reduce_grads(average=False)
-                self.optimizer.step(grad_scale=scale)
+                self.optimizer.step(grad_scale=scale, zero_grad=True)
 
             train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")   # one D2H sync per epoch
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Loss: {train_avg_loss:.05f}")

@@ -216,6 +216,7 @@ class FlatAdam:
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._state = torch.zeros(4, dtype=torch.int32, device=dev)     # [0]: steps taken, kept on the device (sumk_adam_step_dev)
         self._side, self._tail_from = None, None      # side stream / split point of an in-flight early all-reduce
+        self._zero_by_step = False                    # the last thing that touched the gradient bucket was step(zero_grad=True)
         # mixed-precision mode: the gradient bucket crosses the all-reduce as bf16 (half the bytes over xGMI); the fp32 bucket,
         # the moments and the master weights stay fp32.  The bf16 staging buffer exists only under torch.distributed.
         if comm_dtype not in (None, torch.float32, torch.bfloat16):
@@ -224,7 +225,12 @@ class FlatAdam:
         self._comm = None
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        # (a step(zero_grad=True) left the bucket zero inside the Adam kernel: the fill launch of the usual step -> zero_grad -> backward
+        #  order is skipped once; anything else -- a second zero_grad, gradients accumulated meanwhile -- fills as before)
+        if self._zero_by_step:
+            self._zero_by_step = False
+        else:
+            self.flat_grad.zero_()
         off = 0
         for p in self.params:                      # re-attach views in case something replaced .grad
             k = p.numel()
@@ -318,6 +324,7 @@ class FlatAdam:
         # zero_grad: the gradient bucket is left zero by the Adam kernel (the next step's zero_grad(), folded into this pass)
         kernels.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._state, self.lr, self.betas,
                               self.eps, self.weight_decay, grad_scale, sumsq, 0.0 if max_norm is None else max_norm, zero_grad=zero_grad)
+        self._zero_by_step = bool(zero_grad) and not torch.cuda.is_current_stream_capturing()
 
 
 def broadcast_parameters(model, src=0):

@@ -181,7 +181,12 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert tb["frames_per_s"] > 0 and 10e6 < tb["allreduce_bytes_per_step"] < 11e6
     rl = out["dsn_reinforce_step_mode"]           # BASELINE config 4: DSN REINFORCE data-parallel (10.5 MB bucket, clip after the reduce)
     assert "error" not in rl, rl
-    assert rl["frames_per_s"] > 0 and 10e6 < rl["allreduce_bytes_per_step"] < 11e6 and rl["collectives_per_step"] == 1
+    # (round 5: the bucket's tail [reverse direction | head] goes out early on a side stream, the rest after the backward: two collectives)
+    assert rl["frames_per_s"] > 0 and 10e6 < rl["allreduce_bytes_per_step"] < 11e6 and rl["collectives_per_step"] == 2
+    ov = out["dp_one_video_per_rank_mode"]        # the trainers' DEFAULT data-parallel schedule: one video per rank per step, the 21 MB bucket every step
+    assert "error" not in ov, ov
+    assert ov["videos_per_rank_per_step"] == 1 and ov["frames_per_s"] > 0 and ov["allreduce_bytes_per_step"] > 20e6 and ov["collectives_per_step"] == 2
+    assert ov["allreduce_alone_us"] > 0 and ov["exposed_comm_us"] >= 0 and 0 < ov["predicted_efficiency_at_this_world"][0] <= ov["predicted_efficiency_at_this_world"][1] <= 1
     assert out["ranks_seen"] == 2 and out["collective_backend"] == "gloo"
 
 

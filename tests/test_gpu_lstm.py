@@ -222,3 +222,34 @@ def test_flag_in_data_handoff_equals_counter_handoff(tmp_path, H, lens):
         for k in out[tag]:
             a, b = out[tag][k], out["ref"][k]
             assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() + 1e-12, (tag, k, float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+def test_dsn_backward_with_tail_event_equals_plain_backward(dev):
+    """sumk_lstm_layer_grads::tail_ready_event (the data-parallel overlap of DSNTrainer: biases and the reverse direction first, an event, then the
+    forward direction): the same gradients as the plain order -- the two directions' dW_ih run as two split-K launches instead of one, so equal to
+    summation order (2e-5 relative), and the event has fired by the time the call's stream is idle."""
+    from summarizer_amd.models.dsn import DSN
+    torch.manual_seed(5)
+    D = 1024
+    lens = [int(t) for t in np.random.default_rng(4).integers(150, 321, size=6)]
+    x = torch.from_numpy(np.concatenate([R.features(T, 1, D, 50 + i)[:, 0, :] for i, T in enumerate(lens)])).to(dev)
+    m = DSN(input_size=D).to(dev).train()
+    wgt = torch.linspace(-1, 1, x.shape[0], device=dev)
+
+    def grads(event):
+        m.zero_grad(set_to_none=True)
+        m.tail_grads_ready_event = event
+        (m.score_packed(x, lens) * wgt).sum().backward()
+        m.tail_grads_ready_event = None
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    plain = grads(None)
+    ev = torch.cuda.Event()
+    with_ev = grads(ev)
+    torch.cuda.synchronize()
+    assert ev.query()
+    for k in plain:
+        a, b = plain[k], with_ev[k]
+        rel = float((a - b).norm() / a.norm().clamp_min(1e-30))
+        assert rel < 2e-5, (k, rel)
+    for k in ("rnn.weight_hh_l0", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0", "rnn.bias_hh_l0_reverse", "out.0.weight"):
+        assert torch.equal(plain[k], with_ev[k]), k          # the launches that did not change shape are bit-identical
