@@ -56,3 +56,16 @@ for (M, N, K) in [(12003, 3072, 1024), (12003, 1024, 1024), (12003, 2048, 1024)]
                   f"epilogue per tile {np.median(epi / nt):.0f} cyc, clock {np.median(clk):.0f} MHz (min {clk.min():.0f}), wall {np.median(rt) / 100:.1f} us")
         med, best = timeit(lambda: kernels.split_planes(a, npl))
         print(f"   split_planes({M} x {K}, {npl}): {med:.1f} us")
+
+# the two MFMA shapes at two planes: gemm_pw16.hip (16x16x32, the product's) against the 32x32x16 plane kernel (variant 32), same operands, interleaved
+for (M, N, K) in [(12003, 3072, 1024), (12003, 1024, 1024)]:
+    a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev) * 0.03
+    ap, bp = kernels.split_planes(a, 2), kernels.split_planes(b, 2)
+    ref = kernels.gemm_planes(ap, M, bp, N, M, N, K, 2, variant=32)
+    got = kernels.gemm_planes(ap, M, bp, N, M, N, K, 2)
+    err = float((got - ref).abs().max()); scale = float(ref.abs().max())
+    c = torch.empty(M, N, device=dev)
+    fl = 2.0 * M * N * K
+    for variant in (32, 0, 32, 0):
+        med, best = timeit(lambda: kernels.gemm_planes(ap, M, bp, N, M, N, K, 2, variant=variant, out=c))
+        print(f"M={M} N={N} K={K} planes=2  {'32x32x16' if variant == 32 else '16x16x32'}: {med:8.1f} us (best {best:8.1f})  {fl / med / 1e6:7.1f} TF   [max |d| between the shapes {err:.2e} of {scale:.1f}]")

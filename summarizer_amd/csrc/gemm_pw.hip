@@ -30,19 +30,7 @@ namespace sumk {
 
 namespace {
 
-struct PwArgs {
-  const char* A; const char* B;
-  uint32_t a_rp16, b_rp16;             // bytes of one (k16 block, plane, half) sub-array
-  int32_t M, N, K;
-  int32_t tiles_m, tiles_n, total_tiles, xcd_map;
-  float* C; int32_t ldc;
-  char* O; int64_t o_rp16; int32_t o_store_rows;
-  const float* R; int32_t ldr;
-  float* moments;
-  const float* bias; const float* gw; const float* ln_c1; const float* ln_stats; float* head_part;
-};
 
-constexpr int PW_CONST_BYTES = 4096;   // PW_HEAD: the tile's 256 columns of c1 / bias / gw
 
 template <int NP, int BM, int EPI, int NS, int VAR>
 __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
@@ -452,7 +440,15 @@ int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {
   }
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
-  const int rc = g.np == 3 ? launch_np<3, 3>(epi, a, g.variant, stream) : launch_np<2, 4>(epi, a, g.variant, stream);
+  // two planes run on the 16x16x32 MFMA shape (gemm_pw16.hip: -13 % on the same operands); three planes do not fit its five-stage ring
+  int rc;
+  static const bool pw16_on = !(SUMK_TUNE_ENV("SUMK_PW16") && SUMK_TUNE_ENV("SUMK_PW16")[0] == '0');      // (diagnostic build only: scripts/pw16_step_probe.sh)
+  if (g.np == 2 && g.K >= 160 && g.variant != 32 && pw16_on) {
+    if (a.xcd_map == 1) { a.xcd_map = 2; a.total_tiles = 8 * ((a.tiles_m + 7) / 8) * a.tiles_n; }
+    rc = launch_gemm_pw16((int)epi, a, stream);
+  } else {
+    rc = g.np == 3 ? launch_np<3, 3>(epi, a, g.variant, stream) : launch_np<2, 4>(epi, a, g.variant, stream);
+  }
   prof_end(SUMK_PROF_GEMM_ALL, stream);
   if (g.prof_tag >= 0) prof_end(g.prof_tag, stream);
   return rc;

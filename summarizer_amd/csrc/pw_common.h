@@ -23,4 +23,22 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NP]) {
   }
 }
 
+// kernel arguments of the plane GEMMs (gemm_pw.hip: 32x32x16 MFMA; gemm_pw16.hip: 16x16x32 MFMA, two planes)
+struct PwArgs {
+  const char* A; const char* B;
+  uint32_t a_rp16, b_rp16;             // bytes of one (k16 block, plane, half) sub-array
+  int32_t M, N, K;
+  int32_t tiles_m, tiles_n, total_tiles, xcd_map;
+  float* C; int32_t ldc;
+  char* O; int64_t o_rp16; int32_t o_store_rows;
+  const float* R; int32_t ldr;
+  float* moments;
+  const float* bias; const float* gw; const float* ln_c1; const float* ln_stats; float* head_part;
+};
+
+// gemm_pw16.hip: the same product on v_mfma_f32_16x16x32_bf16 (two planes; K >= 160); `a` as launch_gemm_pw built it
+int launch_gemm_pw16(int epi, const PwArgs& a, hipStream_t stream);
+
+constexpr int PW_CONST_BYTES = 4096;   // PW_HEAD: the tile's 256 columns of c1 / bias / gw
+
 }  // namespace sumk

@@ -306,7 +306,7 @@ struct PwLaunch {
   float* moments = nullptr;
   const float* bias = nullptr; const float* gw = nullptr; const float* ln_c1 = nullptr; const float* ln_stats = nullptr; float* head_part = nullptr;
   int32_t prof_tag = -1;
-  int32_t variant = 0;                                  // schedule variant (probes; 0 = the product's)
+  int32_t variant = 0;                                  // schedule variant (probes; 0 = the product's; 32 = two planes on the 32x32x16 kernel instead of gemm_pw16.hip)
 };
 // M >= 1, N % 256 == 0, K % 32 == 0, K >= 128, plane arrays below 2^31 bytes
 inline int pw_ok(int64_t M, int64_t N, int64_t K, int64_t a_rows, int64_t b_rows, int np) {
@@ -315,6 +315,7 @@ inline int pw_ok(int64_t M, int64_t N, int64_t K, int64_t a_rows, int64_t b_rows
           (int64_t)pw_planes_bytes(a_rows, (int)K, np) < lim && (int64_t)pw_planes_bytes(b_rows, (int)K, np) < lim) ? 1 : 0;
 }
 int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream);
+
 // Per-video attention on planes (attn_pw.hip; T <= 320): logits + softmax -> alpha planes (rows = packed frames, k = key index inside the
 // video, written up to T rounded up to 32) [+ fp32 alpha in E], then context = alpha . V -> planes of the (rows x D) context matrix.
 // alpha / context planes use the row pitch of the [Q | K | V] planes (pw_rows_pitch(rows)).

@@ -74,9 +74,17 @@ def test_gemm_planes_vs_float64_and_inloop_split(dev, shape, n_planes):
     old = torch.empty(M, N, dtype=torch.float32, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.sumk_gemm_prec(0, at.data_ptr(), bt.data_ptr(), old.data_ptr(), M, N, K, 2 if n_planes == 3 else 1, st), "gemm_prec")
-    assert torch.equal(c, old), float((c - old).abs().max())
-    for variant in (1, 2):                                     # schedule variants of the probe: same arithmetic
-        assert torch.equal(kernels.gemm_planes(ap, M, bp, N, M, N, K, n_planes, variant=variant), c)
+    if n_planes == 3:
+        assert torch.equal(c, old), float((c - old).abs().max())
+        for variant in (1, 2):                                 # schedule variants of the probe: same arithmetic
+            assert torch.equal(kernels.gemm_planes(ap, M, bp, N, M, N, K, n_planes, variant=variant), c)
+    else:
+        # two planes run on the 16x16x32 MFMA shape (csrc/gemm_pw16.hip; K >= 160): a term is summed over 32 k before the next starts, so it
+        # equals the 32x32x16 kernels to rounding; variant 32 keeps the 32x32x16 plane kernel, which IS bit-identical to the in-loop split
+        c32 = kernels.gemm_planes(ap, M, bp, N, M, N, K, n_planes, variant=32)
+        assert torch.equal(c32, old), float((c32 - old).abs().max())
+        assert (np.abs(c.cpu().numpy() - old.cpu().numpy()) <= 2.0 ** -20 * bound + 1e-30).all()
+        assert torch.equal(c, c32) == (K < 160)
 
 
 def test_gemm_planes_rejects_ineligible_shapes(dev):
@@ -246,7 +254,8 @@ def test_attention_on_planes_vs_float64(dev, n_planes, mask):
 def test_lstm_scorers_input_projection_on_planes(dev, kind):
     """DSN (dsn.py:38-47) and sLSTM (sumgan.py:23-46) with precision = bf16x6 / bf16x3: the input projection X W_ih^T + b_ih + b_hh of every
     layer runs on operand planes (csrc/gemm_pw.hip; x planes kept with the feature tensor, weight planes per weight change).  The layer output
-    is BIT-IDENTICAL to the same arithmetic on the in-loop split kernels (a call without the weight-plane block), and the scores stay within
+    is BIT-IDENTICAL (bf16x6; bf16x3 runs the 16x16x32 MFMA shape: equal to rounding) to the same arithmetic on the in-loop split kernels (a call
+    without the weight-plane block), and the scores stay within
     2e-6 (bf16x6: fp32-grade) / 5e-5 (bf16x3) of the exact-fp32 path; the planes follow a weight change."""
     from summarizer_amd import kernels
     sys_path_golden()
@@ -273,7 +282,7 @@ def test_lstm_scorers_input_projection_on_planes(dev, kind):
             wpl = m.__dict__["_sumk_wpl"][1]
             h_pl, _ = kernels.bilstm_layer_forward(x, sb, p, prefix, 0, H, precision=prec, wplanes=wpl[0], dataset_input=True)
             h_old, _ = kernels.bilstm_layer_forward(x, sb, p, prefix, 0, H, precision=prec)
-            assert torch.equal(h_pl, h_old)
+            assert torch.equal(h_pl, h_old) if prec == "bf16x6" else float((h_pl - h_old).abs().max()) < 2e-6
         key0 = m.__dict__["_sumk_wpl"][0]
         dict(m.named_parameters())[prefix + "weight_ih_l0"].mul_(1.1)
         got2 = m.score_packed(x, lens)
