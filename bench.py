@@ -123,7 +123,7 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16
         fl = 2.0 * frames * 3 * D * D
         mf = {"bf16x3": 3.0, "bf16x6": 6.0}[precision]
         peak = BF16_MFMA_PEAK_TFLOPS / mf
-        rec["roofline"] = dict(bound="mfma", kernel=f"gemm_pw_kernel<{2 if precision == 'bf16x3' else 3} planes, 192x256> (QKV projection on operand planes)",
+        rec["roofline"] = dict(bound="mfma", kernel=("gemm_pw16_kernel<2 planes, 192x256, 16x16x32 MFMA>" if precision == "bf16x3" else "gemm_pw_kernel<3 planes, 192x256, 32x32x16 MFMA>") + " (QKV projection on operand planes, planes out)",
                                achieved=round(fl / us / 1e6, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(fl / us / 1e6 / peak, 4),
                                avg_launch_us=round(us, 2), launches=int(n.value), flops_per_launch=fl, mfma_flops_per_launch=fl * mf,
                                traffic=None,

@@ -33,6 +33,7 @@
 #include "gemm_regstage.h"
 #include <math.h>
 #include <cstdlib>
+#include <atomic>
 
 namespace sumk {
 
@@ -390,10 +391,14 @@ bool attn_strip_ok(int t_max, int D, int64_t rows, int ld_max) {
 int launch_attn_strip(bool backward, const AttnStripArgs& a_in, hipStream_t stream) {
   const AttnStripArgs& a = a_in;
   const void* fn = backward ? (const void*)attn_strip_kernel<true> : (const void*)attn_strip_kernel<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[backward ? 1 : 0]) {
+  // (the opt-in is per DEVICE: one bit per device, set atomically -- a process that drives a second GPU must not skip it there)
+  static std::atomic<uint64_t> attr_done[2];
+  int dev = 0;
+  SUMK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done[backward ? 1 : 0].load(std::memory_order_acquire) & bit)) {
     SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS));
-    attr_set[backward ? 1 : 0] = true;
+    attr_done[backward ? 1 : 0].fetch_or(bit, std::memory_order_release);
   }
   const unsigned grid = (unsigned)(8 * ((a.n_seq + 7) / 8) * a.strips);
   if (backward) hipLaunchKernelGGL(attn_strip_kernel<true>, dim3(grid), dim3(512), AT_LDS, stream, a);

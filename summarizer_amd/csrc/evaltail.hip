@@ -247,10 +247,13 @@ extern "C" int sumk_eval_videos(sumk_eval_video* vids, int32_t n_videos, double 
   std::vector<int> status((size_t)std::max(1, n_videos), 0);
   auto work = [&](int t) {
     Scratch S;
-    for (int i = t; i < n_videos; i += nt) status[i] = eval_one(vids[i], proportion, method, S);
+    for (int i = t; i < n_videos; i += nt) { try { status[i] = eval_one(vids[i], proportion, method, S); } catch (...) { status[i] = -3; } }
   };
   if (n_threads <= 0 && n_videos > 1) {
-    eval_pool_run(n_videos, [&](int i, Scratch& S) { status[i] = eval_one(vids[i], proportion, method, S); });
+    // (an exception on a detached worker -- std::bad_alloc in a scratch vector -- would be std::terminate: it becomes the item's status)
+    eval_pool_run(n_videos, [&](int i, Scratch& S) {
+      try { status[i] = eval_one(vids[i], proportion, method, S); } catch (...) { status[i] = -3; }
+    });
   } else if (nt == 1) {
     work(0);
   } else {
@@ -259,6 +262,6 @@ extern "C" int sumk_eval_videos(sumk_eval_video* vids, int32_t n_videos, double 
     for (auto& th : pool) th.join();
   }
   for (int i = 0; i < n_videos; ++i)
-    if (status[i] != 0) { set_error("eval_videos: video %d failed (%s)", i, status[i] == -1 ? "more pick intervals than scores + 1" : "knapsack"); return SUMK_ERR_ARG; }
+    if (status[i] != 0) { set_error("eval_videos: video %d failed (%s)", i, status[i] == -1 ? "more pick intervals than scores + 1" : status[i] == -3 ? "out of memory / exception in the evaluation worker" : "knapsack"); return SUMK_ERR_ARG; }
   return SUMK_OK;
 }

@@ -20,6 +20,7 @@
 // kernels otherwise.
 #include "gemm_regstage.h"
 #include <type_traits>
+#include <atomic>
 
 namespace sumk {
 
@@ -363,8 +364,14 @@ int launch_wide_one(const GemmKArgs& ka, int tiles, hipStream_t s) {
   constexpr int LDS = 2 * (A_BYTES + B_BYTES);
   static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
   const void* fn = (const void*)gemm_b16_wide_kernel<BM, A_KC, B_KC, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) { SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set = true; }
+  static std::atomic<uint64_t> attr_done{0};          // one bit per device (the opt-in is a per-device attribute)
+  int dev = 0;
+  SUMK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
   hipLaunchKernelGGL((gemm_b16_wide_kernel<BM, A_KC, B_KC, EPI>), dim3(std::min(tiles, 256)), dim3(512), LDS, s, ka);
   return SUMK_OK;
 }

@@ -146,42 +146,46 @@ def evaluate_batch_device(videos, scores_dev, lens, proportion=0.15, method="kna
     # Two stages on the device, two small transfers into pinned memory: the segment means come home after the short first kernel and the
     # host's key-shot selection + F-scores run while the device is still correlating (buffers are per batch and reused: the call ends
     # synchronised).
-    buf = ent.get("buffers")
-    if buf is None:
-        buf = ent["buffers"] = dict(
-            scratch=torch.empty(frame0, dtype=torch.float32, device=dev), seg=torch.empty(max(seg0, 1), dtype=torch.float32, device=dev),
-            corr=torch.empty(n, dtype=torch.float64, device=dev),
-            part=torch.empty(max(1, lib.sumk_eval_device_spearman_scratch_bytes(n) // 8), dtype=torch.float64, device=dev),
-            seg_host=torch.empty(max(seg0, 1), dtype=torch.float32).pin_memory(), corr_host=torch.empty(n, dtype=torch.float64).pin_memory(),
-            ev_seg=torch.cuda.Event(), ev_corr=torch.cuda.Event())
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(lib.sumk_eval_device_segments(scores_dev.data_ptr(), descr_dev.data_ptr(), n, buf["scratch"].data_ptr(), buf["seg"].data_ptr(), st),
-               "sumk_eval_device_segments")
-    buf["seg_host"].copy_(buf["seg"], non_blocking=True); buf["ev_seg"].record()
-    _lib.check(lib.sumk_eval_device_spearman(scores_dev.data_ptr(), descr_dev.data_ptr(), n, buf["part"].data_ptr(), buf["corr"].data_ptr(), st),
-               "sumk_eval_device_spearman")
-    buf["corr_host"].copy_(buf["corr"], non_blocking=True); buf["ev_corr"].record()
-    seg_means = buf["seg_host"].numpy()[:seg0]       # (a view of the pinned buffer: valid once ev_seg has passed)
-    arr = (_lib.EvalVideo * n)()
-    summaries, seg_at = [], 0
-    try:
-        for i, v in enumerate(videos):
-            e = arr[i]
-            e.n_frames, e.n_steps = v["n_frames"], int(lens[i])
-            e.cps, e.nfps, e.n_segs = v["cps"].ctypes.data, v["nfps"].ctypes.data, v["cps"].shape[0]
-            e.seg_means = seg_means[seg_at:].ctypes.data
-            seg_at += v["cps"].shape[0]
-            e.corr = float("nan")             # (passed through untouched when seg_means is given; the device's value is returned below)
-            if want_summaries:
-                o = np.empty(int(v["nfps"].sum()), dtype=np.float32); summaries.append(o); e.machine_summary = o.ctypes.data
-            if "user_summary" in v:
-                if v["user_summary"].shape[1] != v["n_frames"]:
-                    raise ValueError(f"user_summary has {v['user_summary'].shape[1]} frames, video has {v['n_frames']}")
-                e.user_summary, e.n_users = v["user_summary"].ctypes.data, v["user_summary"].shape[0]
-        buf["ev_seg"].synchronize()
-        _lib.check(lib.sumk_eval_videos(C.cast(arr, C.c_void_p), n, float(proportion), METHODS[method], int(n_threads)), "sumk_eval_videos")
-    finally:
-        buf["ev_corr"].synchronize()      # the call never returns with its pinned buffers still being written
-    corr = buf["corr_host"].numpy().copy()
-    f_avg = np.array([arr[i].f_avg for i in range(n)]); f_max = np.array([arr[i].f_max for i in range(n)])
+    # (the pinned buffers and events of an entry are shared by every call on that test set: calls from different threads / streams take
+    #  turns -- ADVICE r4 -- instead of overwriting each other's results)
+    import threading
+    with ent.setdefault("lock", threading.Lock()):
+        buf = ent.get("buffers")
+        if buf is None:
+            buf = ent["buffers"] = dict(
+                scratch=torch.empty(frame0, dtype=torch.float32, device=dev), seg=torch.empty(max(seg0, 1), dtype=torch.float32, device=dev),
+                corr=torch.empty(n, dtype=torch.float64, device=dev),
+                part=torch.empty(max(1, lib.sumk_eval_device_spearman_scratch_bytes(n) // 8), dtype=torch.float64, device=dev),
+                seg_host=torch.empty(max(seg0, 1), dtype=torch.float32).pin_memory(), corr_host=torch.empty(n, dtype=torch.float64).pin_memory(),
+                ev_seg=torch.cuda.Event(), ev_corr=torch.cuda.Event())
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.sumk_eval_device_segments(scores_dev.data_ptr(), descr_dev.data_ptr(), n, buf["scratch"].data_ptr(), buf["seg"].data_ptr(), st),
+                   "sumk_eval_device_segments")
+        buf["seg_host"].copy_(buf["seg"], non_blocking=True); buf["ev_seg"].record()
+        _lib.check(lib.sumk_eval_device_spearman(scores_dev.data_ptr(), descr_dev.data_ptr(), n, buf["part"].data_ptr(), buf["corr"].data_ptr(), st),
+                   "sumk_eval_device_spearman")
+        buf["corr_host"].copy_(buf["corr"], non_blocking=True); buf["ev_corr"].record()
+        seg_means = buf["seg_host"].numpy()[:seg0]       # (a view of the pinned buffer: valid once ev_seg has passed)
+        arr = (_lib.EvalVideo * n)()
+        summaries, seg_at = [], 0
+        try:
+            for i, v in enumerate(videos):
+                e = arr[i]
+                e.n_frames, e.n_steps = v["n_frames"], int(lens[i])
+                e.cps, e.nfps, e.n_segs = v["cps"].ctypes.data, v["nfps"].ctypes.data, v["cps"].shape[0]
+                e.seg_means = seg_means[seg_at:].ctypes.data
+                seg_at += v["cps"].shape[0]
+                e.corr = float("nan")             # (passed through untouched when seg_means is given; the device's value is returned below)
+                if want_summaries:
+                    o = np.empty(int(v["nfps"].sum()), dtype=np.float32); summaries.append(o); e.machine_summary = o.ctypes.data
+                if "user_summary" in v:
+                    if v["user_summary"].shape[1] != v["n_frames"]:
+                        raise ValueError(f"user_summary has {v['user_summary'].shape[1]} frames, video has {v['n_frames']}")
+                    e.user_summary, e.n_users = v["user_summary"].ctypes.data, v["user_summary"].shape[0]
+            buf["ev_seg"].synchronize()
+            _lib.check(lib.sumk_eval_videos(C.cast(arr, C.c_void_p), n, float(proportion), METHODS[method], int(n_threads)), "sumk_eval_videos")
+        finally:
+            buf["ev_corr"].synchronize()      # the call never returns with its pinned buffers still being written
+        corr = buf["corr_host"].numpy().copy()
+        f_avg = np.array([arr[i].f_avg for i in range(n)]); f_max = np.array([arr[i].f_max for i in range(n)])
     return corr, f_avg, f_max, (summaries if want_summaries else None)

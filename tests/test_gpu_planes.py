@@ -290,3 +290,41 @@ def test_lstm_scorers_input_projection_on_planes(dev, kind):
         m.precision = "fp32"
         assert float((m.score_packed(x, lens) - got2).abs().max()) < 5e-5
     kernels.health_check()
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+def test_plane_path_at_stress_size_and_batching_independence(dev, precision):
+    """(1) BASELINE config 5's shape on the plane path: ONE (T = 10 000, D = 2048) sequence -- T > 320, so the plane GEMMs run around the in-loop
+    attention kernels -- against the exact-fp32 HIP path (itself held to the oracle port at this size by
+    test_gpu_vasnet.py::test_vasnet_full_stress_size_vs_torch_port): scores within 1e-5 (bf16x6) / 1e-4 (bf16x3), logits within 5e-3 where they
+    resolve.  (2) Batching independence of the whole plane path (GEMM row tiles mix videos, attention strips do not): videos scored together
+    equal their separate scores bit for bit (each padded into a batch of the same plane-path eligibility)."""
+    from summarizer_amd.models.vasnet import VASNet
+    D, T = 2048, 10000
+    torch.manual_seed(1234)
+    m = VASNet(input_size=D).to(dev).eval()
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    x = torch.randn(T, D, device=dev, generator=g) * 0.05
+    with torch.no_grad():
+        ref = m.score_packed(x, [T]).double()
+        m.precision = precision
+        got = m.score_packed(x, [T]).double()
+    assert m._wpl is not None and f"planes{3 if precision == 'bf16x6' else 2}" in x._sumk_shadows
+    tol = 1e-5 if precision == "bf16x6" else 1e-4
+    assert float((got - ref).abs().max()) < tol, float((got - ref).abs().max())
+    lg, lr = torch.log(got) - torch.log1p(-got), torch.log(ref) - torch.log1p(-ref)
+    sel = lr.abs() <= 8.0
+    assert int(sel.sum()) > T // 2 and float((lg - lr)[sel].abs().max()) < (5e-3 if precision == "bf16x6" else 5e-2)
+    del x, ref, got
+    # (2) at D = 1024 with T <= 320 (attention on planes): three videos together == the first two together + the third alone
+    D2 = 1024
+    sys_path_golden()
+    import recipes as Rc
+    lens = [300, 163, 320]
+    xs = [torch.from_numpy(Rc.features(t, 1, D2, 900 + i)[:, 0, :]).to(dev) for i, t in enumerate(lens)]
+    m2 = VASNet(input_size=D2, precision=precision).to(dev).eval()
+    with torch.no_grad():
+        allv = m2.score_packed(torch.cat(xs), lens)
+        two = m2.score_packed(torch.cat(xs[:2]), lens[:2])
+        one = m2.score_packed(xs[2], lens[2:])
+    assert torch.equal(allv[:463], two) and torch.equal(allv[463:], one)
