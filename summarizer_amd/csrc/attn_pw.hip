@@ -45,7 +45,7 @@ struct AttnPwArgs {
 template <int NP, int NJ, int VAR>
 __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqInfo& si, const int strip, char* const lds) {
   constexpr int NSUB = 2 * NP, T64 = NJ * 64, ROWS = T64 + 64, STAGE = NSUB * ROWS * 16;
-  constexpr int NS = NP == 3 ? 3 : 4;
+  constexpr int NS = NP == 3 ? 3 : 4;                  // (deeper rings, 4 / 6 stages, were measured: no change -- the stream is not latency-bound)
   constexpr int NTW = (2 * NJ + 3) / 4;
   constexpr int NPIECE = NSUB * (NJ + 1), MAXP = (NPIECE + 7) / 8;
   static_assert(NS * STAGE + 4096 <= 160 * 1024, "LDS map");
@@ -167,6 +167,15 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
     }
     slot = nslot;
   };
+#ifdef SUMK_DIAG
+  if constexpr (VAR == 5) {      // timing probe: the DMA stream alone -- no fragment reads, no MFMAs, no barriers; NS - 1 stages kept in flight
+    for (int s = 0; s < nk; ++s) {
+      if (full) wait_vm<(NS - 1) * MAXP>(); else wait_vm<(NS - 1) * (MAXP - 1)>();
+      if (s + NS < nk) dma(s + NS, s % NS);
+    }
+    wait_vm<0>();
+  } else
+#endif
   for (int s = 0; s < nk; s += 2) {
     kstep(F0, F1, s);
     kstep(F1, F0, s + 1);
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
 // columns per register quad -- the 8-byte piece of a context-plane chunk.
 template <int NP>
 __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
-  constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;
+  constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;           // (rings of 5 / 4 stages: measured, no change)
   constexpr int NSUB = 2 * NP, A_BYTES = KH * NSUB * 1024, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
   constexpr int NA = KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
@@ -457,10 +466,11 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
   constexpr int LDS3 = 3 * (6 * 384 * 16) + 4096, LDS2 = 4 * (4 * 384 * 16) + 4096;
 #define SUMK_A_CASE(NP_, V_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_logits_kernel<NP_, V_>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_logits_kernel<NP_, V_>), dim3(grid), dim3(512), LDS_, stream, a); }
 #ifdef SUMK_DIAG
-  if (np == 3 && var == 3) { SUMK_A_CASE(3, 3, LDS3, 10) } else if (np == 3 && var == 4) { SUMK_A_CASE(3, 4, LDS3, 11) } else
+  if (np == 3 && var == 3) { SUMK_A_CASE(3, 3, LDS3, 10) } else if (np == 3 && var == 4) { SUMK_A_CASE(3, 4, LDS3, 11) } else if (np == 3 && var == 5) { SUMK_A_CASE(3, 5, LDS3, 9) } else
+  if (np == 3 && (var == 1 || var == 2)) { if (var == 1) SUMK_A_CASE(3, 1, LDS3, 0) else SUMK_A_CASE(3, 2, LDS3, 1) } else
+  if (np == 2 && (var == 1 || var == 2)) { if (var == 1) SUMK_A_CASE(2, 1, LDS2, 3) else SUMK_A_CASE(2, 2, LDS2, 4) } else
 #endif
-  if (np == 3) { if (var == 1) SUMK_A_CASE(3, 1, LDS3, 0) else if (var == 2) SUMK_A_CASE(3, 2, LDS3, 1) else SUMK_A_CASE(3, 0, LDS3, 2) }
-  else { if (var == 1) SUMK_A_CASE(2, 1, LDS2, 3) else if (var == 2) SUMK_A_CASE(2, 2, LDS2, 4) else SUMK_A_CASE(2, 0, LDS2, 5) }
+  if (np == 3) SUMK_A_CASE(3, 0, LDS3, 2) else SUMK_A_CASE(2, 0, LDS2, 5)
 #undef SUMK_A_CASE
 #ifdef SUMK_DIAG
   if (a.stamps && ++stamp_calls == 40) {       // one report, from a warm call
