@@ -178,11 +178,13 @@ def tensor_shadow(x, name, build):
             x._sumk_shadows = d
         except AttributeError:          # (an object that takes no attributes: no caching)
             return build()
+    # a shadow is built by kernels on the CURRENT stream: a call on another stream builds its own rather than read one that may not be finished
+    stream = torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0
     hit = d.get(name)
-    if hit is not None and hit[0] == x._version:
+    if hit is not None and hit[0] == x._version and hit[2] == stream:
         return hit[1]
     val = build()
-    d[name] = (x._version, val)
+    d[name] = (x._version, val, stream)
     return val
 
 
@@ -219,8 +221,9 @@ def split_planes(x, n_planes):
     nb = lib.sumk_planes_bytes(rows, K, n_planes)
     if nb == 0:
         raise SumkError(f"split_planes: rows={rows} K={K} planes={n_planes} is not representable (K % 16, 2 or 3 planes)")
-    out = torch.zeros(nb, dtype=torch.uint8, device=x.device)      # (zeros: the slack behind the last sub-array is read by row tiles)
-    _lib.check(lib.sumk_split_planes(_p(x), rows, K, x.stride(0), n_planes, _p(out), _stream()), "sumk_split_planes")
+    out = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    out[nb - 8192:].zero_()          # (the kernel writes every row up to the pitch, zeros behind `rows`; only the slack behind the last sub-array,
+    _lib.check(lib.sumk_split_planes(_p(x), rows, K, x.stride(0), n_planes, _p(out), _stream()), "sumk_split_planes")      #  which row tiles read past, needs a fill)
     return out
 
 

@@ -39,7 +39,8 @@ def _layer_wplanes(model, p, prefix, num_layers, In, H, precision):
     if not n_planes:
         return None
     ps = [v for k, v in sorted(p.items()) if k.startswith(prefix)]
-    key = tuple(t.data_ptr() for t in ps) + tuple(t._version for t in ps) + (kernels.WEIGHTS_EPOCH[0], precision)
+    key = tuple(t.data_ptr() for t in ps) + tuple(t._version for t in ps) + (kernels.WEIGHTS_EPOCH[0], precision,
+                                                                               torch.cuda.current_stream(ps[0].device).cuda_stream if ps[0].is_cuda else 0)
     cache = model.__dict__.get("_sumk_wpl")
     if cache is None or cache[0] != key:
         with torch.no_grad():

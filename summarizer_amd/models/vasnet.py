@@ -150,7 +150,9 @@ class VASNet(nn.Module):
         """What a cache derived from the weights must be keyed by: storage addresses and tensor versions (what torch can see) plus
         kernels.WEIGHTS_EPOCH (bumped by every optimiser step through the C ABI, invisible to torch)."""
         ps = [p for _, p in sorted(self._params().items())]
-        return tuple(p.data_ptr() for p in ps) + tuple(p._version for p in ps) + (kernels.WEIGHTS_EPOCH[0], self.precision, bool(self.fold_vo))
+        # (+ the current stream: the block is built by kernels on it, a call on another stream builds its own)
+        return tuple(p.data_ptr() for p in ps) + tuple(p._version for p in ps) + (kernels.WEIGHTS_EPOCH[0], self.precision, bool(self.fold_vo),
+                                                                                  torch.cuda.current_stream(ps[0].device).cuda_stream if ps[0].is_cuda else 0)
 
     def _wplanes(self, wvo):
         """Cached weight-plane block (kernels.vasnet_wplanes) of the current weights; rebuilt on any weight change (same rules as

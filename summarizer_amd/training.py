@@ -324,7 +324,7 @@ class FlatAdam:
         # zero_grad: the gradient bucket is left zero by the Adam kernel (the next step's zero_grad(), folded into this pass)
         kernels.adam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._state, self.lr, self.betas,
                               self.eps, self.weight_decay, grad_scale, sumsq, 0.0 if max_norm is None else max_norm, zero_grad=zero_grad)
-        self._zero_by_step = bool(zero_grad) and not torch.cuda.is_current_stream_capturing()
+        self._zero_by_step = bool(zero_grad) and not torch.cuda.is_current_stream_capturing()      # (short-circuits: no driver query on plain steps)
 
 
 def broadcast_parameters(model, src=0):
