@@ -60,3 +60,26 @@ def test_product_does_not_import_oracle():
     out = subprocess.run(["grep", "-rlE", r"^\s*(from|import)\s+oracle|from \.+oracle", os.path.join(ROOT, "summarizer_amd")],
                          capture_output=True, text=True).stdout.strip()
     assert out == "", f"product files import the oracle: {out}"
+
+
+def test_plane_size_queries_need_no_gpu(lib):
+    """The size queries of the round-5 plane entry points are pure host arithmetic: they answer (and refuse ineligible shapes with 0) without a GPU."""
+    import ctypes as C
+    lib.sumk_planes_bytes.restype = C.c_size_t; lib.sumk_planes_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.sumk_vasnet_wplanes_bytes.restype = C.c_size_t; lib.sumk_vasnet_wplanes_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.sumk_bilstm_wplanes_bytes.restype = C.c_size_t; lib.sumk_bilstm_wplanes_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.sumk_attn_planes_alpha_bytes.restype = C.c_size_t; lib.sumk_attn_planes_alpha_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    # rows are padded to 64; 2 bytes per element and plane; 8 KiB of slack a row tile may read past the last sub-array
+    assert lib.sumk_planes_bytes(12003, 1024, 3) == 12032 * 1024 * 3 * 2 + 8192
+    assert lib.sumk_planes_bytes(64, 16, 2) == 64 * 16 * 2 * 2 + 8192
+    for bad in ((0, 1024, 3), (100, 24, 3), (100, 1024, 1), (100, 1024, 4), (100, 8, 2)):
+        assert lib.sumk_planes_bytes(*bad) == 0, bad
+    assert lib.sumk_vasnet_wplanes_bytes(1024, 3) > 5 * 1024 * 1024 * 6 and lib.sumk_vasnet_wplanes_bytes(1024, 2) > 5 * 1024 * 1024 * 4
+    for bad in ((1000, 3), (128, 3), (1024, 1), (1024, 4), (0, 3)):
+        assert lib.sumk_vasnet_wplanes_bytes(*bad) == 0, bad
+    assert lib.sumk_bilstm_wplanes_bytes(1024, 256, 3) >= 2048 * 1024 * 6 + 2048 * 4
+    for bad in ((1024, 100, 3), (1000, 256, 3), (64, 256, 3), (1024, 256, 5)):
+        assert lib.sumk_bilstm_wplanes_bytes(*bad) == 0, bad
+    assert lib.sumk_attn_planes_alpha_bytes(12003, 320, 3) == 12032 * 320 * 3 * 2 + 8192
+    assert lib.sumk_attn_planes_alpha_bytes(12003, 300, 2) == 12032 * 320 * 2 * 2 + 8192        # key count rounded up to 32
+    assert lib.sumk_attn_planes_alpha_bytes(0, 320, 3) == 0 and lib.sumk_attn_planes_alpha_bytes(10, 320, 1) == 0

@@ -328,3 +328,44 @@ def test_plane_path_at_stress_size_and_batching_independence(dev, precision):
         two = m2.score_packed(torch.cat(xs[:2]), lens[:2])
         one = m2.score_packed(xs[2], lens[2:])
     assert torch.equal(allv[:463], two) and torch.equal(allv[463:], one)
+
+
+def test_plane_entry_points_argument_checks(dev):
+    """Argument checks of the round-5 entry points: refused with SUMK_ERR_ARG and a message, nothing launched."""
+    from summarizer_amd import kernels, _lib
+    from summarizer_amd._lib import SumkError
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(300, 256, device=dev)
+    with pytest.raises(SumkError, match="16-byte aligned"):
+        buf = torch.empty(lib.sumk_planes_bytes(300, 256, 3) + 64, dtype=torch.uint8, device=dev)
+        _lib.check(lib.sumk_split_planes(x.data_ptr(), 300, 256, 256, 3, buf.data_ptr() + 4, st), "split")
+    with pytest.raises(SumkError, match="K % 16"):
+        _lib.check(lib.sumk_split_planes(x.data_ptr(), 300, 250, 256, 3, buf.data_ptr(), st), "split")
+    # attention on planes: a video longer than 320 frames, offsets that do not cover the rows
+    D = 256
+    qkv = torch.randn(700, 3 * D, device=dev)
+    qp = kernels.split_planes(qkv, 3)
+    ap = torch.empty(lib.sumk_attn_planes_alpha_bytes(700, 320, 3), dtype=torch.uint8, device=dev)
+    off = np.array([0, 400, 700], dtype=np.int32)
+    with pytest.raises(SumkError, match="not eligible"):
+        _lib.check(lib.sumk_attn_planes(qp.data_ptr(), 700, D, 3, 2, _lib.host_i32(off), 0.1, 0, -1, None, ap.data_ptr(), None, st), "attn")
+    off = np.array([0, 300, 600], dtype=np.int32)
+    with pytest.raises(SumkError, match="bad arguments"):
+        _lib.check(lib.sumk_attn_planes(qp.data_ptr(), 700, D, 3, 2, _lib.host_i32(off), 0.1, 0, -1, None, ap.data_ptr(), None, st), "attn")
+    # weight-plane blocks: a buffer that is too small, a D the plane path does not take
+    from summarizer_amd.models.vasnet import VASNet
+    m = VASNet(input_size=256).to(dev).eval()
+    w = _lib.VasnetWeights()
+    for f, k in kernels.VASNET_FIELDS:
+        setattr(w, f, dict(m.named_parameters())[k].data_ptr())
+    small = torch.empty(4096, dtype=torch.uint8, device=dev)
+    with pytest.raises(SumkError, match="needed"):
+        _lib.check(lib.sumk_vasnet_wplanes_build(256, C.byref(w), None, 3, C.c_void_p((small.data_ptr() + 255) // 256 * 256), 1024, st), "wplanes")
+    assert kernels.vasnet_wplanes({k: v.detach() for k, v in m.named_parameters()}, 200, 3) is None        # D % 256: no plane path, the caller keeps the in-loop kernels
+    # a model whose D is not eligible simply scores on the in-loop kernels
+    m2 = VASNet(input_size=192, precision="bf16x6").to(dev).eval()
+    xs = torch.randn(400, 192, device=dev)
+    with torch.no_grad():
+        s = m2.score_packed(xs, [150, 250])
+    assert bool(torch.isfinite(s).all()) and getattr(m2, "_wpl", None) is None
