@@ -290,9 +290,21 @@ typedef struct sumk_tf_opts {
   float head_dropout_p;   /* training: dropout after relu(k1) (0.5)                            transformer.py:46,99 */
   uint64_t seed;          /* keep-masks are a pure function of (seed, site, element), as for VASNet               */
   int32_t precision;      /* SUMK_PRECISION_*, as in sumk_vasnet_opts                                             */
+  const void* wplanes;    /* inference in BF16X6 / BF16X3: the weights as bf16 planes (sumk_transformer_wplanes_build, 256-byte
+                             aligned) -> every projection of the stack runs on the plane GEMM; NULL: the in-loop split kernels */
 } sumk_tf_opts;
 size_t sumk_transformer_workspace_bytes(int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
                                         const int32_t* seq_off_host, int32_t training);
+/* the same plus the two activation-plane buffers of the plane path (inference, BF16X6 / BF16X3, D and F multiples of 256,
+ * at least 128 frames); equal to sumk_transformer_workspace_bytes otherwise */
+size_t sumk_transformer_workspace_bytes_for(int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
+                                            const int32_t* seq_off_host, int32_t training, int32_t precision);
+/* Weight planes of the encoder stack and k1 (transformer.py:49-53: in_proj, out_proj, linear1, linear2 of every layer; k1) for
+ * n_planes = 3 (BF16X6) or 2 (BF16X3); 0 bytes = not eligible.  Rebuild after every weight change. */
+size_t sumk_transformer_wplanes_bytes(int32_t D, int32_t F, int32_t n_layers, int32_t n_planes);
+int sumk_transformer_wplanes_build(int32_t D, int32_t F, int32_t n_layers, const sumk_tf_layer_weights* layers,
+                                   const sumk_tf_head_weights* head, int32_t n_planes, void* out, size_t out_bytes,
+                                   void* stream);
 /* x (n_rows,D) packed -> scores (n_rows,).  pos_table/pos_rows as in sumk_vasnet_forward (in-place add, transformer.py:83-89).
  * training != 0 keeps every layer's activations in the workspace for sumk_transformer_backward. */
 int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,

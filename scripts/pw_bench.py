@@ -10,7 +10,7 @@ import torch
 from summarizer_amd import kernels, _lib
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-VARIANTS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 0, 1]
+VARIANTS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 10, 1]
 STAMPS = "libsumk_diag" in os.environ.get("SUMK_LIB_PATH", "")
 lib = _lib.load()
 dev = torch.device("cuda:0")

@@ -54,7 +54,8 @@ class TfHeadWeights(C.Structure):
 
 class TfOpts(C.Structure):
     _fields_ = [("layer_eps", C.c_float), ("final_eps", C.c_float), ("more_residuals", C.c_int32),
-                ("layer_dropout_p", C.c_float), ("head_dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32)]
+                ("layer_dropout_p", C.c_float), ("head_dropout_p", C.c_float), ("seed", C.c_uint64), ("precision", C.c_int32),
+                ("wplanes", C.c_void_p)]
 
 
 class EvalVideo(C.Structure):
@@ -136,6 +137,9 @@ _SIGS = {
     "sumk_frame_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
                                            c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_transformer_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32]),
+    "sumk_transformer_workspace_bytes_for": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, C.c_int32, C.c_int32]),
+    "sumk_transformer_wplanes_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "sumk_transformer_wplanes_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sumk_transformer_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, HOST_I32P, c_i32p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
                                            C.c_int32, C.c_void_p]),

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
 
   while (true) {
     f32x16 acc[TM][TN];
-    if constexpr (EPI == PW_RES_MOM_PLANES) {
+    if constexpr (EPI == PW_RES_MOM_PLANES || EPI == PW_RES_F32) {
       // lane = row m, registers 4 g .. 4 g + 3 = columns n0w + 32 tn + 8 g + 4 lh + (0..3)
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
@@ -165,7 +165,10 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(rp + tn * 32 + 8 * g);
+            float4 v = *reinterpret_cast<const float4*>(rp + tn * 32 + 8 * g);
+            if constexpr (EPI == PW_RES_F32) {
+              if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + wn * 64 + 4 * lh + tn * 32 + 8 * g); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            }
             acc[tm][tn][4 * g] = v.x; acc[tm][tn][4 * g + 1] = v.y; acc[tm][tn][4 * g + 2] = v.z; acc[tm][tn][4 * g + 3] = v.w;
           }
       }
@@ -246,7 +249,12 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = row_w + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[tm][tn][r] + bv;
+            if (row < a.M) {
+              float v = acc[tm][tn][r] + bv;
+              if (a.R) v += a.R[(int64_t)row * a.ldr + col];
+              if (a.relu) v = (v < 0.f) ? 0.f : v;            // NaN-propagating like torch.relu
+              a.C[(int64_t)row * a.ldc + col] = v;
+            }
           }
       }
     } else if constexpr (EPI == PW_PLANES || EPI == PW_RES_MOM_PLANES) {
@@ -268,12 +276,33 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               u32x2 pl[NP];
-              split4<NP>(f32x4{acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]}, pl);
+              f32x4 v = f32x4{acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]};
+              if constexpr (EPI == PW_PLANES) {
+                if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + col_w + tn * 32 + 8 * g + 4 * lh); v += f32x4{b.x, b.y, b.z, b.w}; }
+                if (a.relu) {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) v[c] = (v[c] < 0.f) ? 0.f : v[c];
+                }
+              }
+              split4<NP>(v, pl);
               const int kb = (col_w >> 4) + tn * 2 + (g >> 1), h = g & 1;
               char* const op = a.O + ((int64_t)(kb * NP) * 2 + h) * a.o_rp16 + (int64_t)m * 16 + 8 * lh;
 #pragma unroll
               for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.o_rp16) = pl[p];
             }
+        }
+      }
+    } else if constexpr (EPI == PW_RES_F32) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = row_w + tm * 32 + li;
+        if (m < a.M) {
+          float* const cp = a.C + (int64_t)m * a.ldc + col_w + 4 * lh;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(cp + tn * 32 + 8 * g) = make_float4(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]);
         }
       }
     } else {   // PW_HEAD
@@ -352,7 +381,7 @@ int launch_np(PwEpi epi, const PwArgs& a, int variant, hipStream_t s) {
   switch (epi) {
     case PW_F32:
       switch (variant) {
-        case 0: return launch_one<NP, 192, PW_F32, NS, 0>(a, base + 4, s);
+        case 10: return launch_one<NP, 192, PW_F32, NS, 0>(a, base + 4, s);      // (probe: waves 0-3 issue their DMA early)
         case 1: return launch_one<NP, 192, PW_F32, NS, 1>(a, base + 5, s);
         case 3: return launch_one<NP, 192, PW_F32, NS, 3>(a, base + 6, s);
         default: return launch_one<NP, 192, PW_F32, NS, 2>(a, base + 0, s);
@@ -360,6 +389,7 @@ int launch_np(PwEpi epi, const PwArgs& a, int variant, hipStream_t s) {
     case PW_PLANES: return launch_one<NP, 192, PW_PLANES, NS, 2>(a, base + 1, s);
     case PW_RES_MOM_PLANES: return launch_one<NP, 192, PW_RES_MOM_PLANES, NS, 2>(a, base + 2, s);
     case PW_HEAD: return launch_one<NP, 192, PW_HEAD, NS, 2>(a, base + 3, s);
+    case PW_RES_F32: return launch_one<NP, 192, PW_RES_F32, NS, 2>(a, base + 7, s);
   }
   set_error("gemm_pw: bad epilogue %d", (int)epi);
   return SUMK_ERR_ARG;
@@ -431,12 +461,14 @@ int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {
   a.total_tiles = a.xcd_map == 2 ? 8 * ((a.tiles_m + 7) / 8) * a.tiles_n : a.xcd_map == 1 ? 8 * ((a.tiles_m + 1) / 2) * (a.tiles_n / 4) : a.tiles_m * a.tiles_n;
   a.C = g.C; a.ldc = g.ldc; a.O = (char*)g.O; a.o_rp16 = pw_rows_pitch(g.o_rows) * 16;
   a.o_store_rows = (int32_t)std::max<int64_t>(g.M, std::min<int64_t>(g.o_store_rows, std::min<int64_t>(pw_rows_pitch(g.o_rows), pw_rows_pitch(g.a_rows)))); a.R = g.R; a.ldr = g.ldr; a.moments = g.moments;
-  a.bias = g.bias; a.gw = g.gw; a.ln_c1 = g.ln_c1; a.ln_stats = g.ln_stats; a.head_part = g.head_part;
+  a.bias = g.bias; a.gw = g.gw; a.ln_c1 = g.ln_c1; a.ln_stats = g.ln_stats; a.head_part = g.head_part; a.relu = g.relu;
   switch (epi) {
-    case PW_F32: SUMK_ARG(g.C && g.ldc >= g.N, "gemm_pw: fp32 output missing"); break;
+    case PW_F32: SUMK_ARG(g.C && g.ldc >= g.N && (!g.R || g.ldr >= g.N), "gemm_pw: fp32 output missing / residual pitch"); break;
     case PW_PLANES: SUMK_ARG(g.O && g.o_rows >= g.M, "gemm_pw: plane output missing"); break;
     case PW_RES_MOM_PLANES: SUMK_ARG(g.O && g.o_rows >= g.M && g.R && g.ldr >= g.N && g.ldr % 4 == 0 && g.moments, "gemm_pw: residual / moments / plane output missing"); break;
     case PW_HEAD: SUMK_ARG(g.bias && g.gw && g.ln_c1 && g.ln_stats && g.head_part, "gemm_pw: head epilogue operands missing"); break;
+    case PW_RES_F32: SUMK_ARG(g.C && g.ldc >= g.N && g.ldc % 4 == 0 && g.R && g.ldr >= g.N && g.ldr % 4 == 0 && ((uintptr_t)g.C & 15) == 0 && ((uintptr_t)g.R & 15) == 0 && !g.relu,
+                              "gemm_pw: residual epilogue needs 16-byte aligned C and R with pitches %% 4 (and no ReLU)"); break;
   }
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512) void gemm_pw16_kernel(PwArgs a) {
 
   while (true) {
     const int row_w = m0 + wm * 96, col_w = n0 + wn * 64;
-    if constexpr (EPI == PW_RES_MOM_PLANES) {
+    if constexpr (EPI == PW_RES_MOM_PLANES || EPI == PW_RES_F32) {
       // transposed product: lane = row m (r16 of tile i), registers = columns 16 u + 4 kq + (0..3)
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -122,7 +122,10 @@ __global__ __launch_bounds__(512) void gemm_pw16_kernel(PwArgs a) {
         const float* const rp = a.R + (int64_t)min(m, a.M - 1) * a.ldr + col_w + 4 * kq;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float4 v = *reinterpret_cast<const float4*>(rp + u * 16);
+          float4 v = *reinterpret_cast<const float4*>(rp + u * 16);
+          if constexpr (EPI == PW_RES_F32) {
+            if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + col_w + 4 * kq + u * 16); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+          }
           acc[i][u] = f32x4acc{v.x, v.y, v.z, v.w};
         }
       }
@@ -193,7 +196,12 @@ __global__ __launch_bounds__(512) void gemm_pw16_kernel(PwArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = row_w + i * 16 + 4 * kq + r;
-            if (row < a.M) a.C[(int64_t)row * a.ldc + col] = acc[i][j][r] + bv;
+            if (row < a.M) {
+              float v = acc[i][j][r] + bv;
+              if (a.R) v += a.R[(int64_t)row * a.ldr + col];
+              if (a.relu) v = (v < 0.f) ? 0.f : v;            // NaN-propagating like torch.relu
+              a.C[(int64_t)row * a.ldc + col] = v;
+            }
           }
       }
     } else if constexpr (EPI == PW_PLANES || EPI == PW_RES_MOM_PLANES) {
@@ -214,12 +222,30 @@ __global__ __launch_bounds__(512) void gemm_pw16_kernel(PwArgs a) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {         // columns col_w + 16 u + 4 kq + (0..3): chunk (row m, k-block (col_w >> 4) + u, half kq >> 1), byte 8 (kq & 1)
             u32x2 pl[NP];
-            split4<NP>(f32x4{acc[i][u][0], acc[i][u][1], acc[i][u][2], acc[i][u][3]}, pl);
+            f32x4 v = f32x4{acc[i][u][0], acc[i][u][1], acc[i][u][2], acc[i][u][3]};
+            if constexpr (EPI == PW_PLANES) {
+              if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + col_w + 16 * u + 4 * kq); v += f32x4{b.x, b.y, b.z, b.w}; }
+              if (a.relu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = (v[c] < 0.f) ? 0.f : v[c];
+              }
+            }
+            split4<NP>(v, pl);
             const int kb = (col_w >> 4) + u;
             char* const op = a.O + ((int64_t)(kb * NP) * 2 + (kq >> 1)) * a.o_rp16 + (int64_t)m * 16 + 8 * (kq & 1);
 #pragma unroll
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.o_rp16) = pl[p];
           }
+        }
+      }
+    } else if constexpr (EPI == PW_RES_F32) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int m = row_w + i * 16 + r16;
+        if (m < a.M) {
+          float* const cp = a.C + (int64_t)m * a.ldc + col_w + 4 * kq;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(cp + u * 16) = make_float4(acc[i][u][0], acc[i][u][1], acc[i][u][2], acc[i][u][3]);
         }
       }
     } else {   // PW_HEAD
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm_pw16_kernel(PwArgs a) {
   }
 }
 
-std::atomic<uint64_t> g_attr16[4];
+std::atomic<uint64_t> g_attr16[5];
 
 template <int EPI>
 int launch16(const PwArgs& a, hipStream_t stream) {
@@ -284,6 +310,7 @@ int launch_gemm_pw16(int epi, const PwArgs& a, hipStream_t stream) {
     case PW_PLANES: return launch16<PW_PLANES>(a, stream);
     case PW_RES_MOM_PLANES: return launch16<PW_RES_MOM_PLANES>(a, stream);
     case PW_HEAD: return launch16<PW_HEAD>(a, stream);
+    case PW_RES_F32: return launch16<PW_RES_F32>(a, stream);
   }
   set_error("gemm_pw16: bad epilogue %d", epi);
   return SUMK_ERR_ARG;

@@ -34,6 +34,7 @@ struct PwArgs {
   const float* R; int32_t ldr;
   float* moments;
   const float* bias; const float* gw; const float* ln_c1; const float* ln_stats; float* head_part;
+  int32_t relu;                        // PW_F32 / PW_PLANES: max(v, 0) after the bias (and before nothing else: a residual and ReLU never meet)
 };
 
 // gemm_pw16.hip: the same product on v_mfma_f32_16x16x32_bf16 (two planes; K >= 160); `a` as launch_gemm_pw built it

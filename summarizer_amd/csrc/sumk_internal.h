@@ -289,10 +289,12 @@ int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* pl
 // LAST row of the array): stacking several matrices into one operand ([Wq; Wk; Wv])
 int split_planes_at(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t row0, int64_t total_rows, hipStream_t stream);
 enum PwEpi {
-  PW_F32 = 0,             // C (fp32, row-major, ldc) = product
-  PW_PLANES = 1,          // O (KB planes of the (M, N) result: the K-contiguous operand of a later product over N) = product
+  PW_F32 = 0,             // C (fp32, row-major, ldc) = product [+ bias[n]] [+ R[m][n]] [relu]
+  PW_PLANES = 1,          // O (KB planes of the (M, N) result: the K-contiguous operand of a later product over N) = product [+ bias[n]] [relu]
   PW_RES_MOM_PLANES = 2,  // v = product + R; moments float2[M][N / 64] {sum v, sum v^2} per 64-column slot; O = planes of v
   PW_HEAD = 3,            // v = relu(rstd_m (product - mean_m c1[n]) + bias[n]) is NOT stored: head_part float4[M][N / 64] {sum v, sum v^2, sum v gw[n], 0}
+  PW_RES_F32 = 4,         // C (fp32) = product + R [+ bias[n]] in the transposed orientation (lane = row, 16-byte pieces): R is preloaded into the
+                          // accumulators, the epilogue is float4 stores alone (the residual projections of the Transformer scorer)
 };
 struct PwLaunch {
   const void* A = nullptr; const void* B = nullptr;    // KB planes of A (M x K) and B (N x K): C = A B^T
@@ -305,6 +307,7 @@ struct PwLaunch {
   const float* R = nullptr; int32_t ldr = 0;
   float* moments = nullptr;
   const float* bias = nullptr; const float* gw = nullptr; const float* ln_c1 = nullptr; const float* ln_stats = nullptr; float* head_part = nullptr;
+  int32_t relu = 0;                                     // PW_F32 / PW_PLANES: ReLU after the bias (the feed-forward layers of the Transformer scorer)
   int32_t prof_tag = -1;
   int32_t variant = 0;                                  // schedule variant (probes; 0 = the product's; 32 = two planes on the 32x32x16 kernel instead of gemm_pw16.hip)
 };

@@ -24,6 +24,37 @@ struct TfWs {
   int64_t e_elems; int32_t n_rows;
 };
 enum { TT_S = 0, TT_PV = 1, TT_DV = 2, TT_DP = 3, TT_DQ = 4, TT_DK = 5, TT_COUNT = 6 };
+
+// Plane path (inference in bf16x6 / bf16x3; gemm_pw.hip): every projection of the stack reads bf16 planes of both operands.  The
+// weights' planes are built once per weight change (sumk_transformer_wplanes_build: per layer [Win | Wo | W1 | W2], then k1), the
+// activations' by split_planes (layer input, context, LayerNorm output) or by the producing epilogue (ReLU(lin1): PW_PLANES with bias +
+// ReLU, never stored as fp32).  Two plane buffers behind the regular carve-up (sumk_transformer_workspace_bytes_for).
+struct TfWPlanes { size_t win, wo, w1, w2, lay_stride, k1, total; };
+static bool tf_wplanes_ok(int D, int F, int np) {
+  return (np == 2 || np == 3) && D >= 256 && D % 256 == 0 && F >= 256 && F % 256 == 0 && pw_ok(256, 3 * (int64_t)D, D, 256, 3 * (int64_t)D, np) &&
+         pw_ok(256, F, D, 256, F, np) && pw_ok(256, D, F, 256, D, np);
+}
+static TfWPlanes tf_wplanes_layout(int D, int F, int n_layers, int np) {
+  TfWPlanes l; size_t p = 0;
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  l.win = take(pw_planes_bytes(3 * (int64_t)D, D, np)); l.wo = take(pw_planes_bytes(D, D, np));
+  l.w1 = take(pw_planes_bytes(F, D, np)); l.w2 = take(pw_planes_bytes(D, F, np));
+  l.lay_stride = p; l.k1 = p * (size_t)n_layers;
+  l.total = l.k1 + align_up(pw_planes_bytes(D, D, np), 256);
+  return l;
+}
+struct TfPwExtra { size_t pa, pb, total; };
+static TfPwExtra tf_pw_extra(int D, int F, int64_t R, int np, size_t base) {
+  TfPwExtra e; size_t p = align_up(base, 256);
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  e.pa = take(pw_planes_bytes(R, std::max(D, F), np)); e.pb = take(pw_planes_bytes(R, std::max(D, F), np));
+  e.total = p;
+  return e;
+}
+static int tf_np(int precision) { return precision == SUMK_PRECISION_BF16X6 ? 3 : precision == SUMK_PRECISION_BF16X3 ? 2 : 0; }
+static bool tf_pw_rows_ok(int D, int F, int64_t R, int np) {
+  return R >= 128 && pw_ok(R, 3 * (int64_t)D, D, R, 3 * (int64_t)D, np) && pw_ok(R, F, D, R, F, np) && pw_ok(R, D, F, R, D, np);
+}
 constexpr int TF_SPLITK_PROBS = 64, TF_COLSUM_CHUNKS = 128;
 
 static int tf_carve(int D, int F, int heads, int n_layers, int n_seq, const int32_t* off, int training, TfWs* w) {
@@ -222,6 +253,43 @@ extern "C" size_t sumk_transformer_workspace_bytes(int32_t D, int32_t F, int32_t
   return w.total;
 }
 
+extern "C" size_t sumk_transformer_workspace_bytes_for(int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
+                                                       const int32_t* seq_off_host, int32_t training, int32_t precision) {
+  TfWs w;
+  if (tf_carve(D, F, n_heads, n_layers, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
+  const int np = tf_np(precision);
+  if (!training && np && tf_wplanes_ok(D, F, np) && tf_pw_rows_ok(D, F, w.n_rows, np)) return tf_pw_extra(D, F, w.n_rows, np, w.total).total;
+  return w.total;
+}
+
+extern "C" size_t sumk_transformer_wplanes_bytes(int32_t D, int32_t F, int32_t n_layers, int32_t n_planes) {
+  if (n_layers < 1 || D < 1 || F < 1 || !tf_wplanes_ok(D, F, n_planes)) return 0;
+  return tf_wplanes_layout(D, F, n_layers, n_planes).total;
+}
+
+extern "C" int sumk_transformer_wplanes_build(int32_t D, int32_t F, int32_t n_layers, const sumk_tf_layer_weights* layers,
+                                              const sumk_tf_head_weights* head, int32_t n_planes, void* out, size_t out_bytes,
+                                              void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SUMK_ARG(layers && head && out && n_layers > 0, "transformer_wplanes_build: null pointer");
+  SUMK_ARG(tf_wplanes_ok(D, F, n_planes), "transformer_wplanes_build: D=%d F=%d planes=%d is not eligible (D, F multiples of 256; 2 or 3 planes)", D, F, n_planes);
+  const TfWPlanes l = tf_wplanes_layout(D, F, n_layers, n_planes);
+  SUMK_ARG(out_bytes >= l.total && ((uintptr_t)out & 255) == 0, "transformer_wplanes_build: %zu bytes (256-byte aligned) needed, got %zu", l.total, out_bytes);
+  char* o = (char*)out;
+  for (int i = 0; i < n_layers; ++i) {
+    const sumk_tf_layer_weights& W = layers[i];
+    SUMK_ARG(W.in_proj_w && W.out_proj_w && W.lin1_w && W.lin2_w, "transformer_wplanes_build: null weight in layer %d", i);
+    char* lb = o + (size_t)i * l.lay_stride;
+    SUMK_TRY(split_planes(W.in_proj_w, 3 * (int64_t)D, D, D, n_planes, lb + l.win, stream));
+    SUMK_TRY(split_planes(W.out_proj_w, D, D, D, n_planes, lb + l.wo, stream));
+    SUMK_TRY(split_planes(W.lin1_w, F, D, D, n_planes, lb + l.w1, stream));
+    SUMK_TRY(split_planes(W.lin2_w, D, F, F, n_planes, lb + l.w2, stream));
+  }
+  SUMK_ARG(head->k1_w, "transformer_wplanes_build: null k1 weight");
+  SUMK_TRY(split_planes(head->k1_w, D, D, D, n_planes, o + l.k1, stream));
+  return SUMK_OK;
+}
+
 extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t n_heads, int32_t n_layers, int32_t n_seq,
                                         const int32_t* seq_off_host, const int32_t* seq_off_dev,
                                         const sumk_tf_layer_weights* layers, const sumk_tf_head_weights* head,
@@ -240,6 +308,23 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
   if (workspace_bytes < L.total) { set_error("transformer_forward: workspace %zu < required %zu", workspace_bytes, L.total); return SUMK_ERR_WORKSPACE; }
   char* ws = (char*)workspace;
   const int R = G.R, dh = G.dh, np = n_seq * n_heads;
+  // the plane path: inference in a split-bf16 arithmetic with the weights' planes at hand
+  const int npl = tf_np(opts->precision);
+  const bool pw = !training && npl && opts->wplanes && tf_wplanes_ok(D, F, npl) && tf_pw_rows_ok(D, F, R, npl);
+  TfPwExtra PX{0, 0, 0}; TfWPlanes WL{};
+  if (pw) {
+    PX = tf_pw_extra(D, F, R, npl, L.total); WL = tf_wplanes_layout(D, F, n_layers, npl);
+    SUMK_ARG(((uintptr_t)opts->wplanes & 255) == 0, "transformer_forward: wplanes must be 256-byte aligned");
+    if (workspace_bytes < PX.total) { set_error("transformer_forward: workspace %zu < %zu the plane path needs (sumk_transformer_workspace_bytes_for)", workspace_bytes, PX.total); return SUMK_ERR_WORKSPACE; }
+  }
+  char* const PA = ws + PX.pa; char* const PB = ws + PX.pb;
+  const char* const wpl = (const char*)opts->wplanes;
+  // C (R, N) = A planes (R, K) x weight planes (N, K)^T + bias [+ Rs] [ReLU]; O: the result as planes instead
+  auto pw_linear = [&](const void* Ap, const char* Wp, int N, int K, const float* bias, const float* Rs, int relu, float* C_, void* O_) {
+    PwLaunch g; g.A = Ap; g.B = Wp; g.a_rows = R; g.b_rows = N; g.M = R; g.N = N; g.K = K; g.np = npl;
+    g.bias = bias; g.R = Rs; g.ldr = N; g.relu = relu; g.C = C_; g.ldc = N; g.O = O_; g.o_rows = R;
+    return launch_gemm_pw(O_ ? PW_PLANES : Rs ? PW_RES_F32 : PW_F32, g, stream);
+  };
   TfSeq* seq = (TfSeq*)(ws + L.seq);
   GemmProb* prow = (GemmProb*)(ws + L.prob_row);
   GemmProb* tabs = (GemmProb*)(ws + L.prob_tabs);
@@ -267,7 +352,11 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       T1a = T1b = T1; hmid = Hb[0]; hout = Hb[1 + (l & 1)];   // never aliases this layer's input (x or the previous hout)
     }
     const uint32_t site = 10u * (uint32_t)l;
-    {  // packed in-projection  [Q|K|V] = h Win^T + bin
+    const char* const wl = pw ? wpl + (size_t)l * WL.lay_stride : nullptr;
+    if (pw) {
+      SUMK_TRY(split_planes(hin, R, D, D, npl, PA, stream));
+      SUMK_TRY(pw_linear(PA, wl + WL.win, 3 * D, D, W.in_proj_b, nullptr, 0, QKV, nullptr));
+    } else {  // packed in-projection  [Q|K|V] = h Win^T + bin
       GemmLaunch g; g.precision = opts->precision;
       g.A = hin; g.B[0] = W.in_proj_w; g.bias0[0] = W.in_proj_b; g.C = QKV; g.probs = prow + P_QKV; g.small_tile = G.c_qkv;
       g.total_tiles = gemm_tiles(R, 3 * D, G.c_qkv); g.xcd_M = R; g.xcd_N = 3 * D; g.lean = gemm_lean_ok(R, 3 * D, D, D, D);
@@ -286,7 +375,10 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       g.total_tiles = G.tiles_pv;
       SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
     }
-    {  // out-projection + bias (+dropout1) + residual
+    if (pw) {
+      SUMK_TRY(split_planes(CTX, R, D, D, npl, PA, stream));
+      SUMK_TRY(pw_linear(PA, wl + WL.wo, D, D, W.out_proj_b, hin, 0, T1a, nullptr));
+    } else {  // out-projection + bias (+dropout1) + residual
       GemmLaunch g; g.precision = opts->precision;
       g.A = CTX; g.B[0] = W.out_proj_w; g.bias0[0] = W.out_proj_b; g.R = hin; g.C = T1a; g.probs = prow + P_DD; g.small_tile = G.c_dd;
       g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);
@@ -294,6 +386,11 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
     }
     SUMK_TRY(launch_layernorm(T1a, hmid, W.norm1_w, W.norm1_b, R, D, opts->layer_eps, stats, stream));
+    if (pw) {  // both feed-forward layers; ReLU(lin1) exists as planes only
+      SUMK_TRY(split_planes(hmid, R, D, D, npl, PA, stream));
+      SUMK_TRY(pw_linear(PA, wl + WL.w1, F, D, W.lin1_b, nullptr, 1, nullptr, PB));
+      SUMK_TRY(pw_linear(PB, wl + WL.w2, D, F, W.lin2_b, hmid, 0, T1b, nullptr));
+    } else {
     {  // feed-forward 1: bias + ReLU (+dropout)
       GemmLaunch g; g.precision = opts->precision;
       g.A = hmid; g.B[0] = W.lin1_w; g.bias0[0] = W.lin1_b; g.C = FF; g.probs = prow + P_DF; g.small_tile = G.c_df;
@@ -308,6 +405,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 3;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
     }
+    }
     SUMK_TRY(launch_layernorm(T1b, hout, W.norm2_w, W.norm2_b, R, D, opts->layer_eps, stats ? stats + 2 * (size_t)R : nullptr, stream));
     hin = hout;
   }
@@ -320,7 +418,10 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     int64_t n4 = (int64_t)R * (D >> 2);
     hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, hfin, x, n4);
   }
-  {
+  if (pw) {
+    SUMK_TRY(split_planes(hfin, R, D, D, npl, PA, stream));
+    SUMK_TRY(pw_linear(PA, wpl + WL.k1, D, D, head->k1_b, nullptr, 1, Z, nullptr));
+  } else {
     GemmLaunch g; g.precision = opts->precision;
     g.A = hfin; g.B[0] = head->k1_w; g.bias0[0] = head->k1_b; g.C = Z; g.probs = prow + P_DD; g.small_tile = G.c_dd;
     g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);

@@ -584,9 +584,29 @@ def _tf_structs(tensors, n_layers, what, layer_cls, head_cls):
 
 
 def _tf_opts(o):
+    wp = o.get("wplanes")
     return _lib.TfOpts(float(o["layer_eps"]), float(o["final_eps"]), int(bool(o.get("more_residuals", False))),
                        float(o.get("layer_dropout_p", 0.0)), float(o.get("head_dropout_p", 0.0)), int(o.get("seed", 0)),
-                       precision_code(o.get("precision")))
+                       precision_code(o.get("precision")), wp.data_ptr() if wp is not None else None)
+
+
+def transformer_wplanes(params, D, dff, n_layers, n_planes, out=None):
+    """The weight-plane block of the Transformer scorer's plane path (sumk_tf_opts.wplanes) for the current weights: planes of in_proj,
+    out_proj, linear1, linear2 of every layer and of k1.  Returns a 256-byte aligned uint8 tensor, or None when (D, dff) is not eligible."""
+    lib = _lib.load()
+    nb = lib.sumk_transformer_wplanes_bytes(int(D), int(dff), int(n_layers), int(n_planes))
+    if nb == 0:
+        return None
+    layers, head = _tf_structs(params, n_layers, "weight", _lib.TfLayerWeights, _lib.TfHeadWeights)
+    dev = params[TF_HEAD_FIELDS[0][1]].device
+    if out is None or out.numel() < nb + 256 or out.device != dev:
+        out = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+    base = (out.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.sumk_transformer_wplanes_build(int(D), int(dff), int(n_layers), C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p),
+                                                  int(n_planes), C.c_void_p(base), nb, _stream()), "sumk_transformer_wplanes_build")
+    view = out[base - out.data_ptr():]
+    view._sumk_keep = out
+    return view
 
 
 def transformer_forward_packed(x, sb, params, n_layers, n_heads, dff, opts, pos_table=None, pos_rows=None, training=False):
@@ -598,9 +618,10 @@ def transformer_forward_packed(x, sb, params, n_layers, n_heads, dff, opts, pos_
     D = x.shape[1]
     layers, head = _tf_structs(params, n_layers, "weight", _lib.TfLayerWeights, _lib.TfHeadWeights)
     o = _tf_opts(opts)
-    nbytes = lib.sumk_transformer_workspace_bytes(D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, int(training))
+    nbytes = lib.sumk_transformer_workspace_bytes_for(D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, int(training),
+                                                      o.precision if o.wplanes else 0)
     if nbytes == 0:
-        _lib.check(-1, "sumk_transformer_workspace_bytes")
+        _lib.check(-1, "sumk_transformer_workspace_bytes_for")
     ws = workspace(nbytes, x.device, persistent=training)
     scores = torch.empty(sb.n_rows, dtype=torch.float32, device=x.device)
     rc = lib.sumk_transformer_forward(_p(x), D, dff, n_heads, n_layers, sb.n_seq, sb.off_host_p, sb.off_dev_p,

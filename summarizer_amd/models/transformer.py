@@ -107,9 +107,26 @@ class Transformer(nn.Module):
             names = kernels.transformer_param_names(self.encoder_layers)
             cfg = dict(n_layers=self.encoder_layers, n_heads=self.attention_heads, dff=self.input_size)
             return TransformerFunction.apply(xp, sb, cfg, opts, table, rows, names, *[p[n] for n in names])
+        if opts["precision"] in kernels.PLANES_OF:          # inference in a split-bf16 arithmetic: every projection on the plane GEMM
+            opts["wplanes"] = self._wplanes(p, opts["precision"])
         scores, _ = kernels.transformer_forward_packed(xp, sb, p, self.encoder_layers, self.attention_heads, self.input_size,
                                                        opts, table, rows)
         return scores
+
+    def _wplanes(self, p, precision):
+        """Cached weight-plane block (kernels.transformer_wplanes) of the current weights.  Keyed like VASNet's: storage addresses and
+        tensor versions (what torch can see), kernels.WEIGHTS_EPOCH (optimiser steps through the C ABI), precision and stream."""
+        names = kernels.transformer_param_names(self.encoder_layers)
+        ps = [p[n] for n in names]
+        key = tuple(q.data_ptr() for q in ps) + tuple(q._version for q in ps) + (
+            kernels.WEIGHTS_EPOCH[0], precision, torch.cuda.current_stream(ps[0].device).cuda_stream if ps[0].is_cuda else 0)
+        if getattr(self, "_wpl", None) is None or self._wpl_key != key:
+            with torch.no_grad():
+                self._wpl = kernels.transformer_wplanes({n: q.detach() for n, q in zip(names, ps)}, self.input_size, self.input_size,
+                                                        self.encoder_layers, kernels.PLANES_OF[precision], out=getattr(self, "_wpl_buf", None))
+            self._wpl_buf = getattr(self._wpl, "_sumk_keep", None) if self._wpl is not None else None
+            self._wpl_key = key
+        return self._wpl
 
 
 class TransformerTrainer(Trainer):

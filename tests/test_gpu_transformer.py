@@ -59,6 +59,56 @@ def test_transformer_full_size_goldens_and_packed_batch():
         np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i}")
 
 
+@pytest.mark.parametrize("precision,tol_fp32", [("bf16x6", 1e-5), ("bf16x3", 1e-4)])
+def test_transformer_plane_path_goldens_and_ragged_batch(precision, tol_fp32):
+    """Inference in a split-bf16 arithmetic runs every projection of the stack on the plane GEMM (weights' planes cached per weight
+    change, ReLU(linear1) as planes only): the REAL reference's full-size golden (D = 1024, 6 layers, 8 heads) at the usual gate, a
+    ragged packed batch vs the oracle, and the distance to the exact-fp32 scores."""
+    from oracle import transformer_np
+    from summarizer_amd import _lib, kernels
+    from summarizer_amd.models.transformer import Transformer
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = load_golden("transformer_full")
+    cfg = js(g["c0/cfg"])
+    w = R.transformer_weights(cfg["D"], cfg["layers"], cfg["wseed"])
+    m = _load(Transformer(input_size=cfg["D"], encoder_layers=cfg["layers"], attention_heads=cfg["heads"]), w, dev)
+    x = torch.from_numpy(R.features(cfg["T"], cfg["B"], cfg["D"], cfg["xseed"])).to(dev)
+    sb = kernels.SeqBatch.get([cfg["T"]], dev)
+    code = kernels.precision_code(precision)
+    args = (cfg["D"], cfg["D"], cfg["heads"], cfg["layers"], sb.n_seq, sb.off_host_p, 0)
+    assert lib.sumk_transformer_workspace_bytes_for(*args, code) > lib.sumk_transformer_workspace_bytes(*args)      # the plane path applies
+    with torch.no_grad():
+        y32 = m(x).cpu().numpy()
+        m.precision = precision
+        y = m(x).cpu().numpy()
+        assert m._wpl is not None
+        blk = m._wpl
+        assert m(x).cpu().numpy().tobytes() == y.tobytes() and m._wpl is blk                    # repeatable; the block is cached ...
+        w0 = m.k1.weight.clone()
+        m.k1.weight.mul_(1.5)
+        y_moved = m(x).cpu().numpy()
+        m.k1.weight.copy_(w0)
+        assert np.abs(y_moved - y).max() > 1e-4                                                    # ... and follows the weights
+        np.testing.assert_array_equal(m(x).cpu().numpy(), y)
+    np.testing.assert_allclose(y, g["c0/y"], atol=TOL, rtol=0)
+    assert np.abs(y - y32).max() < tol_fp32, np.abs(y - y32).max()
+    # ragged packed batch (D = 256, 4 heads, 2 layers): one-frame and two-frame videos among longer ones
+    D, L, Hh = 256, 2, 4
+    w = R.transformer_weights(D, L, 123)
+    m = _load(Transformer(input_size=D, encoder_layers=L, attention_heads=Hh), w, dev)
+    m.precision = precision
+    lens = [1, 2, 65, 130, 7, 300]
+    xs = [R.features(T, 1, D, 200 + i) - 0.1 for i, T in enumerate(lens)]
+    with torch.no_grad():
+        s = m.score_packed(torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev), lens).cpu().numpy()
+    assert m._wpl is not None
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, x in enumerate(xs):
+        ref = transformer_np.transformer_forward(x, w, L, Hh)[:, 0, 0]
+        np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i}")
+
+
 @pytest.mark.parametrize("tag,kw", [("tf", dict(input_size=64, encoder_layers=2, attention_heads=4)),
                                     ("tf_res", dict(input_size=64, encoder_layers=1, attention_heads=8, more_residuals=True))])
 def test_transformer_train_step_goldens(tag, kw):
