@@ -429,6 +429,38 @@ def recurrent_legs(x, lens, dev, frames):
     return out
 
 
+def transformer_legs(x, lens, dev, frames):
+    """SURVEY 8 row f2 on the headline batch: the Transformer-encoder scorer (6 post-norm layers, 8 heads, transformer.py:74-103), exact
+    fp32 and the fp32-grade bf16x6 arithmetic (every projection of the stack on the plane GEMM, csrc/gemm_pw.hip)."""
+    from summarizer_amd.models.transformer import Transformer
+    torch.manual_seed(1234)
+    m = Transformer(input_size=x.shape[1]).to(dev).eval()
+    flops = frames * 6 * (2 * 6 * x.shape[1] ** 2) + 2 * frames * x.shape[1] ** 2 + 6 * 4 * sum(t * t for t in lens) * x.shape[1]
+    out = {}
+    ref = None
+    for prec, key in (("fp32", "transformer_score_mode"), ("bf16x6", "transformer_score_bf16x6_mode")):
+        m.precision = prec
+        with torch.no_grad():
+            for _ in range(3):
+                s = m.score_packed(x, lens)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                s = m.score_packed(x, lens)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        assert bool(torch.isfinite(s).all())
+        rec = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), whole_path_tflops=round(flops / dt / 1e12, 1))
+        if ref is None:
+            ref = s
+            rec["note"] = "Transformer-encoder scorer, 50 videos packed, exact fp32 MFMA (fraction of the 157.3 TFLOP/s fp32 peak: %.2f)" % (flops / dt / 157.3e12)
+        else:
+            rec["max_abs_diff_vs_fp32_scores"] = float((s - ref).abs().max())
+            rec["note"] = "the same in bf16x6: weights as cached bf16 planes, activations split once per projection or by the producing epilogue; attention products on the in-loop split kernels"
+        out[key] = rec
+    return out
+
+
 def stress_leg(dev, steps=3):
     """BASELINE config 5 at one GPU's share: 8 sequences of T = 10 000 frames, D = 2048, exact fp32 (the attention matrix of one sequence is
     400 MB: E is materialised, 3.2 GB).  Reports the whole-path fraction of the fp32 MFMA peak (the path is matrix-bound, not HBM-bound:
@@ -892,7 +924,7 @@ def main():
             single = single_video_leg(dev)
         except Exception as e:          # noqa: BLE001
             single = dict(error=f"{type(e).__name__}: {e}"[:300])
-    e2e = stream = recurrent = stress = None
+    e2e = stream = recurrent = stress = tf_legs = None
     if args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only and rank == 0:
         def _side(fn, *a):
             try:
@@ -904,6 +936,7 @@ def main():
         stream = _side(stream_leg, model, x, lens, dev)
         recurrent = _side(recurrent_legs, x, lens, dev, frames)
         stress = _side(stress_leg, dev)
+        tf_legs = _side(transformer_legs, x, lens, dev, frames)
     if dist is not None and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
         barrier()          # the rank-0-only legs above take a few seconds: the other ranks wait here, not inside destroy_process_group
     if rank == 0:
@@ -955,6 +988,11 @@ def main():
                 out.update(recurrent)
         if stress is not None:
             out["stress_mode"] = stress
+        if tf_legs is not None:
+            if "error" in tf_legs:
+                out["transformer_score_mode"] = tf_legs
+            else:
+                out.update(tf_legs)
         if world == 1 and not args.no_cpu_baseline and args.model in ("vasnet", "dsn", "slstm") and args.mode == "score" and args.workload == "tvsum":
             try:
                 out["cpu_baseline"] = cpu_baseline(lens, D, kind=args.model, gpu_scores=s if args.precision != "bf16" else None, seed_base=1000 * rank)

@@ -146,16 +146,43 @@ __global__ __launch_bounds__(256) void tf_softmax_kernel(float* E, float* E2, co
   const int i = row - si.row0, T = si.T;
   const int64_t ro = si.eoff + ((int64_t)h * T + i) * si.ldE;
   float* e = E + ro;
+  if (T <= 512) {        // the row lives in registers: one read, one exp per element (same operations in the same order as the loops below)
+    float v[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int j = lane + 64 * q; v[q] = j < T ? e[j] : -INFINITY; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m = fmaxf(m, v[q] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (lane + 64 * q < T) { v[q] = expf(__builtin_fmaf(v[q], scale, -m)); sum += v[q]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = lane + 64 * q;
+      if (j < si.ldE) {
+        const float a = j < T ? v[q] / sum : 0.f;
+        e[j] = a;
+        if (E2) E2[ro + j] = drop.thr ? drop_apply(drop, site, ((uint64_t)wid << 20) | (uint64_t)j, a) : a;
+      }
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int j = lane; j < T; j += 64) m = fmaxf(m, e[j] * scale);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   float sum = 0.f;
-  for (int j = lane; j < T; j += 64) sum += expf(e[j] * scale - m);
+  for (int j = lane; j < T; j += 64) sum += expf(__builtin_fmaf(e[j], scale, -m));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
   for (int j = lane; j < si.ldE; j += 64) {
-    const float v = j < T ? expf(e[j] * scale - m) / sum : 0.f;
+    const float v = j < T ? expf(__builtin_fmaf(e[j], scale, -m)) / sum : 0.f;
     e[j] = v;
     if (E2) E2[ro + j] = drop.thr ? drop_apply(drop, site, ((uint64_t)wid << 20) | (uint64_t)j, v) : v;
   }
