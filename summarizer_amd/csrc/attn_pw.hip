@@ -32,6 +32,8 @@ struct AttnPwArgs {
   char* CP; uint32_t cp_rp16;              // context planes (kernel B): rows = packed frames, k = D columns
   const SeqInfo* seq; int32_t n_seq, strips;
   float scale; int32_t ignore_self, aperture;
+  int32_t heads, dh;                       // multi-head form (Transformer scorer): head h contracts columns [h dh, (h + 1) dh) of Q / K and owns alpha planes
+  int64_t ap_head_bytes;                   // AP + h * ap_head_bytes; its context lands in columns [h dh, (h + 1) dh).  heads = 1, dh = D: VASNet
   unsigned long long* stamps;              // diagnostic build: per block {T, prologue, k-loop, row op, total} shader cycles + realtime
 };
 
@@ -42,10 +44,12 @@ struct AttnPwArgs {
 // rows; NS stages in a ring, ONE barrier per step behind all but the last key tile's MFMAs (gemm_pw.hip's loop).
 // VAR (when a wave issues the DMA pieces that refill the slot a barrier freed): 0 = after the step's last MFMAs, 1 = right behind the
 // barrier, 2 = spread: a share behind every key tile's MFMAs, from the step's last tile through the next step's tiles in front of the barrier.
-template <int NP, int NJ, int VAR>
-__device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqInfo& si, const int strip, char* const lds) {
+template <int NP, int NJ, int VAR, bool MH = false>
+__device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqInfo& si, const int strip, const int head, char* const lds) {
   constexpr int NSUB = 2 * NP, T64 = NJ * 64, ROWS = T64 + 64, STAGE = NSUB * ROWS * 16;
-  constexpr int NS = NP == 3 ? 3 : 4;                  // (deeper rings, 4 / 6 stages, were measured: no change -- the stream is not latency-bound)
+  // (deeper rings, 4 / 6 stages, were measured: no change -- the stream is not latency-bound).  MH (multi-head form: dh / 16 = 8 steps per block, the
+  // prologue and the row op are most of a block's time): one stage less, so that TWO blocks fit a CU and overlap each other's phases
+  constexpr int NS = (NP == 3 ? 3 : 4) - (MH ? 1 : 0);
   constexpr int NTW = (2 * NJ + 3) / 4;
   constexpr int NPIECE = NSUB * (NJ + 1), MAXP = (NPIECE + 7) / 8;
   static_assert(NS * STAGE + 4096 <= 160 * 1024, "LDS map");
@@ -64,7 +68,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
     const int sub = idx / (NJ + 1), blk = idx - sub * (NJ + 1);
     const bool key = blk < NJ;
     // K columns are k-blocks D / 16 ... 2 D / 16 - 1 of the [Q | K | V] planes, Q columns the first D / 16
-    pg[i] = ((key ? (D >> 4) * NSUB : 0) + sub) * (int)a.rp16 + (si.row0 + (key ? blk * 64 : i0)) * 16;
+    pg[i] = (((key ? (D >> 4) : 0) + head * (a.dh >> 4)) * NSUB + sub) * (int)a.rp16 + (si.row0 + (key ? blk * 64 : i0)) * 16;
     pl[i] = (sub * ROWS + (key ? blk * 64 : T64)) * 16;
   }
   const bool full = (NPIECE % 8 == 0) || wave < NPIECE % 8;          // this wave issues MAXP pieces (else MAXP - 1)
@@ -116,7 +120,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
     }
   };
 
-  const int nk = D >> 4;
+  const int nk = a.dh >> 4;
 #ifdef SUMK_DIAG
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -130,7 +134,9 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   Frags F0, F1;
   read_frags(0, F0);
   int slot = 0;
-  constexpr int P1 = NTW > 1 ? NTW - 1 : 0;
+  // MH: ONE fragment set (two blocks per CU need <= 128 VGPRs): all of a step's MFMAs run in front of its barrier, the next fragments are read behind it into
+  // the same registers -- the other block's waves cover the read latency
+  constexpr int P1 = MH ? NTW : (NTW > 1 ? NTW - 1 : 0);
   int pend_kb = -1, pend_slot = 0;               // VAR 2: the refill in progress (stage, slot)
   auto kstep = [&](const Frags& cur, Frags& nxt, int s) {
     __builtin_amdgcn_sched_barrier(0);
@@ -177,8 +183,13 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   } else
 #endif
   for (int s = 0; s < nk; s += 2) {
-    kstep(F0, F1, s);
-    kstep(F1, F0, s + 1);
+    if constexpr (MH) {
+      kstep(F0, F0, s);
+      kstep(F0, F0, s + 1);
+    } else {
+      kstep(F0, F1, s);
+      kstep(F1, F0, s + 1);
+    }
   }
 
   // ---- row op: acc[j][r]: key = (kg + 4 j) * 32 + 8 (r >> 2) + 4 lh + (r & 3), query = qt * 32 + li
@@ -220,7 +231,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   const float rsum = 1.0f / sum;
   const int T32 = (T + 31) & ~31;                 // alpha planes are written (zeros past T) up to the k32 step the context kernel ends on
   float* const erow = a.E ? a.E + si.eoff + (int64_t)i * si.ldE : nullptr;
-  char* const arow = a.AP + (int64_t)(si.row0 + i) * 16 + 8 * lh;
+  char* const arow = a.AP + head * a.ap_head_bytes + (int64_t)(si.row0 + i) * 16 + 8 * lh;
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -248,20 +259,43 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
 #endif
 }
 
-template <int NP, int VAR>
-__global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
+template <int NP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_pw_logits_mh_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  int slot = blockIdx.x >> 3;
+  const int head = slot % a.heads;           // (the heads of one strip are neighbours in the grid: they share the strip's query rows and the video's keys in L2)
+  slot /= a.heads;
   const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
   if (s >= a.n_seq) return;
   const SeqInfo si = a.seq[s];
   if (strip * AP_ROWS >= si.T) return;
   switch ((si.T + 63) >> 6) {
-    case 1: attn_logits_body<NP, 1, VAR>(a, si, strip, lds); break;
-    case 2: attn_logits_body<NP, 2, VAR>(a, si, strip, lds); break;
-    case 3: attn_logits_body<NP, 3, VAR>(a, si, strip, lds); break;
-    case 4: attn_logits_body<NP, 4, VAR>(a, si, strip, lds); break;
-    default: attn_logits_body<NP, 5, VAR>(a, si, strip, lds); break;
+    case 1: attn_logits_body<NP, 1, 0, true>(a, si, strip, head, lds); break;
+    case 2: attn_logits_body<NP, 2, 0, true>(a, si, strip, head, lds); break;
+    case 3: attn_logits_body<NP, 3, 0, true>(a, si, strip, head, lds); break;
+    case 4: attn_logits_body<NP, 4, 0, true>(a, si, strip, head, lds); break;
+    default: attn_logits_body<NP, 5, 0, true>(a, si, strip, head, lds); break;
+  }
+}
+
+template <int NP, int VAR>
+__global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int xcd = blockIdx.x & 7;
+  int slot = blockIdx.x >> 3;
+  const int head = slot % a.heads;           // (the heads of one strip are neighbours in the grid: they share the strip's query rows and the video's keys in L2)
+  slot /= a.heads;
+  const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
+  if (s >= a.n_seq) return;
+  const SeqInfo si = a.seq[s];
+  if (strip * AP_ROWS >= si.T) return;
+  switch ((si.T + 63) >> 6) {
+    case 1: attn_logits_body<NP, 1, VAR>(a, si, strip, head, lds); break;
+    case 2: attn_logits_body<NP, 2, VAR>(a, si, strip, head, lds); break;
+    case 3: attn_logits_body<NP, 3, VAR>(a, si, strip, head, lds); break;
+    case 4: attn_logits_body<NP, 4, VAR>(a, si, strip, head, lds); break;
+    default: attn_logits_body<NP, 5, VAR>(a, si, strip, head, lds); break;
   }
 }
 
@@ -275,11 +309,14 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
 //          of one ds_read_b64_tr_b16 half then cover 256 contiguous bytes: no bank conflict, no padding.
 // MFMA A operand = V^T (columns on the M axis), B operand = alpha (queries on the N axis): a lane ends with ONE query row and 4 consecutive
 // columns per register quad -- the 8-byte piece of a context-plane chunk.
-template <int NP>
+// HP2 (multi-head form, dh = 128): a 256-column pass holds TWO heads -- waves 0-3 multiply the alpha of head 2 nc, waves 4-7 of head 2 nc + 1; a stage
+// carries both alpha sets (V pieces unchanged: the pass's 256 V columns are those two heads').
+template <int NP, bool HP2>
 __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
   constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;           // (rings of 5 / 4 stages: measured, no change)
-  constexpr int NSUB = 2 * NP, A_BYTES = KH * NSUB * 1024, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
-  constexpr int NA = KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
+  constexpr int NSETS = HP2 ? 2 : 1;
+  constexpr int NSUB = 2 * NP, A_SET = KH * NSUB * 1024, A_BYTES = NSETS * A_SET, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
+  constexpr int NA = NSETS * KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
   const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
   const int sv = (bslot / a.strips) * 8 + xcd, strip = bslot - (bslot / a.strips) * a.strips;
@@ -294,14 +331,16 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(a.AP, (short)0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.QKV), (short)0, 0x80000000u, 0x00020000);
   // pieces of a stage: idx < NA: alpha (k16 block kbh = idx / NSUB of the stage, sub-array idx % NSUB); else V (fbp, plane, kbh)
-  bool pa[MAXP]; int pg[MAXP], pl[MAXP];
+  bool pa[MAXP]; int pg[MAXP], pl[MAXP], pset[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     int idx = wave + 8 * i;
     idx = idx < NPIECE ? idx : NPIECE - 1;
     pa[i] = idx < NA;
+    pset[i] = 0;
     if (pa[i]) {
-      pg[i] = idx * (int)a.ap_rp16 + (si.row0 + i0) * 16;                       // + ks * KH NSUB ap_rp16
+      pset[i] = idx / (KH * NSUB);
+      pg[i] = (idx - pset[i] * KH * NSUB) * (int)a.ap_rp16 + (si.row0 + i0) * 16;                       // + ks * KH NSUB ap_rp16 (+ the head's alpha planes)
       pl[i] = idx * 1024;
     } else {
       const int v = idx - NA, fbp = v / (KH * NP), rem = v - fbp * KH * NP, p = rem / KH, kbh = rem - p * KH;
@@ -319,13 +358,13 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       if (i == MAXP - 1 && !full) break;
-      if (pa[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(st + pl[i]), 16, vlane, ga + pg[i], 0, 0);
+      if (pa[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vptr)(st + pl[i]), 16, vlane, ga + pg[i] + (HP2 ? (2 * nc + pset[i]) * (int)a.ap_head_bytes : 0), 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_vptr)(st + pl[i]), 16, vperm, gv + pg[i], 0, 0);
     }
   };
   // fragments of the k16 block kbh of a stage: V plane p (tr reads), alpha plane p of query tile u
   const int fv = A_BYTES + wave * NP * 1024 + (2 * lh) * 256 + ((((lane >> 4) & 1) << 1) | ((lane & 3) >> 1)) * 64 + ((lane & 15) >> 2) * 16 + (lane & 1) * 8;
-  const int fa = (lh * 64 + li) * 16;
+  const int fa = (lh * 64 + li) * 16 + (HP2 ? (wave >> 2) * A_SET : 0);
   struct Frags { bf16x8 v[KH][NP], al[KH][NP][2]; };
   auto read_frags = [&](int slot, Frags& f) {
     const char* const st = lds + slot * STAGE;
@@ -415,13 +454,13 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   }
 }
 
-template <int NP>
+template <int NP, bool HP2>
 __global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  attn_context_body<NP>(a, lds);
+  attn_context_body<NP, HP2>(a, lds);
 }
 
-std::atomic<uint64_t> g_attr[12];
+std::atomic<uint64_t> g_attr[16];
 constexpr int ATTN_VAR_A = 0;      // the product's schedule variant of the logits kernel (measured: profiles/r05_attn_pw_dma_variants.txt)
 
 template <typename K>
@@ -444,14 +483,22 @@ bool attn_pw_ok(int t_max, int D, int64_t rows, int np) {
   return t_max >= 1 && t_max <= AP_TMAX && D % 256 == 0 && D >= 256 && (np == 2 || np == 3) && (int64_t)pw_planes_bytes(rows, 3 * D, np) < lim;
 }
 
+// the multi-head form: heads of 128 columns (a context pass of 256 columns = two heads), every head's alpha planes inside 31 bits of offset
+bool attn_pw_heads_ok(int t_max, int D, int heads, int64_t rows, int np) {
+  if (heads == 1) return attn_pw_ok(t_max, D, rows, np);
+  const int64_t lim = ((int64_t)1 << 31) - 65536;
+  return heads >= 2 && D == heads * 128 && attn_pw_ok(t_max, D, rows, np) && (int64_t)heads * (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256) < lim;
+}
+
 int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, float* E, void* alpha_planes, const SeqInfo* seq, int n_seq,
-                          int t_max, float scale, int ignore_self, int aperture, hipStream_t stream) {
-  SUMK_ARG(qkv_planes && alpha_planes && seq && attn_pw_ok(t_max, D, rows, np), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes)");
+                          int t_max, float scale, int ignore_self, int aperture, hipStream_t stream, int heads) {
+  SUMK_ARG(qkv_planes && alpha_planes && seq && attn_pw_heads_ok(t_max, D, heads, rows, np) && (heads == 1 || !E), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes; heads of 128 columns, no fp32 alpha)");
   AttnPwArgs a;
   a.QKV = (const char*)qkv_planes; a.rp16 = (uint32_t)(pw_rows_pitch(rows) * 16); a.D = D; a.E = E;
   a.AP = (char*)alpha_planes; a.ap_rp16 = a.rp16; a.CP = nullptr; a.cp_rp16 = 0;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = scale; a.ignore_self = ignore_self; a.aperture = aperture;
-  const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
+  a.heads = heads; a.dh = D / heads; a.ap_head_bytes = heads == 1 ? 0 : (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256);
+  const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips * heads);
   a.stamps = nullptr;
 #ifdef SUMK_DIAG
   static unsigned long long* stamp_buf = nullptr;
@@ -470,6 +517,11 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
   if (np == 3 && (var == 1 || var == 2)) { if (var == 1) SUMK_A_CASE(3, 1, LDS3, 0) else SUMK_A_CASE(3, 2, LDS3, 1) } else
   if (np == 2 && (var == 1 || var == 2)) { if (var == 1) SUMK_A_CASE(2, 1, LDS2, 3) else SUMK_A_CASE(2, 2, LDS2, 4) } else
 #endif
+  if (heads > 1) {
+    constexpr int LDSH3 = 2 * (6 * 384 * 16) + 4096, LDSH2 = 3 * (4 * 384 * 16) + 4096;      // 76 KB each: two blocks per CU
+    if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_logits_mh_kernel<3>, 8, LDSH3)); hipLaunchKernelGGL(attn_pw_logits_mh_kernel<3>, dim3(grid), dim3(512), LDSH3, stream, a); }
+    else { SUMK_TRY(set_lds_once(attn_pw_logits_mh_kernel<2>, 9 + 5, LDSH2)); hipLaunchKernelGGL(attn_pw_logits_mh_kernel<2>, dim3(grid), dim3(512), LDSH2, stream, a); }
+  } else
   if (np == 3) SUMK_A_CASE(3, 0, LDS3, 2) else SUMK_A_CASE(2, 0, LDS2, 5)
 #undef SUMK_A_CASE
 #ifdef SUMK_DIAG
@@ -484,7 +536,7 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
       const unsigned long long* e = &h[b * 8];
       if (!e[0] || (b % 9 != 0 && e[0] < 300)) continue;
       fprintf(stderr, "  block %3u T %3llu start +%.1f us: prologue %6llu  k-loop %7llu (%.0f / k16 step)  row op + stores %6llu  total %7llu cycles = %.1f us, clock %.0f MHz, xcc %llu cu-id %llx\n",
-              b, e[0], (e[6] - rmin) / 100.0, e[1], e[2], e[2] / (double)(a.D / 16), e[3], e[4], e[5] / 100.0, e[4] / (e[5] / 100.0), e[7] & 0xf, e[7] >> 32);
+              b, e[0], (e[6] - rmin) / 100.0, e[1], e[2], e[2] / (double)(a.dh / 16), e[3], e[4], e[5] / 100.0, e[4] / (e[5] / 100.0), e[7] & 0xf, e[7] >> 32);
     }
   }
 #endif
@@ -493,16 +545,20 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
 }
 
 int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, const void* alpha_planes, void* ctx_planes, const SeqInfo* seq,
-                           int n_seq, int t_max, hipStream_t stream) {
-  SUMK_ARG(qkv_planes && alpha_planes && ctx_planes && seq && attn_pw_ok(t_max, D, rows, np), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes)");
+                           int n_seq, int t_max, hipStream_t stream, int heads) {
+  SUMK_ARG(qkv_planes && alpha_planes && ctx_planes && seq && attn_pw_heads_ok(t_max, D, heads, rows, np), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes; heads of 128 columns)");
   AttnPwArgs a;
   a.QKV = (const char*)qkv_planes; a.rp16 = (uint32_t)(pw_rows_pitch(rows) * 16); a.D = D; a.E = nullptr;
   a.AP = (char*)const_cast<void*>(alpha_planes); a.ap_rp16 = a.rp16; a.CP = (char*)ctx_planes; a.cp_rp16 = a.rp16;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = 0.f; a.ignore_self = 0; a.aperture = -1;
   const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
-  constexpr int LDS3 = 4 * (6 + 24) * 1024, LDS2 = 3 * (8 + 32) * 1024;
-  if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3>, 6, LDS3)); hipLaunchKernelGGL(attn_pw_context_kernel<3>, dim3(grid), dim3(512), LDS3, stream, a); }
-  else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2>, 7, LDS2)); hipLaunchKernelGGL(attn_pw_context_kernel<2>, dim3(grid), dim3(512), LDS2, stream, a); }
+  a.heads = heads; a.dh = D / heads; a.ap_head_bytes = heads == 1 ? 0 : (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256);
+  constexpr int LDS3 = 4 * (6 + 24) * 1024, LDS2 = 3 * (8 + 32) * 1024, LDS3H = 4 * (12 + 24) * 1024, LDS2H = 3 * (16 + 32) * 1024;
+  if (heads > 1) {
+    if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3, true>, 12, LDS3H)); hipLaunchKernelGGL((attn_pw_context_kernel<3, true>), dim3(grid), dim3(512), LDS3H, stream, a); }
+    else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2, true>, 13, LDS2H)); hipLaunchKernelGGL((attn_pw_context_kernel<2, true>), dim3(grid), dim3(512), LDS2H, stream, a); }
+  } else if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3, false>, 6, LDS3)); hipLaunchKernelGGL((attn_pw_context_kernel<3, false>), dim3(grid), dim3(512), LDS3, stream, a); }
+  else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2, false>, 7, LDS2)); hipLaunchKernelGGL((attn_pw_context_kernel<2, false>), dim3(grid), dim3(512), LDS2, stream, a); }
   SUMK_HIP(hipGetLastError());
   return SUMK_OK;
 }

@@ -324,10 +324,13 @@ int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream);
 // alpha / context planes use the row pitch of the [Q | K | V] planes (pw_rows_pitch(rows)).
 bool attn_pw_ok(int t_max, int D, int64_t rows, int np);
 inline size_t pw_alpha_bytes(int64_t rows, int t_max, int np) { return (size_t)pw_rows_pitch(rows) * ((t_max + 31) / 32 * 32) * np * 2 + 8192; }
+// heads > 1 (Transformer scorer; heads of 128 columns, E = nullptr): head h contracts columns [128 h, 128 h + 128) of Q / K, its alpha planes start at
+// alpha_planes + h * align_up(pw_alpha_bytes(rows, t_max, np), 256), its context lands in the same columns of the context planes
+bool attn_pw_heads_ok(int t_max, int D, int heads, int64_t rows, int np);
 int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, float* E, void* alpha_planes, const SeqInfo* seq, int n_seq,
-                          int t_max, float scale, int ignore_self, int aperture, hipStream_t stream);
+                          int t_max, float scale, int ignore_self, int aperture, hipStream_t stream, int heads = 1);
 int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, const void* alpha_planes, void* ctx_planes, const SeqInfo* seq,
-                           int n_seq, int t_max, hipStream_t stream);
+                           int n_seq, int t_max, hipStream_t stream, int heads = 1);
 
 // ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
 // Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.

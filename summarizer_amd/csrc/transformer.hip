@@ -43,13 +43,32 @@ static TfWPlanes tf_wplanes_layout(int D, int F, int n_layers, int np) {
   l.total = l.k1 + align_up(pw_planes_bytes(D, D, np), 256);
   return l;
 }
-struct TfPwExtra { size_t pa, pb, total; };
-static TfPwExtra tf_pw_extra(int D, int F, int64_t R, int np, size_t base) {
+// ... and, when the batch is eligible (T <= 320, heads of 128 columns: attn_pw.hip's multi-head form), the attention on planes too: [Q | K | V] planes
+// written by the in-projection's epilogue, one set of alpha planes per head, the SeqInfo table those kernels read.
+struct TfPwExtra { size_t pa, pb, qp, ap, seqinfo, total; bool attn; };
+static TfPwExtra tf_pw_extra(int D, int F, int64_t R, int np, size_t base, int heads, int n_seq, int t_max) {
   TfPwExtra e; size_t p = align_up(base, 256);
   auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
   e.pa = take(pw_planes_bytes(R, std::max(D, F), np)); e.pb = take(pw_planes_bytes(R, std::max(D, F), np));
+  e.attn = attn_pw_heads_ok(t_max, D, heads, R, np);
+  e.qp = e.ap = e.seqinfo = 0;
+  if (e.attn) {
+    e.qp = take(pw_planes_bytes(R, 3 * D, np)); e.ap = take((size_t)heads * align_up(pw_alpha_bytes(R, t_max, np), 256));
+    e.seqinfo = take((size_t)n_seq * sizeof(SeqInfo));
+  }
   e.total = p;
   return e;
+}
+static int tf_t_max(int n_seq, const int32_t* off) {
+  int t = 0;
+  for (int s = 0; s < n_seq; ++s) t = std::max(t, off[s + 1] - off[s]);
+  return t;
+}
+__global__ void tf_seqinfo_kernel(const int32_t* off, int n_seq, SeqInfo* out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seq) return;
+  SeqInfo si; si.eoff = 0; si.row0 = off[s]; si.T = off[s + 1] - off[s]; si.ldE = (si.T + 3) & ~3; si.pad_ = 0; si.e16off = 0;
+  out[s] = si;
 }
 static int tf_np(int precision) { return precision == SUMK_PRECISION_BF16X6 ? 3 : precision == SUMK_PRECISION_BF16X3 ? 2 : 0; }
 static bool tf_pw_rows_ok(int D, int F, int64_t R, int np) {
@@ -285,7 +304,8 @@ extern "C" size_t sumk_transformer_workspace_bytes_for(int32_t D, int32_t F, int
   TfWs w;
   if (tf_carve(D, F, n_heads, n_layers, n_seq, seq_off_host, training, &w) != SUMK_OK) return 0;
   const int np = tf_np(precision);
-  if (!training && np && tf_wplanes_ok(D, F, np) && tf_pw_rows_ok(D, F, w.n_rows, np)) return tf_pw_extra(D, F, w.n_rows, np, w.total).total;
+  if (!training && np && tf_wplanes_ok(D, F, np) && tf_pw_rows_ok(D, F, w.n_rows, np))
+    return tf_pw_extra(D, F, w.n_rows, np, w.total, n_heads, n_seq, tf_t_max(n_seq, seq_off_host)).total;
   return w.total;
 }
 
@@ -338,13 +358,17 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
   // the plane path: inference in a split-bf16 arithmetic with the weights' planes at hand
   const int npl = tf_np(opts->precision);
   const bool pw = !training && npl && opts->wplanes && tf_wplanes_ok(D, F, npl) && tf_pw_rows_ok(D, F, R, npl);
-  TfPwExtra PX{0, 0, 0}; TfWPlanes WL{};
+  TfPwExtra PX{}; TfWPlanes WL{};
+  const int t_max = tf_t_max(n_seq, seq_off_host);
   if (pw) {
-    PX = tf_pw_extra(D, F, R, npl, L.total); WL = tf_wplanes_layout(D, F, n_layers, npl);
+    PX = tf_pw_extra(D, F, R, npl, L.total, n_heads, n_seq, t_max); WL = tf_wplanes_layout(D, F, n_layers, npl);
     SUMK_ARG(((uintptr_t)opts->wplanes & 255) == 0, "transformer_forward: wplanes must be 256-byte aligned");
     if (workspace_bytes < PX.total) { set_error("transformer_forward: workspace %zu < %zu the plane path needs (sumk_transformer_workspace_bytes_for)", workspace_bytes, PX.total); return SUMK_ERR_WORKSPACE; }
   }
   char* const PA = ws + PX.pa; char* const PB = ws + PX.pb;
+  const bool pw_attn = pw && PX.attn;
+  SeqInfo* const seqinfo = (SeqInfo*)(ws + PX.seqinfo);
+  if (pw_attn) hipLaunchKernelGGL(tf_seqinfo_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, seq_off_dev, n_seq, seqinfo);
   const char* const wpl = (const char*)opts->wplanes;
   // C (R, N) = A planes (R, K) x weight planes (N, K)^T + bias [+ Rs] [ReLU]; O: the result as planes instead
   auto pw_linear = [&](const void* Ap, const char* Wp, int N, int K, const float* bias, const float* Rs, int relu, float* C_, void* O_) {
@@ -380,6 +404,17 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
     }
     const uint32_t site = 10u * (uint32_t)l;
     const char* const wl = pw ? wpl + (size_t)l * WL.lay_stride : nullptr;
+    if (pw_attn) {   // in-projection -> planes of [Q | K | V] (+ bias); per (video, head): logits + softmax -> alpha planes, alpha . V -> context planes
+      SUMK_TRY(split_planes(hin, R, D, D, npl, PA, stream));
+      {
+        PwLaunch g; g.A = PA; g.B = wl + WL.win; g.a_rows = R; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = npl;
+        g.bias = W.in_proj_b; g.O = ws + PX.qp; g.o_rows = R; g.o_store_rows = (R + 31) & ~31;      // (pad rows = the bias: finite, the context kernel multiplies them by alpha = 0)
+        SUMK_TRY(launch_gemm_pw(PW_PLANES, g, stream));
+      }
+      SUMK_TRY(launch_attn_pw_logits(npl, ws + PX.qp, R, D, nullptr, ws + PX.ap, seqinfo, n_seq, t_max, att_scale, 0, -1, stream, n_heads));
+      SUMK_TRY(launch_attn_pw_context(npl, ws + PX.qp, R, D, ws + PX.ap, PA, seqinfo, n_seq, t_max, stream, n_heads));      // PA: the planes of hin are spent
+      SUMK_TRY(pw_linear(PA, wl + WL.wo, D, D, W.out_proj_b, hin, 0, T1a, nullptr));
+    } else {
     if (pw) {
       SUMK_TRY(split_planes(hin, R, D, D, npl, PA, stream));
       SUMK_TRY(pw_linear(PA, wl + WL.win, 3 * D, D, W.in_proj_b, nullptr, 0, QKV, nullptr));
@@ -411,6 +446,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);
       g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 1;
       SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
+    }
     }
     SUMK_TRY(launch_layernorm(T1a, hmid, W.norm1_w, W.norm1_b, R, D, opts->layer_eps, stats, stream));
     if (pw) {  // both feed-forward layers; ReLU(lin1) exists as planes only

@@ -93,20 +93,22 @@ def test_transformer_plane_path_goldens_and_ragged_batch(precision, tol_fp32):
         np.testing.assert_array_equal(m(x).cpu().numpy(), y)
     np.testing.assert_allclose(y, g["c0/y"], atol=TOL, rtol=0)
     assert np.abs(y - y32).max() < tol_fp32, np.abs(y - y32).max()
-    # ragged packed batch (D = 256, 4 heads, 2 layers): one-frame and two-frame videos among longer ones
-    D, L, Hh = 256, 2, 4
+    # ragged packed batches (D = 256, 2 layers): one-frame and two-frame videos among longer ones.  4 heads of 64 columns: the per-head
+    # products stay on the in-loop kernels between plane GEMMs; 2 heads of 128 columns: the attention runs on planes too (attn_pw.hip's
+    # multi-head form), first with every video inside 320 frames, then with one beyond it (the whole batch falls back)
+    D, L = 256, 2
     w = R.transformer_weights(D, L, 123)
-    m = _load(Transformer(input_size=D, encoder_layers=L, attention_heads=Hh), w, dev)
-    m.precision = precision
-    lens = [1, 2, 65, 130, 7, 300]
-    xs = [R.features(T, 1, D, 200 + i) - 0.1 for i, T in enumerate(lens)]
-    with torch.no_grad():
-        s = m.score_packed(torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev), lens).cpu().numpy()
-    assert m._wpl is not None
-    off = np.concatenate([[0], np.cumsum(lens)])
-    for i, x in enumerate(xs):
-        ref = transformer_np.transformer_forward(x, w, L, Hh)[:, 0, 0]
-        np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"video {i}")
+    for Hh, lens in ((4, [1, 2, 65, 130, 7, 300]), (2, [1, 2, 65, 130, 7, 300, 320, 64]), (2, [130, 7, 321])):
+        m = _load(Transformer(input_size=D, encoder_layers=L, attention_heads=Hh), w, dev)
+        m.precision = precision
+        xs = [R.features(T, 1, D, 200 + i) - 0.1 for i, T in enumerate(lens)]
+        with torch.no_grad():
+            s = m.score_packed(torch.from_numpy(np.concatenate([x[:, 0, :] for x in xs])).to(dev), lens).cpu().numpy()
+        assert m._wpl is not None
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for i, x in enumerate(xs):
+            ref = transformer_np.transformer_forward(x, w, L, Hh)[:, 0, 0]
+            np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"heads {Hh} video {i}")
 
 
 @pytest.mark.parametrize("tag,kw", [("tf", dict(input_size=64, encoder_layers=2, attention_heads=4)),
