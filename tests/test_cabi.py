@@ -80,6 +80,20 @@ def test_plane_size_queries_need_no_gpu(lib):
     assert lib.sumk_bilstm_wplanes_bytes(1024, 256, 3) >= 2048 * 1024 * 6 + 2048 * 4
     for bad in ((1024, 100, 3), (1000, 256, 3), (64, 256, 3), (1024, 256, 5)):
         assert lib.sumk_bilstm_wplanes_bytes(*bad) == 0, bad
+    lib.sumk_transformer_wplanes_bytes.restype = C.c_size_t; lib.sumk_transformer_wplanes_bytes.argtypes = [C.c_int32] * 4
+    per_layer = 6 * 1024 * 1024 * 6          # in_proj (3 D^2) + out_proj + linear1 + linear2 at three planes, 2 bytes each
+    assert lib.sumk_transformer_wplanes_bytes(1024, 1024, 6, 3) >= 6 * per_layer + 1024 * 1024 * 6
+    assert lib.sumk_transformer_wplanes_bytes(1024, 1024, 6, 3) < 6 * per_layer + 1024 * 1024 * 6 + 64 * 9000
+    for bad in ((1000, 1024, 6, 3), (1024, 1000, 6, 3), (1024, 1024, 0, 3), (1024, 1024, 6, 1), (128, 128, 2, 2)):
+        assert lib.sumk_transformer_wplanes_bytes(*bad) == 0, bad
+    # the inference workspace grows by the plane buffers only in the split-bf16 precisions, only in inference, only for eligible shapes
+    lib.sumk_transformer_workspace_bytes.restype = C.c_size_t; lib.sumk_transformer_workspace_bytes_for.restype = C.c_size_t
+    off = (C.c_int32 * 3)(0, 200, 500)
+    base = lib.sumk_transformer_workspace_bytes(1024, 1024, 8, 2, 2, off, 0)
+    assert base > 0 and lib.sumk_transformer_workspace_bytes_for(1024, 1024, 8, 2, 2, off, 0, 0) == base
+    assert lib.sumk_transformer_workspace_bytes_for(1024, 1024, 8, 2, 2, off, 0, 2) > base + 2 * 512 * 1024 * 6        # bf16x6: two activation-plane buffers at least
+    assert lib.sumk_transformer_workspace_bytes_for(1024, 1024, 8, 2, 2, off, 1, 2) == lib.sumk_transformer_workspace_bytes(1024, 1024, 8, 2, 2, off, 1)
+    assert lib.sumk_transformer_workspace_bytes_for(64, 64, 4, 2, 2, off, 0, 2) == lib.sumk_transformer_workspace_bytes(64, 64, 4, 2, 2, off, 0)
     assert lib.sumk_attn_planes_alpha_bytes(12003, 320, 3) == 12032 * 320 * 3 * 2 + 8192
     assert lib.sumk_attn_planes_alpha_bytes(12003, 300, 2) == 12032 * 320 * 2 * 2 + 8192        # key count rounded up to 32
     assert lib.sumk_attn_planes_alpha_bytes(0, 320, 3) == 0 and lib.sumk_attn_planes_alpha_bytes(10, 320, 1) == 0
