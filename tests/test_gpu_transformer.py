@@ -111,6 +111,28 @@ def test_transformer_plane_path_goldens_and_ragged_batch(precision, tol_fp32):
             np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"heads {Hh} video {i}")
 
 
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+def test_transformer_plane_path_is_batch_independent(precision):
+    """On the plane path a video's scores do not depend on what else is in the packed batch or where it sits in it (rows of the plane GEMMs,
+    per-(video, head) attention strips and row kernels are independent; every accumulation order is fixed): bit-identical at BASELINE width."""
+    from summarizer_amd.models.transformer import Transformer
+    dev = torch.device("cuda:0")
+    D = 1024
+    torch.manual_seed(7)
+    m = Transformer(input_size=D, encoder_layers=2, attention_heads=8).to(dev).eval()
+    m.precision = precision
+    lens = [300, 150, 320, 1, 201, 64]
+    xs = [torch.from_numpy(R.features(T, 1, D, 900 + i)[:, 0, :]).to(dev) for i, T in enumerate(lens)]
+    with torch.no_grad():
+        full = torch.split(m.score_packed(torch.cat(xs), lens), lens)
+        order = [2, 5, 0, 4]                                    # a sub-batch in another order: other row offsets, other tile positions
+        part = torch.split(m.score_packed(torch.cat([xs[i] for i in order]), [lens[i] for i in order]), [lens[i] for i in order])
+    assert m._wpl is not None
+    for j, i in enumerate(order):
+        assert torch.equal(part[j], full[i]), f"video {i}: {float((part[j] - full[i]).abs().max())}"
+    assert all(bool(torch.isfinite(f).all()) and float(f.min()) >= 0 and float(f.max()) <= 1 for f in full)
+
+
 @pytest.mark.parametrize("tag,kw", [("tf", dict(input_size=64, encoder_layers=2, attention_heads=4)),
                                     ("tf_res", dict(input_size=64, encoder_layers=1, attention_heads=8, more_residuals=True))])
 def test_transformer_train_step_goldens(tag, kw):
