@@ -470,6 +470,7 @@ int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {
     case PW_RES_F32: SUMK_ARG(g.C && g.ldc >= g.N && g.ldc % 4 == 0 && g.R && g.ldr >= g.N && g.ldr % 4 == 0 && ((uintptr_t)g.C & 15) == 0 && ((uintptr_t)g.R & 15) == 0 && !g.relu,
                               "gemm_pw: residual epilogue needs 16-byte aligned C and R with pitches %% 4 (and no ReLU)"); break;
   }
+  SUMK_ARG(!(g.bias && (epi == PW_PLANES || epi == PW_RES_F32)) || ((uintptr_t)g.bias & 15) == 0, "gemm_pw: the bias of the transposed epilogues is read as float4: 16-byte aligned");
   if (g.prof_tag >= 0) prof_begin(g.prof_tag, stream);
   prof_begin(SUMK_PROF_GEMM_ALL, stream);
   // two planes run on the 16x16x32 MFMA shape (gemm_pw16.hip: -13 % on the same operands); three planes do not fit its five-stage ring
