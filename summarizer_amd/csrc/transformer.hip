@@ -368,7 +368,11 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
   char* const PA = ws + PX.pa; char* const PB = ws + PX.pb;
   const bool pw_attn = pw && PX.attn;
   SeqInfo* const seqinfo = (SeqInfo*)(ws + PX.seqinfo);
-  if (pw_attn) hipLaunchKernelGGL(tf_seqinfo_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, seq_off_dev, n_seq, seqinfo);
+  if (pw_attn) {
+    hipLaunchKernelGGL(tf_seqinfo_kernel, dim3((n_seq + 63) / 64), dim3(64), 0, stream, seq_off_dev, n_seq, seqinfo);
+    // (the slack a V read past the LAST sub-array's pitch lands in: cleared once per call, no kernel writes it -- 0 x stale NaN bits would be NaN)
+    SUMK_HIP(hipMemsetAsync(ws + PX.qp + pw_planes_bytes(R, 3 * D, npl) - 8192, 0, 8192, stream));
+  }
   const char* const wpl = (const char*)opts->wplanes;
   // C (R, N) = A planes (R, K) x weight planes (N, K)^T + bias [+ Rs] [ReLU]; O: the result as planes instead
   auto pw_linear = [&](const void* Ap, const char* Wp, int N, int K, const float* bias, const float* Rs, int relu, float* C_, void* O_) {
@@ -408,7 +412,7 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       SUMK_TRY(split_planes(hin, R, D, D, npl, PA, stream));
       {
         PwLaunch g; g.A = PA; g.B = wl + WL.win; g.a_rows = R; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = npl;
-        g.bias = W.in_proj_b; g.O = ws + PX.qp; g.o_rows = R; g.o_store_rows = (R + 31) & ~31;      // (pad rows = the bias: finite, the context kernel multiplies them by alpha = 0)
+        g.bias = W.in_proj_b; g.O = ws + PX.qp; g.o_rows = R; g.o_store_rows = pw_rows_pitch(R);      // (pad rows = the bias: finite -- the context kernel multiplies V rows up to 31 past the last video by alpha = 0)
         SUMK_TRY(launch_gemm_pw(PW_PLANES, g, stream));
       }
       SUMK_TRY(launch_attn_pw_logits(npl, ws + PX.qp, R, D, nullptr, ws + PX.ap, seqinfo, n_seq, t_max, att_scale, 0, -1, stream, n_heads));

@@ -1539,7 +1539,10 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   const bool pw_attn = pw && !Wvo && attn_pw_ok(G.t_max, D, R, np) && workspace_bytes >= px.total;
   if (pw_attn) {  // 1-4: projection -> planes of [Q | K | V]; logits + softmax -> alpha planes; alpha . V -> context planes
     PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
-    g.O = ws + px.qkv; g.o_rows = R; g.o_store_rows = (R + 31) & ~31; g.prof_tag = SUMK_PROF_GEMM_QKV;
+    // the context kernel multiplies V rows up to 31 past the last video's end by alpha = 0: every row up to the pitch is stored (zeros: x's pad rows are
+    // zero) and the slack a read past the LAST sub-array lands in is cleared -- 0 x (stale NaN bits) would be NaN
+    g.O = ws + px.qkv; g.o_rows = R; g.o_store_rows = pw_rows_pitch(R); g.prof_tag = SUMK_PROF_GEMM_QKV;
+    SUMK_HIP(hipMemsetAsync(ws + px.qkv + pw_planes_bytes(R, 3 * D, np) - 8192, 0, 8192, stream));
     SUMK_TRY(launch_gemm_pw(PW_PLANES, g, stream));
     prof_begin(SUMK_PROF_GEMM_QKT, stream);
     SUMK_TRY(launch_attn_pw_logits(np, ws + px.qkv, R, D, nullptr, ws + px.ap, seq, n_seq, G.t_max, opts->scale, opts->ignore_self, opts->aperture, stream));

@@ -369,3 +369,31 @@ def test_plane_entry_points_argument_checks(dev):
     with torch.no_grad():
         s = m2.score_packed(xs, [150, 250])
     assert bool(torch.isfinite(s).all()) and getattr(m2, "_wpl", None) is None
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
+def test_plane_paths_read_nothing_stale_past_the_last_video(dev, precision):
+    """The context kernel multiplies V rows up to 31 past the last video's end by alpha = 0; those rows (and the slack behind the last
+    sub-array) must hold finite data whatever the workspace held before.  The scratch is poisoned with NaN bit patterns between two calls:
+    same scores, bit for bit (a batch whose frame count leaves the last key block hanging past a multiple of 32 frames)."""
+    from summarizer_amd import kernels
+    from summarizer_amd.models.vasnet import VASNet
+    from summarizer_amd.models.transformer import Transformer
+    D = 256
+    torch.manual_seed(3)
+    for lens in ([200, 150], [300, 81], [129, 64, 190]):
+        x = torch.randn(sum(lens), D, device=dev) * 0.3
+        for m in (VASNet(input_size=D, precision=precision).to(dev).eval(), Transformer(input_size=D, encoder_layers=2, attention_heads=2).to(dev).eval()):
+            m.precision = precision
+            with torch.no_grad():
+                m.score_packed(x, lens)                                   # (allocates the scratch)
+                for buf in kernels._ws_cache.values():
+                    buf.fill_(255)                                        # 0xFFFF = a bf16 NaN, 0xFFFFFFFF = an fp32 NaN
+                a = m.score_packed(x, lens)
+                for buf in kernels._ws_cache.values():
+                    buf.fill_(255)
+                b = m.score_packed(x, lens)
+            assert m._wpl is not None
+            assert bool(torch.isfinite(a).all()), (type(m).__name__, lens)
+            assert torch.equal(a, b), (type(m).__name__, lens)
+

@@ -111,6 +111,51 @@ def test_transformer_plane_path_goldens_and_ragged_batch(precision, tol_fp32):
             np.testing.assert_allclose(s[off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"heads {Hh} video {i}")
 
 
+def test_transformer_plane_entry_points_check_their_arguments():
+    """sumk_transformer_wplanes_build refuses a short or misaligned output block and ineligible widths; the forward refuses a workspace
+    that lacks the plane buffers when it is handed weight planes -- statuses and messages, no crash, the library stays usable."""
+    import ctypes as C
+    from summarizer_amd import _lib, kernels
+    from summarizer_amd._lib import SumkError
+    from summarizer_amd.models.transformer import Transformer
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    D, L, Hh = 256, 2, 2
+    m = Transformer(input_size=D, encoder_layers=L, attention_heads=Hh).to(dev).eval()
+    p = {k: v.detach() for k, v in m.named_parameters()}
+    layers, head = kernels._tf_structs(p, L, "weight", _lib.TfLayerWeights, _lib.TfHeadWeights)
+    nb = lib.sumk_transformer_wplanes_bytes(D, D, L, 3)
+    assert nb > 0
+    buf = torch.empty(nb + 512, dtype=torch.uint8, device=dev)
+    base = (buf.data_ptr() + 255) // 256 * 256
+    args = (D, D, L, C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p), 3)
+    assert lib.sumk_transformer_wplanes_build(*args, C.c_void_p(base), nb - 1, None) == -1
+    assert b"bytes" in lib.sumk_last_error()
+    assert lib.sumk_transformer_wplanes_build(*args, C.c_void_p(base + 16), nb, None) == -1
+    assert lib.sumk_transformer_wplanes_build(D, D, L, C.cast(layers, C.c_void_p), C.cast(C.pointer(head), C.c_void_p), 4, C.c_void_p(base), nb, None) == -1
+    assert lib.sumk_transformer_wplanes_build(*args, C.c_void_p(base), nb, None) == 0
+    # forward: weight planes given, workspace sized by the plain query -> refused with the name of the right query
+    lens = [200, 150]
+    sb = kernels.SeqBatch.get(lens, dev)
+    x = torch.randn(sum(lens), D, device=dev)
+    o = kernels._tf_opts(dict(layer_eps=1e-5, final_eps=1e-5, precision="bf16x6"))
+    o.wplanes = base
+    small = lib.sumk_transformer_workspace_bytes(D, D, Hh, L, sb.n_seq, sb.off_host_p, 0)
+    assert lib.sumk_transformer_workspace_bytes_for(D, D, Hh, L, sb.n_seq, sb.off_host_p, 0, o.precision) > small
+    ws = torch.empty(small, dtype=torch.uint8, device=dev)
+    scores = torch.empty(sum(lens), device=dev)
+    rc = lib.sumk_transformer_forward(x.data_ptr(), D, D, Hh, L, sb.n_seq, sb.off_host_p, sb.off_dev_p, C.cast(layers, C.c_void_p),
+                                      C.cast(C.pointer(head), C.c_void_p), C.cast(C.pointer(o), C.c_void_p), None, None, scores.data_ptr(),
+                                      ws.data_ptr(), small, 0, None)
+    assert rc == -2 and b"sumk_transformer_workspace_bytes_for" in lib.sumk_last_error()
+    m.precision = "bf16x6"
+    with torch.no_grad():
+        s = m.score_packed(x, lens)                 # the library is fine afterwards
+    assert bool(torch.isfinite(s).all())
+    with pytest.raises(SumkError):
+        kernels.transformer_forward_packed(x[:-1], sb, p, L, Hh, D, dict(layer_eps=1e-5, final_eps=1e-5))
+
+
 @pytest.mark.parametrize("precision", ["bf16x6", "bf16x3"])
 def test_transformer_plane_path_is_batch_independent(precision):
     """On the plane path a video's scores do not depend on what else is in the packed batch or where it sits in it (rows of the plane GEMMs,
