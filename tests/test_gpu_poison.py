@@ -7,6 +7,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+LENS_LONG = [330, 64, 100]                   # one video above 320 frames: the plane paths keep the per-video products on the in-loop kernels
 LENS = [1, 2, 65, 130, 22, 300, 150]         # 670 frames: the last video's last key block (keys 144..159) ends 8 rows past the next multiple of 32 frames
 
 
@@ -56,9 +57,9 @@ def _same(clean, dirty, what):
         assert torch.equal(a, b), f"{what}[{i}]: differs by {float((a - b).abs().max())} under poisoned scratch"
 
 
-def _x(D, dev, seed=0):
+def _x(D, dev, seed=0, lens=None):
     g = torch.Generator(device="cpu"); g.manual_seed(seed)
-    return (torch.randn(sum(LENS), D, generator=g).abs() * 0.5).to(dev)
+    return (torch.randn(sum(lens or LENS), D, generator=g).abs() * 0.5).to(dev)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
@@ -66,17 +67,18 @@ def _x(D, dev, seed=0):
 def test_vasnet_scoring(dev, monkeypatch, D, precision):
     from summarizer_amd.models.vasnet import VASNet
     torch.manual_seed(1)
-    x = _x(D, dev)
-    for fold in (False, True):
-        m = VASNet(input_size=D, precision=precision, fold_vo=fold).to(dev).eval()
+    for lens in (LENS, LENS_LONG):
+        x = _x(D, dev, 0, lens)
+        for fold in (False, True):
+            m = VASNet(input_size=D, precision=precision, fold_vo=fold).to(dev).eval()
 
-        def run():
-            from summarizer_amd import kernels
-            kernels.drop_shadows(x)                  # the planes / bf16 copies of x and the weight-plane block are rebuilt in both runs
-            m._wpl = None
-            with torch.no_grad():
-                return m.score_packed(x, LENS).clone()
-        _same(*_both(monkeypatch, run), f"VASNet D={D} {precision} fold={fold}")
+            def run():
+                from summarizer_amd import kernels
+                kernels.drop_shadows(x)                  # the planes / bf16 copies of x and the weight-plane block are rebuilt in both runs
+                m._wpl = None
+                with torch.no_grad():
+                    return m.score_packed(x, lens).clone()
+            _same(*_both(monkeypatch, run), f"VASNet D={D} {precision} fold={fold} lens={lens}")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -129,15 +131,16 @@ def test_transformer(dev, monkeypatch, precision):
     torch.manual_seed(4)
     D = 256
     x = _x(D, dev, 3)
+    xl = _x(D, dev, 5, LENS_LONG)
     for heads in (2, 4):                        # heads of 128 columns: attention on planes in the split modes; 64: in-loop products
         m = Transformer(input_size=D, encoder_layers=2, attention_heads=heads).to(dev).eval()
         m.precision = precision
-
-        def score():
-            m._wpl = None
-            with torch.no_grad():
-                return m.score_packed(x, LENS).clone()
-        _same(*_both(monkeypatch, score), f"Transformer {precision} heads={heads}")
+        for xx, lens in ((x, LENS), (xl, LENS_LONG)):
+            def score():
+                m._wpl = None
+                with torch.no_grad():
+                    return m.score_packed(xx, lens).clone()
+            _same(*_both(monkeypatch, score), f"Transformer {precision} heads={heads} lens={lens}")
     if precision == "fp32":
         w = torch.rand(sum(LENS), device=dev)
 
