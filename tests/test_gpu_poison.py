@@ -164,3 +164,36 @@ def test_dsn_reward(dev, monkeypatch):
     def reward():
         return kernels.dsn_reward(x, sb, actions).clone()
     _same(*_both(monkeypatch, reward), "DSN reward")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3", "bf16"])
+def test_vasnet_at_baseline_size(dev, monkeypatch, precision):
+    """The S-TVSum batch (50 videos, 12 003 frames, D = 1024) takes other kernel instances than the small batches above (128 x 128 lean
+    tiles, XCD maps, the wide bf16 kernels): scoring in every arithmetic and the training gradients in fp32 / bf16."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from summarizer_amd import kernels
+    from summarizer_amd.models.vasnet import VASNet
+    lens = bench.tvsum_lens(50)
+    torch.manual_seed(6)
+    x = _x(1024, dev, 6, lens)
+    m = VASNet(input_size=1024, precision=precision).to(dev).eval()
+    if precision != "bf16":
+        def score():
+            kernels.drop_shadows(x)
+            m._wpl = None
+            with torch.no_grad():
+                return m.score_packed(x, lens).clone()
+        _same(*_both(monkeypatch, score), f"VASNet S-TVSum {precision}")
+    if precision in ("fp32", "bf16"):
+        w = torch.rand(sum(lens), device=dev)
+
+        def grads():
+            kernels.drop_shadows(x)
+            for p in m.parameters():
+                p.grad = None
+            s = m.score_packed(x, lens)
+            (s * w).sum().backward()
+            return [s.detach().clone()] + [p.grad.clone() for p in m.parameters()]
+        _same(*_both(monkeypatch, grads), f"VASNet S-TVSum gradients {precision}")
