@@ -34,6 +34,8 @@ struct AttnPwArgs {
   float scale; int32_t ignore_self, aperture;
   int32_t heads, dh;                       // multi-head form (Transformer scorer): head h contracts columns [h dh, (h + 1) dh) of Q / K and owns alpha planes
   int64_t ap_head_bytes;                   // AP + h * ap_head_bytes; its context lands in columns [h dh, (h + 1) dh).  heads = 1, dh = D: VASNet
+  const float* R; int32_t ldr;             // kernel B, folded VASNet path (V = x Wvo^T): context + R is what leaves as planes, with its LayerNorm moments
+  float* moments;                          // float2[rows][D / 32] {sum v, sum v^2} per 32-column slot
   unsigned long long* stamps;              // diagnostic build: per block {T, prologue, k-loop, row op, total} shader cycles + realtime
 };
 
@@ -311,7 +313,9 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
 // columns per register quad -- the 8-byte piece of a context-plane chunk.
 // HP2 (multi-head form, dh = 128): a 256-column pass holds TWO heads -- waves 0-3 multiply the alpha of head 2 nc, waves 4-7 of head 2 nc + 1; a stage
 // carries both alpha sets (V pieces unchanged: the pass's 256 V columns are those two heads').
-template <int NP, bool HP2>
+// RM (folded VASNet path): the accumulators start from the residual R[query][column] instead of zero, and a pass also leaves {sum v, sum v^2} of every
+// (query, 32-column slot) -- what the output projection's PW_RES_MOM_PLANES epilogue does on the unfolded path.
+template <int NP, bool HP2, bool RM = false>
 __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
   constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;           // (rings of 5 / 4 stages: measured, no change)
   constexpr int NSETS = HP2 ? 2 : 1;
@@ -403,10 +407,25 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   Frags F0, F1;
   read_frags(0, F0);
   int slot = 0, ks = 0, nc = 0;
+  auto init_o = [&](int pass) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u) {
+      if constexpr (RM) {
+        if (pass < NC) {
+          const float* const rp = a.R + (int64_t)(si.row0 + min(i0 + u * 32 + li, T - 1)) * a.ldr + pass * 256 + 32 * wave + 4 * lh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+          for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(rp + 8 * g);
+            o[u][4 * g] = v.x; o[u][4 * g + 1] = v.y; o[u][4 * g + 2] = v.z; o[u][4 * g + 3] = v.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+      }
+    }
+  };
+  init_o(0);
   auto step = [&](const Frags& cur, Frags& nxt, int it) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_part(cur, 0);
@@ -430,6 +449,13 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int q = i0 + u * 32 + li;
+        if constexpr (RM) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = o[u][r]; s1 += v; s2 += v * v; }
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          if (lh == 0 && q < T) reinterpret_cast<float2*>(a.moments)[(int64_t)(si.row0 + q) * (D >> 5) + nc * 8 + wave] = make_float2(s1, s2);
+        }
         if (q < T) {
           char* const orow = a.CP + (int64_t)(si.row0 + q) * 16 + 8 * lh;
 #pragma unroll
@@ -442,10 +468,9 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
             for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.cp_rp16) = pl2[p];
           }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
       }
       ks = 0; ++nc;
+      init_o(nc);
     }
   };
   for (int it = 0; it < n_it; it += 2) {
@@ -454,13 +479,13 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   }
 }
 
-template <int NP, bool HP2>
+template <int NP, bool HP2, bool RM = false>
 __global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  attn_context_body<NP, HP2>(a, lds);
+  attn_context_body<NP, HP2, RM>(a, lds);
 }
 
-std::atomic<uint64_t> g_attr[16];
+std::atomic<uint64_t> g_attr[18];
 constexpr int ATTN_VAR_A = 0;      // the product's schedule variant of the logits kernel (measured: profiles/r05_attn_pw_dma_variants.txt)
 
 template <typename K>
@@ -498,6 +523,7 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
   a.AP = (char*)alpha_planes; a.ap_rp16 = a.rp16; a.CP = nullptr; a.cp_rp16 = 0;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = scale; a.ignore_self = ignore_self; a.aperture = aperture;
   a.heads = heads; a.dh = D / heads; a.ap_head_bytes = heads == 1 ? 0 : (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256);
+  a.R = nullptr; a.ldr = 0; a.moments = nullptr;
   const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips * heads);
   a.stamps = nullptr;
 #ifdef SUMK_DIAG
@@ -545,18 +571,23 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
 }
 
 int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, const void* alpha_planes, void* ctx_planes, const SeqInfo* seq,
-                           int n_seq, int t_max, hipStream_t stream, int heads) {
+                           int n_seq, int t_max, hipStream_t stream, int heads, const float* R, int ldr, float* moments) {
   SUMK_ARG(qkv_planes && alpha_planes && ctx_planes && seq && attn_pw_heads_ok(t_max, D, heads, rows, np), "attn_pw: not eligible (T <= 320, D %% 256, 2 or 3 planes; heads of 128 columns)");
+  SUMK_ARG(!R || (heads == 1 && moments && ldr >= D && ldr % 4 == 0 && ((uintptr_t)R & 15) == 0), "attn_pw: the residual form is single-head and needs moments, a pitch %% 4 and a 16-byte aligned residual");
   AttnPwArgs a;
   a.QKV = (const char*)qkv_planes; a.rp16 = (uint32_t)(pw_rows_pitch(rows) * 16); a.D = D; a.E = nullptr;
   a.AP = (char*)const_cast<void*>(alpha_planes); a.ap_rp16 = a.rp16; a.CP = (char*)ctx_planes; a.cp_rp16 = a.rp16;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = 0.f; a.ignore_self = 0; a.aperture = -1;
   const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
   a.heads = heads; a.dh = D / heads; a.ap_head_bytes = heads == 1 ? 0 : (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256);
+  a.R = R; a.ldr = ldr; a.moments = moments;
   constexpr int LDS3 = 4 * (6 + 24) * 1024, LDS2 = 3 * (8 + 32) * 1024, LDS3H = 4 * (12 + 24) * 1024, LDS2H = 3 * (16 + 32) * 1024;
   if (heads > 1) {
     if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3, true>, 12, LDS3H)); hipLaunchKernelGGL((attn_pw_context_kernel<3, true>), dim3(grid), dim3(512), LDS3H, stream, a); }
     else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2, true>, 13, LDS2H)); hipLaunchKernelGGL((attn_pw_context_kernel<2, true>), dim3(grid), dim3(512), LDS2H, stream, a); }
+  } else if (R) {
+    if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3, false, true>, 16, LDS3)); hipLaunchKernelGGL((attn_pw_context_kernel<3, false, true>), dim3(grid), dim3(512), LDS3, stream, a); }
+    else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2, false, true>, 17, LDS2)); hipLaunchKernelGGL((attn_pw_context_kernel<2, false, true>), dim3(grid), dim3(512), LDS2, stream, a); }
   } else if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3, false>, 6, LDS3)); hipLaunchKernelGGL((attn_pw_context_kernel<3, false>), dim3(grid), dim3(512), LDS3, stream, a); }
   else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2, false>, 7, LDS2)); hipLaunchKernelGGL((attn_pw_context_kernel<2, false>), dim3(grid), dim3(512), LDS2, stream, a); }
   SUMK_HIP(hipGetLastError());

@@ -329,8 +329,9 @@ inline size_t pw_alpha_bytes(int64_t rows, int t_max, int np) { return (size_t)p
 bool attn_pw_heads_ok(int t_max, int D, int heads, int64_t rows, int np);
 int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, float* E, void* alpha_planes, const SeqInfo* seq, int n_seq,
                           int t_max, float scale, int ignore_self, int aperture, hipStream_t stream, int heads = 1);
+// R (single head; the folded VASNet path where V = x Wvo^T): context + R[row][column] leaves as planes, with {sum, sum of squares} per (row, 32-column slot) in moments
 int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, const void* alpha_planes, void* ctx_planes, const SeqInfo* seq,
-                           int n_seq, int t_max, hipStream_t stream, int heads = 1);
+                           int n_seq, int t_max, hipStream_t stream, int heads = 1, const float* R = nullptr, int ldr = 0, float* moments = nullptr);
 
 // ------------------------------------------------------------------------------------------- shared row kernels (vasnet.hip)
 // Y = LayerNorm(X) * g + b over D (one wave per row); optional (mean, rstd) per row into stats.

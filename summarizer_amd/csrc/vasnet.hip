@@ -1536,7 +1536,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   const char* const wp = (const char*)opts->wplanes;
   // ... and the per-video attention on planes as well (attn_pw.hip): T <= 320, not the folded path, the extra workspace present
   const PwExtra px = pw ? pw_extra(D, R, G.t_max, np, L.total_core) : PwExtra();
-  const bool pw_attn = pw && !Wvo && attn_pw_ok(G.t_max, D, R, np) && workspace_bytes >= px.total;
+  const bool pw_attn = pw && attn_pw_ok(G.t_max, D, R, np) && workspace_bytes >= px.total;
   if (pw_attn) {  // 1-4: projection -> planes of [Q | K | V]; logits + softmax -> alpha planes; alpha . V -> context planes
     PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
     // the context kernel multiplies V rows up to 31 past the last video's end by alpha = 0: every row up to the pitch is stored (zeros: x's pad rows are
@@ -1548,7 +1548,11 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     SUMK_TRY(launch_attn_pw_logits(np, ws + px.qkv, R, D, nullptr, ws + px.ap, seq, n_seq, G.t_max, opts->scale, opts->ignore_self, opts->aperture, stream));
     prof_end(SUMK_PROF_GEMM_QKT, stream);
     prof_begin(SUMK_PROF_GEMM_PV, stream);
-    SUMK_TRY(launch_attn_pw_context(np, ws + px.qkv, R, D, ws + px.ap, ws + px.ctx, seq, n_seq, G.t_max, stream));
+    if (Wvo) {   // folded: "V" = x Wvo^T, so alpha . V + x IS Y0 -- it leaves as planes with its LayerNorm moments (D / 32 slots per row; the small arrays live in Z)
+      SUMK_TRY(launch_attn_pw_context(np, ws + px.qkv, R, D, ws + px.ap, ws + px.ctx, seq, n_seq, G.t_max, stream, 1, x, D, (float*)(ws + L.z)));
+    } else {
+      SUMK_TRY(launch_attn_pw_context(np, ws + px.qkv, R, D, ws + px.ap, ws + px.ctx, seq, n_seq, G.t_max, stream));
+    }
     prof_end(SUMK_PROF_GEMM_PV, stream);
   } else
   if (pw) {  // 1: QKV projection from planes (fp32 output: the per-video products below read it)
@@ -1613,7 +1617,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   const bool fused_ln = pw || (fused_tail && fused_ln_on && (!Wvo || G.cfg_pv == 1) && ln_mom_f + ln_w_f + ln_c_f + (size_t)2 * R <= (size_t)R * D);
   // plane path: CTX planes span the Y0 / Y1 regions, Y0's planes take the (by then dead) fp32 Q/K/V region, the small per-row arrays live in Z
   char* const pw_ctxp = pw_attn ? ws + px.ctx : ws + L.y0;
-  char* const pw_y0p = pw_attn ? ws + px.qkv : ws + L.qkv;          // ([Q | K | V]'s planes are dead once the context exists)
+  char* const pw_y0p = (pw_attn && Wvo) ? ws + px.ctx : pw_attn ? ws + px.qkv : ws + L.qkv;          // ([Q | K | V]'s planes are dead once the context exists; folded: the context strips wrote Y0's planes)
   float* const pw_mom = Z;                                                        // float2[R][slots]
   float* const pw_stats = Z + align_up((size_t)R * (D / 16) * 2, 64);             // float2[R]
   float* const pw_part = pw_stats + align_up((size_t)R * 2, 64);                  // float4[R][D / 64]
@@ -1639,6 +1643,10 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
       SUMK_HIP(hipGetLastError());
     }
   }
+  if (pw_attn && Wvo) {   // (4 + 5 happened in the context strips) moments -> {mean, rstd}
+    hipLaunchKernelGGL(ln_row_stats_kernel, dim3((R + 31) / 32), dim3(256), 0, stream, (const float2*)pw_mom, D / 32, R, D, opts->eps, (float2*)pw_stats);
+    SUMK_HIP(hipGetLastError());
+  } else
   if (pw && !Wvo) {  // 5: output projection + residual from planes: CTX is split once, Y0 leaves as planes + per-row moments only
     if (!pw_attn) SUMK_TRY(split_planes(CTX, R, D, D, np, pw_ctxp, stream));
     PwLaunch g; g.A = pw_ctxp; g.a_rows = R; g.B = wp + wl.wo; g.b_rows = D; g.M = R; g.N = D; g.K = D; g.np = np;
