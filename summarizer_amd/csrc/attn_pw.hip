@@ -24,6 +24,10 @@ namespace {
 
 constexpr int AP_ROWS = 64, AP_TMAX = 320;
 
+#ifndef SUMK_ATTN_NLW
+#define SUMK_ATTN_NLW 8              // waves of a block that issue the LDS-DMA pieces of a stage (probe: scripts/attn_nlw_probe.sh)
+#endif
+
 struct AttnPwArgs {
   const char* QKV; uint32_t rp16;          // KB planes of [Q | K | V] (rows = packed frames, k = 3 D columns)
   int32_t D;
@@ -53,7 +57,8 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   // prologue and the row op are most of a block's time): one stage less, so that TWO blocks fit a CU and overlap each other's phases
   constexpr int NS = (NP == 3 ? 3 : 4) - (MH ? 1 : 0);
   constexpr int NTW = (2 * NJ + 3) / 4;
-  constexpr int NPIECE = NSUB * (NJ + 1), MAXP = (NPIECE + 7) / 8;
+  constexpr int NLW = SUMK_ATTN_NLW;                                   // waves that issue the DMA pieces (the others only wait at the barrier)
+  constexpr int NPIECE = NSUB * (NJ + 1), MAXP = (NPIECE + NLW - 1) / NLW;
   static_assert(NS * STAGE + 4096 <= 160 * 1024, "LDS map");
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,7 +70,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   int pg[MAXP], pl[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
-    int idx = wave + 8 * i;
+    int idx = wave + NLW * i;
     idx = idx < NPIECE ? idx : NPIECE - 1;
     const int sub = idx / (NJ + 1), blk = idx - sub * (NJ + 1);
     const bool key = blk < NJ;
@@ -73,9 +78,11 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
     pg[i] = (((key ? (D >> 4) : 0) + head * (a.dh >> 4)) * NSUB + sub) * (int)a.rp16 + (si.row0 + (key ? blk * 64 : i0)) * 16;
     pl[i] = (sub * ROWS + (key ? blk * 64 : T64)) * 16;
   }
-  const bool full = (NPIECE % 8 == 0) || wave < NPIECE % 8;          // this wave issues MAXP pieces (else MAXP - 1)
+  const bool full = (NPIECE % NLW == 0) || wave < NPIECE % NLW;          // this wave issues MAXP pieces (else MAXP - 1)
+  const bool loader = wave < NLW;
   const int vlane = lane * 16, k_step = NSUB * (int)a.rp16;
   auto dma_share = [&](int kb, int slot, int share, int n_shares) {      // pieces i with i % n_shares == share
+    if (!loader) return;
 #ifdef SUMK_DIAG
     if (VAR == 4 && kb >= NS) return;                                     // timing probe: MFMAs + reads + barriers only (stale stages)
 #endif
@@ -320,7 +327,8 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;           // (rings of 5 / 4 stages: measured, no change)
   constexpr int NSETS = HP2 ? 2 : 1;
   constexpr int NSUB = 2 * NP, A_SET = KH * NSUB * 1024, A_BYTES = NSETS * A_SET, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
-  constexpr int NA = NSETS * KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + 7) / 8;
+  constexpr int NLW = SUMK_ATTN_NLW;
+  constexpr int NA = NSETS * KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + NLW - 1) / NLW;
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
   const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
   const int sv = (bslot / a.strips) * 8 + xcd, strip = bslot - (bslot / a.strips) * a.strips;
@@ -338,7 +346,7 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   bool pa[MAXP]; int pg[MAXP], pl[MAXP], pset[MAXP];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
-    int idx = wave + 8 * i;
+    int idx = wave + NLW * i;
     idx = idx < NPIECE ? idx : NPIECE - 1;
     pa[i] = idx < NA;
     pset[i] = 0;
@@ -352,10 +360,12 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
       pl[i] = A_BYTES + ((kbh * 8 + fbp) * NP + p) * 1024;
     }
   }
-  const bool full = (NPIECE % 8 == 0) || wave < NPIECE % 8;
+  const bool full = (NPIECE % NLW == 0) || wave < NPIECE % NLW;
+  const bool loader = wave < NLW;
   const int vlane = lane * 16;
   const int vperm = ((lane >> 3) & 1) * NSUB * (int)a.rp16 + ((lane >> 2) & 1) * (int)a.rp16 + (4 * (lane >> 4) + (lane & 3)) * 16;
   auto dma = [&](int it, int slot) {
+    if (!loader) return;
     const int nc = it / nks, ks = it - nc * nks;
     char* const st = lds + slot * STAGE;
     const int ga = ks * KH * NSUB * (int)a.ap_rp16, gv = nc * 16 * NSUB * (int)a.rp16 + ks * KH * 256;
