@@ -26,6 +26,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no spa
 HBM_PEAK_GBS = 8000.0
 
 
+def _k_one(loss):
+    from summarizer_amd import kernels as _kk
+    return _kk.one(loss.device)
+
+
 def tvsum_lens(n_videos=50):
     return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
 
@@ -233,7 +238,7 @@ def make_reinforce_step(model, x, lens, dev):
         actions = dist_.sample((5,))
         rewards = kernels.dsn_reward(x, sb, actions.contiguous())
         loss = PolicyLossFunction.apply(probs, sb, actions, rewards, base, 0.01, 0.5).mean()    # dsn.py:113-140 in two HIP kernels
-        loss.backward()
+        loss.backward(gradient=_k_one(loss))
         if reduce and tail_from is not None:
             opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
         opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / dist_info()[1], max_norm=5.0, zero_grad=True)
@@ -299,7 +304,7 @@ def single_video_leg(dev, D=1024, T=300, iters=400):
             if not captured:
                 opt.zero_grad()
             loss = SegmentMseMeanFunction.apply(m.score_packed(x2, [T]), target, sb, 1.0)      # one video (VASNetTrainer._single_video_step)
-            loss.backward()
+            loss.backward(gradient=_k_one(loss))
             opt.step(grad_scale=1.0, max_norm=5.0 if name == "dsn" else None, zero_grad=captured)
             seed.add_(1)
         tt_eager = timed(step, n=iters // 2, warm=50)
@@ -408,7 +413,7 @@ def recurrent_legs(x, lens, dev, frames):
     def train_step():
         opt.zero_grad()
         loss = SegmentMseMeanFunction.apply(dsn.score_packed(x, lens), target, sb, 1.0 / len(lens))
-        loss.backward()
+        loss.backward(gradient=_k_one(loss))
         opt.step(grad_scale=1.0, zero_grad=True)
         return loss.detach()
     dt = timed(train_step, 10)
@@ -609,7 +614,7 @@ def main():
         def run_step():
             opt.zero_grad()
             loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))   # the trainers' loss: mean over videos of nn.MSELoss per video
-            loss.backward()
+            loss.backward(gradient=_k_one(loss))
             opt.step(grad_scale=opt.all_reduce_grads(), zero_grad=True)      # (the Adam kernel leaves the bucket zero: the next zero_grad() is free)
             return loss.detach()
     elif args.mode == "reinforce":
@@ -827,7 +832,7 @@ def main():
             def train_step(reduce=True):
                 opt.zero_grad()
                 loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))
-                loss.backward()
+                loss.backward(gradient=_k_one(loss))
                 if reduce and tail_from is not None:
                     opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
                 opt.step(grad_scale=opt.all_reduce_grads() if reduce else 1.0 / world, zero_grad=True)
@@ -879,7 +884,7 @@ def main():
             def step1(reduce=True):
                 opt.zero_grad()
                 loss = SegmentMseMeanFunction.apply(model.score_packed(x1, [T1]), t1, sb1, 1.0 / world)
-                loss.backward()
+                loss.backward(gradient=_k_one(loss))
                 if reduce and tail_from is not None:
                     opt.reduce_tail_async(tail_from, model.tail_grads_ready_event)
                 opt.step(grad_scale=opt.all_reduce_grads(average=False) if reduce else 1.0, zero_grad=True)

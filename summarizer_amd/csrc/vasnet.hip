@@ -725,7 +725,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       for (int c = lane; c < D4; c += 64) acc(ld(c), g4[c], b4[c], w4[c]);
     }
     dot = wave_sum(dot);
-    if (lane == 0) scores[row] = 1.0f / (1.0f + expf(-(dot + b2[0])));
+    if (lane == 0) {
+      const float sc = 1.0f / (1.0f + expf(-(dot + b2[0])));
+      scores[row] = sc;
+      if (Y != nullptr) Y[row] = sc;        // (HEAD: Y = a second destination for the scores -- the copy the backward reads from the workspace)
+    }
   }
   if (stats != nullptr && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
@@ -1454,10 +1458,9 @@ static int vasnet_forward_sk(const Geometry& G, float* x, int32_t D, int32_t n_s
     const SkCall c2{Y1, {w->W1, nullptr, nullptr, nullptr}, {scratch, nullptr, nullptr, nullptr}, nullptr, nullptr, SUMK_PROF_GEMM_K1};
     SUMK_TRY(launch_sk(G, n_seq, ws, tb, GEMM_NT, EPI_NONE, SR_K1, -1, c2, stream));
     SlabIn s2; s2.n = G.P.row[SR_K1].S; s2.stride = (int64_t)R * D; s2.bias = w->b1; s2.relu = 1; s2.store = training ? Z : nullptr;
-    launch_ln_rows<true>(scratch, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream, nullptr, s2);
+    launch_ln_rows<true>(scratch, training ? (float*)(ws + L.scores) : nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream, nullptr, s2);      // (the backward reads the scores from the workspace: written here, not copied)
   }
   SUMK_HIP(hipGetLastError());
-  if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
   return SUMK_OK;
 }
 
@@ -1711,9 +1714,8 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
   }
   // 8: dropout + LayerNorm (same weights) + k2 + sigmoid
-  launch_ln_rows<true>(Z, nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
+  launch_ln_rows<true>(Z, training ? (float*)(ws + L.scores) : nullptr, w->ln_w, w->ln_b, w->w2, w->b2, scores, R, D, opts->eps, stats ? stats + 2 * (size_t)R : nullptr, drop, 2u, stream);
   SUMK_HIP(hipGetLastError());
-  if (training) SUMK_HIP(hipMemcpyAsync(ws + L.scores, scores, (size_t)R * 4, hipMemcpyDeviceToDevice, stream));
   return SUMK_OK;
 }
 

@@ -82,6 +82,19 @@ def workspace(nbytes, device, persistent=False):
     return buf
 
 
+_ONES = {}
+
+
+def one(device):
+    """A cached float32 scalar 1.0 on `device`: `loss.backward(gradient=kernels.one(dev))` spares autograd's ones_like + fill launch in
+    every training step (the root gradient of a scalar loss)."""
+    key = str(device)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 

@@ -18,6 +18,10 @@ from ._bilstm import pack_time_major, bilstm_scores, bigru_scores
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
+def _k_one(loss):
+    return kernels.one(loss.device) if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 else None
+
+
 class DSN(nn.Module):
     """Deep Summarization Network"""
     def __init__(self, input_size=1024, hidden_size=256, num_layers=1, cell="lstm"):
@@ -158,7 +162,7 @@ class DSNTrainer(Trainer):
                     loss = l_v.mean() if world == 1 else l_v.sum() / step_video_total(sizes, bv, step)
                     for i, k in enumerate(keys):
                         dist_scores[k] = probs[off[i]:off[i + 1]].detach().view(-1, 1, 1)
-                    loss.backward()
+                    loss.backward(gradient=_k_one(loss))
                     losses.append(loss.detach())
                     mean_r = rewards.detach().mean(dim=0).double()
                     baselines.index_copy_(0, idx, 0.9 * baselines[idx] + 0.1 * mean_r)     # dsn.py:149

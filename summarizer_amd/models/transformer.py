@@ -21,6 +21,10 @@ from .vasnet import _sinusoid_table
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
+def _k_one(loss):
+    return kernels.one(loss.device) if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 else None
+
+
 class Transformer(nn.Module):
     def __init__(self, input_size=1024, encoder_layers=6, attention_heads=8, more_residuals=False, max_length=None,
                  pos_embed="simple", epsilon=1e-5, weight_init=None):
@@ -188,7 +192,7 @@ class TransformerTrainer(Trainer):
                             sc = self.model(seq.unsqueeze(1).clone())
                             loss = loss + torch.mean((sc.view(-1) - target) ** 2) / (len(vids) if world == 1 else step_video_total(sizes, bv, step))
                             dist_scores[k] = sc.detach()
-                    loss.backward()
+                    loss.backward(gradient=_k_one(loss))
                     losses.append(loss.detach())
                 self.optimizer.step(grad_scale=self.optimizer.all_reduce_grads(average=False))
             train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")

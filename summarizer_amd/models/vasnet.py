@@ -22,6 +22,10 @@ from . import Trainer
 from ..training import FlatAdam, dist_info, plan_shards, step_video_total
 
 
+def _k_one(loss):
+    return kernels.one(loss.device) if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 else None
+
+
 class VASNet(nn.Module):
     def __init__(self, input_size=1024, max_length=None, pos_embed="simple", ignore_self=False,
                  attention_aperture=None, scale=None, epsilon=1e-6, weight_init="xavier", precision="fp32", fold_vo=False):
@@ -313,7 +317,7 @@ class VASNetTrainer(Trainer):
                             sc = self.model(seq.unsqueeze(1).clone())   # clone: the positional add is in place, seq is the HBM-cached copy
                             loss = loss + torch.mean((sc.view(-1) - target) ** 2) / (len(vids) if world == 1 else step_video_total(sizes, bv, step))
                             dist_scores[k] = sc.detach()
-                    loss.backward()
+                    loss.backward(gradient=_k_one(loss))
                     losses.append(loss.detach())
                 if tail_from is not None and use_packed:          # every rank issues the same two collectives, videos or not
                     if not keys:
@@ -352,7 +356,7 @@ class VASNetTrainer(Trainer):
             self.optimizer.zero_grad()
         scores = self.model.score_packed(seq, lens_b)
         loss = SegmentMseMeanFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev), 1.0)    # one video: the mean over videos is the value itself
-        loss.backward()
+        loss.backward(gradient=_k_one(loss))
         self.optimizer.step(grad_scale=1.0, zero_grad=grads_are_zero)
         if self.model.graph_seed is not None:
             # next replay: other dropout masks.  The kernels add this word to the seed captured with the step, and the captured seeds of
@@ -378,6 +382,7 @@ class VASNetTrainer(Trainer):
         # copies of the last step's loss while the weights were exactly right
         loss_out = torch.zeros((), dtype=torch.float32, device=dev)
         scores_out = torch.empty(seq.shape[0], 1, 1, dtype=torch.float32, device=dev)
+        kernels.one(dev)                                   # (the cached root gradient of loss.backward exists before the capture, outside the pool)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool):
