@@ -1537,7 +1537,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
                   G.st_d == 0 && pw_ok(R, 3 * (int64_t)D, D, R, 3 * (int64_t)D, np) && (Wvo == nullptr || G.cfg_pv == 1);
   const WPlanes wl = pw ? wplanes_layout(D, np) : WPlanes();
   const char* const wp = (const char*)opts->wplanes;
-  // ... and the per-video attention on planes as well (attn_pw.hip): T <= 320, not the folded path, the extra workspace present
+  // ... and the per-video attention on planes as well (attn_pw.hip): T <= 320, the extra workspace present (folded path: the context strips add the residual and emit the moments)
   const PwExtra px = pw ? pw_extra(D, R, G.t_max, np, L.total_core) : PwExtra();
   const bool pw_attn = pw && attn_pw_ok(G.t_max, D, R, np) && workspace_bytes >= px.total;
   if (pw_attn) {  // 1-4: projection -> planes of [Q | K | V]; logits + softmax -> alpha planes; alpha . V -> context planes
