@@ -75,3 +75,27 @@ def test_transformer_plane_path_on_boundary_batches(dev, precision):
             assert torch.equal(a, b), (lens, m.attention_heads)
             d = float((a - ref).abs().max())
             assert d < GATE[precision] * 2, (d, lens, m.attention_heads)
+
+
+def test_dsn_projection_on_planes_on_boundary_batches(dev):
+    """DSN in bf16x6: the input projection of both directions on the plane GEMM (1 024 packed frames and more), the recurrence in fp32 --
+    against the all-fp32 path on batches around the eligibility threshold and the row-tile boundaries."""
+    from summarizer_amd.models.dsn import DSN
+    rng = np.random.default_rng(13)
+    torch.manual_seed(13)
+    m = DSN(1024, 256, 1).to(dev).eval()
+    for total in (1000, 1023, 1024, 1025, 1151, 1152, 1153, 1344, 2049, 3071, 3072, 3073):
+        lens, rest = [], total
+        while rest > 0:
+            t = min(rest, int(rng.choice([1, 2, 63, 64, 65, 300, int(rng.integers(1, 321))]))); lens.append(t); rest -= t
+        x = (torch.randn(total, 1024, device=dev).abs() * 0.5)
+        with torch.no_grad():
+            m.precision = "fp32"
+            ref = m.score_packed(x, lens)
+            m.precision = "bf16x6"
+            a = m.score_packed(x, lens)
+            b = m.score_packed(x, lens)
+        assert bool(torch.isfinite(a).all()), lens
+        assert torch.equal(a, b), lens
+        d = float((a - ref).abs().max())
+        assert d < 2e-5, (d, total, lens)
