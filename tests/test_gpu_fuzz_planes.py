@@ -99,3 +99,34 @@ def test_dsn_projection_on_planes_on_boundary_batches(dev):
         assert torch.equal(a, b), lens
         d = float((a - ref).abs().max())
         assert d < 2e-5, (d, total, lens)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_vasnet_training_step_on_boundary_batches(dev, precision):
+    """Forward + backward of the packed training path (fused attention strips in bf16 for T <= 320, split-K weight gradients) on the same
+    kind of batches: finite, repeatable bit for bit, and the bf16 gradients within mixed-precision distance of the fp32 ones."""
+    from summarizer_amd.models.vasnet import VASNet
+    rng = np.random.default_rng(14)
+    D = 256
+    torch.manual_seed(14)
+    m = VASNet(input_size=D).to(dev).eval()                       # eval(): the training path without dropout
+
+    def grads(x, lens, w, prec):
+        m.precision = prec
+        for p in m.parameters():
+            p.grad = None
+        s = m.score_packed(x, lens)
+        (s * w).sum().backward()
+        return [s.detach().clone()] + [p.grad.clone() for p in m.parameters()]
+    for lens in _batches(rng, 16):
+        x = (torch.randn(sum(lens), D, device=dev).abs() * 0.5)
+        w = torch.rand(sum(lens), device=dev)
+        a, b = grads(x, lens, w, precision), grads(x, lens, w, precision)
+        for i, (u, v) in enumerate(zip(a, b)):
+            assert bool(torch.isfinite(u).all()), (i, lens)
+            assert torch.equal(u, v), (i, lens)
+        if precision == "bf16":
+            ref = grads(x, lens, w, "fp32")
+            for i, (u, r) in enumerate(zip(a, ref)):
+                scale = float(r.abs().max()) + 1e-6
+                assert float((u - r).abs().max()) < 0.06 * scale, (i, float((u - r).abs().max()), scale, lens)
