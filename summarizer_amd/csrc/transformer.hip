@@ -7,6 +7,8 @@
 // in its epilogue); per-(video, head) logits and context are grouped GEMMs over a device table with one sub-problem per
 // (video, head) that address Q/K/V head slices in place (ld = 3D) and write the context straight into the concatenated
 // (frames, D) layout; softmax is one wave per (query row, head) with shuffle reductions.
+// Inference in bf16x6 / bf16x3 with the weights' planes given (round 5): every projection on the plane GEMM (gemm_pw.hip), and -- heads of 128
+// columns, videos of at most 320 frames -- the per-head attention on the multi-head form of attn_pw.hip; see "plane path" below.
 #include "sumk_internal.h"
 #include <math.h>
 #include <algorithm>
@@ -418,39 +420,39 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       SUMK_TRY(launch_attn_pw_logits(npl, ws + PX.qp, R, D, nullptr, ws + PX.ap, seqinfo, n_seq, t_max, att_scale, 0, -1, stream, n_heads));
       SUMK_TRY(launch_attn_pw_context(npl, ws + PX.qp, R, D, ws + PX.ap, PA, seqinfo, n_seq, t_max, stream, n_heads));      // PA: the planes of hin are spent
       SUMK_TRY(pw_linear(PA, wl + WL.wo, D, D, W.out_proj_b, hin, 0, T1a, nullptr));
-    } else {
-    if (pw) {
-      SUMK_TRY(split_planes(hin, R, D, D, npl, PA, stream));
-      SUMK_TRY(pw_linear(PA, wl + WL.win, 3 * D, D, W.in_proj_b, nullptr, 0, QKV, nullptr));
-    } else {  // packed in-projection  [Q|K|V] = h Win^T + bin
-      GemmLaunch g; g.precision = opts->precision;
-      g.A = hin; g.B[0] = W.in_proj_w; g.bias0[0] = W.in_proj_b; g.C = QKV; g.probs = prow + P_QKV; g.small_tile = G.c_qkv;
-      g.total_tiles = gemm_tiles(R, 3 * D, G.c_qkv); g.xcd_M = R; g.xcd_N = 3 * D; g.lean = gemm_lean_ok(R, 3 * D, D, D, D);
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
-    }
-    {  // logits per (video, head)
-      GemmLaunch g; g.precision = opts->precision;
-      g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + (size_t)TT_S * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_s;
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
-    }
-    hipLaunchKernelGGL(tf_softmax_kernel, dim3((unsigned)(((int64_t)R * n_heads + 3) / 4)), dim3(256), 0, stream, E, E2, seq,
-                       seq_off_dev, n_seq, R, n_heads, att_scale, dl, site + 0);
-    {  // context, heads written side by side
-      GemmLaunch g; g.precision = opts->precision;
-      g.A = E2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + (size_t)TT_PV * np; g.nprob = np; g.small_tile = 1;
-      g.total_tiles = G.tiles_pv;
-      SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
-    }
-    if (pw) {
-      SUMK_TRY(split_planes(CTX, R, D, D, npl, PA, stream));
-      SUMK_TRY(pw_linear(PA, wl + WL.wo, D, D, W.out_proj_b, hin, 0, T1a, nullptr));
-    } else {  // out-projection + bias (+dropout1) + residual
-      GemmLaunch g; g.precision = opts->precision;
-      g.A = CTX; g.B[0] = W.out_proj_w; g.bias0[0] = W.out_proj_b; g.R = hin; g.C = T1a; g.probs = prow + P_DD; g.small_tile = G.c_dd;
-      g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);
-      g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 1;
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
-    }
+    } else {   // the per-(video, head) products stay on the in-loop kernels (fp32 Q / K / V, logits, context), between plane GEMMs when the weights' planes are given
+      if (pw) {
+        SUMK_TRY(split_planes(hin, R, D, D, npl, PA, stream));
+        SUMK_TRY(pw_linear(PA, wl + WL.win, 3 * D, D, W.in_proj_b, nullptr, 0, QKV, nullptr));
+      } else {  // packed in-projection  [Q|K|V] = h Win^T + bin
+        GemmLaunch g; g.precision = opts->precision;
+        g.A = hin; g.B[0] = W.in_proj_w; g.bias0[0] = W.in_proj_b; g.C = QKV; g.probs = prow + P_QKV; g.small_tile = G.c_qkv;
+        g.total_tiles = gemm_tiles(R, 3 * D, G.c_qkv); g.xcd_M = R; g.xcd_N = 3 * D; g.lean = gemm_lean_ok(R, 3 * D, D, D, D);
+        SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS2, g, stream));
+      }
+      {  // logits per (video, head)
+        GemmLaunch g; g.precision = opts->precision;
+        g.A = QKV; g.B[0] = QKV; g.C = E; g.probs = tabs + (size_t)TT_S * np; g.nprob = np; g.small_tile = 1; g.total_tiles = G.tiles_s;
+        SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
+      }
+      hipLaunchKernelGGL(tf_softmax_kernel, dim3((unsigned)(((int64_t)R * n_heads + 3) / 4)), dim3(256), 0, stream, E, E2, seq,
+                         seq_off_dev, n_seq, R, n_heads, att_scale, dl, site + 0);
+      {  // context, heads written side by side
+        GemmLaunch g; g.precision = opts->precision;
+        g.A = E2 ? E2 : E; g.B[0] = QKV; g.C = CTX; g.probs = tabs + (size_t)TT_PV * np; g.nprob = np; g.small_tile = 1;
+        g.total_tiles = G.tiles_pv;
+        SUMK_TRY(launch_gemm(GEMM_NN, EPI_NONE, g, stream));
+      }
+      if (pw) {
+        SUMK_TRY(split_planes(CTX, R, D, D, npl, PA, stream));
+        SUMK_TRY(pw_linear(PA, wl + WL.wo, D, D, W.out_proj_b, hin, 0, T1a, nullptr));
+      } else {  // out-projection + bias (+dropout1) + residual
+        GemmLaunch g; g.precision = opts->precision;
+        g.A = CTX; g.B[0] = W.out_proj_w; g.bias0[0] = W.out_proj_b; g.R = hin; g.C = T1a; g.probs = prow + P_DD; g.small_tile = G.c_dd;
+        g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, D, D, D);
+        g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 1;
+        SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
+      }
     }
     SUMK_TRY(launch_layernorm(T1a, hmid, W.norm1_w, W.norm1_b, R, D, opts->layer_eps, stats, stream));
     if (pw) {  // both feed-forward layers; ReLU(lin1) exists as planes only
@@ -458,20 +460,20 @@ extern "C" int sumk_transformer_forward(float* x, int32_t D, int32_t F, int32_t 
       SUMK_TRY(pw_linear(PA, wl + WL.w1, F, D, W.lin1_b, nullptr, 1, nullptr, PB));
       SUMK_TRY(pw_linear(PB, wl + WL.w2, D, F, W.lin2_b, hmid, 0, T1b, nullptr));
     } else {
-    {  // feed-forward 1: bias + ReLU (+dropout)
-      GemmLaunch g; g.precision = opts->precision;
-      g.A = hmid; g.B[0] = W.lin1_w; g.bias0[0] = W.lin1_b; g.C = FF; g.probs = prow + P_DF; g.small_tile = G.c_df;
-      g.total_tiles = gemm_tiles(R, F, G.c_df); g.xcd_M = R; g.xcd_N = F; g.lean = gemm_lean_ok(R, F, D, D, D);
-      g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 2;
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
-    }
-    {  // feed-forward 2: bias (+dropout2) + residual
-      GemmLaunch g; g.precision = opts->precision;
-      g.A = FF; g.B[0] = W.lin2_w; g.bias0[0] = W.lin2_b; g.R = hmid; g.C = T1b; g.probs = prow + P_FD; g.small_tile = G.c_dd;
-      g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, F, F, F);
-      g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 3;
-      SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
-    }
+      {  // feed-forward 1: bias + ReLU (+dropout)
+        GemmLaunch g; g.precision = opts->precision;
+        g.A = hmid; g.B[0] = W.lin1_w; g.bias0[0] = W.lin1_b; g.C = FF; g.probs = prow + P_DF; g.small_tile = G.c_df;
+        g.total_tiles = gemm_tiles(R, F, G.c_df); g.xcd_M = R; g.xcd_N = F; g.lean = gemm_lean_ok(R, F, D, D, D);
+        g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 2;
+        SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RELU, g, stream));
+      }
+      {  // feed-forward 2: bias (+dropout2) + residual
+        GemmLaunch g; g.precision = opts->precision;
+        g.A = FF; g.B[0] = W.lin2_w; g.bias0[0] = W.lin2_b; g.R = hmid; g.C = T1b; g.probs = prow + P_FD; g.small_tile = G.c_dd;
+        g.total_tiles = gemm_tiles(R, D, G.c_dd); g.xcd_M = R; g.xcd_N = D; g.lean = gemm_lean_ok(R, D, F, F, F);
+        g.drop_seed = dl.seed; g.drop_thr = dl.thr; g.drop_scale = dl.scale; g.drop_site = site + 3;
+        SUMK_TRY(launch_gemm(GEMM_NT, EPI_BIAS_RESIDUAL, g, stream));
+      }
     }
     SUMK_TRY(launch_layernorm(T1b, hout, W.norm2_w, W.norm2_b, R, D, opts->layer_eps, stats ? stats + 2 * (size_t)R : nullptr, stream));
     hin = hout;
