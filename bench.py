@@ -443,7 +443,7 @@ def transformer_legs(x, lens, dev, frames):
     flops = frames * 6 * (2 * 6 * x.shape[1] ** 2) + 2 * frames * x.shape[1] ** 2 + 6 * 4 * sum(t * t for t in lens) * x.shape[1]
     out = {}
     ref = None
-    for prec, key in (("fp32", "transformer_score_mode"), ("bf16x6", "transformer_score_bf16x6_mode")):
+    for prec, key in (("fp32", "transformer_score_mode"), ("bf16x6", "transformer_score_bf16x6_mode"), ("bf16x3", "transformer_score_bf16x3_mode")):
         m.precision = prec
         with torch.no_grad():
             for _ in range(3):
@@ -461,7 +461,8 @@ def transformer_legs(x, lens, dev, frames):
             rec["note"] = "Transformer-encoder scorer, 50 videos packed, exact fp32 MFMA (fraction of the 157.3 TFLOP/s fp32 peak: %.2f)" % (flops / dt / 157.3e12)
         else:
             rec["max_abs_diff_vs_fp32_scores"] = float((s - ref).abs().max())
-            rec["note"] = "the same in bf16x6: weights as cached bf16 planes, activations split once per projection or by the producing epilogue; attention products on the in-loop split kernels"
+            rec["note"] = (f"the same in {prec}: weights as cached bf16 planes, activations split once per projection or written as planes by the producing epilogue, "
+                           "per-head attention on planes (heads of 128 columns, T <= 320)")
         out[key] = rec
     return out
 
