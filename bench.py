@@ -535,11 +535,15 @@ def main():
                     help="--mode stream only: bf16 = the native packer converts while it copies, half the PCIe bytes, LOSSY (scores of bf16(features))")
     ap.add_argument("--workload", choices=["tvsum", "stress"], default="tvsum",
                     help="tvsum = S-TVSum headline; stress = BASELINE config 5: T=10000, D=2048, 8 sequences per GPU")
+    ap.add_argument("--fold-vo", action="store_true",
+                    help="VASNet scoring with Wo.Wv folded (VASNet(fold_vo=True), opt-in inference mode): a non-headline line of its own, for profiling")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16x6", "bf16"], default="fp32",
                     help="GEMM arithmetic: fp32 = exact fp32 MFMA (headline); bf16x6 / bf16x3 = fp32 operands split into 3 / 2 bf16 "
                          "planes, 6 / 3 bf16 MFMAs per product, fp32 accumulate (fp32-grade / ~1e-5 on scores); bf16 = plain bf16 "
                          "operands, 1 MFMA per product: the mixed-precision TRAINING mode of BASELINE config 2 (use with --mode train)")
     args = ap.parse_args()
+    if args.fold_vo:
+        args.headline_only = True          # (the side legs toggle fold_vo themselves)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
@@ -597,6 +601,9 @@ def main():
         from summarizer_amd.models.dsn import DSN
         model = DSN(input_size=D).to(dev)
     model.precision = args.precision
+    if args.fold_vo:
+        assert args.model == "vasnet" and args.mode == "score", "--fold-vo: VASNet scoring only"
+        model.fold_vo = True
     model.train(args.mode not in ("score", "stream"))
     if args.workload == "stress":
         g = torch.Generator(device=dev); g.manual_seed(rank)
@@ -972,6 +979,8 @@ def main():
             out["train_step_bf16_mode"] = train_leg_bf16
             out["dsn_reinforce_step_mode"] = reinforce_leg
             out["dp_one_video_per_rank_mode"] = one_video_leg
+        if args.fold_vo:
+            out["config"]["workload"] += ", fold_vo=True (NOT the headline configuration: 18 % fewer executed FLOPs)"
         if args.model != "vasnet" or args.mode != "score" or args.workload != "tvsum":
             out["note"] = "non-headline mode: roofline/whole_path figures refer to the VASNet scoring FLOP model"
         if args.mode == "stream":
