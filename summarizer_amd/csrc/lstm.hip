@@ -28,13 +28,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PSTATE_WORDS = 16 + 1024;   // word 0: error flag; words 16..: one step counter per work item
+constexpr int PSTATE_WORDS = 16 + 16384;  // word 0: error flag; words 16..: step counters per work item (one word; lstm_wide2_kernel: four shards on
+                                          // lines of their own, 128 words per item); the last 512 words: phase stamps of the diagnostic build
 
 struct LstmWs {
   size_t g, cstate, prob, pstate, gates, call, hprev, dg, slab, dhrec, dcstate, prob_sk, colpart, pstate_b, xchg, partial, total;
   size_t xchg_bytes;
   size_t ll, ll_bytes;     // forward recurrence hand-off buffer (H <= 256): directly behind pstate, zeroed with it
   size_t llb, llb_bytes;   // backward recurrence hand-off buffer (H <= 256): directly behind pstate_b, zeroed with it
+  size_t wx, wx_bytes;     // forward recurrence exchange of lstm_wide2_kernel (256 < H <= 1024): [group][step parity 2][direction 2][k/4 256][row 64][4 floats]
   size_t slab_elems;
   int32_t n_rows, t_max;
 };
@@ -78,6 +80,8 @@ static int lstm_carve(int In, int H, int n_seq, const int32_t* off, int training
   // flag-in-data hand-off of the H <= 256 forward recurrence: [step parity 2][direction 2][video][H] x {float h, uint32 step tag}
   w->ll_bytes = H <= 256 ? (size_t)4 * n_seq * H * 8 : 0;
   w->ll = take(w->ll_bytes);
+  w->wx_bytes = (H > 256 && H <= 1024) ? (size_t)((n_seq + 63) / 64) * 4 * 256 * 64 * 16 : 0;
+  w->wx = take(w->wx_bytes);
   w->gates = w->call = w->hprev = w->dg = w->slab = w->dhrec = w->dcstate = w->prob_sk = w->colpart = 0;
   w->pstate_b = w->xchg = 0; w->xchg_bytes = 0; w->llb = 0; w->llb_bytes = 0;
   w->slab_elems = 0;
@@ -1153,6 +1157,344 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_kernel(WideArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- wide persistent recurrence, round 6
+// The same team structure as lstm_wide_kernel (two teams of 128, W_hh slices in registers, counter hand-off R1), re-partitioned around
+// what that kernel's step consisted of ("Round 6: the wide recurrence"):
+//  * h_{t-1} travels through an EXCHANGE buffer laid out for the consumers, [step parity][direction][k / 4][video row 64][4 floats],
+//    not through the output matrix: one A-fragment load instruction of a wave is two contiguous 512-byte runs (the old form touched 32
+//    rows x 32 bytes -- 32 half-used 64-byte requests per instruction, twice the bytes through L2), and a member's publish is two
+//    contiguous 1-KB runs of 16-byte sc1 stores (was 512 dword stores, one fabric write each).  Parity by step: a member can publish
+//    step t + 1 only after every member published step t, i.e. after all of them finished reading step t - 1 -- the slot it overwrites.
+//    Each group of 64 videos has its own exchange region (a short group could otherwise be overrun by the next one's step 0).
+//  * the group's videos are SORTED by length (descending, ties by index) onto the 64 MFMA rows, so the second 32-row tile -- its
+//    loads, its MFMAs, its partial tiles -- stops as soon as fewer than 33 videos are still running (t >= the 33rd longest length).
+//    A row's result does not depend on which row it is (one fixed k order per output element): batch composition still cannot
+//    change a video's scores.
+//  * the step counter is SHARDED four ways (member % 4 = its XCD under round-robin dispatch; each shard on a line of its own) and
+//    polled by four lanes of one wave: 128 atomics on one word serialise at ~12 ns each (MI355X_MICROARCH.md, fanin).
+//  * the next step's input-projection slice is requested at the TOP of a step, and the output / training-save stores are issued
+//    AFTER the signal: the producer's vmcnt(0) drain in front of the signal then waits for the exchange stores only (it used to
+//    wait for four strided G loads issued just before it, and for up to eight plain stores).
+//  * MODE 2 ("bf16x6", fp32-grade): x = x1 + x2 + x3 exactly, the six products with i + j <= 4 on v_mfma_f32_32x32x16_bf16 in the
+//    term order of gemm_regstage.h (smallest first): 96 matrix instructions of 32 cycles per wave and step instead of 128 of 64.
+//    W_hh planes 1, 2 in registers (64 VGPRs), plane 3 as fragments in LDS (64 KB, one ds_read_b128 per k16 step); h is split in
+//    registers after the load; the second tile's loads re-use the first tile's registers as they are consumed.
+struct Wide2Args {
+  const float* G; const float* whh[2]; float* Hout;
+  float* gates; float* c_all; float* hprev;   // training-mode saves (nullptr in inference)
+  const int32_t* off; unsigned* state; float* xchg;
+  int32_t n_seq, H, n_groups, upm, n_active, pack16;
+};
+constexpr int W2_SLICE_FLOATS = 256 * 64 * 4;   // one (parity, direction) slice of the exchange: [k4 256][row 64][4 floats] = 256 KB
+constexpr int W2_ITEM_WORDS = 128;              // state words per work item: four counter shards, 32 words (128 B) apart
+constexpr int W2_STAMP_WORD = PSTATE_WORDS - 512;   // diagnostic build: phase stamps at the end of the state block
+
+__device__ __forceinline__ void split8x3(f32x4 x0, f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+  f32x8 x = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  p1 = __builtin_convertvector(x, bf16x8);
+  x = x - __builtin_convertvector(p1, f32x8);
+  p2 = __builtin_convertvector(x, bf16x8);
+  x = x - __builtin_convertvector(p2, f32x8);
+  p3 = __builtin_convertvector(x, bf16x8);
+}
+
+template <int MODE>   // 0: exact fp32 MFMA, 1: bf16x3 (hi / lo), 2: bf16x6 (three planes)
+__global__ __launch_bounds__(PK_THREADS) void lstm_wide2_kernel(Wide2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H;
+  constexpr int PP = 32;
+  float* part = smem;                                     // [8 waves][64 rows][PP] split-K partial tiles (64 KB)
+  int* sR0 = reinterpret_cast<int*>(part + 8 * 64 * PP);  // [64] first frame row of the video on MFMA row r (sorted by length)
+  int* sT = sR0 + 64;                                     // [64] its length (0 past the group)
+  int* sR0u = sT + 64;                                    // [64] the same two in batch order (input of the sort)
+  int* sTu = sR0u + 64;
+  bf16x8* w3s = reinterpret_cast<bf16x8*>(sTu + 64);      // MODE 2: [8 k16 steps][512 threads] third W_hh plane (64 KB)
+
+  const int d = (blockIdx.x & 7) >> 2;                    // team = direction
+  const int slot = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
+  if (slot >= a.n_active) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
+  bool dead = false;   // (wave 0) a wait timed out: results are invalid, state[0] says so
+
+  constexpr int NS = WK_CPW / 2;    // k16 steps per wave
+  float4 wreg[MODE == 0 ? WK_CPW : 1];
+  bf16x8 wA[MODE != 0 ? NS : 1], wB[MODE != 0 ? NS : 1];
+  {
+    const float* wrow = a.whh[d] + (int64_t)((li & 3) * H + min(u0 + (li >> 2), H - 1)) * H;     // column li = 4 unit + gate
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int c = 0; c < WK_CPW; ++c) {
+        const int k = (wave * WK_CPW + c) * 8 + 4 * lh;
+        wreg[c] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        const int k = (wave * NS + sidx) * 16 + 8 * lh;
+        const float4 w0 = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 w1 = k + 4 < H ? *reinterpret_cast<const float4*>(wrow + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (MODE == 1) {
+          split8(f32x4{w0.x, w0.y, w0.z, w0.w}, f32x4{w1.x, w1.y, w1.z, w1.w}, wA[sidx], wB[sidx]);
+        } else {
+          bf16x8 p3;
+          split8x3(f32x4{w0.x, w0.y, w0.z, w0.w}, f32x4{w1.x, w1.y, w1.z, w1.w}, wA[sidx], wB[sidx], p3);
+          w3s[sidx * PK_THREADS + tid] = p3;
+        }
+      }
+    }
+  }
+  constexpr unsigned OOB = 0x7ffffff0u;   // beyond num_records: the buffer load returns zeros
+#ifdef SUMK_DIAG
+  unsigned long long dg_poll = 0, dg_mfma = 0, dg_bar1 = 0, dg_epi = 0, dg_pub = 0, dg_steps = 0, dg_two = 0;
+  const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  for (int g = 0; g < a.n_groups; ++g) {
+    const int item = 2 * g + d;
+    const int v0 = g * WK_GROUP, nv = min(WK_GROUP, a.n_seq - v0);
+    unsigned* bar = a.state + 16 + item * W2_ITEM_WORDS;
+    float* xg = a.xchg + (size_t)g * 4 * W2_SLICE_FLOATS;
+    // one descriptor per step parity over THIS direction's slice, ending behind its last written k4 row (k < H): rows of k >= H -- never
+    // written -- and the OOB offsets of finished videos read as zeros, so no load needs a compare
+    const __amdgpu_buffer_rsrc_t xr0 = __builtin_amdgcn_make_buffer_rsrc(xg + (0 * 2 + d) * W2_SLICE_FLOATS, (short)0, (H >> 2) * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr1 = __builtin_amdgcn_make_buffer_rsrc(xg + (1 * 2 + d) * W2_SLICE_FLOATS, (short)0, (H >> 2) * 1024, 0x00020000);
+    __syncthreads();   // previous item fully done with LDS
+    if (tid < 64) {
+      int r0 = 0, T = 0;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; }
+      sR0u[tid] = r0; sTu[tid] = (T << 6) | (63 - tid);
+    }
+    __syncthreads();
+    if (tid < 64) {     // MFMA row = rank by length, descending; ties by batch index
+      const int key = sTu[tid];     // (T << 6) | (63 - batch index): distinct keys
+      int rank = 0;
+#pragma unroll 8
+      for (int q = 0; q < 64; ++q) rank += sTu[q] > key ? 1 : 0;
+      sT[rank] = key >> 6; sR0[rank] = sR0u[tid];
+    }
+    __syncthreads();
+    const int Tg = sT[0], T32 = sT[32];       // the second tile runs while t < T32
+    const int Ta = sT[li], Tb = sT[32 + li];  // the two rows this lane feeds to the MFMAs
+
+    // epilogue role: thread (row ei, unit eu); cell state and last h live in registers for the whole item
+    const int ei = tid >> 3, eu = tid & 7;
+    const bool erole = ei < nv && eu < nu;
+    const int er0 = sR0[ei], eT = erole ? sT[ei] : 0;
+    const int j = u0 + eu;
+    float c = 0.f, hlast = 0.f;
+    float gcur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (eT > 0) {
+      const int64_t row = d == 0 ? er0 : er0 + eT - 1;
+      const float* gp = a.G + row * (8 * H) + d * 4 * H;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gcur[q] = gp[q * H + j];
+    }
+    const unsigned xrow_w = (unsigned)(((j >> 2) * 64 + ei) * 4 + (j & 3));   // this thread's float inside a slice
+
+    for (int t = 0; t < Tg; ++t) {
+#ifdef SUMK_DIAG
+      const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
+      float gnext[4] = {0.f, 0.f, 0.f, 0.f};
+      if (t + 1 < eT) {   // next step's input-projection slice: requested a whole step before it is used
+        const int64_t nrow = d == 0 ? er0 + t + 1 : er0 + eT - 2 - t;
+        const float* gp = a.G + nrow * (8 * H) + d * 4 * H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gnext[q] = gp[q * H + j];
+      }
+      const bool two = t < T32;
+      if (t > 0) {
+        if (wave == 0 && !dead) {   // wait until every member published step t-1: lanes 0..3 poll the four shards
+          const unsigned cnt = (lane < 4 && lane < a.n_active) ? (unsigned)((a.n_active - lane + 3) >> 2) : 0u;
+          const unsigned want = (unsigned)t * cnt;
+          unsigned spins = 0;
+          while (true) {
+            const unsigned v = lane < 4 ? __hip_atomic_load(bar + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(v >= want)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
+                 __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+              dead = true; break;   // never hang the GPU: flag the failure and stop waiting
+            }
+          }
+        }
+        __syncthreads();
+#ifdef SUMK_DIAG
+        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+        dg_poll += s1 - s0;
+#endif
+        // A fragments: h_{t-1}[row][k..], sc1 (L1-bypassing) 16-B buffer loads of the exchange slice ONLY; finished rows read zeros.
+        // Sixteen loads (the first tile) are in flight; the second tile's loads take each register pair as it is consumed.
+        const __amdgpu_buffer_rsrc_t xr = ((t - 1) & 1) ? xr1 : xr0;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        u32x4 va[WK_CPW];
+        if constexpr (MODE == 0) {
+          // chunk c8 = 16 wave + cc: k = 8 c8 + 4 lh .. + 3  ->  k4 row 2 c8 + lh (a 512-byte run per lane half)
+          const unsigned voa = (t < Ta ? (unsigned)li * 16u : OOB) + (unsigned)lh * 1024u;
+          const unsigned vob = (t < Tb ? (unsigned)(32 + li) * 16u : OOB) + (unsigned)lh * 1024u;
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) va[cc] = __builtin_amdgcn_raw_buffer_load_b128(xr, voa, (wave * WK_CPW + cc) * 2048, 16 /* sc1 */);
+          // (the whole vector is bit-cast before its elements are taken: see lstm_wide_kernel)
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const float4 bv = wreg[cc];
+            const f32x4 av = __builtin_bit_cast(f32x4, va[cc]);
+            if (two) va[cc] = __builtin_amdgcn_raw_buffer_load_b128(xr, vob, (wave * WK_CPW + cc) * 2048, 16 /* sc1 */);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc0, 0, 0, 0);
+          }
+          if (two)
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) {
+            const float4 bv = wreg[cc];
+            const f32x4 av = __builtin_bit_cast(f32x4, va[cc]);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv.x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv.y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv.z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv.w, acc1, 0, 0, 0);
+          }
+        } else {
+          // k16 step s of this wave: k = 16 (8 wave + s) + 8 lh .. + 7  ->  k4 rows 4 (8 wave + s) + 2 lh, + 1: two loads, each a 512-byte run per lane half
+          const unsigned voa = (t < Ta ? (unsigned)li * 16u : OOB) + (unsigned)lh * 2048u;
+          const unsigned vob = (t < Tb ? (unsigned)(32 + li) * 16u : OOB) + (unsigned)lh * 2048u;
+#pragma unroll
+          for (int cc = 0; cc < WK_CPW; ++cc) va[cc] = __builtin_amdgcn_raw_buffer_load_b128(xr, voa, ((wave * NS + (cc >> 1)) * 4 + (cc & 1)) * 1024, 16 /* sc1 */);
+#pragma unroll
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            const f32x4 x0 = __builtin_bit_cast(f32x4, va[2 * sidx]), x1 = __builtin_bit_cast(f32x4, va[2 * sidx + 1]);
+            if (two) {
+              va[2 * sidx] = __builtin_amdgcn_raw_buffer_load_b128(xr, vob, ((wave * NS + sidx) * 4) * 1024, 16 /* sc1 */);
+              va[2 * sidx + 1] = __builtin_amdgcn_raw_buffer_load_b128(xr, vob, ((wave * NS + sidx) * 4 + 1) * 1024, 16 /* sc1 */);
+            }
+            if constexpr (MODE == 1) {
+              bf16x8 ah, al;
+              split8(x0, x1, ah, al);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wA[sidx], acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wB[sidx], acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wA[sidx], acc0, 0, 0, 0);
+            } else {
+              bf16x8 h1, h2, h3;
+              split8x3(x0, x1, h1, h2, h3);
+              const bf16x8 w3 = w3s[sidx * PK_THREADS + tid];
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h3, wA[sidx], acc0, 0, 0, 0);   // (i, j) = (2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wB[sidx], acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w3, acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wA[sidx], acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wB[sidx], acc0, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wA[sidx], acc0, 0, 0, 0);
+            }
+          }
+          if (two)
+#pragma unroll
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            const f32x4 x0 = __builtin_bit_cast(f32x4, va[2 * sidx]), x1 = __builtin_bit_cast(f32x4, va[2 * sidx + 1]);
+            if constexpr (MODE == 1) {
+              bf16x8 bh, bl;
+              split8(x0, x1, bh, bl);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, wA[sidx], acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wB[sidx], acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wA[sidx], acc1, 0, 0, 0);
+            } else {
+              bf16x8 h1, h2, h3;
+              split8x3(x0, x1, h1, h2, h3);
+              const bf16x8 w3 = w3s[sidx * PK_THREADS + tid];
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h3, wA[sidx], acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wB[sidx], acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w3, acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wA[sidx], acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wB[sidx], acc1, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wA[sidx], acc1, 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(wave * 64 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PP + li] = acc0[r];
+        if (two)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[(wave * 64 + 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PP + li] = acc1[r];
+#ifdef SUMK_DIAG
+        const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+        dg_mfma += s2 - s1;
+#endif
+        __syncthreads();
+#ifdef SUMK_DIAG
+        dg_bar1 += __builtin_amdgcn_s_memtime() - s2; dg_steps += 1; dg_two += two ? 1 : 0;
+#endif
+      }
+#ifdef SUMK_DIAG
+      const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+#endif
+      const bool live = t < eT;     // (eT = 0 for threads without a role; rows >= 32 are never live when the second tile was skipped)
+      const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+      float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
+      if (live) {
+        float pre[4] = {gcur[0], gcur[1], gcur[2], gcur[3]};
+        if (t > 0) {
+          float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int w8 = 0; w8 < 8; ++w8) {     // fixed order: wave 0 .. 7
+            const float4 pw = *reinterpret_cast<const float4*>(&part[(w8 * 64 + ei) * PP + 4 * eu]);
+            ps.x += pw.x; ps.y += pw.y; ps.z += pw.z; ps.w += pw.w;
+          }
+          pre[0] += ps.x; pre[1] += ps.y; pre[2] += ps.z; pre[3] += ps.w;
+        }
+        ig = fast_sigmoid(pre[0]); fg = fast_sigmoid(pre[1]); gg = fast_tanh(pre[2]); og = fast_sigmoid(pre[3]);
+        c = fg * c + ig * gg;
+        h = og * fast_tanh(c);
+      }
+      // publish step t into the exchange slice of parity t & 1
+      const unsigned wslice = (unsigned)(((t & 1) * 2 + d) * W2_SLICE_FLOATS);
+      if (a.pack16) {     // every member owns 8 aligned units: lanes eu = 0, 4 store four units of their row as ONE 16-byte piece
+        const float h1 = __shfl_down(h, 1), h2 = __shfl_down(h, 2), h3 = __shfl_down(h, 3);
+        if (live && (eu & 3) == 0) {
+          const f32x4 hv = {h, h1, h2, h3};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv), (t & 1) ? xr1 : xr0, xrow_w * 4u, 0, 16 /* sc1 */);
+        }
+      } else if (live) {
+        st_sc1(xg + wslice + xrow_w, h);
+      }
+#ifdef SUMK_DIAG
+      const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+      dg_epi += s4 - s3;
+#endif
+      // every storing wave drains its stores (and nothing younger than the G loads of the step's top), then one lane signals
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(bar + 32 * (slot & 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SUMK_DIAG
+      dg_pub += __builtin_amdgcn_s_memtime() - s4;
+#endif
+      if (live) {   // the layer's output and the training saves: nobody reads them in this launch, they leave behind the signal
+        a.Hout[row * (2 * H) + d * H + j] = h;
+        if constexpr (MODE != 2) {     // (the bf16x6 recurrence is an inference mode: the host never selects it with training saves)
+          if (a.gates) {
+            float* gs = a.gates + row * (8 * H) + d * 4 * H;
+            gs[j] = ig; gs[H + j] = fg; gs[2 * H + j] = gg; gs[3 * H + j] = og;
+            a.c_all[row * (2 * H) + d * H + j] = c;
+            a.hprev[row * (2 * H) + d * H + j] = hlast;
+          }
+          hlast = h;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gcur[q] = gnext[q];
+    }
+  }
+#ifdef SUMK_DIAG
+  if (blockIdx.x < 12 && lane == 0 && (wave == 0 || wave == 7)) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(a.state + W2_STAMP_WORD) + (blockIdx.x * 2 + (wave == 7)) * 8;
+    q[0] = __builtin_amdgcn_s_memtime() - dg_t0; q[1] = dg_poll; q[2] = dg_mfma; q[3] = dg_bar1; q[4] = dg_epi; q[5] = dg_pub; q[6] = dg_steps; q[7] = dg_two;
+  }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------- BPTT step kernel
 // Step t (run for t = t_max-1 .. 0).  Block = (32 videos) x (32 hidden units) x direction, 512 threads = 8 waves that
 // split the K = 4H contraction  dh_rec[video, j] = sum_k dG[next row][k] * W_hh[k][j]  (MFMA, fragments straight from
@@ -1953,6 +2295,47 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     wa.n_seq = n_seq; wa.H = H; wa.hout_bytes = (int32_t)((size_t)R * 2 * H * 4);
     wa.n_groups = (n_seq + WK_GROUP - 1) / WK_GROUP;
     wa.upm = (H + 127) / 128; wa.n_active = (H + wa.upm - 1) / wa.upm;     // <= 8 units per member, <= 128 members per team
+    // round 6: the re-partitioned form (exchange buffer laid out for the consumers, rows sorted by length, sharded counter, bf16x6 mode);
+    // SUMK_LSTM_WIDE2=0 keeps lstm_wide_kernel (A/B switch: tests/test_gpu_lstm.py::test_wide_recurrence_forms_agree)
+    static const bool wide2_on = !(getenv("SUMK_LSTM_WIDE2") && getenv("SUMK_LSTM_WIDE2")[0] == '0');
+    if (wide2_on && L.wx_bytes > 0 && 2 * wa.n_groups * W2_ITEM_WORDS <= PSTATE_WORDS - 16 - 512) {
+      Wide2Args w2;
+      w2.G = wa.G; w2.whh[0] = wa.whh[0]; w2.whh[1] = wa.whh[1]; w2.Hout = h_out;
+      w2.gates = wa.gates; w2.c_all = wa.c_all; w2.hprev = wa.hprev; w2.off = wa.off; w2.state = wa.state;
+      w2.xchg = (float*)(ws + L.wx);
+      w2.n_seq = n_seq; w2.H = H; w2.n_groups = wa.n_groups; w2.upm = wa.upm; w2.n_active = wa.n_active;
+      w2.pack16 = (wa.upm == 8 && wa.n_active * 8 == H) ? 1 : 0;
+      // the recurrent product follows the layer's arithmetic: exact fp32 MFMA, bf16x3 (hi / lo) or the fp32-grade bf16x6 (three planes);
+      // training keeps exact fp32 in the bf16x6 mode (the BPTT multiplies in fp32)
+      const int mode = precision == SUMK_PRECISION_BF16X3 ? 1 : (precision == SUMK_PRECISION_BF16X6 && !training) ? 2 : 0;
+      const void* fn2 = mode == 2 ? (const void*)lstm_wide2_kernel<2> : mode == 1 ? (const void*)lstm_wide2_kernel<1> : (const void*)lstm_wide2_kernel<0>;
+      static bool w2_attr_set[3] = {false, false, false};
+      if (!w2_attr_set[mode]) {
+        SUMK_HIP(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        w2_attr_set[mode] = true;
+      }
+      const size_t shmem2 = mode == 2 ? (size_t)(64 + 1 + 64) * 1024 : (size_t)96 * 1024;   // 65 KB (+ 64 KB of W_hh plane 3); > 80 KB keeps one block per CU
+      void* kargs2[] = {&w2};
+      prof_begin(SUMK_PROF_LSTM_REC, stream);
+      SUMK_HIP(hipLaunchCooperativeKernel(fn2, dim3(256), dim3(PK_THREADS), kargs2, (unsigned)shmem2, stream));
+      prof_end(SUMK_PROF_LSTM_REC, stream);
+#ifdef SUMK_DIAG
+      if (getenv("SUMK_LSTM_STAMPS")) {
+        unsigned long long q[12 * 2 * 8];
+        SUMK_HIP(hipStreamSynchronize(stream));
+        SUMK_HIP(hipMemcpy(q, (const char*)(ws + L.pstate) + W2_STAMP_WORD * 4, sizeof(q), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 12; b += 5)
+          for (int wv = 0; wv < 2; ++wv) {
+            const unsigned long long* e = q + (b * 2 + wv) * 8;
+            const double n = e[6] ? (double)e[6] : 1.0;
+            fprintf(stderr, "[wide2 stamps] mode %d block %d wave %d: steps %llu (two tiles in %llu)  cycles/step: total %.0f = poll + barrier %.0f + loads, MFMAs, partial tiles %.0f + "
+                            "barrier %.0f + cell update, exchange stores %.0f + drain, barrier, signal %.0f\n",
+                    mode, b, wv ? 7 : 0, e[6], e[7], (double)e[0] / n, e[1] / n, e[2] / n, e[3] / n, e[4] / n, e[5] / n);
+          }
+      }
+#endif
+      return SUMK_OK;
+    }
     const size_t shmem = 96 * 1024;   // 68 KB used; > 80 KB keeps one block per CU
     const bool x3 = precision == SUMK_PRECISION_BF16X3;
     const void* fn = x3 ? (const void*)lstm_wide_kernel<true> : (const void*)lstm_wide_kernel<false>;

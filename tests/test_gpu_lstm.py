@@ -253,3 +253,52 @@ def test_dsn_backward_with_tail_event_equals_plain_backward(dev):
         assert rel < 2e-5, (k, rel)
     for k in ("rnn.weight_hh_l0", "rnn.weight_hh_l0_reverse", "rnn.bias_ih_l0", "rnn.bias_hh_l0_reverse", "out.0.weight"):
         assert torch.equal(plain[k], with_ev[k]), k          # the launches that did not change shape are bit-identical
+
+
+_WIDE_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests/golden"); sys.path.insert(0, ".")
+import recipes as R
+from summarizer_amd.models.dsn import DSN
+D, H, lens = 64, int(sys.argv[2]), [int(v) for v in sys.argv[3].split(",")]
+w = R.lstm_weights("rnn.", D, H, 1, 31, "out.0.")
+m = DSN(D, H, 1); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to("cuda:0").eval()
+x = torch.from_numpy(np.concatenate([(R.features(T, 1, D, 60 + i) - 0.2)[:, 0, :] for i, T in enumerate(lens)])).to("cuda:0")
+out = {}
+for prec in ("fp32", "bf16x3", "bf16x6"):
+    m.precision = prec
+    with torch.no_grad():
+        out[prec] = m.score_packed(x, lens).cpu().numpy()
+m.precision = "fp32"; m.train()
+xg = x.clone().requires_grad_(True)
+s = m.score_packed(xg, lens)
+(s * torch.linspace(-1, 1, s.numel(), device=s.device)).sum().backward()
+out["train_scores"] = s.detach().cpu().numpy(); out["gx"] = xg.grad.cpu().numpy()
+for k, p in m.named_parameters(): out["g_" + k] = p.grad.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+@pytest.mark.parametrize("H,lens", [(1024, [70, 33, 1, 70, 12] * 8 + [5, 64, 64]), (320, [1, 2, 33, 64, 5, 90] + [3, 7] * 32), (512, [40] * 33 + [9, 17])])
+def test_wide_recurrence_forms_agree(tmp_path, H, lens):
+    """lstm_wide2_kernel (round 6: exchange buffer laid out for the consumers, rows sorted by length with the second MFMA tile dropped once
+    fewer than 33 videos run, sharded step counter, stores behind the signal) against lstm_wide_kernel (SUMK_LSTM_WIDE2=0): the k order of
+    every output element is the same, so exact fp32 and bf16x3 must agree BIT FOR BIT -- inference scores, training-mode scores and every
+    gradient (the BPTT reads the forward's saves) -- on ragged groups (43 and 70 videos: one and two work items per direction, tile
+    boundaries at 32 / 33 videos, one-frame videos, ties in length), at H = 1024 (packed 16-byte publish), H = 320 (3 units per member,
+    scalar publish, k tail) and H = 512 (4 units per member).  The fp32-grade bf16x6 recurrence exists in the new form only: within 2e-6
+    of exact fp32 (the old form ran the recurrent product of that mode in fp32)."""
+    import os, subprocess, sys
+    out = {}
+    for tag, env in (("old", {"SUMK_LSTM_WIDE2": "0"}), ("new", {})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _WIDE_CHILD, str(f), str(H), ",".join(map(str, lens))], env=dict(os.environ, **env),
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    for k in out["new"]:
+        if k == "bf16x6":
+            continue
+        assert np.array_equal(out["new"][k], out["old"][k]), (k, float(np.abs(out["new"][k] - out["old"][k]).max()))
+    assert np.abs(out["new"]["bf16x6"] - out["new"]["fp32"]).max() < 2e-6
+    assert np.abs(out["new"]["bf16x6"] - out["new"]["fp32"]).max() > 0 or H < 1024      # (a different arithmetic did run)
