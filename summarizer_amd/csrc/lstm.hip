@@ -19,6 +19,7 @@
 #include <math.h>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace sumk {
 
@@ -122,8 +123,26 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // Gate math of the persistent H <= 256 recurrence, whose per-step latency chain contains it: v_exp_f32 / v_rcp_f32 forms (a few ulp:
 // ~3e-7 relative for the sigmoid, ~1e-7 ABSOLUTE for tanh) instead of the library expf / IEEE division / tanhf (~170 instructions per
 // step and thread against ~30).  tanh(x) = 1 - 2 / (1 + e^{2x}) saturates correctly at both ends (e^{2x} -> inf gives 1, -> 0 gives -1).
-__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.0f + __expf(-v)); }
-__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * v)); }
+// (round 6: __frcp_rn is the CORRECTLY ROUNDED reciprocal -- hipcc expands it to the v_div_scale / v_div_fmas / v_div_fixup sequence, 5 x ~10
+//  instructions in every cell update; __builtin_amdgcn_rcpf is the bare v_rcp_f32 these forms were written for: 1 ulp)
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * v)); }
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the operand split of the bf16x3 arithmetic (gemm_f32.hip)
+__device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, bf16x8& hi, bf16x8& lo) {
+  const f32x8 x = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  hi = __builtin_convertvector(x, bf16x8);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+// x = p1 + p2 + p3 EXACTLY (three bf16 planes: 3 x 8 significand bits), the operand split of the bf16x6 arithmetic
+__device__ __forceinline__ void split8x3(f32x4 x0, f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+  f32x8 x = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+  p1 = __builtin_convertvector(x, bf16x8);
+  x = x - __builtin_convertvector(p1, f32x8);
+  p2 = __builtin_convertvector(x, bf16x8);
+  x = x - __builtin_convertvector(p2, f32x8);
+  p3 = __builtin_convertvector(x, bf16x8);
+}
 
 // ------------------------------------------------------------------------------------------- small-batch (mat-vec) steps
 // With a handful of sequences (SumGAN trains one video at a time) a recurrence step is a matrix-VECTOR product: nothing to
@@ -924,6 +943,245 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------- persistent recurrence with the input projection inside (round 6)
+// Inference in the split-bf16 modes: the hoisted projection GEMM G = X W_ih^T + b (215 us in front of an 836-us recurrence on the S-TVSum
+// batch) disappears INTO the recurrence.  A member's slice of it -- the group's <= 16 videos x its 32 gate columns x In = 1024 -- does not
+// depend on h, and a step of the flag-in-data kernel spends two thirds of its ~4 700 cycles waiting (hand-off latency, arrival skew).
+// Each wave multiplies its k range (128) of the NEXT step's x rows with its W_ih fragments (registers / LDS for the whole item: 2 column
+// tiles x 4 k32 steps x NP planes of 16-byte chunks -- exactly the lane fragment of v_mfma_f32_16x16x32_bf16 in the "KB planes" format of
+// the weight-plane block) while it would otherwise wait: the waves without a cell-update role right behind the step's barrier, the others
+// behind their publish.  The products START the next step's accumulators; the recurrent MFMAs add on top and the existing cross-wave sum
+// delivers  x W_ih^T + h W_hh^T  in one piece; the epilogue adds the two biases.  G (R x 8H fp32, 98 MB here) is never written or read.
+// x comes from the fp32 feature matrix itself: a lane's k range of a k32 step is 32 contiguous bytes, the four lanes of a row cover one
+// 128-byte line (the x PLANES would be a gather here: one 16-byte chunk per 128-byte line, eight frames of a video to a line -- measured
+// 8.4 us per step, 786 KB per member and step through L2); it is split into the planes in registers (the roundings of split_planes).
+// The partial tiles are double-buffered by step parity, so the step has ONE workgroup barrier.  Same hand-off (flag in the data), same
+// 16-row MFMAs, same gate arithmetic as lstm_persist_kernel<4, true, true, true>; term order of the split products as gemm_regstage.h.
+#ifndef SUMK_PROJ_KA
+#define SUMK_PROJ_KA 4
+#endif
+constexpr int PROJ_KA = SUMK_PROJ_KA;
+constexpr int PROJ_RF = 12;     // W_ih fragments a lane keeps in registers; the rest of its 8 / 16 / 24 are read from LDS every step
+struct PersistProjArgs {
+  const float* x; const char* wpl; const float* bias;     // x (n_rows x In, fp32); KB planes of [w_ih[0]; w_ih[1]] (8H x In); b_ih + b_hh (8H)
+  const float* whh[2]; float* Hout;
+  const int32_t* off; unsigned* state;
+  unsigned long long* ll; int32_t ll_bytes;
+  int32_t n_seq, H, In, gsize, n_groups, upm, n_active, n_teams;
+  uint32_t w_rp16;                                         // bytes of one (k16 block, plane, half) sub-array of the weight planes
+};
+
+// KA: k32 steps of the projection per wave 0..3 (the waves with the cell update); waves 4..7 take KB = 8 - KA each (4 KA + 4 KB = 32 steps
+// = In = 1024): the cell-update waves have the step's critical chain and only the hand-off latency behind their publish to work in, the
+// others idle from the step's barrier on.  A wave holds its first RF = 12 W_ih fragments (in (k32 step, tile, plane) order) in registers,
+// the rest in LDS.
+template <int NP, int KA>
+__global__ __launch_bounds__(PK_THREADS) void lstm_persist_proj_kernel(PersistProjArgs a) {
+  constexpr int KB = 8 - KA, KMAX = KB > KA ? KB : KA;
+  constexpr int RF = PROJ_RF;       // W_ih fragments per lane in registers (4 VGPRs each)
+  constexpr int FA = KA * 2 * NP;                                            // fragments per wave of role A (role B: KB * 2 * NP)
+  constexpr int LA = FA > RF ? FA - RF : 0;                                  // of them in LDS (role A's come first)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H;
+  constexpr int PP = 32;
+  float* part = smem;               // [step parity 2][8 waves][16 rows][PP] split-K partial tiles
+  int* sR0 = reinterpret_cast<int*>(part + 2 * 8 * 16 * PP);
+  int* sT = sR0 + 32;
+  int* sTg = sT + 32;
+  bf16x8* wlds = reinterpret_cast<bf16x8*>(sTg + 32);      // [(LA | LB) fragments][256 threads of the role] x 16 B: waves 0..3 first
+
+  const int team = blockIdx.x % a.n_teams, slot = blockIdx.x / a.n_teams;
+  if (slot >= a.n_active) return;
+  const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(a.ll, (short)0, a.ll_bytes, 0x00020000);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
+  const int n_items = 2 * a.n_groups;
+  const int vl = lane & 15, kq = lane >> 4;     // this lane's MFMA row (video of the group) / column, and its k quarter
+  int loaded_dir = -1;
+  bool dead = false;
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);  // the waves with the cell update (the step's critical chain) win the SIMD's issue arbitration
+
+  float4 wreg[4];                   // W_hh fragments (fp32 16x16x4 form): column n = 16 tile + lane % 16; k = 32 wave + 8 kq + 0..7
+  bf16x8 wih[RF];                   // W_ih fragments f = (s 2 + tile) NP + plane < RF: column n = 16 tile + lane % 16, k = 32 (ks0 + s) + 8 kq + 0..7
+  const bool roleA = wave < 4;
+  const int ks0 = roleA ? KA * wave : 4 * KA + KB * (wave - 4);               // the wave's first k32 step
+  bf16x8* wl = wlds + (roleA ? 0 : LA * 256) + (tid & 255);                  // this thread's LDS fragments: wl[f' * 256]
+  for (int item = team; item < n_items; item += a.n_teams) {
+    const int g = item >> 1, d = item & 1;
+    const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
+    __syncthreads();   // previous item fully done with LDS
+    if (loaded_dir != d) {
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile) {
+        const int n = 16 * tile + vl;
+        const int wr = (n & 3) * H + min(u0 + (n >> 2), H - 1);
+        const float* wrow = a.whh[d] + (int64_t)wr * H;
+        const int k = wave * 32 + 8 * kq;
+        wreg[2 * tile] = k < H ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wreg[2 * tile + 1] = k + 4 < H ? *reinterpret_cast<const float4*>(wrow + k + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      auto load_w = [&](auto nk_) {
+        constexpr int NK = decltype(nk_)::value;
+#pragma unroll
+        for (int sl = 0; sl < NK; ++sl)
+#pragma unroll
+          for (int tile = 0; tile < 2; ++tile) {
+            const int n = 16 * tile + vl;
+            const char* wp = a.wpl + (size_t)(d * 4 * H + (n & 3) * H + min(u0 + (n >> 2), H - 1)) * 16;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+              const unsigned sub = (unsigned)((((2 * (ks0 + sl) + (kq >> 1)) * NP + pl) * 2) + (kq & 1));
+              const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + (size_t)sub * a.w_rp16);
+              const int f = (sl * 2 + tile) * NP + pl;
+              if (f < RF) wih[f < RF ? f : 0] = wv; else wl[(f - RF) * 256] = wv;
+            }
+          }
+      };
+      if (roleA) load_w(std::integral_constant<int, KA>{}); else load_w(std::integral_constant<int, KB>{});
+      loaded_dir = d;
+    }
+    if (tid == 0) *sTg = 0;
+    __syncthreads();
+    if (tid < 32) {
+      int r0 = 0, T = 0;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; atomicMax(sTg, T); }
+      sR0[tid] = r0; sT[tid] = T;
+    }
+    __syncthreads();
+    const int Tg = *sTg;
+
+    // epilogue role: thread (video i, unit u) for tid < 256; cell state lives in a register for the whole item
+    const int ei = tid >> 3, eu = tid & 7;
+    const bool erole = tid < 256 && ei < nv && eu < nu;
+    const int er0 = erole ? sR0[ei] : 0, eT = erole ? sT[ei] : 0;
+    const int j = u0 + eu;
+    float c = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (erole) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bsum[q] = a.bias[d * 4 * H + q * H + j];
+    }
+    const int r0l = sR0[vl], Tl = sT[vl];
+    // x of a step: row (r0 + t | r0 + T - 1 - t), the wave's k32 steps, 8 floats per lane and step (32 contiguous bytes)
+    f32x4 xr[KMAX][2], xn[KMAX][2];     // two steps of x rows in flight / in use; the step loop alternates their roles
+    auto load_x = [&](int t, f32x4 (&xr)[KMAX][2]) {
+      const bool on = t < Tl;
+      const float* xp = a.x + (size_t)(d == 0 ? r0l + t : r0l + Tl - 1 - t) * a.In + 32 * ks0 + 8 * kq;
+#pragma unroll
+      for (int sl = 0; sl < KMAX; ++sl) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (on && (sl < KA || !roleA)) { v0 = *reinterpret_cast<const f32x4*>(xp + 32 * sl); v1 = *reinterpret_cast<const f32x4*>(xp + 32 * sl + 4); }
+        xr[sl][0] = v0; xr[sl][1] = v1;
+      }
+    };
+    // the slice of the input projection of one step -> accn (i + j descending, as gemm_regstage.h)
+    f32x4 accn[2];
+    auto project_n = [&](auto nk_, f32x4 (&xr)[KMAX][2]) {
+      constexpr int NK = decltype(nk_)::value;
+#pragma unroll
+      for (int sl = 0; sl < NK; ++sl) {
+        bf16x8 xp[3];
+        if constexpr (NP == 3) split8x3(xr[sl][0], xr[sl][1], xp[0], xp[1], xp[2]);
+        else { split8(xr[sl][0], xr[sl][1], xp[0], xp[1]); xp[2] = xp[1]; }
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+          for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+            for (int i = NP - 1; i >= 0; --i) {
+              const int jj = sum - i;
+              if (jj < 0 || jj >= NP) continue;
+              const int f = (sl * 2 + tile) * NP + jj;
+              const bf16x8 wv = f < RF ? wih[f < RF ? f : 0] : wl[(f - RF) * 256];
+              accn[tile] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xp[i], wv, accn[tile], 0, 0, 0);
+            }
+      }
+    };
+    auto project = [&](f32x4 (&xb)[KMAX][2]) {
+      accn[0] = f32x4{0.f, 0.f, 0.f, 0.f}; accn[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (roleA) project_n(std::integral_constant<int, KA>{}, xb); else project_n(std::integral_constant<int, KB>{}, xb);
+    };
+    load_x(0, xn);
+    load_x(1, xr);
+    project(xn);
+
+    // one step: xa holds the x rows of step t + 1 (projected behind this step's publish), xb receives those of step t + 2
+    auto step = [&](const int t, f32x4 (&xa)[KMAX][2], f32x4 (&xb)[KMAX][2]) {
+      const bool need_row = t < Tl;
+      const unsigned want = (unsigned)t;
+      const int k0 = wave * 32 + 8 * kq;
+      const unsigned rowb = (unsigned)((((unsigned)((t - 1) & 1) * 2u + (unsigned)d) * (unsigned)a.n_seq + (unsigned)(v0 + vl)) * (unsigned)H) * 8u;
+      f32x4 acc16[2] = {accn[0], accn[1]};
+      if (t > 0) {
+        u32x4 va[4];
+        unsigned spins = 0;
+        unsigned long long ll_t0 = 0;
+        while (true) {
+          asm volatile("" ::: "memory");   // the loads below are a poll: they must be re-issued every turn
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const unsigned o = (need_row && k0 + 2 * p < H) ? rowb + 8u * (unsigned)(k0 + 2 * p) : 0x7ffffff0u;     // beyond num_records: zeros
+            va[p] = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, o, 0, 16 /* sc1 */);
+          }
+          bool ok = true;
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (need_row && k0 + 2 * p < H) ok = ok && va[p][1] == want && va[p][3] == want;
+          if (__all(ok) || dead) break;
+          if (pk_ll_timed_out(spins, ll_t0)) {     // never hang the GPU: flag the failure and stop waiting
+            if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+            dead = true;
+          }
+        }
+        f32x4 hv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) hv[p] = __builtin_bit_cast(f32x4, va[p]);     // {h_k, tag, h_k+1, tag}
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+          const float4 w0 = wreg[2 * tile], w1 = wreg[2 * tile + 1];
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[0][0], w0.x, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[0][2], w0.y, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[1][0], w0.z, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[1][2], w0.w, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[2][0], w1.x, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[2][2], w1.y, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[3][0], w1.z, acc16[tile], 0, 0, 0);
+          acc16[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[3][2], w1.w, acc16[tile], 0, 0, 0);
+        }
+      }
+      if (t + 2 < Tg) load_x(t + 2, xb);     // the x rows of the step after next: a whole step in flight (8 waves x 8 KB per step queue for ~1 000 cycles in the CU's load path)
+      // C/D map of the 16x16 MFMAs: row = 4 (lane / 16) + r, column = lane % 16
+      float* pt = part + (t & 1) * (8 * 16 * PP);
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pt[(wave * 16 + 4 * kq + r) * PP + 16 * tile + vl] = acc16[tile][r];
+      __syncthreads();
+      if (erole && t < eT) {
+        const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
+        float4 ps = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {     // fixed order: wave 0 .. 7
+          const float4 pw = *reinterpret_cast<const float4*>(&pt[(w8 * 16 + ei) * PP + 4 * eu]);
+          ps.x += pw.x; ps.y += pw.y; ps.z += pw.z; ps.w += pw.w;
+        }
+        const float ig = fast_sigmoid(ps.x + bsum[0]), fg = fast_sigmoid(ps.y + bsum[1]), gg = fast_tanh(ps.z + bsum[2]), og = fast_sigmoid(ps.w + bsum[3]);
+        c = fg * c + ig * gg;
+        const float h = og * fast_tanh(c);
+        const unsigned long long pkt = ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, h);
+        __hip_atomic_store(a.ll + ((int64_t)((t & 1) * 2 + d) * a.n_seq + (v0 + ei)) * H + j, pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.Hout[row * (2 * H) + d * H + j] = h;
+      }
+      // (no second barrier: the next step writes the OTHER parity of the partial tiles, and the step after that comes behind the next barrier)
+      if (t + 1 < Tg) project(xa);        // the next step's projection: under the hand-off latency of the publish above
+    };
+    for (int t = 0; t < Tg; t += 2) {
+      step(t, xr, xn);
+      if (t + 1 < Tg) step(t + 1, xn, xr);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- wide persistent recurrence
 // The same one-launch recurrence for 256 < H <= 1024 (sLSTM: H = 1024, W_hh = 16 MB per direction -- the launch chain
 // re-reads it from the Infinity Cache every step, 28 us per step).  Here W_hh never moves: the 256 CUs split into TWO teams
@@ -944,12 +1202,6 @@ struct WideArgs {
 constexpr int WK_GROUP = 64;    // videos per work item
 constexpr int WK_CPW = 16;      // 8-wide k chunks per wave: 8 waves x 16 x 8 = 1024 >= H
 
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the operand split of the bf16x3 arithmetic (gemm_f32.hip)
-__device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, bf16x8& hi, bf16x8& lo) {
-  const f32x8 x = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-  hi = __builtin_convertvector(x, bf16x8);
-  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
-}
 
 // X3: the recurrent product in bf16x3 arithmetic (3 v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 fp32 MFMAs): W_hh is
 // split once into hi/lo bf16 fragments (the same 64 VGPRs), h_{t-1} is split in registers after the load.
@@ -1187,16 +1439,8 @@ struct Wide2Args {
 };
 constexpr int W2_SLICE_FLOATS = 256 * 64 * 4;   // one (parity, direction) slice of the exchange: [k4 256][row 64][4 floats] = 256 KB
 constexpr int W2_ITEM_WORDS = 128;              // state words per work item: four counter shards, 32 words (128 B) apart
-constexpr int W2_STAMP_WORD = PSTATE_WORDS - 512;   // diagnostic build: phase stamps at the end of the state block
+[[maybe_unused]] constexpr int W2_STAMP_WORD = PSTATE_WORDS - 512;   // diagnostic build: phase stamps at the end of the state block
 
-__device__ __forceinline__ void split8x3(f32x4 x0, f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-  f32x8 x = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-  p1 = __builtin_convertvector(x, bf16x8);
-  x = x - __builtin_convertvector(p1, f32x8);
-  p2 = __builtin_convertvector(x, bf16x8);
-  x = x - __builtin_convertvector(p2, f32x8);
-  p3 = __builtin_convertvector(x, bf16x8);
-}
 
 template <int MODE>   // 0: exact fp32 MFMA, 1: bf16x3 (hi / lo), 2: bf16x6 (three planes)
 __global__ __launch_bounds__(PK_THREADS) void lstm_wide2_kernel(Wide2Args a) {
@@ -1617,6 +1861,11 @@ struct PersistBwdArgs {
   const float* whh[2]; const float* dHout; const float* gates; const float* c_all;
   float* dG; float* xchg; const int32_t* off; unsigned* state;
   int32_t n_seq, H, gsize, n_groups, upm, n_active, n_items;
+  // round 6 (counter hand-off): item_words / n_shards -- the step counter of an item as n_shards words 32 words (128 B) apart, member m adds to
+  // shard m % n_shards, n_shards lanes poll (32 atomics on one word serialise at ~12 ns each); coal -- the exchange laid out for its READERS
+  // (members own 8 aligned units): [parity][item][reader c = column / 8][producer m][video < gsize][8 columns], so the 32 partials a cell-update
+  // thread sums are 32 loads of ONE contiguous 13-KB block per member instead of 32 B out of every producer's 1-KB rows
+  int32_t item_words, n_shards, coal;
   unsigned long long* ll;     // LL instances: {partial, step tag} packets [parity 2][item][member 32][video < gsize][H]
 };
 
@@ -1651,7 +1900,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
   for (int item = team; item < a.n_items; item += PK_TEAMS) {
     const int g = item >> 1, d = item & 1;
     const int v0 = g * a.gsize, nv = min(a.gsize, a.n_seq - v0);
-    unsigned* bar = a.state + 16 + item;
+    unsigned* bar = a.state + 16 + item * a.item_words;
     __syncthreads();
     if (M16 && loaded_dir != d) {   // B fragments: W_hh[row k = 8 (lane / 16) + m of this member's 32][column 32 wave + 16 tile + lane % 16]
 #pragma unroll
@@ -1691,31 +1940,43 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
     float dcarry = 0.f;
     // saved activations of the step about to be processed (prefetched one step ahead)
     float sv_i = 0.f, sv_f = 0.f, sv_g = 0.f, sv_o = 0.f, sv_c = 0.f, sv_cp = 0.f, sv_dh = 0.f;
+    float nx_i = 0.f, nx_f = 0.f, nx_g = 0.f, nx_o = 0.f, nx_c = 0.f, nx_cp = 0.f, nx_dh = 0.f;     // the step after: requested at the TOP of a step (round 6)
     auto fetch = [&](int t) {
       const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
       const float* gs = a.gates + row * (8 * H) + d * H4;
-      sv_i = gs[j]; sv_f = gs[H + j]; sv_g = gs[2 * H + j]; sv_o = gs[3 * H + j];
-      sv_c = a.c_all[row * (2 * H) + d * H + j];
-      sv_cp = t > 0 ? a.c_all[(d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j] : 0.f;
-      sv_dh = a.dHout[row * (2 * H) + d * H + j];
+      nx_i = gs[j]; nx_f = gs[H + j]; nx_g = gs[2 * H + j]; nx_o = gs[3 * H + j];
+      nx_c = a.c_all[row * (2 * H) + d * H + j];
+      nx_cp = t > 0 ? a.c_all[(d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j] : 0.f;
+      nx_dh = a.dHout[row * (2 * H) + d * H + j];
     };
-    if (erole && eT > 0 && eT - 1 == Tg - 1) fetch(Tg - 1);
+    if (erole && eT > 0 && eT - 1 == Tg - 1) {
+      fetch(Tg - 1);
+      sv_i = nx_i; sv_f = nx_f; sv_g = nx_g; sv_o = nx_o; sv_c = nx_c; sv_cp = nx_cp; sv_dh = nx_dh;
+    }
 
     for (int t = Tg - 1; t >= 0; --t) {
 #ifdef SUMK_DIAG
       const unsigned long long bs0 = __builtin_amdgcn_s_memtime();
 #endif
+      // next step's saved activations: seven strided loads per thread, requested here so that they have the whole step -- the producer's
+      // vmcnt(0) drain in front of the signal used to wait for them (they were issued behind the cell update)
+      const bool have_next = erole && t - 1 >= 0 && t - 1 < eT;
+      if (have_next) fetch(t - 1);
       // zero this step's A tile (rows of inactive videos and columns of absent units must contribute nothing)
       for (int idx = tid; idx < 32 * 36; idx += PK_THREADS) sA[idx] = 0.f;
       if (!LL && t < Tg - 1) {
-        if (tid == 0 && !dead) {   // wait until every member published step t+1
-          const unsigned want = (unsigned)(Tg - 1 - t) * (unsigned)a.n_active;
+        if (wave == 0 && !dead) {   // wait until every member published step t+1: lanes 0 .. n_shards-1 poll one shard each
+          const unsigned cnt = (lane < a.n_shards && lane < a.n_active) ? (unsigned)((a.n_active - lane + a.n_shards - 1) / a.n_shards) : 0u;
+          const unsigned want = (unsigned)(Tg - 1 - t) * cnt;
           unsigned spins = 0;
-          while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          while (true) {
+            const unsigned v = lane < a.n_shards ? __hip_atomic_load(bar + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(v >= want)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
                  __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); dead = true; break;
+              if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+              dead = true; break;
             }
           }
         }
@@ -1759,16 +2020,18 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
           if (t + 1 < eT) dh += rec_ll;
         } else
         if (t + 1 < eT) {   // recurrent part: fixed-order sum of the 32 members' partials of step t+1 (sc1 loads)
-          const float* xp = a.xchg + ((((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * 32 + ei) * H + j;
+          const float* xb = a.xchg + (((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * 32 * H;
+          const float* xp = a.coal ? xb + ((int64_t)slot * 32 * a.gsize + ei) * 8 + eu : xb + (int64_t)ei * H + j;
+          const int64_t xs = a.coal ? (int64_t)a.gsize * 8 : (int64_t)32 * H;        // producer to producer
           float pv[32];
 #pragma unroll
-          for (int m = 0; m < 32; ++m) pv[m] = m < a.n_active ? ld_sc1(xp + (int64_t)m * 32 * H) : 0.f;
+          for (int m = 0; m < 32; ++m) pv[m] = m < a.n_active ? ld_sc1(xp + (int64_t)m * xs) : 0.f;
           float rec = 0.f;
 #pragma unroll
           for (int m = 0; m < 32; ++m) rec += pv[m];
           dh += rec;
         }
-        const float tc = tanhf(sv_c);
+        const float tc = fast_tanh(sv_c);     // (round 6: the forward kernels' v_exp / v_rcp form, ~1e-7 absolute, instead of the library tanhf's ~40 instructions)
         const float dc = dcarry + dh * sv_o * (1.f - tc * tc);
         const float d_i = dc * sv_g * sv_i * (1.f - sv_i);
         const float d_f = dc * sv_cp * sv_f * (1.f - sv_f);
@@ -1780,7 +2043,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
         dg[j] = d_i; dg[H + j] = d_f; dg[2 * H + j] = d_g; dg[3 * H + j] = d_o;
         sA[ei * 36 + eu] = d_i; sA[ei * 36 + 8 + eu] = d_f; sA[ei * 36 + 16 + eu] = d_g; sA[ei * 36 + 24 + eu] = d_o;
       }
-      if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, one step ahead
+      if (have_next) { sv_i = nx_i; sv_f = nx_f; sv_g = nx_g; sv_o = nx_o; sv_c = nx_c; sv_cp = nx_cp; sv_dh = nx_dh; }
 #ifdef SUMK_DIAG
       const unsigned long long bs2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1816,8 +2079,11 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
               const int n4 = wave * 32 + 16 * tile + 4 * g4;           // first of this lane's four columns (H % 4 == 0: all four inside or outside)
               if (n4 < H && i16 < nv && t < sT[i16]) {
                 typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xf, (short)0, 0x7FFFFFFF, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc), xr, (unsigned)((i16 * H + n4) * 4), 0, 16 /* sc1 */);
+                // coal: the reader of columns n4 .. n4 + 3 is member n4 / 8; its block of THIS producer is [video < gsize][8 columns]
+                float* xw = a.coal ? a.xchg + (((int64_t)(t & 1) * a.n_items + item) * 32) * 32 * H : xf;
+                const unsigned xo4 = a.coal ? (unsigned)(((((n4 >> 3) * 32 + slot) * a.gsize + i16) * 8 + (n4 & 7)) * 4) : (unsigned)((i16 * H + n4) * 4);
+                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(xw, (short)0, 0x7FFFFFFF, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc), xr, xo4, 0, 16 /* sc1 */);
               }
             }
           } else
@@ -1843,7 +2109,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
                     __hip_atomic_store(xo + (int64_t)i * H + n, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv_),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   else
-                    st_sc1(xf + (int64_t)i * H + n, pv_);
+                    st_sc1(a.coal ? a.xchg + (((int64_t)(t & 1) * a.n_items + item) * 32) * 32 * H + ((((int64_t)(n >> 3) * 32 + slot) * a.gsize + i) * 8 + (n & 7)) : xf + (int64_t)i * H + n, pv_);
                 }
               }
             }
@@ -1878,7 +2144,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
                   __hip_atomic_store(xl + (int64_t)i * H + n, ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv_),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else
-                  st_sc1(xo + (int64_t)i * H + n, acc[r]);
+                  st_sc1(a.coal ? a.xchg + (((int64_t)(t & 1) * a.n_items + item) * 32) * 32 * H + ((((int64_t)(n >> 3) * 32 + slot) * a.gsize + i) * 8 + (n & 7)) : xo + (int64_t)i * H + n, acc[r]);
               }
             }
           }
@@ -1893,7 +2159,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(bar + 32 * (slot % a.n_shards), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
 #ifdef SUMK_DIAG
       bg_wait += bs1 - bs0; bg_cell += bs2 - bs1; bg_bar += bs3 - bs2; bg_mfma += bs4 - bs3; bg_drain += __builtin_amdgcn_s_memtime() - bs4; bg_steps += 1;
@@ -2203,7 +2469,46 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
   // 1: input projection for both directions, biases fused
   const int small = gemm_tiles(R, 8 * H, 0) >= 512 ? 0 : 1;
   const int np_in = precision == SUMK_PRECISION_BF16X6 ? 3 : precision == SUMK_PRECISION_BF16X3 ? 2 : 0;
-  if (!training && np_in && w->x_planes && w->w_planes && bilstm_wplanes_ok(In, H, np_in) && R >= 1024 && pw_ok(R, 8 * (int64_t)H, In, R, 8 * (int64_t)H, np_in)) {
+  static const bool persist_ok = persistent_kernels_usable();
+  const bool planes_in = !training && np_in && w->x_planes && w->w_planes && bilstm_wplanes_ok(In, H, np_in) && R >= 1024 && pw_ok(R, 8 * (int64_t)H, In, R, 8 * (int64_t)H, np_in);
+  // round 6: with operand planes at hand and the H <= 256 persistent recurrence on 16-row MFMAs, the projection runs INSIDE the recurrence
+  // (lstm_persist_proj_kernel): no G, no GEMM launch.  SUMK_LSTM_PROJ=0 keeps the plane GEMM in front (A/B: tests/test_gpu_lstm.py)
+  {
+    static const bool proj_on = !(getenv("SUMK_LSTM_PROJ") && getenv("SUMK_LSTM_PROJ")[0] == '0');
+    static const bool ll_on = !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');
+    static const bool m16_on = !(getenv("SUMK_LSTM_M16") && getenv("SUMK_LSTM_M16")[0] == '0');
+    const int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));
+    const int n_groups = (n_seq + gsize - 1) / gsize;
+    if (planes_in && proj_on && ll_on && m16_on && persist_ok && H <= 256 && In == 1024 && gsize <= 16 && (size_t)R * 2 * H * 4 < 0x7fffffff &&
+        L.ll_bytes > 0 && L.ll_bytes < 0x7fffffe0 && 2 * n_groups <= PSTATE_WORDS - 16 && 16 * (uint64_t)pw_rows_pitch(R) < 0xffffffffull) {
+      const size_t words = (L.ll + L.ll_bytes - L.pstate) / 4;
+      hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(64, (words + 255) / 256)), dim3(256), 0, stream, (unsigned*)(ws + L.pstate), (int)words);
+      PersistProjArgs pa;
+      pa.x = x; pa.In = In; pa.wpl = (const char*)w->w_planes;
+      pa.bias = (const float*)((const char*)w->w_planes + align_up(pw_planes_bytes(8 * (int64_t)H, In, np_in), 256));
+      pa.whh[0] = w->w_hh[0]; pa.whh[1] = w->w_hh[1]; pa.Hout = h_out;
+      pa.off = seq_off_dev; pa.state = (unsigned*)(ws + L.pstate);
+      pa.ll = (unsigned long long*)(ws + L.ll); pa.ll_bytes = (int32_t)L.ll_bytes;
+      pa.n_seq = n_seq; pa.H = H; pa.gsize = gsize; pa.n_groups = n_groups; pa.n_teams = PK_TEAMS;
+      pa.upm = std::min(8, (H + 31) / 32); pa.n_active = (H + pa.upm - 1) / pa.upm;
+      pa.w_rp16 = (uint32_t)(16 * pw_rows_pitch(8 * (int64_t)H));
+      const void* fn = np_in == 3 ? (const void*)lstm_persist_proj_kernel<3, PROJ_KA> : (const void*)lstm_persist_proj_kernel<2, PROJ_KA>;
+      static bool pp_attr_set[2] = {false, false};
+      if (!pp_attr_set[np_in - 2]) {
+        SUMK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        pp_attr_set[np_in - 2] = true;
+      }
+      void* kargs[] = {&pa};
+      prof_begin(SUMK_PROF_LSTM_REC, stream);
+      // LDS: 33 KB of partial tiles and video tables + the W_ih fragments beyond the PROJ_RF a lane keeps in registers; > 80 KB keeps one block per CU
+      const int frag_a = PROJ_KA * 2 * np_in, frag_b = (8 - PROJ_KA) * 2 * np_in;
+      const size_t shmem = std::max<size_t>(96 * 1024, 34 * 1024 + (size_t)(std::max(frag_a - PROJ_RF, 0) + std::max(frag_b - PROJ_RF, 0)) * 256 * 16);
+      SUMK_HIP(hipLaunchCooperativeKernel(fn, dim3(256), dim3(PK_THREADS), kargs, (unsigned)shmem, stream));
+      prof_end(SUMK_PROF_LSTM_REC, stream);
+      return SUMK_OK;
+    }
+  }
+  if (planes_in) {
     // operand planes (x per dataset / per call, weights per weight change): the plane-aware wide GEMM, no split in the k-loop
     PwLaunch g; g.A = w->x_planes; g.a_rows = R; g.B = w->w_planes; g.b_rows = 8 * (int64_t)H; g.M = R; g.N = 8 * H; g.K = In; g.np = np_in;
     g.C = G; g.ldc = 8 * H; g.bias = (const float*)((const char*)w->w_planes + align_up(pw_planes_bytes(8 * (int64_t)H, In, np_in), 256));
@@ -2225,7 +2530,6 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
     const size_t words = (L.ll + L.ll_bytes - L.pstate) / 4;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<size_t>(64, (words + 255) / 256)), dim3(256), 0, stream, (unsigned*)(ws + L.pstate), (int)words);
   }
-  static const bool persist_ok = persistent_kernels_usable();
   // H <= 256: 8 XCD teams with an LDS panel; 256 < H <= 1024: the two-team register-resident kernel; otherwise the launch chain
   if (persist_ok && H <= 256 && (size_t)R * 2 * H * 4 < 0x7fffffff) {
     PersistArgs pa;
@@ -2420,6 +2724,12 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     pa.upm = std::min(8, (H + 31) / 32); pa.n_active = (H + pa.upm - 1) / pa.upm;
     int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));
     pa.gsize = gsize; pa.n_groups = (n_seq + gsize - 1) / gsize; pa.n_items = 2 * pa.n_groups;
+    // round 6: sharded step counter (while the items fit the state block; the last 512 words hold the diagnostic stamps) and the reader-shaped
+    // exchange (members own 8 aligned units); SUMK_LSTM_BWD_R6=0 keeps the round-5 forms (A/B: tests/test_gpu_lstm.py)
+    static const bool r6_on = !(getenv("SUMK_LSTM_BWD_R6") && getenv("SUMK_LSTM_BWD_R6")[0] == '0');
+    const bool shard = r6_on && pa.n_items * 128 <= PSTATE_WORDS - 16 - 512;
+    pa.item_words = shard ? 128 : 1; pa.n_shards = shard ? 4 : 1;
+    pa.coal = (r6_on && pa.upm == 8 && pa.n_active * 8 == H) ? 1 : 0;
     if (pa.n_items <= PSTATE_WORDS - 16) {
       const size_t shmem = std::max<size_t>(((size_t)32 * (H + 4) + 32 * 36 + 96) * sizeof(float), 96 * 1024);  // >80 KB: one block per CU
       pa.ll = (unsigned long long*)(ws + L.llb);

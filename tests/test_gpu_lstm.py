@@ -302,3 +302,74 @@ def test_wide_recurrence_forms_agree(tmp_path, H, lens):
         assert np.array_equal(out["new"][k], out["old"][k]), (k, float(np.abs(out["new"][k] - out["old"][k]).max()))
     assert np.abs(out["new"]["bf16x6"] - out["new"]["fp32"]).max() < 2e-6
     assert np.abs(out["new"]["bf16x6"] - out["new"]["fp32"]).max() > 0 or H < 1024      # (a different arithmetic did run)
+
+
+_PROJ_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests/golden"); sys.path.insert(0, ".")
+import recipes as R
+from summarizer_amd.models.dsn import DSN
+D, H = 1024, int(sys.argv[2])
+lens = [int(v) for v in sys.argv[3].split(",")]
+w = R.lstm_weights("rnn.", D, H, 1, 41, "out.0.")
+m = DSN(D, H, 1); m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.to("cuda:0").eval()
+x = torch.from_numpy(np.concatenate([(R.features(T, 1, D, 90 + i) - 0.2)[:, 0, :] for i, T in enumerate(lens)])).to("cuda:0")
+out = {}
+for prec in ("fp32", "bf16x6", "bf16x3"):
+    m.precision = prec
+    with torch.no_grad():
+        out[prec] = m.score_packed(x, lens).cpu().numpy()
+        out[prec + "_again"] = m.score_packed(x, lens).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+@pytest.mark.parametrize("H,lens", [(256, [300, 1, 2, 177, 320, 33] + [64, 150, 7] * 14), (96, [200, 3, 150, 150, 1, 90, 320, 17] + [29] * 9)])
+def test_dsn_projection_inside_the_recurrence(tmp_path, H, lens):
+    """Round 6: in the split-bf16 inference modes (operand planes at hand, groups of <= 16 videos, In = 1024) the input projection of the
+    H <= 256 BiLSTM runs INSIDE the persistent recurrence (lstm_persist_proj_kernel: the step's x rows times the member's W_ih fragments
+    start the accumulators of the recurrent product; G is never formed).  Against the plane GEMM in front of the recurrence
+    (SUMK_LSTM_PROJ=0) the scores agree to summation order -- 2e-6 at three planes, 1e-5 at two -- on ragged batches with one- and
+    two-frame videos, 48 videos (groups of 12) and 17 (groups of 5; H = 96: three units per member, k tail of the recurrent product), and
+    every video stays within 1e-4 of the numpy oracle (tests/golden/recipes + oracle/lstm_np.py); a second call is bit-identical."""
+    import os, subprocess, sys
+    from oracle import lstm_np
+    out = {}
+    for tag, env in (("gemm", {"SUMK_LSTM_PROJ": "0"}), ("fused", {})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _PROJ_CHILD, str(f), str(H), ",".join(map(str, lens))], env=dict(os.environ, **env),
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    assert np.array_equal(out["fused"]["fp32"], out["gemm"]["fp32"])          # exact fp32 does not take the fused path
+    for prec, tol in (("bf16x6", 2e-6), ("bf16x3", 1e-5)):
+        a, b = out["fused"][prec], out["gemm"][prec]
+        assert np.array_equal(a, out["fused"][prec + "_again"])
+        assert np.abs(a - b).max() < tol, (prec, float(np.abs(a - b).max()))
+        assert not np.array_equal(a, b) or H != 256                            # (a different kernel did run at the headline shape)
+    w = R.lstm_weights("rnn.", 1024, H, 1, 41, "out.0.")
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i in (0, 1, 2, 3, len(lens) - 1):
+        ref = lstm_np.dsn_forward(R.features(lens[i], 1, 1024, 90 + i) - 0.2, w)[:, 0, 0]
+        for prec in ("bf16x6", "bf16x3"):
+            np.testing.assert_allclose(out["fused"][prec][off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"{prec} video {i} T={lens[i]}")
+
+
+@pytest.mark.parametrize("H,lens", [(256, [37, 64, 12] * 14), (256, [5, 9, 1, 30] * 35), (40, [50, 1, 33, 7] + [4] * 30)])
+def test_bptt_round6_exchange_equals_round5_exchange(tmp_path, H, lens):
+    """Round 6, persistent BPTT (counter hand-off): the exchange of the members' partial products laid out for its READERS
+    ([reader][producer][video][8 columns]: the 32 partials a cell-update thread sums come out of one contiguous block) and the step counter
+    as four shards on lines of their own -- against the round-5 forms (SUMK_LSTM_BWD_R6=0: producer-major rows, one counter word).  Same
+    products, same fixed summation order: scores and EVERY gradient bit for bit, on 42 videos (groups of 11: 16-row MFMAs, 16-byte
+    publish), 140 videos (groups of 32: 32-row MFMAs, scalar publish) and H = 40 (members of 2 units: the round-5 layout stays, the
+    sharded counter does not)."""
+    import os, subprocess, sys
+    out = {}
+    for tag, env in (("r5", {"SUMK_LSTM_BWD_R6": "0"}), ("r6", {})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _HANDOFF_CHILD, str(f), str(H), ",".join(map(str, lens))], env=dict(os.environ, **env),
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    for k in out["r6"]:
+        assert np.array_equal(out["r6"][k], out["r5"][k]), (k, float(np.abs(out["r6"][k] - out["r5"][k]).max()))

@@ -282,7 +282,9 @@ def test_lstm_scorers_input_projection_on_planes(dev, kind):
             wpl = m.__dict__["_sumk_wpl"][1]
             h_pl, _ = kernels.bilstm_layer_forward(x, sb, p, prefix, 0, H, precision=prec, wplanes=wpl[0], dataset_input=True)
             h_old, _ = kernels.bilstm_layer_forward(x, sb, p, prefix, 0, H, precision=prec)
-            assert torch.equal(h_pl, h_old) if prec == "bf16x6" else float((h_pl - h_old).abs().max()) < 2e-6
+            # (round 6: with planes at hand DSN's projection runs INSIDE the persistent recurrence -- csrc/lstm.hip, lstm_persist_proj_kernel --
+            #  whose k order differs from the GEMM's: equal to rounding there; tests/test_gpu_lstm.py holds that path to the plane GEMM and the oracle)
+            assert torch.equal(h_pl, h_old) if (prec == "bf16x6" and kind == "slstm") else float((h_pl - h_old).abs().max()) < 2e-6
         key0 = m.__dict__["_sumk_wpl"][0]
         dict(m.named_parameters())[prefix + "weight_ih_l0"].mul_(1.1)
         got2 = m.score_packed(x, lens)
