@@ -31,11 +31,24 @@ def _k_one(loss):
     return _kk.one(loss.device)
 
 
+_VERBOSE_KEYS = ("note", "traffic_source", "pmc_reference", "flops_per_launch", "mfma_flops_per_launch", "launches", "sample_detail")
+
+
+def _compact(o, top=True):
+    """The JSON line without free text: every leg's numbers stay, notes / provenance go (--notes keeps them).  The contract's own text
+    fields (metric, unit, config.workload, cpu_baseline.sample, roofline.kernel) stay."""
+    if isinstance(o, dict):
+        return {k: _compact(v, False) for k, v in o.items() if k not in _VERBOSE_KEYS}
+    if isinstance(o, list):
+        return [_compact(v, False) for v in o]
+    return o
+
+
 def tvsum_lens(n_videos=50):
     return [int(np.ceil(v)) for v in np.random.default_rng(0).uniform(150, 320, n_videos)]
 
 
-def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None, seed_base=0):
+def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None, seed_base=0, threads=None):
     """Reference-equivalent stock-PyTorch CPU path (oracle/torch_port.py), one video per call as in
     Trainer.test (summarizer/models/__init__.py:45-54).  torch's intra-op pool is swept over a few thread
     counts (a 256-thread pool is far slower than 16-32 threads on (T<=320, 1024) matrices); the BEST setting is
@@ -59,7 +72,7 @@ def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None, seed_ba
     xs = [torch.from_numpy(R.features(T, 1, D, seed_base + i)) for i, T in enumerate(lens)]      # = the GPU batch of that rank (main: 1000 * rank + i)
     # (an intra-op pool as wide as a 256-cpu host is pathological on these sizes -- 95 frames/s for VASNet, minutes per video for
     #  the LSTMs -- so the sweep stops at 64 threads)
-    cands = sorted({t for t in (1, 8, 16, 32, 64, min(ncores, 64)) if t <= ncores})
+    cands = sorted({t for t in (threads or (1, 8, 16, 32, 64, min(ncores, 64))) if t <= ncores}) or [1]
     per = budget_s / len(cands)
     res = {}
     with torch.no_grad():
@@ -85,9 +98,9 @@ def cpu_baseline(lens, D, budget_s=20.0, kind="vasnet", gpu_scores=None, seed_ba
             ref = torch.cat([score(x).reshape(-1) for x in xs])
         parity = float((gpu_scores.detach().cpu().reshape(-1) - ref).abs().max())
     return dict(value=round(res[best][0], 1), unit="frames/s", cores=best, kind="port", parity_max_abs_diff_vs_port=parity,
-                sample=f"single-video {kind} forwards (S-TVSum lengths, D={D}, fp32, torch {torch.__version__} CPU ops) on a "
-                       f"{ncores}-cpu host; frames/s by intra-op threads: " +
-                       ", ".join(f"{k}t={v[0]:.0f} ({v[1]} videos/{v[2]:.1f}s)" for k, v in res.items()))
+                sample=f"{sum(v[1] for v in res.values())} single-video {kind} forwards (S-TVSum lengths, D={D}, fp32, torch CPU ops) in "
+                       f"{sum(v[2] for v in res.values()):.0f} s on a {ncores}-cpu host; best of intra-op threads {list(res)}",
+                sample_detail="frames/s by intra-op threads: " + ", ".join(f"{k}t={v[0]:.0f} ({v[1]} videos/{v[2]:.1f}s)" for k, v in res.items()))
 
 
 def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16x3"):
@@ -118,11 +131,26 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16
     finally:
         model.precision = "fp32"
     D = x.shape[1]
+    # what the timed steps do NOT contain: the x -> planes split (once per data set: the planes are kept with the feature tensor) and the
+    # weight-plane build (once per weight change); a streaming caller pays the split on every batch
+    from summarizer_amd import kernels as _kk
+    npl = _kk.PLANES_OF[precision]
+    for _ in range(3):
+        _kk.split_planes(x, npl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        _kk.split_planes(x, npl)
+    torch.cuda.synchronize()
+    split_us = (time.perf_counter() - t0) / 10 * 1e6
     rec = dict(frames_per_s_this_gpu=round(frames / dt, 1), ms_per_step=round(dt * 1e3, 4),
-               max_abs_score_diff_vs_fp32=float((s - ref_scores).abs().max()),
+               max_abs_score_diff_vs_fp32=float((s - ref_scores).abs().max()), split_planes_us=round(split_us, 1),
+               resident_planes_bytes_per_frame=int(D * 2 * npl),
                note=("products as bf16 hi/lo splits (3 bf16 MFMAs), fp32 accumulate; select with --precision bf16x3" if precision == "bf16x3"
                      else "operands split EXACTLY into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-grade "
-                          "(same error bound vs float64 as the fp32 MFMA path); select with --precision bf16x6"))
+                          "(same error bound vs float64 as the fp32 MFMA path); select with --precision bf16x6") +
+                    ".  x planes and weight planes built once in warm-up (per data set / per weight change), not in the timed steps: a caller that "
+                    "streams new features pays split_planes_us per batch, and resident planes cost resident_planes_bytes_per_frame of HBM beside the fp32 features")
     if n.value > 0:
         us = ms.value / n.value * 1e3
         fl = 2.0 * frames * 3 * D * D
@@ -134,7 +162,13 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16
                                traffic=None,
                                note=f"algorithmic fp32 FLOP of the product; the kernel issues {int(mf)} dense bf16 MFMA FLOP per algorithmic FLOP, so the "
                                     f"ceiling is the 2.5 PFLOP/s bf16 peak / {int(mf)}.  The chip holds ~1.7 GHz (not 2.4) under this load (in-kernel "
-                                    "s_memtime / s_memrealtime stamps, profiles/r05_pw_stamps.txt): PMC passes under profiles/r05_pmc_pw_*")
+                                    "s_memtime / s_memrealtime stamps, profiles/r05_pw_stamps.txt): PMC passes under profiles/r06_pmc_pw_*")
+        # `traffic` as the headline's: from separate rocprofv3 --pmc passes of THIS launch (scripts/pmc_pass.sh + pmc_to_json.py), kept under profiles/
+        tp = os.path.join(ROOT, "profiles", f"r06_pmc_pw_{'x3' if precision == 'bf16x3' else 'x6'}_qkv.json")
+        if os.path.exists(tp) and frames == 12003 and D == 1024:
+            pmc = json.load(open(tp))
+            rec["roofline"]["traffic"] = pmc.get("gemm_qkv_hbm_bytes_per_launch")
+            rec["roofline"]["traffic_source"] = f"static: profiles/{os.path.basename(tp)} ({pmc.get('kernel', '')[:70]}; algorithmic {pmc.get('algorithmic_bytes_per_launch')} B)"
     return rec
 
 
@@ -232,7 +266,7 @@ def make_reinforce_step(model, x, lens, dev):
         model.tail_grads_ready_event = torch.cuda.Event()
 
     def run_step(reduce=True):
-        opt.zero_grad()
+        opt.zero_grad(zeroed_by_step=True)
         probs = model.score_packed(x, lens)
         dist_ = Bernoulli(probs, validate_args=False)          # (validation is a D2H sync per step)
         actions = dist_.sample((5,))
@@ -302,13 +336,13 @@ def single_video_leg(dev, D=1024, T=300, iters=400):
         def step(captured=False):
             # (captured: the trainers' graph form -- the Adam kernel leaves the gradient bucket zero, so no fill kernel opens the step)
             if not captured:
-                opt.zero_grad()
+                opt.zero_grad(zeroed_by_step=True)
             loss = SegmentMseMeanFunction.apply(m.score_packed(x2, [T]), target, sb, 1.0)      # one video (VASNetTrainer._single_video_step)
             loss.backward(gradient=_k_one(loss))
             opt.step(grad_scale=1.0, max_norm=5.0 if name == "dsn" else None, zero_grad=captured)
             seed.add_(1)
         tt_eager = timed(step, n=iters // 2, warm=50)
-        opt.zero_grad()
+        opt.zero_grad(zeroed_by_step=True)
         tt_graph = timed(graphed(lambda: step(True)), n=iters // 2, warm=50)
         kernels.health_check()
         rec = lambda t: dict(us_per_video=round(t * 1e6, 1), frames_per_s=round(T / t, 1))
@@ -370,15 +404,18 @@ def stream_leg(model, x, lens, dev, steps=60):
                 note="host -> host: fp32 features from pageable host memory, scores back to host memory, every step")
 
 
-def recurrent_legs(x, lens, dev, frames):
-    """BASELINE config 3 on the headline batch: DSN (BiLSTM 1024 -> 2 x 256, dsn.py:38-47) scoring and MSE training step, sLSTM
-    (2-layer BiLSTM, H = 1024, sumgan.py:23-46) scoring.  A recurrence has no roofline worth quoting (T dependent steps): the legs report
-    time per recurrence step of the longest video beside frames/s."""
-    from summarizer_amd import kernels as _k
+def recurrent_legs(x, lens, dev, frames, with_cpu=True):
+    """BASELINE config 3 on the headline batch: DSN (BiLSTM 1024 -> 2 x 256, dsn.py:38-47) scoring, MSE training step, and sLSTM
+    (2-layer BiLSTM, H = 1024, sumgan.py:23-46) scoring, each scoring leg in exact fp32 and the split-bf16 modes.  A recurrence is a
+    chain of T dependent steps: next to frames/s a leg reports the time of ONE step of its recurrence launch (HIP events on the launch
+    stream, a separate pass) against the step's MFMA floor -- the padded product of one step on the CUs of one team at the nominal clock --
+    and (scoring, fp32) the oracle port (torch's own nn.LSTM) on the host cores: a bounded sample, best of a short thread sweep."""
+    from summarizer_amd import _lib, kernels as _k
     from summarizer_amd.models.dsn import DSN
     from summarizer_amd.models.sumgan import sLSTM
     from summarizer_amd.training import FlatAdam
     from summarizer_amd.autograd import SegmentMseMeanFunction
+    lib = _lib.load()
     t_max = max(lens)
     out = {}
 
@@ -393,25 +430,54 @@ def recurrent_legs(x, lens, dev, frames):
         assert bool(torch.isfinite(r).all())
         return (time.perf_counter() - t0) / n
 
+    def rec_us(fn, n):          # the recurrence launches of a call (tag SUMK_PROF_LSTM_REC), microseconds per launch
+        lib.sumk_prof_read(_lib.PROF_LSTM_REC, None, None, 1)
+        lib.sumk_prof_enable(1 << _lib.PROF_LSTM_REC)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        lib.sumk_prof_enable(0)
+        ms = C.c_double(0); cnt = C.c_int64(0)
+        lib.sumk_prof_read(_lib.PROF_LSTM_REC, C.byref(ms), C.byref(cnt), 1)
+        return ms.value / max(cnt.value, 1) * 1e3
+
+    cu_f32 = FP32_MFMA_PEAK_TFLOPS * 1e12 / 256      # FLOP/s of one CU at the nominal clock
+    cu_b16 = BF16_MFMA_PEAK_TFLOPS * 1e12 / 256
+
+    def score_leg(m, prec, n, layers, floor_us, what):
+        m.precision = prec
+        with torch.no_grad():
+            dt = timed(lambda: m.score_packed(x, lens), n)
+            us = rec_us(lambda: m.score_packed(x, lens), max(2, n // 2))
+        m.precision = "fp32"
+        return dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), recurrence_launch_us=round(us, 1),
+                    recurrence_us_per_step=round(us / t_max, 2), mfma_floor_us_per_step=round(floor_us, 2), frac_of_floor=round(floor_us / (us / t_max), 3),
+                    us_per_recurrence_step=round(dt * 1e6 / (layers * t_max), 2), note=what)
+
     torch.manual_seed(1234)
     dsn = DSN(input_size=x.shape[1]).to(dev).eval()
-    with torch.no_grad():
-        dt = timed(lambda: dsn.score_packed(x, lens), 20)
-    out["dsn_score_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / t_max, 2),
-                                 note=f"DSN scoring, 50 videos packed: input projection GEMM + one persistent bidirectional recurrence of {t_max} dependent steps + head (the per-step figure is the whole call / {t_max})")
-    dsn.precision = "bf16x6"
-    with torch.no_grad():
-        dt = timed(lambda: dsn.score_packed(x, lens), 20)
-    dsn.precision = "fp32"
-    out["dsn_score_bf16x6_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / t_max, 2),
-                                        note="the same with the input projection in the fp32-grade bf16x6 arithmetic on operand planes (csrc/gemm_pw.hip); the recurrence stays fp32")
+    # one step of one team (32 CUs): 16 video rows (13 used) x 1024 gate columns x 256, exact fp32 MFMA
+    dsn_floor = 2.0 * 16 * 1024 * 256 / (32 * cu_f32) * 1e6
+    out["dsn_score_mode"] = score_leg(dsn, "fp32", 20, 1, dsn_floor,
+        f"DSN scoring, 50 videos packed: input projection GEMM + one persistent bidirectional recurrence of {t_max} dependent steps + head; the step is a hand-off "
+        "latency chain (flag-in-data publish -> poll -> 16 fp32 MFMAs per wave -> cell update), not a throughput: the floor is quoted for scale")
+    out["dsn_score_bf16x6_mode"] = score_leg(dsn, "bf16x6", 20, 1, dsn_floor,
+        "input projection in the fp32-grade bf16x6 arithmetic, computed INSIDE the persistent recurrence (csrc/lstm.hip, lstm_persist_proj_kernel: the step's x rows x "
+        "the member's W_ih planes start the accumulators of the recurrent product while the wave would wait for the hand-off; no G, no GEMM launch); recurrent product exact fp32")
+    out["dsn_score_bf16x3_mode"] = score_leg(dsn, "bf16x3", 20, 1, dsn_floor, "the same with two planes (bf16x3)")
+    if with_cpu:
+        try:
+            out["dsn_score_mode"]["cpu_baseline"] = cpu_baseline(lens, x.shape[1], budget_s=4.0, kind="dsn", threads=(8, 16, 32))
+            out["dsn_score_mode"]["cpu_baseline"].pop("parity_max_abs_diff_vs_port", None)
+        except Exception as e:          # noqa: BLE001
+            out["dsn_score_mode"]["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:200])
     dsn.train()
     opt = FlatAdam(dsn.parameters(), lr=1e-5, weight_decay=1e-5)
     target = torch.rand(frames, device=dev)
     sb = _k.SeqBatch.get(lens, dev)
 
     def train_step():
-        opt.zero_grad()
+        opt.zero_grad(zeroed_by_step=True)
         loss = SegmentMseMeanFunction.apply(dsn.score_packed(x, lens), target, sb, 1.0 / len(lens))
         loss.backward(gradient=_k_one(loss))
         opt.step(grad_scale=1.0, zero_grad=True)
@@ -421,15 +487,20 @@ def recurrent_legs(x, lens, dev, frames):
                                  note="DSN MSE training step (forward + per-video MSE + BPTT + fused Adam); recurrence steps = forward + backward")
     del dsn, opt
     sl = sLSTM(input_size=x.shape[1]).to(dev).eval()
-    with torch.no_grad():
-        dt = timed(lambda: sl.score_packed(x, lens), 5)
-    out["slstm_score_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
-                                   note=f"sLSTM scoring (2 layers x {t_max} dependent steps, H = 1024, wide persistent recurrence) + 4 input projections")
-    sl.precision = "bf16x6"
-    with torch.no_grad():
-        dt = timed(lambda: sl.score_packed(x, lens), 5)
-    out["slstm_score_bf16x6_mode"] = dict(ms_per_step=round(dt * 1e3, 4), frames_per_s=round(frames / dt, 1), us_per_recurrence_step=round(dt * 1e6 / (2 * t_max), 2),
-                                          note="the same with both layers' input projections in the fp32-grade bf16x6 arithmetic on operand planes; the recurrences stay fp32")
+    # one step of one direction's team (128 CUs): 64 video rows (two 32-row tiles; 50 used) x 4096 gate columns x 1024
+    sl_fl = 2.0 * 64 * 4096 * 1024
+    out["slstm_score_mode"] = score_leg(sl, "fp32", 5, 2, sl_fl / (128 * cu_f32) * 1e6,
+        f"sLSTM scoring (2 layers x {t_max} dependent steps, H = 1024): lstm_wide2_kernel -- exchange buffer laid out for the consumers, rows sorted by length "
+        "(the second 32-row tile stops once fewer than 33 videos run: the floor quoted is the TWO-tile step), sharded step counter -- + 4 input projections")
+    out["slstm_score_bf16x6_mode"] = score_leg(sl, "bf16x6", 5, 2, 6.0 * sl_fl / (128 * cu_b16) * 1e6,
+        "input projections on operand planes AND the recurrent product in the fp32-grade bf16x6 arithmetic (three planes of W_hh, h split in registers, 6 bf16 MFMAs per product)")
+    out["slstm_score_bf16x3_mode"] = score_leg(sl, "bf16x3", 5, 2, 3.0 * sl_fl / (128 * cu_b16) * 1e6, "the same with two planes (bf16x3)")
+    if with_cpu:
+        try:
+            out["slstm_score_mode"]["cpu_baseline"] = cpu_baseline(lens, x.shape[1], budget_s=6.0, kind="slstm", threads=(16, 32))
+            out["slstm_score_mode"]["cpu_baseline"].pop("parity_max_abs_diff_vs_port", None)
+        except Exception as e:          # noqa: BLE001
+            out["slstm_score_mode"]["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:200])
     _k.health_check()
     return out
 
@@ -468,9 +539,9 @@ def transformer_legs(x, lens, dev, frames):
 
 
 def stress_leg(dev, steps=3):
-    """BASELINE config 5 at one GPU's share: 8 sequences of T = 10 000 frames, D = 2048, exact fp32 (the attention matrix of one sequence is
-    400 MB: E is materialised, 3.2 GB).  Reports the whole-path fraction of the fp32 MFMA peak (the path is matrix-bound, not HBM-bound:
-    ~10 D^2 + 4 T D FLOP per frame against ~30 KB of HBM traffic per frame)."""
+    """BASELINE config 5 at one GPU's share: 8 sequences of T = 10 000 frames, D = 2048 (the attention matrix of one sequence is 400 MB: E
+    is materialised, 3.2 GB), exact fp32 and the fp32-grade bf16x6 arithmetic.  Reports the whole-path fraction of the arithmetic's MFMA peak
+    (the path is matrix-bound, not HBM-bound: ~10 D^2 + 4 T D FLOP per frame against ~30 KB of HBM traffic per frame)."""
     from summarizer_amd.models.vasnet import VASNet
     D, lens = 2048, [10000] * 8
     frames = sum(lens)
@@ -478,23 +549,33 @@ def stress_leg(dev, steps=3):
     model = VASNet(input_size=D).to(dev).eval()
     g = torch.Generator(device=dev); g.manual_seed(0)
     x = torch.randn(frames, D, device=dev, generator=g) * 0.05
-    with torch.no_grad():
-        s = model.score_packed(x, lens)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            s = model.score_packed(x, lens)
-        torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    assert bool(torch.isfinite(s).all())
     flops = frames * (10.0 * D * D + 2.0 * D) + 4.0 * sum(t * t for t in lens) * D
-    tf = flops / dt / 1e12
-    del x, model, s
+    out = {}
+    ref = None
+    for prec, peak, key in (("fp32", FP32_MFMA_PEAK_TFLOPS, "stress_mode"), ("bf16x6", BF16_MFMA_PEAK_TFLOPS / 6.0, "stress_bf16x6_mode")):
+        model.precision = prec
+        with torch.no_grad():
+            s = model.score_packed(x, lens)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                s = model.score_packed(x, lens)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        assert bool(torch.isfinite(s).all())
+        tf = flops / dt / 1e12
+        out[key] = dict(ms_per_step=round(dt * 1e3, 3), frames_per_s=round(frames / dt, 1), steps=steps, whole_path_tflops=round(tf, 2),
+                        roofline=dict(bound="mfma", achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4), traffic=None,
+                                      note="whole step (all kernels) against the arithmetic's MFMA peak (bf16x6: 2.5 PFLOP/s / 6); 45 % of the FLOP are the (T x T) attention products"),
+                        workload=f"vasnet score, S-stress (BASELINE config 5): 8 sequences/GPU, T=10000, D=2048, packed batch, {prec}")
+        if ref is None:
+            ref = s
+        else:
+            out[key]["max_abs_score_diff_vs_fp32"] = float((s - ref).abs().max())
+    model.precision = "fp32"
+    del x, model, s, ref
     torch.cuda.empty_cache()
-    return dict(ms_per_step=round(dt * 1e3, 3), frames_per_s=round(frames / dt, 1), steps=steps, whole_path_tflops=round(tf, 2),
-                roofline=dict(bound="mfma", achieved=round(tf, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                              traffic=None, note="whole step (all kernels) against the fp32 MFMA peak; 45 % of the FLOP are the (T x T) attention products"),
-                workload="vasnet score, S-stress (BASELINE config 5): 8 sequences/GPU, T=10000, D=2048, packed batch, exact fp32")
+    return out
 
 
 def spawn_ranks(args):
@@ -519,6 +600,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--videos", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--notes", action="store_true",
+                    help="keep every leg's free-text note / provenance fields in the JSON line (about 2x its length).  Default: numbers only, so that "
+                         "the whole line fits the 8 KB of stdout tail the round driver keeps; profiles/ holds a --notes copy of the line")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side legs (split-bf16 / folded modes, per-kernel pass, training leg): what profiling runs use")
     ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer", "sumgan"], default="vasnet",
@@ -620,7 +704,7 @@ def main():
         from summarizer_amd.autograd import SegmentMseMeanFunction
         sb_t = _k.SeqBatch.get(lens, dev)
         def run_step():
-            opt.zero_grad()
+            opt.zero_grad(zeroed_by_step=True)
             loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))   # the trainers' loss: mean over videos of nn.MSELoss per video
             loss.backward(gradient=_k_one(loss))
             opt.step(grad_scale=opt.all_reduce_grads(), zero_grad=True)      # (the Adam kernel leaves the bucket zero: the next zero_grad() is free)
@@ -838,7 +922,7 @@ def main():
             tail_from = opt.tail_offset(model.attention_head_projection.weight) if dist is not None else None
             model.tail_grads_ready_event = torch.cuda.Event() if dist is not None else None
             def train_step(reduce=True):
-                opt.zero_grad()
+                opt.zero_grad(zeroed_by_step=True)
                 loss = SegmentMseMeanFunction.apply(model.score_packed(x, lens), target, sb_t, 1.0 / len(lens))
                 loss.backward(gradient=_k_one(loss))
                 if reduce and tail_from is not None:
@@ -890,7 +974,7 @@ def main():
             T1 = lens[0]
             x1, t1, sb1 = x[:T1].contiguous(), target[:T1].contiguous(), _k.SeqBatch.get([T1], dev)
             def step1(reduce=True):
-                opt.zero_grad()
+                opt.zero_grad(zeroed_by_step=True)
                 loss = SegmentMseMeanFunction.apply(model.score_packed(x1, [T1]), t1, sb1, 1.0 / world)
                 loss.backward(gradient=_k_one(loss))
                 if reduce and tail_from is not None:
@@ -948,7 +1032,7 @@ def main():
         model.eval(); model.precision = "fp32"
         e2e = _side(trainer_test_leg, dev)
         stream = _side(stream_leg, model, x, lens, dev)
-        recurrent = _side(recurrent_legs, x, lens, dev, frames)
+        recurrent = _side(recurrent_legs, x, lens, dev, frames, not args.no_cpu_baseline)
         stress = _side(stress_leg, dev)
         tf_legs = _side(transformer_legs, x, lens, dev, frames)
     if dist is not None and args.model == "vasnet" and args.mode == "score" and args.workload == "tvsum" and not args.headline_only:
@@ -1004,7 +1088,10 @@ def main():
             else:
                 out.update(recurrent)
         if stress is not None:
-            out["stress_mode"] = stress
+            if "error" in stress:
+                out["stress_mode"] = stress
+            else:
+                out.update(stress)
         if tf_legs is not None:
             if "error" in tf_legs:
                 out["transformer_score_mode"] = tf_legs
@@ -1021,6 +1108,9 @@ def main():
                     single["vasnet"]["score_vs_cpu_port"] = {k: round(single["vasnet"][k]["frames_per_s"] / cpu, 1) for k in ("score_eager",)}
             except Exception as e:          # noqa: BLE001
                 out["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+        if not args.notes:
+            out = _compact(out)
+            out["notes"] = "per-leg notes and provenance: python bench.py --notes (a copy of that line: profiles/r06_bench_default_line_notes.json)"
         print(json.dumps(out), flush=True)
         pd = out.get("parity_max_abs_diff_vs_port")
         if pd is not None and not pd < out["parity_gate"]:

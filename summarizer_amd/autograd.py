@@ -90,7 +90,8 @@ class BiLstmScorerFunction(torch.autograd.Function):
         dh = kernels.frame_head_backward(acts[-1], scores, dscores, p[head_w], grads[head_w], grads[head_b])
         for layer in range(num_layers - 1, -1, -1):
             want_dx = layer > 0 or ctx.needs_input_grad[0]
-            # (the event goes with the LAST layer processed, layer 0: by then every other gradient of the bucket's tail is final)
+            # (the event is passed for ONE-layer models only -- DSN: layer 0 is then the last layer processed and every other gradient of the
+            #  bucket's tail is final; a deeper stack gets no early piece: its all-reduce simply starts after the backward)
             dh = kernels.bilstm_layer_backward(acts[layer], acts[layer + 1], dh, sb, p, grads, prefix, layer, H,
                                                ctx.wss[layer], want_dx, precision=precision,
                                                tail_event=ctx.tail_event if (layer == 0 and num_layers == 1) else None)

@@ -166,6 +166,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
     if (more) {
       if (s + NS - 1 < nk) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
       else wait_vm<0>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave holds every fragment of the stage whose slot is refilled behind the barrier
       __builtin_amdgcn_s_barrier();
       read_frags(nslot, nxt);
       __builtin_amdgcn_sched_barrier(0);
@@ -447,6 +448,7 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
       //  drain fully)
       if (it + NS - 1 < n_it && !(ks == 0 && nc > 0)) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
       else wait_vm<0>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave holds every fragment of the stage whose slot is refilled behind the barrier
       __builtin_amdgcn_s_barrier();
       read_frags(nslot, nxt);
     }
@@ -545,7 +547,7 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
     a.stamps = grid <= 4096 ? stamp_buf : nullptr;
   }
 #endif
-  static const int var = SUMK_TUNE_ENV("SUMK_ATTN_VAR_A") ? atoi(SUMK_TUNE_ENV("SUMK_ATTN_VAR_A")) : ATTN_VAR_A;      // (diagnostic build only)
+  [[maybe_unused]] static const int var = SUMK_TUNE_ENV("SUMK_ATTN_VAR_A") ? atoi(SUMK_TUNE_ENV("SUMK_ATTN_VAR_A")) : ATTN_VAR_A;      // (diagnostic build only)
   constexpr int LDS3 = 3 * (6 * 384 * 16) + 4096, LDS2 = 4 * (4 * 384 * 16) + 4096;
 #define SUMK_A_CASE(NP_, V_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_logits_kernel<NP_, V_>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_logits_kernel<NP_, V_>), dim3(grid), dim3(512), LDS_, stream, a); }
 #ifdef SUMK_DIAG

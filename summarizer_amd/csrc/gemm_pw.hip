@@ -202,7 +202,8 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
       const int nslot = slot + 1 == NS ? 0 : slot + 1;
       if (more) {
         if constexpr (MAIN) wait_vm<IN_FLIGHT>(); else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                         // stage s + 1 has landed; every wave is past its reads of stage s
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave HOLDS every fragment of stage s (the ones its second MFMA group uses included)
+        __builtin_amdgcn_s_barrier();                         // stage s + 1 has landed; every wave is past its reads of stage s: its slot may be refilled
         read_frags(nslot, nxt);
         __builtin_amdgcn_sched_barrier(0);
         if (fill && early) dma(m0, n0, s + NS, slot);

@@ -1090,12 +1090,6 @@ static void sk_plan(int R, int D, int n_seq, const int32_t* off, const VasnetWs&
   P->spec[SR_DWO1].b_goff64 = ((int64_t)ws_off_y1 - (int64_t)ws_off_ctx) / 4;
   row(SR_DWQKV, GEMM_TN, D, D, R, 3 * D, D, D, 0, 3, D, 0, 0, 1, 0);        // d[Wq;Wk;Wv] += dQKV^T X: group g = columns g D.. of dQKV, output g
   for (int t = 0; t < TB_COUNT; ++t) {
-    int tiles = 0, k_sum = 0;
-    for (int q = 0; q < n_seq; ++q) {
-      int M, N, K;
-      sk_seq_dims(t, off[q + 1] - off[q], D, &M, &N, &K);
-      tiles += ((M + te - 1) / te) * ((N + te - 1) / te); k_sum += K;
-    }
     int kc;
     // (per-video products: the request is the cap; vasnet_sk_setup_kernel / sk_slice_seq give a video with K = T_s frames min(4, T_s / 128)
     //  slices -- a function of that video alone)
@@ -1814,7 +1808,6 @@ extern "C" int sumk_vasnet_backward(const float* x, int32_t D, int32_t n_seq, co
   SeqInfo* seq = (SeqInfo*)(tb + L.seq);
   GemmProb* prow = (GemmProb*)(tb + L.prob_row);
   GemmProb* tabs = (GemmProb*)(tb + L.prob_seq);
-  GemmProb* psk = (GemmProb*)(ws + L.prob_sk);
   // K-slice tables of the two weight-gradient launches: in the table block; prebuilt when the caller keeps the block (opts->tables)
   GemmProb* pskw = (GemmProb*)(tb + L.prob_skw);
   const bool skw_ready = tb != ws;

@@ -268,22 +268,30 @@ def vasnet_forward_packed(x, sb, params, opts, pos_table=None, pos_rows=None, tr
     if not x.is_contiguous() or x.dim() != 2 or x.shape[0] != sb.n_rows:
         raise SumkError(f"vasnet input must be contiguous (n_rows={sb.n_rows}, D), got {tuple(x.shape)}")
     D = x.shape[1]
+    # Entries this function derives (tables of the batch geometry, the bf16 / plane shadows of x) are written back into `opts` so that the
+    # backward pass of the same step finds them; they are tied to THIS (x, batch): a caller that re-uses the dict for another batch gets
+    # them rebuilt instead of silently scoring with the first batch's planes (sumk.h: stale planes give wrong results, not errors).
+    dkey = (x.data_ptr(), x._version, tuple(x.shape), id(sb))
+    if opts.get("_derived_for") != dkey:
+        for k in opts.pop("_derived", ()):
+            opts.pop(k, None)
+        opts["_derived_for"], opts["_derived"] = dkey, []
     if "tables" not in opts and not torch.cuda.is_current_stream_capturing():      # (built outside a capture; a captured call reuses what exists)
-        opts["tables"] = vasnet_tables(sb, D, training, precision_code(opts.get("precision")))
+        opts["tables"] = vasnet_tables(sb, D, training, precision_code(opts.get("precision"))); opts["_derived"].append("tables")
     elif "tables" not in opts:
         # inside a capture nothing may be allocated or built for the (private) capture stream: the step reuses the tables an eager call
         # of the same geometry built before (a replay runs where the eager calls ran); none yet -> the setup kernel is captured instead
         want = (int(D), int(bool(training)), precision_code(opts.get("precision")))
         hit = [v for k, v in getattr(sb, "_vasnet_tables", {}).items() if k[:3] == want]
-        opts["tables"] = hit[-1][1] if hit else None
+        opts["tables"] = hit[-1][1] if hit else None; opts["_derived"].append("tables")
     if (training and "x16" not in opts and precision_code(opts.get("precision")) == precision_code("bf16") and pos_table is None
             and x.numel() % 4 == 0 and not x.requires_grad and not torch.cuda.is_current_stream_capturing()):
-        opts["x16"] = vasnet_x16(x, sb)        # (an input that asks for dX is an activation, not a dataset: cast per call)
+        opts["x16"] = vasnet_x16(x, sb); opts["_derived"].append("x16")        # (an input that asks for dX is an activation, not a dataset: cast per call)
     n_planes = PLANES_OF.get(opts.get("precision"))
     if (n_planes and not training and "xplanes" not in opts and opts.get("wplanes") is not None and pos_table is None
             and D % 256 == 0 and sb.n_rows >= 256 and not torch.cuda.is_current_stream_capturing()):
         # plane path (csrc/gemm_pw.hip): the operand planes of x are kept with the tensor object (constant per dataset)
-        opts["xplanes"] = tensor_shadow(x, f"planes{n_planes}", lambda: split_planes(x, n_planes))
+        opts["xplanes"] = tensor_shadow(x, f"planes{n_planes}", lambda: split_planes(x, n_planes)); opts["_derived"].append("xplanes")
     w, o = _vasnet_structs(params, opts)
     nbytes = lib.sumk_vasnet_workspace_bytes_for(D, sb.n_seq, sb.off_host_p, int(training), int(o.precision))
     if nbytes == 0:

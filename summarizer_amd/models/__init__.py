@@ -58,6 +58,29 @@ class Trainer:
     def _device(self):
         return next(self.model.parameters()).device
 
+    # ------------------------------------------------------------------ per-fold bookkeeping shared by every trainer
+    @staticmethod
+    def _fold_best():
+        """What train(fold) hands back, as a mutable record: [best correlation, best mean F-score, best max F-score]."""
+        return [-1.0, 0.0, 0.0]
+
+    def _evaluate_epoch(self, fold, epoch, best):
+        """End of a training epoch.  On the epochs the configuration asks for, the fold's test videos are scored and the three
+        metrics go to the TensorBoard writer under the reference's tag scheme (`<dataset>/Fold_<n>/Test/...`, vasnet.py:222-236 --
+        the tags are the protocol benchmark.py's readers expect).  `best` (see _fold_best) keeps the running maxima; whenever the
+        correlation improves, `best_weights` is pointed at the live state_dict, as the reference does."""
+        if epoch % self.hps.test_every_epochs != 0:
+            return
+        corr, (f_avg, f_max) = self.test(fold)
+        self.model.train()
+        stem = f"{self.dataset_name}/Fold_{fold+1}/Test/"
+        for tag, value in (("Correlation", corr), ("F-score_avg", f_avg), ("F-score_max", f_max)):
+            self.hps.writer.add_scalar(stem + tag, value, epoch)
+        best[1], best[2] = max(best[1], f_avg), max(best[2], f_max)
+        if corr > best[0]:
+            best[0] = corr
+            self.best_weights = self.model.state_dict()
+
     # ------------------------------------------------------------------ feature ingest
     def _video_on_device(self, key, dev, want_target=False):
         """(features (T,D), min-max normalised gtscore (T,) or None) as device tensors, uploaded once.  The reference

@@ -44,7 +44,7 @@ def _layer_wplanes(model, p, prefix, num_layers, In, H, precision):
     cache = model.__dict__.get("_sumk_wpl")
     if cache is None or cache[0] != key:
         with torch.no_grad():
-            old = cache[2] if cache is not None else [None] * num_layers
+            old = cache[2] if cache is not None and cache[0][-1] == key[-1] else [None] * num_layers      # (VASNet._wplanes: no re-use across streams)
             blocks = [kernels.bilstm_wplanes({k: v.detach() for k, v in p.items()}, prefix, layer, In if layer == 0 else 2 * H, H, n_planes,
                                              out=old[layer]) for layer in range(num_layers)]
         cache = (key, blocks, [getattr(b, "_sumk_keep", None) if b is not None else None for b in blocks])

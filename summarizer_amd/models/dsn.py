@@ -127,7 +127,7 @@ class DSNTrainer(Trainer):
         key_index = {key: i for i, key in enumerate(my_keys)}
         baselines = torch.zeros(max(len(my_keys), 1), dtype=torch.float64, device=dev)
         last_reward = torch.full((max(len(my_keys), 1),), float("nan"), dtype=torch.float64, device=dev)
-        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        best = self._fold_best()
         E = self.num_episodes
 
         for epoch in range(self.hps.epochs):
@@ -136,7 +136,7 @@ class DSNTrainer(Trainer):
             order = torch.tensor([key_index[k] for k in my_keys], dtype=torch.int64).to(dev) if my_keys else None   # one H2D per epoch
             for step in range(steps_per_epoch):
                 keys = my_keys[step * bv:(step + 1) * bv]
-                self.optimizer.zero_grad()
+                self.optimizer.zero_grad(zeroed_by_step=True)
                 if keys:
                     vids = [self._load_video(k, dev) for k in keys]
                     lens_b = [v[0].shape[0] for v in vids]
@@ -181,18 +181,8 @@ class DSNTrainer(Trainer):
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Reward", epoch_avg_reward, epoch)
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", epoch_avg_loss, epoch)
 
-            if epoch % self.hps.test_every_epochs == 0:
-                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
-                self.model.train()
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/Correlation", avg_corr, epoch)
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_avg", avg_f_score, epoch)
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_max", max_f_score, epoch)
-                best_avg_f_score = max(best_avg_f_score, avg_f_score)
-                best_max_f_score = max(best_max_f_score, max_f_score)
-                if avg_corr > best_corr:
-                    best_corr = avg_corr
-                    self.best_weights = self.model.state_dict()
+            self._evaluate_epoch(fold, epoch, best)
 
         self.draw_scores(fold, dist_scores)
         self.model.tail_grads_ready_event = None
-        return best_corr, best_avg_f_score, best_max_f_score
+        return best[0], best[1], best[2]

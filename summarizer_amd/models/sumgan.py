@@ -374,7 +374,7 @@ class SumGANTrainer(Trainer):
             self.pretrain(fold)
         dev = self._device()
         self.setup_optimizers()
-        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        best = self._fold_best()
         tags = ("Lse", "Ld", "Lc", "D_x", "D_x_hat", "D_x_hat_p")
         for epoch in range(self.hps.epochs):
             log = {t: [] for t in tags}
@@ -393,16 +393,6 @@ class SumGANTrainer(Trainer):
                                                      ("D(x_hat)", "D_x_hat"), ("D(x_hat_p)", "D_x_hat_p"))))
             for t in tags:
                 self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/{t}", means[t], epoch)
-            if epoch % self.hps.test_every_epochs == 0:
-                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
-                self.model.train()
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/Correlation", avg_corr, epoch)
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_avg", avg_f_score, epoch)
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_max", max_f_score, epoch)
-                best_avg_f_score = max(best_avg_f_score, avg_f_score)
-                best_max_f_score = max(best_max_f_score, max_f_score)
-                if avg_corr > best_corr:
-                    best_corr = avg_corr
-                    self.best_weights = self.model.state_dict()
+            self._evaluate_epoch(fold, epoch, best)
         self.draw_scores(fold, dist_scores)
-        return best_corr, best_avg_f_score, best_max_f_score
+        return best[0], best[1], best[2]

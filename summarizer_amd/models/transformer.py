@@ -125,11 +125,12 @@ class Transformer(nn.Module):
         key = tuple(q.data_ptr() for q in ps) + tuple(q._version for q in ps) + (
             kernels.WEIGHTS_EPOCH[0], precision, torch.cuda.current_stream(ps[0].device).cuda_stream if ps[0].is_cuda else 0)
         if getattr(self, "_wpl", None) is None or self._wpl_key != key:
+            same_stream = getattr(self, "_wpl_stream", None) == key[-1]      # (VASNet._wplanes: no re-use across streams)
             with torch.no_grad():
                 self._wpl = kernels.transformer_wplanes({n: q.detach() for n, q in zip(names, ps)}, self.input_size, self.input_size,
-                                                        self.encoder_layers, kernels.PLANES_OF[precision], out=getattr(self, "_wpl_buf", None))
+                                                        self.encoder_layers, kernels.PLANES_OF[precision], out=getattr(self, "_wpl_buf", None) if same_stream else None)
             self._wpl_buf = getattr(self._wpl, "_sumk_keep", None) if self._wpl is not None else None
-            self._wpl_key = key
+            self._wpl_key, self._wpl_stream = key, key[-1]
         return self._wpl
 
 
@@ -167,7 +168,7 @@ class TransformerTrainer(Trainer):
                                   comm_dtype=torch.bfloat16 if getattr(self.model, "precision", "fp32") == "bf16" else None)
         self.optimizer.broadcast()                 # identical weights on every rank: ONE collective over the flat bucket
         my_keys, sizes, steps_per_epoch = plan_shards(train_keys, lambda: [self.dataset[k]["features"].shape[0] for k in train_keys], bv)
-        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        best = self._fold_best()
         packed = self.model.max_length is None
         for epoch in range(self.hps.epochs):
             losses, dist_scores = [], {}
@@ -198,13 +199,6 @@ class TransformerTrainer(Trainer):
             train_avg_loss = float(torch.stack(losses).mean()) if losses else float("nan")
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Loss: {train_avg_loss:.05f}")
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", train_avg_loss, epoch)
-            if epoch % self.hps.test_every_epochs == 0:
-                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
-                self.model.train()
-                for tag, val in (("Correlation", avg_corr), ("F-score_avg", avg_f_score), ("F-score_max", max_f_score)):
-                    self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/{tag}", val, epoch)
-                best_avg_f_score, best_max_f_score = max(best_avg_f_score, avg_f_score), max(best_max_f_score, max_f_score)
-                if avg_corr > best_corr:
-                    best_corr, self.best_weights = avg_corr, self.model.state_dict()
+            self._evaluate_epoch(fold, epoch, best)
         self.draw_scores(fold, dist_scores)
-        return best_corr, best_avg_f_score, best_max_f_score
+        return best[0], best[1], best[2]

@@ -163,11 +163,13 @@ class VASNet(nn.Module):
         _folded; invalidate_folded() drops it too)."""
         key = self._weights_key()
         if getattr(self, "_wpl", None) is None or self._wpl_key != key:
+            # the backing block is re-used only by the stream that built it: kernels another stream has queued may still read the old planes
+            same_stream = getattr(self, "_wpl_stream", None) == key[-1]
             with torch.no_grad():
                 self._wpl = kernels.vasnet_wplanes({k: v.detach() for k, v in self._params().items()}, self.input_size,
-                                                   kernels.PLANES_OF[self.precision], wvo=wvo, out=getattr(self, "_wpl_buf", None))
+                                                   kernels.PLANES_OF[self.precision], wvo=wvo, out=getattr(self, "_wpl_buf", None) if same_stream else None)
             self._wpl_buf = getattr(self._wpl, "_sumk_keep", None) if self._wpl is not None else None
-            self._wpl_key = key
+            self._wpl_key, self._wpl_stream = key, key[-1]
         return self._wpl
 
     def _folded(self):
@@ -207,6 +209,10 @@ def _sinusoid_table(max_length, d):
     tab[:, 0::2] = np.sin(pos / (10000 ** ((2 * i) / d)))
     tab[:, 1::2] = np.cos(pos / (10000 ** ((2 * (i + 1)) / d)))
     return torch.from_numpy(tab)
+
+
+class _NotResident(RuntimeError):
+    """_capture_step: the video's tensors are not kept in the HBM cache, so a captured step could not keep them alive."""
 
 
 class VASNetTrainer(Trainer):
@@ -267,7 +273,7 @@ class VASNetTrainer(Trainer):
         tail_from = self.optimizer.tail_offset(self.model.attention_head_projection.weight) if world > 1 else None
         self.model.tail_grads_ready_event = torch.cuda.Event() if world > 1 else None
 
-        best_corr, best_avg_f_score, best_max_f_score = -1.0, 0.0, 0.0
+        best = self._fold_best()
         use_packed = self.model.max_length is None
         # reference schedule as HIP graphs: one captured step per video, replayed from the second epoch on (class docstring)
         use_graph = (world == 1 and bv == 1 and use_packed and dev.type == "cuda"
@@ -286,17 +292,20 @@ class VASNetTrainer(Trainer):
                         try:
                             ent = graphs[keys[0]] = self._capture_step(keys[0], dev, graph_pool)
                             graph_pool = ent[0].pool()
+                        except _NotResident:        # a video beyond the HBM cache: THIS key steps eagerly from now on (not retried), the others keep their graphs
+                            ent = graphs[keys[0]] = False
                         except Exception as e:      # noqa: BLE001  (a configuration that does not capture keeps the eager loop)
                             self.log.warning(f"HIP graph capture failed ({type(e).__name__}: {e}); training continues eagerly")
                             use_graph, self.model.graph_seed = False, None
                             torch.cuda.synchronize(dev)      # leave no half-finished capture work behind the eager steps
-                    if use_graph:
+                    if use_graph and ent:
                         if not graphs_zeroed:          # the captured steps keep the gradient bucket zero between them (Adam kernel); the
-                            self.optimizer.zero_grad(); graphs_zeroed = True      # first replay after eager steps starts from an explicit one
+                            self.optimizer.zero_grad(zeroed_by_step=True); graphs_zeroed = True      # first replay after eager steps starts from an explicit one
                         ent[0].replay()
+                        kernels.WEIGHTS_EPOCH[0] += 1      # (the replayed Adam kernel changed the weights behind the Python wrappers: weight-derived caches follow)
                         losses.append(ent[1]); dist_scores[keys[0]] = ent[2]
                         continue
-                self.optimizer.zero_grad()
+                self.optimizer.zero_grad(zeroed_by_step=True)
                 if keys:
                     vids = [self._load_video(k, dev) for k in keys]
                     if use_packed:
@@ -330,21 +339,11 @@ class VASNetTrainer(Trainer):
             self.log.info(f"Epoch: {f'{epoch+1}/{self.hps.epochs}':6}   Loss: {train_avg_loss:.05f}")
             self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Train/Loss", train_avg_loss, epoch)
 
-            if epoch % self.hps.test_every_epochs == 0:
-                avg_corr, (avg_f_score, max_f_score) = self.test(fold)
-                self.model.train()
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/Correlation", avg_corr, epoch)
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_avg", avg_f_score, epoch)
-                self.hps.writer.add_scalar(f"{self.dataset_name}/Fold_{fold+1}/Test/F-score_max", max_f_score, epoch)
-                best_avg_f_score = max(best_avg_f_score, avg_f_score)
-                best_max_f_score = max(best_max_f_score, max_f_score)
-                if avg_corr > best_corr:
-                    best_corr = avg_corr
-                    self.best_weights = self.model.state_dict()     # live references, like vasnet.py:233
+            self._evaluate_epoch(fold, epoch, best)
 
         self.draw_scores(fold, dist_scores)
         self.model.graph_seed = None
-        return best_corr, best_avg_f_score, best_max_f_score
+        return best[0], best[1], best[2]
 
     def _single_video_step(self, key, dev, grads_are_zero=False, video=None):
         """One optimiser step on one video (vasnet.py:193-212): (loss, scores) as detached tensors.  grads_are_zero: the captured
@@ -353,7 +352,7 @@ class VASNetTrainer(Trainer):
         seq, target = video if video is not None else self._load_video(key, dev)
         lens_b = [seq.shape[0]]
         if not grads_are_zero:
-            self.optimizer.zero_grad()
+            self.optimizer.zero_grad(zeroed_by_step=True)
         scores = self.model.score_packed(seq, lens_b)
         loss = SegmentMseMeanFunction.apply(scores, target, kernels.SeqBatch.get(lens_b, dev), 1.0)    # one video: the mean over videos is the value itself
         loss.backward(gradient=_k_one(loss))
@@ -374,7 +373,7 @@ class VASNetTrainer(Trainer):
         if (key, str(dev)) not in self._hbm:
             self._load_video(key, dev)
         if (key, str(dev)) not in self._hbm:
-            raise RuntimeError(f"video {key} is not resident in the HBM cache")
+            raise _NotResident(f"video {key} is not resident in the HBM cache")
         video = self._hbm[(key, str(dev))]
         seq = video[0]
         # the outputs live OUTSIDE the shared graph pool (allocated before the capture, written by a copy inside it): tensors a capture

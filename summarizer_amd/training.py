@@ -101,8 +101,8 @@ def predicted_dp_efficiency(kind, precision, world, batch_videos):
 
 def choose_batch_videos(kind, precision, world, shard_videos, target=0.9):
     """Smallest number of videos per rank per step whose PESSIMISTIC predicted efficiency reaches `target`, capped by the rank's shard
-    (extra_params batch_videos=auto).  The default of the trainers stays 1 -- the reference's optimisation schedule scaled out by video,
-    global batch = world -- because the videos per step change the training dynamics, not only the speed."""
+    (extra_params batch_videos=auto; the trainers' default under torch.distributed since round 6).  A single process keeps 1 -- the
+    reference's optimisation schedule -- because the videos per step change the training dynamics, not only the speed."""
     if world <= 1:
         return 1
     for bv in range(1, max(1, shard_videos) + 1):
@@ -112,16 +112,20 @@ def choose_batch_videos(kind, precision, world, shard_videos, target=0.9):
 
 
 def resolve_batch_videos(extra_params, kind, precision, train_keys, log=None):
-    """batch_videos of a trainer run: extra_params["batch_videos"] (an integer, default 1; "auto" = choose_batch_videos).  Under
-    torch.distributed the choice and the predicted efficiency of the step are logged, so that a slow multi-GPU run explains itself."""
+    """batch_videos of a trainer run: extra_params["batch_videos"] = an integer or "auto" (choose_batch_videos).  DEFAULT: 1 in a single
+    process -- the reference's schedule, one optimiser step per video (vasnet.py:193-212) -- and "auto" under torch.distributed (round 6):
+    one video per rank per step is ~0.3 ms of compute against a 21 MB gradient exchange, predicted at 0.68-0.89 weak-scaling efficiency,
+    and that would be the first number a multi-GPU run shows; `batch_videos=1` stays reachable explicitly.  Under torch.distributed the
+    choice and the predicted efficiency of the step are logged, so that a slow multi-GPU run explains itself."""
     rank, world = dist_info()
-    raw = str(extra_params.get("batch_videos", 1))
+    raw = str(extra_params.get("batch_videos", "auto" if world > 1 else 1))
     shard = max(1, -(-len(train_keys) // world))
     bv = choose_batch_videos(kind, precision, world, shard) if raw == "auto" else int(raw)
     if world > 1 and log is not None:
         lo, hi = predicted_dp_efficiency(kind, precision, world, bv)
-        log.info(f"data parallel over {world} ranks: batch_videos={bv} per rank (global batch {bv * world} videos), predicted weak-scaling "
-                 f"efficiency {lo}-{hi} (ring - direct all-reduce; extra_params batch_videos=auto picks the smallest value predicted >= 0.9)")
+        how = "given" if "batch_videos" in extra_params and raw != "auto" else "auto: the smallest value predicted >= 0.9 under the ring estimate, capped by the rank's shard"
+        log.info(f"data parallel over {world} ranks: batch_videos={bv} per rank ({how}; global batch {bv * world} videos), predicted weak-scaling "
+                 f"efficiency {lo}-{hi} (ring - direct all-reduce); extra_params batch_videos=1 keeps the reference's one-video steps")
     return bv
 
 
@@ -224,12 +228,14 @@ class FlatAdam:
         self.comm_dtype = torch.bfloat16 if comm_dtype == torch.bfloat16 else torch.float32
         self._comm = None
 
-    def zero_grad(self):
-        # (a step(zero_grad=True) left the bucket zero inside the Adam kernel: the fill launch of the usual step -> zero_grad -> backward
-        #  order is skipped once; anything else -- a second zero_grad, gradients accumulated meanwhile -- fills as before)
-        if self._zero_by_step:
-            self._zero_by_step = False
-        else:
+    def zero_grad(self, zeroed_by_step=False):
+        """Zero the gradient bucket.  zeroed_by_step=True is the CALLER's statement that nothing has written a gradient since the last
+        step(zero_grad=True) -- the step -> zero_grad -> backward order of the trainers -- in which case the Adam kernel already left the
+        bucket zero and the fill launch is skipped (once; and never while a stream capture is recording: a captured fill must be IN the
+        graph).  Without that statement the bucket is always filled: the optimiser cannot see a backward pass that ran in between."""
+        skip = zeroed_by_step and self._zero_by_step and not torch.cuda.is_current_stream_capturing()
+        self._zero_by_step = False
+        if not skip:
             self.flat_grad.zero_()
         off = 0
         for p in self.params:                      # re-attach views in case something replaced .grad

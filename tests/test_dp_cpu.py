@@ -55,9 +55,9 @@ def test_flat_bucket_allreduce_gloo_world2():
 
 
 def test_dp_schedule_prediction_and_auto_batch_videos():
-    """training.predicted_dp_efficiency / choose_batch_videos / resolve_batch_videos: the trainers keep the reference's
-    one-video-per-step schedule by default (global batch = world), say what it is predicted to cost, and `batch_videos=auto` picks the
-    smallest batch predicted >= 0.9 under the pessimistic (ring) all-reduce estimate, capped by the rank's shard."""
+    """training.predicted_dp_efficiency / choose_batch_videos / resolve_batch_videos: a single process keeps the
+    reference's one-video-per-step schedule; under torch.distributed the trainers say what a step is predicted to cost and default to
+    `batch_videos=auto`: the smallest batch predicted >= 0.9 under the pessimistic (ring) all-reduce estimate, capped by the rank's shard."""
     from summarizer_amd import training as T
     for kind, prec in (("vasnet", "fp32"), ("vasnet", "bf16"), ("dsn", "fp32")):
         prev = 0.0
@@ -77,3 +77,14 @@ def test_dp_schedule_prediction_and_auto_batch_videos():
     assert T.resolve_batch_videos({}, "vasnet", "fp32", list(range(40))) == 1
     assert T.resolve_batch_videos({"batch_videos": "4"}, "vasnet", "fp32", list(range(40))) == 4
     assert T.resolve_batch_videos({"batch_videos": "auto"}, "vasnet", "fp32", list(range(40))) == 1      # single process: nothing to hide
+    # round 6: under torch.distributed the DEFAULT is "auto" (the one-video schedule stays reachable as batch_videos=1)
+    real = T.dist_info
+    T.dist_info = lambda: (0, 8)
+    try:
+        keys = list(range(400))
+        bv = T.resolve_batch_videos({}, "vasnet", "fp32", keys)
+        assert bv > 1 and T.predicted_dp_efficiency("vasnet", "fp32", 8, bv)[0] >= 0.9
+        assert T.resolve_batch_videos({"batch_videos": "1"}, "vasnet", "fp32", keys) == 1
+        assert T.resolve_batch_videos({}, "vasnet", "fp32", list(range(16))) <= 2                     # capped by the rank's shard (16 videos / 8 ranks)
+    finally:
+        T.dist_info = real
