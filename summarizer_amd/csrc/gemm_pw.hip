@@ -431,7 +431,136 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------- long sequences (round 6): V^T planes, softmax -> alpha planes
+// The per-video products of a LONG video (T in the thousands: BASELINE config 5) are big enough to run on gemm_pw_kernel itself, one launch
+// per (video, product): logits = Q K^T from the planes of Q and K (rows of the video, k = D); context = alpha V from the planes of alpha
+// (rows = queries, k = key index) and of V^T (rows = the D columns, k = key index).  Two producers of planes are new:
+
+// fp32 (T x Dm, leading dimension ld) -> KB planes of its TRANSPOSE (rows = the Dm columns, k = t, zero for t in [T, Kp)).
+// One block: 64 output rows (columns d0 ..) x 128 k (rows t0 ..) through an LDS tile; lane = output row writes 16-byte chunks, as split_planes_kernel.
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ src, int T, int Dm, int ld, int Kp, char* __restrict__ dst, int64_t rp16) {
+  __shared__ float tile[128][68];
+  const int tid = threadIdx.x;
+  const int d0 = blockIdx.x * 64, t0 = blockIdx.y * 128;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = tid + 256 * j, tt = i >> 4, c4 = (i & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t0 + tt < T && d0 + c4 < Dm) v = *reinterpret_cast<const float4*>(src + (int64_t)(t0 + tt) * ld + d0 + c4);
+    *reinterpret_cast<float4*>(&tile[tt][c4]) = v;
+  }
+  __syncthreads();
+  const int r = tid & 63, cg = tid >> 6;
+  if (d0 + r >= (int)((Dm + 63) / 64 * 64)) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ch = cg * 4 + q, k = t0 + ch * 8;
+    if (k >= Kp) continue;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { lo[c] = tile[ch * 8 + c][r]; hi[c] = tile[ch * 8 + 4 + c][r]; }
+    u32x2 pa[NP], pb[NP];
+    split4<NP>(lo, pa);
+    split4<NP>(hi, pb);
+    char* const op = dst + ((int64_t)((k >> 4) * NP) * 2 + ((k >> 3) & 1)) * rp16 + (int64_t)(d0 + r) * 16;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<u32x4*>(op + (int64_t)p * 2 * rp16) = u32x4{pa[p].x, pa[p].y, pb[p].x, pb[p].y};
+    }
+  }
+}
+
+// Row softmax of one video's RAW logits E (T x T valid, leading dimension ldE; scale and the masks of vasnet.py:118-128 applied here, as
+// vasnet_softmax_kernel does) -> KB planes of alpha (rows = queries, k = key, zero for keys in [T, Kp)); alpha never exists in fp32.
+// (1) softmax_stats_kernel: one WAVE per row finds {max, sum of exp} in one pass (running maximum with rescaling) -- T / 4 blocks;
+// (2) softmax_split_kernel: one block per (64 rows, 128 keys) tile normalises it into LDS and lane = row writes the 16-byte chunks, as
+//     split_planes_kernel -- (T / 64) x (Kp / 128) blocks.  (A first version did both in one block per 64 rows: 157 blocks of 4 waves for
+//     T = 10 000 -- 2.0 ms per video, a sixth of the step; profiles/r06_stress_x6_first_kernel_stats.csv.)
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ E, int T, int64_t ldE, float scale, int ignore_self, int aperture, float2* __restrict__ stats) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= T) return;
+  const float* e = E + (int64_t)i * ldE;
+  float m = -INFINITY, sum = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float x = masked_logit(e[j], scale, i, j, ignore_self, aperture);
+    if (x > m) { sum = sum * expf(m - x) + 1.f; m = x; }      // (first finite value: sum = 0 x expf(-inf) + 1)
+    else if (x > -INFINITY) sum += expf(x - m);
+  }
+  float M = m;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+  float part = (m > -INFINITY) ? sum * expf(m - M) : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) stats[i] = make_float2(M, part);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void softmax_split_kernel(const float* __restrict__ E, int T, int64_t ldE, int Kp, float scale, int ignore_self, int aperture,
+                                                            const float2* __restrict__ stats, char* __restrict__ dst, int64_t rp16) {
+  __shared__ float tile[64][132];
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 128;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = tid + 256 * j, rr = idx >> 5, c4 = (idx & 31) * 4;
+    const int i = i0 + rr;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < T && c0 + c4 < T) {
+      const float4 x = *reinterpret_cast<const float4*>(E + (int64_t)i * ldE + c0 + c4);      // (ldE % 4 == 0; what columns [T, ldE) hold is masked below)
+      const float xv[4] = {x.x, x.y, x.z, x.w};
+      const float2 st = stats[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c0 + c4 + c < T) v[c] = expf(masked_logit(xv[c], scale, i, c0 + c4 + c, ignore_self, aperture) - st.x) / st.y;     // (an all-masked row: NaN, like torch's softmax)
+    }
+    *reinterpret_cast<float4*>(&tile[rr][c4]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __syncthreads();
+  const int r = tid & 63, cg = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int ch = cg * 4 + q, k = c0 + ch * 8;
+    if (k >= Kp) continue;
+    const float4 lo = *reinterpret_cast<const float4*>(&tile[r][ch * 8]), hi = *reinterpret_cast<const float4*>(&tile[r][ch * 8 + 4]);
+    u32x2 pa[NP], pb[NP];
+    split4<NP>(f32x4{lo.x, lo.y, lo.z, lo.w}, pa);
+    split4<NP>(f32x4{hi.x, hi.y, hi.z, hi.w}, pb);
+    char* const op = dst + ((int64_t)((k >> 4) * NP) * 2 + ((k >> 3) & 1)) * rp16 + (int64_t)(i0 + r) * 16;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<u32x4*>(op + (int64_t)p * 2 * rp16) = u32x4{pa[p].x, pa[p].y, pb[p].x, pb[p].y};
+    }
+  }
+}
+
 }  // namespace
+
+int split_planes_t(const float* src, int T, int Dm, int ld, int np, void* planes, int Kp, hipStream_t stream) {
+  SUMK_ARG(src && planes && T >= 1 && Dm >= 4 && Dm % 4 == 0 && ld >= Dm && ld % 4 == 0 && Kp >= T && Kp % 16 == 0 && (np == 2 || np == 3), "split_planes_t: bad arguments");
+  SUMK_ARG(((uintptr_t)planes & 15) == 0 && ((uintptr_t)src & 15) == 0, "split_planes_t: 16-byte aligned buffers");
+  const int64_t rp = pw_rows_pitch(Dm);
+  const dim3 grid((unsigned)(rp / 64), (unsigned)((Kp + 127) / 128));
+  if (np == 3) hipLaunchKernelGGL(split_planes_t_kernel<3>, grid, dim3(256), 0, stream, src, T, Dm, ld, Kp, (char*)planes, rp * 16);
+  else hipLaunchKernelGGL(split_planes_t_kernel<2>, grid, dim3(256), 0, stream, src, T, Dm, ld, Kp, (char*)planes, rp * 16);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
+
+int softmax_planes(const float* E, int T, int64_t ldE, int np, void* planes, int Kp, float scale, int ignore_self, int aperture, float* stats, hipStream_t stream) {
+  SUMK_ARG(E && planes && stats && T >= 1 && ldE >= T && ldE % 4 == 0 && Kp >= T && Kp % 16 == 0 && (np == 2 || np == 3), "softmax_planes: bad arguments");
+  SUMK_ARG(((uintptr_t)planes & 15) == 0 && ((uintptr_t)E & 15) == 0 && ((uintptr_t)stats & 7) == 0, "softmax_planes: aligned buffers");
+  const int64_t rp = pw_rows_pitch(T);
+  hipLaunchKernelGGL(softmax_stats_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, stream, E, T, ldE, scale, ignore_self, aperture, (float2*)stats);
+  const dim3 grid((unsigned)(rp / 64), (unsigned)((Kp + 127) / 128));
+  if (np == 3) hipLaunchKernelGGL(softmax_split_kernel<3>, grid, dim3(256), 0, stream, E, T, ldE, Kp, scale, ignore_self, aperture, (const float2*)stats, (char*)planes, rp * 16);
+  else hipLaunchKernelGGL(softmax_split_kernel<2>, grid, dim3(256), 0, stream, E, T, ldE, Kp, scale, ignore_self, aperture, (const float2*)stats, (char*)planes, rp * 16);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
+}
 
 int split_planes_at(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t row0, int64_t total_rows, hipStream_t stream) {
   SUMK_ARG(src && planes && rows >= 1 && K >= 16 && K % 16 == 0 && ld >= K && ld % 4 == 0 && (np == 2 || np == 3), "split_planes: bad arguments (K %% 16, ld %% 4, 2 or 3 planes)");
@@ -447,6 +576,18 @@ int split_planes_at(const float* src, int64_t rows, int K, int ld, int np, void*
 }
 int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* planes, hipStream_t stream) {
   return split_planes_at(src, rows, K, ld, np, planes, 0, rows, stream);
+}
+// `rows` rows into a plane array whose pitch was chosen for `pitch_rows` >= rows rows (an operand whose tiles read past its last row):
+// rows up to the next multiple of 64 are written as zeros, the rest of the pitch is left as it is
+int split_planes_pitched(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t pitch_rows, hipStream_t stream) {
+  SUMK_ARG(src && planes && rows >= 1 && pitch_rows >= rows && K >= 16 && K % 16 == 0 && ld >= K && ld % 4 == 0 && (np == 2 || np == 3), "split_planes_pitched: bad arguments");
+  SUMK_ARG(((uintptr_t)planes & 15) == 0 && ((uintptr_t)src & 15) == 0, "split_planes_pitched: 16-byte aligned buffers");
+  const int64_t rp = pw_rows_pitch(pitch_rows);
+  const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((K + 127) / 128));
+  if (np == 3) hipLaunchKernelGGL(split_planes_kernel<3>, grid, dim3(256), 0, stream, src, rows, K, ld, (char*)planes, rp * 16);
+  else hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, stream, src, rows, K, ld, (char*)planes, rp * 16);
+  SUMK_HIP(hipGetLastError());
+  return SUMK_OK;
 }
 
 int launch_gemm_pw(PwEpi epi, const PwLaunch& g, hipStream_t stream) {

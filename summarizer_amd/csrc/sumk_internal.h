@@ -288,6 +288,11 @@ int split_planes(const float* src, int64_t rows, int K, int ld, int np, void* pl
 // the same into rows [row0, row0 + rows) of a plane array built for `total_rows` rows (row0 % 64 == 0; pad rows are written only behind the
 // LAST row of the array): stacking several matrices into one operand ([Wq; Wk; Wv])
 int split_planes_at(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t row0, int64_t total_rows, hipStream_t stream);
+// round 6 (long videos): planes of the TRANSPOSE of an fp32 (T x Dm) matrix (rows = its columns, k = t, zeros for t in [T, Kp)); row softmax
+// of one video's raw logits (T x T valid, masks and scale of vasnet.py:118-128) straight to the planes of alpha (k = key, zeros in [T, Kp))
+int split_planes_pitched(const float* src, int64_t rows, int K, int ld, int np, void* planes, int64_t pitch_rows, hipStream_t stream);
+int split_planes_t(const float* src, int T, int Dm, int ld, int np, void* planes, int Kp, hipStream_t stream);
+int softmax_planes(const float* E, int T, int64_t ldE, int np, void* planes, int Kp, float scale, int ignore_self, int aperture, float* stats /* 2 T floats */, hipStream_t stream);
 enum PwEpi {
   PW_F32 = 0,             // C (fp32, row-major, ldc) = product [+ bias[n]] [+ R[m][n]] [relu]
   PW_PLANES = 1,          // O (KB planes of the (M, N) result: the K-contiguous operand of a later product over N) = product [+ bias[n]] [relu]

@@ -850,6 +850,26 @@ static PwExtra pw_extra(int D, int64_t R, int t_max, int np, size_t base) {
   e.total = p;
   return e;
 }
+// Long videos on planes (round 6; BASELINE config 5): one video at a time -- raw logits E_s (T x Tn fp32, Tn = T rounded up to the plane GEMM's
+// 256-column tile), planes of Q_s, K_s (T x D), of V_s^T (D x Kp) and of alpha_s (T x Kp), Kp = T rounded up to 32 -- behind the regular carve-up.
+constexpr int PW_LONG_TMIN = 1536;       // below this a (T x T) product does not fill the chip with 192 x 256 tiles: the in-loop grouped kernels keep it
+struct PwLong { size_t e, qp, kp, vt, ap, st, total; int tn, kpad; };
+static PwLong pw_long_layout(int D, int t_max, int np, size_t base) {
+  PwLong e; size_t p = align_up(base, 256);
+  auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
+  e.tn = (t_max + 255) / 256 * 256; e.kpad = (t_max + 31) / 32 * 32;
+  e.e = take((size_t)t_max * e.tn * 4);
+  e.qp = take(pw_planes_bytes(e.tn, D, np)); e.kp = take(pw_planes_bytes(e.tn, D, np));          // (rows up to Tn: the logits tile reads K rows up to there)
+  e.vt = take(pw_planes_bytes(D, e.kpad, np)); e.ap = take(pw_planes_bytes(t_max, e.kpad, np));
+  e.st = take((size_t)t_max * 8);                   // {max, sum} per query row
+  e.total = p;
+  return e;
+}
+static bool pw_long_ok(int D, int t_min, int t_max, int np) {
+  if (t_min < PW_LONG_TMIN || D % 256 != 0) return false;
+  const int tn = (t_max + 255) / 256 * 256, kpad = (t_max + 31) / 32 * 32;
+  return pw_ok(t_max, tn, D, tn, tn, np) && pw_ok(t_max, D, kpad, t_max, D, np);
+}
 static bool wplanes_ok(int D, int np) { return D >= 256 && D % 256 == 0 && (np == 2 || np == 3) && pw_ok(256, 3 * (int64_t)D, D, 256, 3 * (int64_t)D, np); }
 
 // one launcher for every LayerNorm call site: picks the register-resident form when the row fits (D <= 2048)
@@ -1389,6 +1409,9 @@ extern "C" size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, cons
     int t_max = 0;
     for (int s = 0; s < n_seq; ++s) t_max = std::max(t_max, seq_off_host[s + 1] - seq_off_host[s]);
     if (w.n_rows >= 256 && attn_pw_ok(t_max, D, w.n_rows, np)) return pw_extra(D, w.n_rows, t_max, np, w.total_core).total;
+    int t_min = t_max;
+    for (int s = 0; s < n_seq; ++s) t_min = std::min(t_min, seq_off_host[s + 1] - seq_off_host[s]);
+    if (w.n_rows >= 256 && pw_long_ok(D, t_min, t_max, np)) return pw_long_layout(D, t_max, np, w.total_core).total;
   }
   return (training && precision == SUMK_PRECISION_BF16) ? w.total : w.total_core;
 }
@@ -1567,6 +1590,38 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
+  // Long videos on planes (round 6): per video, logits and context on the plane GEMM itself; the context leaves as planes (rows of the video inside
+  // the batch's CTX planes), so the output projection below reads them as on the strip path.  SUMK_PW_LONG=0: the in-loop grouped kernels (A/B).
+  int t_min_h = G.t_max;
+  for (int q = 0; q < n_seq; ++q) t_min_h = std::min(t_min_h, seq_off_host[q + 1] - seq_off_host[q]);
+  static const bool pw_long_on = !(getenv("SUMK_PW_LONG") && getenv("SUMK_PW_LONG")[0] == '0');
+  const PwLong pl = (pw && !pw_attn) ? pw_long_layout(D, G.t_max, np, L.total_core) : PwLong();
+  const bool pw_long = pw && !pw_attn && !Wvo && pw_long_on && pw_long_ok(D, t_min_h, G.t_max, np) && workspace_bytes >= pl.total;
+  if (pw_long) {
+    char* const ctxp = ws + L.y0;                       // = pw_ctxp below: planes of the (R x D) context
+    float* const Es = (float*)(ws + pl.e);
+    for (int q = 0; q < n_seq; ++q) {
+      const int r0 = seq_off_host[q], T = seq_off_host[q + 1] - r0;
+      const int Tn = (T + 255) / 256 * 256, Kp = (T + 31) / 32 * 32;
+      // planes of this video's Q and K (the K array has the pitch of Tn rows: the logits tiles read key rows up to there -- whatever they hold lands in
+      // columns [T, Tn) of E, which the softmax never reads as keys)
+      SUMK_TRY(split_planes(QKV + (size_t)r0 * 3 * D, T, D, 3 * D, np, ws + pl.qp, stream));
+      SUMK_TRY(split_planes_pitched(QKV + (size_t)r0 * 3 * D + D, T, D, 3 * D, np, ws + pl.kp, Tn, stream));
+      SUMK_TRY(split_planes_t(QKV + (size_t)r0 * 3 * D + 2 * D, T, D, 3 * D, np, ws + pl.vt, Kp, stream));
+      {  // 2: raw logits  E_s = Q_s K_s^T  (T x Tn, fp32)
+        PwLaunch g; g.A = ws + pl.qp; g.a_rows = T; g.B = ws + pl.kp; g.b_rows = Tn; g.M = T; g.N = Tn; g.K = D; g.np = np;
+        g.C = Es; g.ldc = Tn; g.prof_tag = SUMK_PROF_GEMM_QKT;
+        SUMK_TRY(launch_gemm_pw(PW_F32, g, stream));
+      }
+      // 3: scale, masks, softmax -> planes of alpha_s
+      SUMK_TRY(softmax_planes(Es, T, Tn, np, ws + pl.ap, Kp, opts->scale, opts->ignore_self, opts->aperture, (float*)(ws + pl.st), stream));
+      {  // 4: context rows of this video = alpha_s V_s, straight into the batch's CTX planes
+        PwLaunch g; g.A = ws + pl.ap; g.a_rows = T; g.B = ws + pl.vt; g.b_rows = D; g.M = T; g.N = D; g.K = Kp; g.np = np;
+        g.O = ctxp + (size_t)r0 * 16; g.o_rows = R; g.prof_tag = SUMK_PROF_GEMM_PV;
+        SUMK_TRY(launch_gemm_pw(PW_PLANES, g, stream));
+      }
+    }
+  } else
   if (pw_attn) {
   } else
   if (G.attn_fused) {  // 2-4 in one launch per (video, 64-row strip): logits, softmax (+ dropout), context
@@ -1622,7 +1677,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   float* ln_W1g = Y1 + ln_mom_f;
   float* ln_c1 = ln_W1g + ln_w_f;
   float* ln_stats = ln_c1 + ln_c_f;
-  if (!G.attn_fused && !pw_attn) {  // 4: context
+  if (!G.attn_fused && !pw_attn && !pw_long) {  // 4: context
     GemmLaunch g; g.precision = opts->precision;
     g.A = use_e2 ? E2 : E; g.B[0] = QKV; g.C = Wvo ? Y0 : CTX; g.R = x; g.probs = tabs + TB_PV * n_seq; g.nprob = n_seq; g.small_tile = G.cfg_pv;
     g.total_tiles = G.tiles_pv; g.prof_tag = SUMK_PROF_GEMM_PV;
@@ -1645,7 +1700,7 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     SUMK_HIP(hipGetLastError());
   } else
   if (pw && !Wvo) {  // 5: output projection + residual from planes: CTX is split once, Y0 leaves as planes + per-row moments only
-    if (!pw_attn) SUMK_TRY(split_planes(CTX, R, D, D, np, pw_ctxp, stream));
+    if (!pw_attn && !pw_long) SUMK_TRY(split_planes(CTX, R, D, D, np, pw_ctxp, stream));
     PwLaunch g; g.A = pw_ctxp; g.a_rows = R; g.B = wp + wl.wo; g.b_rows = D; g.M = R; g.N = D; g.K = D; g.np = np;
     g.R = x; g.ldr = D; g.moments = pw_mom; g.O = pw_y0p; g.o_rows = R; g.prof_tag = SUMK_PROF_GEMM_OPROJ;
     SUMK_TRY(launch_gemm_pw(PW_RES_MOM_PLANES, g, stream));

@@ -399,3 +399,62 @@ def test_plane_paths_read_nothing_stale_past_the_last_video(dev, precision):
             assert bool(torch.isfinite(a).all()), (type(m).__name__, lens)
             assert torch.equal(a, b), (type(m).__name__, lens)
 
+
+
+_LONG_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from summarizer_amd.models.vasnet import VASNet
+D = 2048          # (the plane path of the row-wise GEMMs wants the large tiles: R D >= 8.4 M)
+lens = [int(v) for v in sys.argv[2].split(",")]
+torch.manual_seed(77)
+g = torch.Generator().manual_seed(5)
+x = (torch.randn(sum(lens), D, generator=g) * 0.3).to("cuda:0")
+out = {}
+for name, kw in (("plain", {}), ("aperture", dict(attention_aperture=40)), ("noself", dict(ignore_self=True))):
+    torch.manual_seed(77)
+    m = VASNet(input_size=D, **kw).to("cuda:0").eval()
+    for prec in ("fp32", "bf16x6", "bf16x3"):
+        m.precision = prec
+        with torch.no_grad():
+            out[f"{name}_{prec}"] = m.score_packed(x, lens).cpu().numpy()
+            if prec != "fp32":      # the same videos in reverse order (row tiles of the row-wise GEMMs then mix other neighbours)
+                off = np.concatenate([[0], np.cumsum(lens)])
+                xr = torch.cat([x[off[i]:off[i + 1]] for i in reversed(range(len(lens)))])
+                out[f"{name}_{prec}_reversed"] = m.score_packed(xr, lens[::-1]).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_long_videos_on_the_plane_gemm(tmp_path):
+    """Round 6: in bf16x6 / bf16x3 a batch whose videos all have T >= 1536 runs its per-video (T x T) products on the plane GEMM itself
+    (csrc/vasnet.hip `pw_long`: planes of Q_s, K_s, V_s^T per video, raw logits, softmax_planes_kernel -> planes of alpha, context straight
+    into the batch's CTX planes) instead of the in-loop grouped kernels between plane GEMMs (SUMK_PW_LONG=0).  Both are the same arithmetic
+    in other tile shapes and summation orders: scores agree within 5e-6 (three planes) / 5e-5 (two) and stay within the same bounds of
+    exact fp32 -- default attention, a banded mask (`attention_aperture`: the tril * triu == 0 rule) and `ignore_self` -- on ragged
+    lengths (1 600, 2 049, 1 537: none a multiple of the 192 / 256 / 32 tile and pad sizes); the batch in reverse order gives every video the
+    same scores bit for bit (one set of launches per video)."""
+    import os, subprocess, sys
+    lens = [1600, 2049, 1537]
+    out = {}
+    for tag, env in (("inloop", {"SUMK_PW_LONG": "0"}), ("long", {})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _LONG_CHILD, str(f), ",".join(map(str, lens))], env=dict(os.environ, **env),
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    ran_other_kernels = False
+    for name in ("plain", "aperture", "noself"):
+        ref = out["long"][f"{name}_fp32"]
+        assert np.array_equal(ref, out["inloop"][f"{name}_fp32"])
+        for prec, tol in (("bf16x6", 5e-6), ("bf16x3", 5e-5)):
+            a, b = out["long"][f"{name}_{prec}"], out["inloop"][f"{name}_{prec}"]
+            assert np.isfinite(a).all()
+            assert np.abs(a - b).max() < tol, (name, prec, float(np.abs(a - b).max()))
+            assert np.abs(a - ref).max() < 2 * tol, (name, prec, float(np.abs(a - ref).max()))
+            rev, off, offr = out["long"][f"{name}_{prec}_reversed"], np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(lens[::-1])])
+            for i in range(len(lens)):
+                jr = len(lens) - 1 - i
+                assert np.array_equal(rev[offr[jr]:offr[jr + 1]], a[off[i]:off[i + 1]]), (name, prec, i)
+            ran_other_kernels |= not np.array_equal(a, b)
+    assert ran_other_kernels

@@ -228,8 +228,14 @@ def test_vasnet_long_sequence_D2048_vs_oracle(dev):
         np.testing.assert_allclose(y, ref, atol=TOL, rtol=0, err_msg=str(kw))
 
 
-def test_vasnet_full_stress_size_vs_torch_port(dev):
-    """BASELINE config 5 at FULL size against the oracle: ONE (T = 10 000, D = 2048) sequence, default attention and
+_STRESS_REF = {}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "bf16x3"])
+def test_vasnet_full_stress_size_vs_torch_port(dev, precision):
+    """(round 6: parametrised over the arithmetic -- in bf16x6 / bf16x3 a T >= 1536 video runs its (T x T) products on the plane GEMM
+    itself, one launch per product, with the masks applied by csrc/gemm_pw.hip's softmax_planes_kernel; logits gate 5e-2 at two planes.)
+    BASELINE config 5 at FULL size against the oracle: ONE (T = 10 000, D = 2048) sequence, default attention and
     attention_aperture = 64, HIP vs oracle/torch_port (vasnet.py:92-148 op for op, ~5 s of CPU per variant): every score within
     1e-4 (north_star's gate) -- and, because these scores saturate (2e-4 ... 0.9998, where 1e-4 on a score is 0.5 on its logit), the
     PRE-SIGMOID values too: logit(score) in float64 against the port's k2 output within 5e-3 wherever |logit| <= 8 (an fp32 score
@@ -248,15 +254,20 @@ def test_vasnet_full_stress_size_vs_torch_port(dev):
         m = VASNet(input_size=D, **kw)
         m.load_state_dict(base.state_dict())
         m = m.to(dev).eval()
+        m.precision = precision
+        key = tuple(sorted(okw.items()))
         with torch.no_grad():
             y = m(x.to(dev)).cpu().double().reshape(-1)
-            ref, ref_logit = torch_port.vasnet_scores(x, p, return_logits=True, **okw)
+            if key not in _STRESS_REF:                     # (the port's 5 s per variant once for the three arithmetics)
+                _STRESS_REF[key] = torch_port.vasnet_scores(x, p, return_logits=True, **okw)
+            ref, ref_logit = _STRESS_REF[key]
         ref, ref_logit = ref.double().reshape(-1), ref_logit.double().reshape(-1)
         assert float((y - ref).abs().max()) < TOL, (kw, float((y - ref).abs().max()))
         logit = torch.log(y) - torch.log1p(-y)
         sel = ref_logit.abs() <= 8.0
         assert int(sel.sum()) > T // 2, (kw, int(sel.sum()))
-        assert float((logit - ref_logit)[sel].abs().max()) < 5e-3, (kw, float((logit - ref_logit)[sel].abs().max()))
+        gate = 5e-2 if precision == "bf16x3" else 5e-3
+        assert float((logit - ref_logit)[sel].abs().max()) < gate, (kw, precision, float((logit - ref_logit)[sel].abs().max()))
 
 
 def test_vasnet_full_stress_size_properties(dev):
