@@ -2194,6 +2194,7 @@ struct WideBwdArgs {
   const float* whh[2]; const float* dHout; const float* gates; const float* c_all;
   float* dG; float* xchg; const int32_t* off; unsigned* state;
   int32_t n_seq, H, n_groups, KG, NG, n_active, xchg_dir_bytes;
+  int32_t item_words, n_shards;      // round 6: the step counter of an item as n_shards words 32 words apart (lstm_persist_bwd_kernel)
 };
 constexpr int WB_P = 136;   // LDS row pitch of the A tile (floats): 8 lanes x 16 B cover the 32 banks
 
@@ -2201,9 +2202,10 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = a.H, H4 = 4 * H;
   float* sA = smem;                                          // [64 videos][WB_P]  dG_t, this member's 128 gate columns
-  int* sR0 = reinterpret_cast<int*>(sA + 64 * WB_P);         // [64]
-  int* sT = sR0 + 64;                                        // [64]
-  int* sTg = sT + 64;                                        // [1]
+  int* sR0 = reinterpret_cast<int*>(sA + 64 * WB_P);         // [64] first frame row of the video on MFMA row r (rows sorted by length, as lstm_wide2_kernel)
+  int* sT = sR0 + 64;                                        // [64] its length
+  int* sR0u = sT + 64;                                       // [64] the same in batch order (input of the sort)
+  int* sTu = sR0u + 64;
 
   const int d = (blockIdx.x & 7) >> 2;                       // team = direction
   const int slot = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
@@ -2235,17 +2237,23 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a
   for (int g = 0; g < a.n_groups; ++g) {
     const int item = 2 * g + d;
     const int v0 = g * WK_GROUP, nv = min(WK_GROUP, a.n_seq - v0);
-    unsigned* bar = a.state + 16 + item;
-    __syncthreads();
-    if (tid == 0) *sTg = 0;
+    unsigned* bar = a.state + 16 + item * a.item_words;
     __syncthreads();
     if (tid < 64) {
       int r0 = 0, T = 0;
-      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; atomicMax(sTg, T); }
-      sR0[tid] = r0; sT[tid] = T;
+      if (tid < nv) { r0 = a.off[v0 + tid]; T = a.off[v0 + tid + 1] - r0; }
+      sR0u[tid] = r0; sTu[tid] = (T << 6) | (63 - tid);
     }
     __syncthreads();
-    const int Tg = *sTg;
+    if (tid < 64) {     // MFMA row = rank by length, descending; ties by batch index (round 6: the second 32-row tile stops once fewer than 33 videos run)
+      const int key = sTu[tid];
+      int rank = 0;
+#pragma unroll 8
+      for (int q = 0; q < 64; ++q) rank += sTu[q] > key ? 1 : 0;
+      sT[rank] = key >> 6; sR0[rank] = sR0u[tid];
+    }
+    __syncthreads();
+    const int Tg = sT[0], T32 = sT[32];
 
     // cell role: thread = (video ei, unit quad uq): units j..j+3 of this member's 32
     const int ei = tid >> 3, uq = tid & 7;
@@ -2255,29 +2263,39 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a
     float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
     float4 sv_i, sv_f, sv_g, sv_o, sv_c, sv_cp, sv_dh;
     sv_i = sv_f = sv_g = sv_o = sv_c = sv_cp = sv_dh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nx_i = sv_i, nx_f = sv_i, nx_g = sv_i, nx_o = sv_i, nx_c = sv_i, nx_cp = sv_i, nx_dh = sv_i;      // the step after: requested at the TOP of a step (round 6)
     auto fetch = [&](int t) {
       const int64_t row = d == 0 ? er0 + t : er0 + eT - 1 - t;
       const float* gs = a.gates + row * (8 * H) + d * H4 + j;
-      sv_i = *reinterpret_cast<const float4*>(gs); sv_f = *reinterpret_cast<const float4*>(gs + H);
-      sv_g = *reinterpret_cast<const float4*>(gs + 2 * H); sv_o = *reinterpret_cast<const float4*>(gs + 3 * H);
-      sv_c = *reinterpret_cast<const float4*>(a.c_all + row * (2 * H) + d * H + j);
-      sv_cp = t > 0 ? *reinterpret_cast<const float4*>(a.c_all + (d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j)
+      nx_i = *reinterpret_cast<const float4*>(gs); nx_f = *reinterpret_cast<const float4*>(gs + H);
+      nx_g = *reinterpret_cast<const float4*>(gs + 2 * H); nx_o = *reinterpret_cast<const float4*>(gs + 3 * H);
+      nx_c = *reinterpret_cast<const float4*>(a.c_all + row * (2 * H) + d * H + j);
+      nx_cp = t > 0 ? *reinterpret_cast<const float4*>(a.c_all + (d == 0 ? row - 1 : row + 1) * (2 * H) + d * H + j)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
-      sv_dh = *reinterpret_cast<const float4*>(a.dHout + row * (2 * H) + d * H + j);
+      nx_dh = *reinterpret_cast<const float4*>(a.dHout + row * (2 * H) + d * H + j);
     };
-    if (erole && eT == Tg) fetch(Tg - 1);
+    if (erole && eT == Tg) {
+      fetch(Tg - 1);
+      sv_i = nx_i; sv_f = nx_f; sv_g = nx_g; sv_o = nx_o; sv_c = nx_c; sv_cp = nx_cp; sv_dh = nx_dh;
+    }
     const size_t gbase = (size_t)(g & 1) * 2 * slab;
 
     for (int t = Tg - 1; t >= 0; --t) {
+      const bool have_next = erole && t - 1 >= 0 && t - 1 < eT;
+      if (have_next) fetch(t - 1);      // next step's saved activations: the whole step in flight (they used to sit in front of the publish drain)
       if (t < Tg - 1) {
-        if (tid == 0 && !dead) {   // wait until every member published step t+1
-          const unsigned want = (unsigned)(Tg - 1 - t) * (unsigned)a.n_active;
+        if (wave == 0 && !dead) {   // wait until every member published step t+1: lanes 0 .. n_shards-1 poll one shard each
+          const unsigned cnt = (lane < a.n_shards && lane < a.n_active) ? (unsigned)((a.n_active - lane + a.n_shards - 1) / a.n_shards) : 0u;
+          const unsigned want = (unsigned)(Tg - 1 - t) * cnt;
           unsigned spins = 0;
-          while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          while (true) {
+            const unsigned v = lane < a.n_shards ? __hip_atomic_load(bar + 32 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(v >= want)) break;
             __builtin_amdgcn_s_sleep(1);
             if (++spins > PK_SPIN_LIMIT || ((spins & 1023) == 0 &&
                  __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); dead = true; break;
+              if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
+              dead = true; break;
             }
           }
         }
@@ -2309,7 +2327,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a
         float di[4], df[4], dg_[4], do_[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float tc = tanhf(sc[e]);
+          const float tc = fast_tanh(sc[e]);      // (round 6: the forward kernels' v_exp / v_rcp form instead of the library tanhf)
           const float dc = dcarry[e] + dh[e] * so[e] * (1.f - tc * tc);
           di[e] = dc * sg[e] * si[e] * (1.f - si[e]);
           df[e] = dc * scp[e] * sf[e] * (1.f - sf[e]);
@@ -2331,11 +2349,11 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a
         *reinterpret_cast<float4*>(ap) = o_i; *reinterpret_cast<float4*>(ap + 32) = o_f;
         *reinterpret_cast<float4*>(ap + 64) = o_g; *reinterpret_cast<float4*>(ap + 96) = o_o;
       }
-      if (erole && t - 1 >= 0 && t - 1 < eT) fetch(t - 1);   // next step's saved activations, in flight during the MFMAs
+      if (have_next) { sv_i = nx_i; sv_f = nx_f; sv_g = nx_g; sv_o = nx_o; sv_c = nx_c; sv_cp = nx_cp; sv_dh = nx_dh; }
       __syncthreads();
       if (t > 0) {   // partial_kg(t) is only ever read by step t-1
         float* xo = xbase + gbase + (size_t)(t & 1) * slab + (size_t)kg * 64 * H;
-        const int ntile = nv > 32 ? 2 : 1;
+        const int ntile = t < T32 ? 2 : 1;      // rows 32.. hold videos of length <= T32: past that step they publish nothing and nobody reads them
         for (int tile = 0; tile < ntile; ++tile) {
           f32x16 acc;
 #pragma unroll
@@ -2366,7 +2384,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide_bwd_kernel(WideBwdArgs a
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) __hip_atomic_fetch_add(bar + 32 * (slot % a.n_shards), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -2777,6 +2795,11 @@ extern "C" int sumk_bilstm_layer_backward(const float* x, const float* h_out, co
     wa.n_seq = n_seq; wa.H = H; wa.n_groups = (n_seq + WK_GROUP - 1) / WK_GROUP;
     wa.KG = H / 32; wa.NG = (H + 255) / 256; wa.n_active = wa.KG * wa.NG;
     wa.xchg_dir_bytes = (int32_t)(L.xchg_bytes / 2);
+    {   // round 6: sharded step counter while the items fit the state block (SUMK_LSTM_BWD_R6=0: one word per item, as round 5)
+      static const bool r6_on = !(getenv("SUMK_LSTM_BWD_R6") && getenv("SUMK_LSTM_BWD_R6")[0] == '0');
+      const bool shard = r6_on && 2 * wa.n_groups * 128 <= PSTATE_WORDS - 16 - 512;
+      wa.item_words = shard ? 128 : 1; wa.n_shards = shard ? 4 : 1;
+    }
     static bool wb_attr_set = false;
     if (!wb_attr_set) {
       SUMK_HIP(hipFuncSetAttribute((const void*)lstm_wide_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

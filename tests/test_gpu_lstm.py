@@ -355,14 +355,14 @@ def test_dsn_projection_inside_the_recurrence(tmp_path, H, lens):
             np.testing.assert_allclose(out["fused"][prec][off[i]:off[i + 1]], ref, atol=TOL, rtol=0, err_msg=f"{prec} video {i} T={lens[i]}")
 
 
-@pytest.mark.parametrize("H,lens", [(256, [37, 64, 12] * 14), (256, [5, 9, 1, 30] * 35), (40, [50, 1, 33, 7] + [4] * 30)])
+@pytest.mark.parametrize("H,lens", [(256, [37, 64, 12] * 14), (256, [5, 9, 1, 30] * 35), (40, [50, 1, 33, 7] + [4] * 30), (384, [20, 7, 33, 12, 5, 40, 3, 18, 25, 9, 1] * 7)])
 def test_bptt_round6_exchange_equals_round5_exchange(tmp_path, H, lens):
     """Round 6, persistent BPTT (counter hand-off): the exchange of the members' partial products laid out for its READERS
     ([reader][producer][video][8 columns]: the 32 partials a cell-update thread sums come out of one contiguous block) and the step counter
     as four shards on lines of their own -- against the round-5 forms (SUMK_LSTM_BWD_R6=0: producer-major rows, one counter word).  Same
     products, same fixed summation order: scores and EVERY gradient bit for bit, on 42 videos (groups of 11: 16-row MFMAs, 16-byte
-    publish), 140 videos (groups of 32: 32-row MFMAs, scalar publish) and H = 40 (members of 2 units: the round-5 layout stays, the
-    sharded counter does not)."""
+    publish), 140 videos (groups of 32: 32-row MFMAs, scalar publish), H = 40 (members of 2 units: the round-5 layout stays, the
+    sharded counter does not) and H = 384 with 77 videos (lstm_wide_bwd_kernel: two groups per direction, the sharded counter alone)."""
     import os, subprocess, sys
     out = {}
     for tag, env in (("r5", {"SUMK_LSTM_BWD_R6": "0"}), ("r6", {})):
