@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512) void gemm_pw_kernel(PwArgs a) {
               const int kb = (col_w >> 4) + tn * 2 + (g >> 1), h = g & 1;
               char* const op = a.O + ((int64_t)(kb * NP) * 2 + h) * a.o_rp16 + (int64_t)m * 16 + 8 * lh;
 #pragma unroll
-              for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.o_rp16) = pl[p];
+              for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(op + (int64_t)p * 2 * a.o_rp16) = pl[p];      // (non-temporal stores here: measured, no gain -- profiles/r06_pw_nt_stores_probe.txt)
             }
         }
       }
