@@ -88,7 +88,9 @@ typedef struct sumk_vasnet_opts {
      With both given (and D % 256 == 0, n_rows >= 256, no pos_table) the three row-wise GEMMs of the call -- K/Q/V projection, output
      projection, k1 (vasnet.py:114-116,132,138) -- run on the plane-aware wide kernel (csrc/gemm_pw.hip): no fp32 -> bf16 split inside any
      k-loop.  Same arithmetic as without them (the planes are the roundings the in-loop kernels make), faster.  x planes are constant per
-     dataset, weight planes per weight change; stale planes give wrong results, not errors. */
+     dataset, weight planes per weight change; stale planes give wrong results, not errors.  The per-video products follow: T <= 320 on the
+     plane strips (csrc/attn_pw.hip), every video of the batch with T >= 1536 (round 6) as launches of the plane GEMM itself -- both need the
+     larger workspace sumk_vasnet_workspace_bytes_for reports for the precision; anything else keeps the in-loop kernels between plane GEMMs. */
   const void* xplanes;
   const void* wplanes;
 } sumk_vasnet_opts;
@@ -157,8 +159,11 @@ size_t sumk_bilstm_wplanes_bytes(int32_t In, int32_t H, int32_t n_planes);
 int sumk_bilstm_wplanes_build(int32_t In, int32_t H, const sumk_lstm_layer_weights* w, int32_t n_planes, void* out, size_t out_bytes, void* stream);
 
 size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
-/* precision: SUMK_PRECISION_FP32, or SUMK_PRECISION_BF16X3 for the input projection (and, for 256 < H <= 1024, the
- * recurrent product) in the bf16 hi/lo split arithmetic described at sumk_vasnet_opts. */
+/* precision: SUMK_PRECISION_FP32, or SUMK_PRECISION_BF16X3 / SUMK_PRECISION_BF16X6 for the input projection (and, for 256 < H <= 1024, the
+ * recurrent product: inference only for BF16X6) in the split-bf16 arithmetics described at sumk_vasnet_opts.  Round 6: with w->w_planes given
+ * (inference, H <= 256, In = 1024, <= 64 videos) the projection is computed INSIDE the persistent recurrence from x itself -- no G, no GEMM
+ * launch (csrc/lstm.hip, lstm_persist_proj_kernel); x_planes then only serves the fallback.  The workspace of 256 < H <= 1024 holds the
+ * forward recurrence's exchange buffer (1 MB per 64 videos): ask sumk_bilstm_workspace_bytes again after upgrading the library. */
 int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq,
                               const int32_t* seq_off_host, const int32_t* seq_off_dev,
                               const sumk_lstm_layer_weights* w, float* h_out,
