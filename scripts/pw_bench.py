@@ -48,6 +48,13 @@ for (M, N, K) in [(12003, 3072, 1024), (12003, 1024, 1024), (12003, 2048, 1024)]
                 kernels.gemm_planes(ap, M, bp, N, M, N, K, npl, variant=3, out=c)
             torch.cuda.synchronize()
             st_ = c.view(-1)[:256 * 16].cpu().numpy().view(np.uint64).reshape(256, 8)
+            # a grid of fewer than 256 blocks (N = 1024: 252 tiles), or a block whose XCD map names no tile, leaves its slot unwritten -- it then holds
+            # product values, not stamps (round 5's record printed "max 1.38e19", "tiles/block 1-1.38e19", "min clock 32" from such slots): keep the
+            # slots whose fields are mutually consistent (1 <= tiles <= 64, k-loop + epilogue <= total, a wall time that gives 0.5-3 GHz)
+            ok = ((st_[:, 3] >= 1) & (st_[:, 3] <= 64) & (st_[:, 4] > 0) & (st_[:, 1] + st_[:, 2] <= st_[:, 0]) &
+                  (st_[:, 0] > 5 * st_[:, 4]) & (st_[:, 0] < 30 * st_[:, 4]))
+            st_ = st_[ok]
+            print(f"   ({int(ok.sum())} of 256 stamp slots written)")
             tot, loop, epi, nt, rt = (st_[:, i].astype(np.float64) for i in range(5))
             clk = tot / rt * 100.0          # MHz: shader cycles per 100 MHz tick
             steps = nt * (K // 16)
