@@ -55,6 +55,8 @@ for (M, N, K) in [(12003, 3072, 1024), (12003, 1024, 1024), (12003, 2048, 1024)]
                   (st_[:, 0] > 5 * st_[:, 4]) & (st_[:, 0] < 30 * st_[:, 4]))
             st_ = st_[ok]
             print(f"   ({int(ok.sum())} of 256 stamp slots written)")
+            if not ok.any():          # (two planes run on gemm_pw16.hip unless variant 32 is asked for: that kernel carries no stamps)
+                continue
             tot, loop, epi, nt, rt = (st_[:, i].astype(np.float64) for i in range(5))
             clk = tot / rt * 100.0          # MHz: shader cycles per 100 MHz tick
             steps = nt * (K // 16)
