@@ -483,10 +483,27 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restr
   if (i >= T) return;
   const float* e = E + (int64_t)i * ldE;
   float m = -INFINITY, sum = 0.f;
-  for (int j = lane; j < T; j += 64) {
-    const float x = masked_logit(e[j], scale, i, j, ignore_self, aperture);
-    if (x > m) { sum = sum * expf(m - x) + 1.f; m = x; }      // (first finite value: sum = 0 x expf(-inf) + 1)
-    else if (x > -INFINITY) sum += expf(x - m);
+  // sixteen loads in flight per lane (a row of T = 10 000 is 40 KB: one load at a time ran at 2 TB/s), then a block maximum first so that the
+  // running sum is rescaled once per 16 values instead of at every new maximum
+  for (int j0 = 0; j0 < T; j0 += 64 * 16) {
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = j0 + 64 * u + lane;
+      x[u] = j < T ? e[j] : 0.f;
+    }
+    float bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = j0 + 64 * u + lane;
+      x[u] = j < T ? masked_logit(x[u], scale, i, j, ignore_self, aperture) : -INFINITY;
+      bm = fmaxf(bm, x[u]);
+    }
+    if (bm > -INFINITY) {
+      if (bm > m) { sum *= expf(m - bm); m = bm; }            // (m = -inf: sum is 0 and expf(-inf) = 0)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sum += expf(x[u] - m);     // (masked values: expf(-inf) = 0)
+    }
   }
   float M = m;
 #pragma unroll

@@ -853,13 +853,17 @@ static PwExtra pw_extra(int D, int64_t R, int t_max, int np, size_t base) {
 // Long videos on planes (round 6; BASELINE config 5): one video at a time -- raw logits E_s (T x Tn fp32, Tn = T rounded up to the plane GEMM's
 // 256-column tile), planes of Q_s, K_s (T x D), of V_s^T (D x Kp) and of alpha_s (T x Kp), Kp = T rounded up to 32 -- behind the regular carve-up.
 constexpr int PW_LONG_TMIN = 1536;       // below this a (T x T) product does not fill the chip with 192 x 256 tiles: the in-loop grouped kernels keep it
-struct PwLong { size_t e, qp, kp, vt, ap, st, total; int tn, kpad; };
-static PwLong pw_long_layout(int D, int t_max, int np, size_t base) {
+struct PwLong { size_t e, qp, kp, vt, ap, st, qk, total; int tn, kpad, qk_direct; };
+static PwLong pw_long_layout(int D, int64_t R, int t_max, int np, size_t base) {
   PwLong e; size_t p = align_up(base, 256);
   auto take = [&](size_t bytes) { size_t at = p; p += align_up(bytes, 256); return at; };
   e.tn = (t_max + 255) / 256 * 256; e.kpad = (t_max + 31) / 32 * 32;
   e.e = take((size_t)t_max * e.tn * 4);
-  e.qp = take(pw_planes_bytes(e.tn, D, np)); e.kp = take(pw_planes_bytes(e.tn, D, np));          // (rows up to Tn: the logits tile reads K rows up to there)
+  // the planes of [Q | K] of the WHOLE batch straight from the projection's epilogue when that array stays below 2 GiB (every video's Q / K are row ranges of
+  // it); otherwise the projection leaves as fp32 and each video's Q and K are split on their own (qp / kp)
+  e.qk_direct = (R >= e.tn && pw_ok(R, 2 * (int64_t)D, D, R, 3 * (int64_t)D, np) && (int64_t)pw_planes_bytes(R, 2 * D, np) < (((int64_t)1 << 31) - 65536)) ? 1 : 0;      // (R >= Tn: a lone video's logits tiles read key rows up to Tn)
+  e.qk = take(e.qk_direct ? pw_planes_bytes(R, 2 * D, np) : 0);
+  e.qp = take(e.qk_direct ? 0 : pw_planes_bytes(e.tn, D, np)); e.kp = take(e.qk_direct ? 0 : pw_planes_bytes(e.tn, D, np));          // (rows up to Tn: the logits tile reads K rows up to there)
   e.vt = take(pw_planes_bytes(D, e.kpad, np)); e.ap = take(pw_planes_bytes(t_max, e.kpad, np));
   e.st = take((size_t)t_max * 8);                   // {max, sum} per query row
   e.total = p;
@@ -1411,7 +1415,7 @@ extern "C" size_t sumk_vasnet_workspace_bytes_for(int32_t D, int32_t n_seq, cons
     if (w.n_rows >= 256 && attn_pw_ok(t_max, D, w.n_rows, np)) return pw_extra(D, w.n_rows, t_max, np, w.total_core).total;
     int t_min = t_max;
     for (int s = 0; s < n_seq; ++s) t_min = std::min(t_min, seq_off_host[s + 1] - seq_off_host[s]);
-    if (w.n_rows >= 256 && pw_long_ok(D, t_min, t_max, np)) return pw_long_layout(D, t_max, np, w.total_core).total;
+    if (w.n_rows >= 256 && pw_long_ok(D, t_min, t_max, np)) return pw_long_layout(D, w.n_rows, t_max, np, w.total_core).total;
   }
   return (training && precision == SUMK_PRECISION_BF16) ? w.total : w.total_core;
 }
@@ -1557,6 +1561,13 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
   // ... and the per-video attention on planes as well (attn_pw.hip): T <= 320, the extra workspace present (folded path: the context strips add the residual and emit the moments)
   const PwExtra px = pw ? pw_extra(D, R, G.t_max, np, L.total_core) : PwExtra();
   const bool pw_attn = pw && attn_pw_ok(G.t_max, D, R, np) && workspace_bytes >= px.total;
+  // Long videos on planes (round 6): per video, logits and context on the plane GEMM itself; the context leaves as planes (rows of the video inside
+  // the batch's CTX planes), so the output projection below reads them as on the strip path.  SUMK_PW_LONG=0: the in-loop grouped kernels (A/B).
+  int t_min_h = G.t_max;
+  for (int q = 0; q < n_seq; ++q) t_min_h = std::min(t_min_h, seq_off_host[q + 1] - seq_off_host[q]);
+  static const bool pw_long_on = !(getenv("SUMK_PW_LONG") && getenv("SUMK_PW_LONG")[0] == '0');
+  const PwLong pl = (pw && !pw_attn) ? pw_long_layout(D, R, G.t_max, np, L.total_core) : PwLong();
+  const bool pw_long = pw && !pw_attn && !Wvo && pw_long_on && pw_long_ok(D, t_min_h, G.t_max, np) && workspace_bytes >= pl.total;
   if (pw_attn) {  // 1-4: projection -> planes of [Q | K | V]; logits + softmax -> alpha planes; alpha . V -> context planes
     PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
     // the context kernel multiplies V rows up to 31 past the last video's end by alpha = 0: every row up to the pitch is stored (zeros: x's pad rows are
@@ -1575,6 +1586,15 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     }
     prof_end(SUMK_PROF_GEMM_PV, stream);
   } else
+  if (pw_long && pl.qk_direct) {  // 1: [Q | K] straight to planes (every video's Q and K are row ranges of them), V as fp32 (R x D: its transpose is split per video)
+    PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 2 * D; g.K = D; g.np = np;
+    g.O = ws + pl.qk; g.o_rows = R; g.o_store_rows = pw_rows_pitch(R); g.prof_tag = SUMK_PROF_GEMM_QKV;
+    SUMK_HIP(hipMemsetAsync(ws + pl.qk + pw_planes_bytes(R, 2 * D, np) - 8192, 0, 8192, stream));      // the last video's logits tiles read key rows past the array's last sub-array
+    SUMK_TRY(launch_gemm_pw(PW_PLANES, g, stream));
+    PwLaunch gv; gv.A = opts->xplanes; gv.a_rows = R; gv.B = wp + wl.wqkv + (size_t)2 * D * 16; gv.b_rows = 3 * (int64_t)D; gv.M = R; gv.N = D; gv.K = D; gv.np = np;
+    gv.C = QKV; gv.ldc = D; gv.prof_tag = SUMK_PROF_GEMM_QKV;
+    SUMK_TRY(launch_gemm_pw(PW_F32, gv, stream));
+  } else
   if (pw) {  // 1: QKV projection from planes (fp32 output: the per-video products below read it)
     PwLaunch g; g.A = opts->xplanes; g.a_rows = R; g.B = wp + wl.wqkv; g.b_rows = 3 * (int64_t)D; g.M = R; g.N = 3 * D; g.K = D; g.np = np;
     g.C = QKV; g.ldc = 3 * D; g.prof_tag = SUMK_PROF_GEMM_QKV;
@@ -1590,26 +1610,26 @@ static int vasnet_forward_impl(float* x, int32_t D, int32_t n_seq, const int32_t
     if (b16) { to_b16(g, x16, Wqkv16, R, 3 * D, prow, RP_QKV_W); g.C16 = ws + L.qkv16; g.C = nullptr; }
     SUMK_TRY(launch_gemm(GEMM_NT, EPI_NONE, g, stream));
   }
-  // Long videos on planes (round 6): per video, logits and context on the plane GEMM itself; the context leaves as planes (rows of the video inside
-  // the batch's CTX planes), so the output projection below reads them as on the strip path.  SUMK_PW_LONG=0: the in-loop grouped kernels (A/B).
-  int t_min_h = G.t_max;
-  for (int q = 0; q < n_seq; ++q) t_min_h = std::min(t_min_h, seq_off_host[q + 1] - seq_off_host[q]);
-  static const bool pw_long_on = !(getenv("SUMK_PW_LONG") && getenv("SUMK_PW_LONG")[0] == '0');
-  const PwLong pl = (pw && !pw_attn) ? pw_long_layout(D, G.t_max, np, L.total_core) : PwLong();
-  const bool pw_long = pw && !pw_attn && !Wvo && pw_long_on && pw_long_ok(D, t_min_h, G.t_max, np) && workspace_bytes >= pl.total;
   if (pw_long) {
     char* const ctxp = ws + L.y0;                       // = pw_ctxp below: planes of the (R x D) context
     float* const Es = (float*)(ws + pl.e);
     for (int q = 0; q < n_seq; ++q) {
       const int r0 = seq_off_host[q], T = seq_off_host[q + 1] - r0;
       const int Tn = (T + 255) / 256 * 256, Kp = (T + 31) / 32 * 32;
-      // planes of this video's Q and K (the K array has the pitch of Tn rows: the logits tiles read key rows up to there -- whatever they hold lands in
-      // columns [T, Tn) of E, which the softmax never reads as keys)
-      SUMK_TRY(split_planes(QKV + (size_t)r0 * 3 * D, T, D, 3 * D, np, ws + pl.qp, stream));
-      SUMK_TRY(split_planes_pitched(QKV + (size_t)r0 * 3 * D + D, T, D, 3 * D, np, ws + pl.kp, Tn, stream));
-      SUMK_TRY(split_planes_t(QKV + (size_t)r0 * 3 * D + 2 * D, T, D, 3 * D, np, ws + pl.vt, Kp, stream));
+      // planes of this video's Q and K: row ranges of the batch's [Q | K] planes, or split here from the fp32 projection (the K array then has the pitch of
+      // Tn rows).  Either way the logits tiles read key rows up to Tn -- whatever those hold lands in columns [T, Tn) of E, which the softmax never reads as keys
+      const char* qpl; const char* kpl; int64_t qrows, krows;
+      if (pl.qk_direct) {
+        qpl = ws + pl.qk + (size_t)r0 * 16; kpl = ws + pl.qk + (size_t)(D >> 4) * np * 2 * (pw_rows_pitch(R) * 16) + (size_t)r0 * 16; qrows = krows = R;
+        SUMK_TRY(split_planes_t(QKV + (size_t)r0 * D, T, D, D, np, ws + pl.vt, Kp, stream));
+      } else {
+        SUMK_TRY(split_planes(QKV + (size_t)r0 * 3 * D, T, D, 3 * D, np, ws + pl.qp, stream));
+        SUMK_TRY(split_planes_pitched(QKV + (size_t)r0 * 3 * D + D, T, D, 3 * D, np, ws + pl.kp, Tn, stream));
+        SUMK_TRY(split_planes_t(QKV + (size_t)r0 * 3 * D + 2 * D, T, D, 3 * D, np, ws + pl.vt, Kp, stream));
+        qpl = ws + pl.qp; kpl = ws + pl.kp; qrows = T; krows = Tn;
+      }
       {  // 2: raw logits  E_s = Q_s K_s^T  (T x Tn, fp32)
-        PwLaunch g; g.A = ws + pl.qp; g.a_rows = T; g.B = ws + pl.kp; g.b_rows = Tn; g.M = T; g.N = Tn; g.K = D; g.np = np;
+        PwLaunch g; g.A = qpl; g.a_rows = qrows; g.B = kpl; g.b_rows = krows; g.M = T; g.N = Tn; g.K = D; g.np = np;
         g.C = Es; g.ldc = Tn; g.prof_tag = SUMK_PROF_GEMM_QKT;
         SUMK_TRY(launch_gemm_pw(PW_F32, g, stream));
       }
