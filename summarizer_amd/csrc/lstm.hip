@@ -973,7 +973,8 @@ struct PersistProjArgs {
 
 // KA: k32 steps of the projection per wave 0..3 (the waves with the cell update); waves 4..7 take KB = 8 - KA each (4 KA + 4 KB = 32 steps
 // = In = 1024): the cell-update waves have the step's critical chain and only the hand-off latency behind their publish to work in, the
-// others idle from the step's barrier on.  A wave holds its first RF = 12 W_ih fragments (in (k32 step, tile, plane) order) in registers,
+// others idle from the step's barrier on.  (Measured: the symmetric 4 : 4 is the fastest -- 3 : 5, 2 : 6 and 5 : 3 all lose 0.1-0.5 us per step,
+// profiles/r06_dsn_fused_projection_probe.txt -- so PROJ_KA = 4; the parameter stays as the record of that sweep.)  A wave holds its first RF = 12 W_ih fragments (in (k32 step, tile, plane) order) in registers,
 // the rest in LDS.
 template <int NP, int KA>
 __global__ __launch_bounds__(PK_THREADS) void lstm_persist_proj_kernel(PersistProjArgs a) {
