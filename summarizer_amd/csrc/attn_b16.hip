@@ -20,8 +20,8 @@
 //   [0, 41984)        after GEMM-1: P, 64 queries x (320 bf16 + 16 B)   (pitch 41 x 16 B: conflict-free ds_read_b128)
 //   [43008, 141312)   GEMM-2: three stages of [64 keys][256 cols] x 2 B
 //   [147456, 149504)  row-statistic exchange
-// Workgroup ids are dealt round-robin over the 8 XCDs, so id = xcd + 8 k: the strips of one video are given ids of the same residue and
-// its K / V rows (1.3 MB bf16) are fetched into ONE L2 instead of eight.
+// Workgroup ids are dealt round-robin over the 8 XCDs, so id = xcd + 8 k: XCD x takes a contiguous eighth of the flat strip list (locate_block, pw_common.h) --
+// the strips of one video run on one XCD and its K / V rows (1.3 MB bf16) are fetched into ONE L2 instead of eight, and every XCD gets the same number of strips.
 //
 // Where the time goes (T = 320, in-kernel stamps, shader cycles per strip): GEMM-1 33 k, row op 14-18 k, GEMM-2 44 k against 12 k + 10 k of
 // MFMA: an iteration of either product costs ~2,000 cycles whatever the number of tiles in flight (one or two: equal), whichever of the
@@ -30,7 +30,7 @@
 // the fragment reads + MFMAs alone at ~1,200, and the two add instead of overlapping: at 64 query rows per strip a k-tile carries
 // 54 FLOP per staged byte against the ~100 a CU needs to be matrix-bound.  Not tried: 2 x 3 register blocking per wave (-40 % fragment
 // reads), 128-row strips on half the CUs.
-#include "gemm_regstage.h"
+#include "pw_common.h"
 #include <math.h>
 #include <cstdlib>
 #include <atomic>
@@ -54,18 +54,13 @@ constexpr int AT_LDS = AT_RED + 8 * 64 * 4;
 static_assert(AT_ROWS * AT_PP <= AT_ST2 && AT_ST2 + 3 * AT_STAGE2 <= AT_RED && AT_LDS <= 160 * 1024, "LDS map");
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_vptr;
 
 __device__ __forceinline__ u32x2 pack_bf16x4(float a, float b, float c, float d) {
   return __builtin_bit_cast(u32x2, __builtin_convertvector(f32x4v{a, b, c, d}, bf16x4v));
 }
-// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
-// workgroup barrier for LDS traffic alone: unlike __syncthreads() it does not drain the LDS-DMA requests in flight (vmcnt)
-__device__ __forceinline__ void lds_barrier() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_s_barrier(); }
-template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
+// (wait_vm<N>, lds_barrier, u32x2, lds_vptr: pw_common.h)
 
 
 // NJ = T64 / 64 (1 ... 5) is a template parameter, not a run-time bound: with `if (j < nj)` around every fragment read and MFMA the compiler
@@ -366,11 +361,9 @@ __device__ __forceinline__ void attn_strip_body(const AttnStripArgs& a, const Se
 template <bool BWD>
 __global__ __launch_bounds__(512) void attn_strip_kernel(AttnStripArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
-  if (s >= a.n_seq) return;
+  int s, strip;
+  if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AT_ROWS - 1) / AT_ROWS; }, s, strip)) return;      // pw_common.h: every XCD the same number of strips
   const SeqInfo si = a.seq[s];
-  if (strip * AT_ROWS >= si.T) return;
   switch ((si.T + 63) >> 6) {
     case 1: attn_strip_body<BWD, 1>(a, si, strip, lds); break;
     case 2: attn_strip_body<BWD, 2>(a, si, strip, lds); break;

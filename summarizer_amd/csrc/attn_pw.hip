@@ -24,6 +24,9 @@ namespace {
 
 constexpr int AP_ROWS = 64, AP_TMAX = 320;
 
+#ifndef SUMK_CTX_ABL
+#define SUMK_CTX_ABL 0               // kernel B timing probes (WRONG results; variant libraries only, scripts/probes/ctx_wide_ab.sh): 1 no MFMAs, 2 no DMA behind the prologue,
+#endif                               // 4 no fragment reads in the loop, 8 no barriers, 16 no pass epilogue
 #ifndef SUMK_ATTN_NLW
 #define SUMK_ATTN_NLW 8              // waves of a block that issue the LDS-DMA pieces of a stage (probe: scripts/attn_nlw_probe.sh)
 #endif
@@ -40,6 +43,7 @@ struct AttnPwArgs {
   int64_t ap_head_bytes;                   // AP + h * ap_head_bytes; its context lands in columns [h dh, (h + 1) dh).  heads = 1, dh = D: VASNet
   const float* R; int32_t ldr;             // kernel B, folded VASNet path (V = x Wvo^T): context + R is what leaves as planes, with its LayerNorm moments
   float* moments;                          // float2[rows][D / 32] {sum v, sum v^2} per 32-column slot
+  int32_t csplit;                          // kernel B, QT = 4 form: a block owns 128 query rows and 1 / csplit of the 256-column passes
   unsigned long long* stamps;              // diagnostic build: per block {T, prologue, k-loop, row op, total} shader cycles + realtime
 };
 
@@ -111,22 +115,45 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // (key tiles interleaved per plane product: consecutive MFMAs write different accumulators -- see kernel B's mfma_part)
   auto mfma_tiles = [&](const Frags& f, int j_lo, int j_hi) {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      if (j < j_lo || j >= j_hi) continue;
+    for (int sum = NP - 1; sum >= 0; --sum)              // (Q plane i, K plane j2), smallest products first: the order of the NT GEMM Q . K^T
 #pragma unroll
-      for (int sum = NP - 1; sum >= 0; --sum)            // (Q plane i, K plane j2), smallest products first: the order of the NT GEMM Q . K^T
+      for (int i = NP - 1; i >= 0; --i) {
+        const int j2 = sum - i;
+        if (j2 < 0 || j2 >= NP) continue;
 #pragma unroll
-        for (int i = NP - 1; i >= 0; --i) {
-          const int j2 = sum - i;
-          if (j2 < 0 || j2 >= NP) continue;
+        for (int j = 0; j < NTW; ++j) {
+          if (j < j_lo || j >= j_hi) continue;
 #ifdef SUMK_DIAG
           if constexpr (VAR == 3) { asm volatile("" :: "v"(f.k[j2][j]), "v"(f.q[i])); continue; }      // timing probe: DMA + reads + barriers only
 #endif
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[j2][j], f.q[i], acc[j], 0, 0, 0);
         }
-    }
+      }
+  };
+  // the step's MFMAs as two groups of PLANE PRODUCTS (every key tile in each): products [p_lo, p_hi) of the NP (NP + 1) / 2, in the order above
+  constexpr int NPROD = NP * (NP + 1) / 2;
+  auto mfma_prods = [&](const Frags& f, int p_lo, int p_hi) {
+    int pi = 0;
+#pragma unroll
+    for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+      for (int i = NP - 1; i >= 0; --i) {
+        const int j2 = sum - i;
+        if (j2 < 0 || j2 >= NP) continue;
+        const bool on = pi >= p_lo && pi < p_hi;
+        ++pi;
+        if (!on) continue;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+#ifdef SUMK_DIAG
+          if constexpr (VAR == 3) { asm volatile("" :: "v"(f.k[j2][j]), "v"(f.q[i])); continue; }
+#endif
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.k[j2][j], f.q[i], acc[j], 0, 0, 0);
+        }
+      }
   };
 
   const int nk = a.dh >> 4;
@@ -146,6 +173,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
   // MH: ONE fragment set (two blocks per CU need <= 128 VGPRs): all of a step's MFMAs run in front of its barrier, the next fragments are read behind it into
   // the same registers -- the other block's waves cover the read latency
   constexpr int P1 = MH ? NTW : (NTW > 1 ? NTW - 1 : 0);
+  constexpr int PA = MH ? NPROD : (2 * NPROD + 2) / 3;        // products in front of the barrier (two thirds), the rest behind it
   int pend_kb = -1, pend_slot = 0;               // VAR 2: the refill in progress (stage, slot)
   auto kstep = [&](const Frags& cur, Frags& nxt, int s) {
     __builtin_amdgcn_sched_barrier(0);
@@ -158,7 +186,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      mfma_tiles(cur, 0, P1);
+      mfma_prods(cur, 0, PA);
     }
     __builtin_amdgcn_sched_barrier(0);
     const bool more = s + 1 < nk, fill = s + NS < nk;
@@ -173,7 +201,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
       if (VAR == 1 && fill) dma(s + NS, slot);
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfma_tiles(cur, P1, NTW);
+    if constexpr (VAR == 2 && NTW > 1) mfma_tiles(cur, P1, NTW); else mfma_prods(cur, PA, NPROD);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (VAR == 2 && NTW > 1) {
       pend_kb = (more && fill) ? s + NS : -1; pend_slot = slot;
@@ -290,16 +318,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 template <int NP, int VAR>
-__global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
+__global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {       // single head (the multi-head form: attn_pw_logits_mh_kernel)
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int xcd = blockIdx.x & 7;
-  int slot = blockIdx.x >> 3;
-  const int head = slot % a.heads;           // (the heads of one strip are neighbours in the grid: they share the strip's query rows and the video's keys in L2)
-  slot /= a.heads;
-  const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
-  if (s >= a.n_seq) return;
+  const int head = 0;
+  int s, strip;
+  if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AP_ROWS - 1) / AP_ROWS; }, s, strip)) return;      // every XCD the same number of strips
   const SeqInfo si = a.seq[s];
-  if (strip * AP_ROWS >= si.T) return;
   switch ((si.T + 63) >> 6) {
     case 1: attn_logits_body<NP, 1, VAR>(a, si, strip, head, lds); break;
     case 2: attn_logits_body<NP, 2, VAR>(a, si, strip, head, lds); break;
@@ -323,23 +347,36 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {
 // carries both alpha sets (V pieces unchanged: the pass's 256 V columns are those two heads').
 // RM (folded VASNet path): the accumulators start from the residual R[query][column] instead of zero, and a pass also leaves {sum v, sum v^2} of every
 // (query, 32-column slot) -- what the output projection's PW_RES_MOM_PLANES epilogue does on the unfolded path.
-template <int NP, bool HP2, bool RM = false>
+// QT = 4 (round 6): a block owns 128 query rows (four 32-query tiles per wave) and HALF of the 256-column passes (a.csplit = 2) -- the V rows a video's
+// blocks stream through their CUs halve (T / 128 x D instead of T / 64 x D per video) while the block count stays at about one per CU; the stream is what
+// bounds these launches (~35-45 GB/s per CU, MI355X_MICROARCH.md "Indexed rows": the Infinity-Cache rate).  One k16 block per stage in both plane counts.
+template <int NP, bool HP2, bool RM = false, int QT = 2>
 __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
-  constexpr int KH = NP == 3 ? 1 : 2, NS = NP == 3 ? 4 : 3;           // (rings of 5 / 4 stages: measured, no change)
+  constexpr int KH = (NP == 3 || QT == 4) ? 1 : 2, NS = QT == 4 ? (NP == 3 ? 4 : 6) : (NP == 3 ? 4 : 3);           // (rings of 5 / 4 stages: measured, no change)
   constexpr int NSETS = HP2 ? 2 : 1;
-  constexpr int NSUB = 2 * NP, A_SET = KH * NSUB * 1024, A_BYTES = NSETS * A_SET, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
+  constexpr int QR = 32 * QT, QH = QT / 2;                             // query rows per block; 64-row alpha pieces per sub-array
+  constexpr int NSUB = 2 * NP, A_SET = KH * NSUB * QR * 16, A_BYTES = NSETS * A_SET, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
   constexpr int NLW = SUMK_ATTN_NLW;
-  constexpr int NA = NSETS * KH * NSUB, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + NLW - 1) / NLW;
+  constexpr int NA = NSETS * KH * NSUB * QH, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + NLW - 1) / NLW;
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
-  const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
-  const int sv = (bslot / a.strips) * 8 + xcd, strip = bslot - (bslot / a.strips) * a.strips;
-  if (sv >= a.n_seq) return;
+  static_assert(!(HP2 && QT != 2), "the multi-head form keeps 64-query strips");
+  int sv, bsub;
+  if constexpr (QT == 4) {
+    const int cs = a.csplit;
+    if (!locate_block(a.seq, a.n_seq, [cs](int t) { return ((t + QR - 1) / QR) * cs; }, sv, bsub)) return;
+  } else {
+    const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+    sv = (bslot / a.strips) * 8 + xcd; bsub = bslot - (bslot / a.strips) * a.strips;
+    if (sv >= a.n_seq) return;
+  }
+  const int strip = bsub / a.csplit, chalf = bsub - strip * a.csplit;
   const SeqInfo si = a.seq[sv];
-  if (strip * AP_ROWS >= si.T) return;
+  if (strip * QR >= si.T) return;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = si.T, i0 = strip * AP_ROWS, D = a.D;
-  const int nks = (T + 16 * KH - 1) / (16 * KH), NC = D >> 8, n_it = NC * nks;       // (alpha planes hold zeros from T up to T rounded up to 32)
+  const int T = si.T, i0 = strip * QR, D = a.D;
+  const int NC = (D >> 8) / a.csplit, nc0 = chalf * NC;                              // this block's 256-column passes: nc0 ... nc0 + NC - 1
+  const int nks = (T + 16 * KH - 1) / (16 * KH), n_it = NC * nks;       // (alpha planes hold zeros from T up to T rounded up to 32)
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(a.AP, (short)0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.QKV), (short)0, 0x80000000u, 0x00020000);
@@ -352,9 +389,10 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
     pa[i] = idx < NA;
     pset[i] = 0;
     if (pa[i]) {
-      pset[i] = idx / (KH * NSUB);
-      pg[i] = (idx - pset[i] * KH * NSUB) * (int)a.ap_rp16 + (si.row0 + i0) * 16;                       // + ks * KH NSUB ap_rp16 (+ the head's alpha planes)
-      pl[i] = idx * 1024;
+      pset[i] = idx / (KH * NSUB * QH);
+      const int rem = idx - pset[i] * KH * NSUB * QH, sa = rem / QH, qh = rem - sa * QH;               // sub-array (k16 block of the stage, plane, k half), 64-row piece
+      pg[i] = sa * (int)a.ap_rp16 + (si.row0 + i0 + 64 * qh) * 16;                                      // + ks * KH NSUB ap_rp16 (+ the head's alpha planes)
+      pl[i] = pset[i] * A_SET + (sa * QR + 64 * qh) * 16;
     } else {
       const int v = idx - NA, fbp = v / (KH * NP), rem = v - fbp * KH * NP, p = rem / KH, kbh = rem - p * KH;
       pg[i] = (((2 * D) >> 4) + 2 * fbp) * NSUB * (int)a.rp16 + p * 2 * (int)a.rp16 + (si.row0 + 16 * kbh) * 16;      // + nc * 16 NSUB rp16 + ks * 16 KH rows
@@ -367,7 +405,8 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   const int vperm = ((lane >> 3) & 1) * NSUB * (int)a.rp16 + ((lane >> 2) & 1) * (int)a.rp16 + (4 * (lane >> 4) + (lane & 3)) * 16;
   auto dma = [&](int it, int slot) {
     if (!loader) return;
-    const int nc = it / nks, ks = it - nc * nks;
+    if ((SUMK_CTX_ABL & 2) && it >= NS) return;
+    const int ncl = it / nks, ks = it - ncl * nks, nc = nc0 + ncl;
     char* const st = lds + slot * STAGE;
     const int ga = ks * KH * NSUB * (int)a.ap_rp16, gv = nc * 16 * NSUB * (int)a.rp16 + ks * KH * 256;
 #pragma unroll
@@ -379,8 +418,8 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   };
   // fragments of the k16 block kbh of a stage: V plane p (tr reads), alpha plane p of query tile u
   const int fv = A_BYTES + wave * NP * 1024 + (2 * lh) * 256 + ((((lane >> 4) & 1) << 1) | ((lane & 3) >> 1)) * 64 + ((lane & 15) >> 2) * 16 + (lane & 1) * 8;
-  const int fa = (lh * 64 + li) * 16 + (HP2 ? (wave >> 2) * A_SET : 0);
-  struct Frags { bf16x8 v[KH][NP], al[KH][NP][2]; };
+  const int fa = (lh * QR + li) * 16 + (HP2 ? (wave >> 2) * A_SET : 0);
+  struct Frags { bf16x8 v[KH][NP], al[KH][NP][QT]; };
   auto read_frags = [&](int slot, Frags& f) {
     const char* const st = lds + slot * STAGE;
 #pragma unroll
@@ -389,26 +428,36 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
       for (int p = 0; p < NP; ++p) {
         f.v[kbh][p] = tr_frag(st + fv + (kbh * 8 * NP + p) * 1024, 64);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) f.al[kbh][p][u] = *reinterpret_cast<const bf16x8*>(st + fa + ((kbh * NSUB + p * 2) * 64 + u * 32) * 16);
+        for (int u = 0; u < QT; ++u) f.al[kbh][p][u] = *reinterpret_cast<const bf16x8*>(st + fa + ((kbh * NSUB + p * 2) * QR + u * 32) * 16);
       }
   };
-  f32x16 o[2];
-  // the step's MFMAs in two parts around its barrier: part 0 = the first k16 block (KH = 2) or query tile 0 (KH = 1), part 1 = the rest
+  f32x16 o[QT];
+  // the step's MFMAs in two parts around its barrier: part 0 = the first k16 block (KH = 2) or the first half of the plane products (KH = 1), part 1 = the rest
+  // Issue order: inside a part the query tiles are interleaved per plane product -- consecutive MFMAs write different accumulators (measured against tile by
+  // tile, each tile's products in a row: no difference; per accumulator the order of the products is the same either way: same bits).  What the loop's MFMAs cost
+  // by themselves: builds with everything else removed (SUMK_CTX_ABL) run the launch's 1 920 MFMAs per SIMD in ~46 us = 24 ns each, the rate the plane GEMM
+  // sustains as well (1.3 PFLOP/s over the chip) -- profiles/r06_attn_ctx_ablation.txt.
+  constexpr int NPROD = NP * (NP + 1) / 2, PA = (NPROD + 1) / 2;     // KH = 1: part 0 = the first PA plane products of every query tile, part 1 = the rest
   auto mfma_part = [&](const Frags& f, int part) {
 #pragma unroll
-    for (int kbh = 0; kbh < KH; ++kbh)
+    for (int kbh = 0; kbh < KH; ++kbh) {
+      int pi = 0;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if ((KH == 2 ? kbh : u) != part) continue;
+      for (int sum = NP - 1; sum >= 0; --sum)              // (alpha plane i, V plane j), smallest products first: the order of the NN GEMM alpha . V
 #pragma unroll
-        for (int sum = NP - 1; sum >= 0; --sum)            // (alpha plane i, V plane j), smallest products first: the order of the NN GEMM alpha . V
+        for (int i = NP - 1; i >= 0; --i) {
+          const int j = sum - i;
+          if (j < 0 || j >= NP) continue;
+          const int ppart = pi < PA ? 0 : 1;
+          ++pi;
+          if ((KH == 2 ? kbh : ppart) != part) continue;
 #pragma unroll
-          for (int i = NP - 1; i >= 0; --i) {
-            const int j = sum - i;
-            if (j < 0 || j >= NP) continue;
+          for (int u = 0; u < QT; ++u) {
+            if constexpr ((SUMK_CTX_ABL & 1) != 0) { asm volatile("" :: "v"(f.v[kbh][j]), "v"(f.al[kbh][i][u])); continue; }
             o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[kbh][j], f.al[kbh][i][u], o[u], 0, 0, 0);
           }
-      }
+        }
+    }
   };
 
 #pragma unroll
@@ -417,12 +466,12 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   __builtin_amdgcn_s_barrier();
   Frags F0, F1;
   read_frags(0, F0);
-  int slot = 0, ks = 0, nc = 0;
+  int slot = 0, ks = 0, nc = nc0;
   auto init_o = [&](int pass) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < QT; ++u) {
       if constexpr (RM) {
-        if (pass < NC) {
+        if (pass < nc0 + NC) {
           const float* const rp = a.R + (int64_t)(si.row0 + min(i0 + u * 32 + li, T - 1)) * a.ldr + pass * 256 + 32 * wave + 4 * lh;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -436,30 +485,34 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
       }
     }
   };
-  init_o(0);
+  init_o(nc0);
+  // (Tried for the QT = 4 form: the barrier of step `it` publishing stage it + 2, so that the fragments of stage it + 1 are requested at the START of the step,
+  //  under all of its MFMAs, and the slot refilled behind the barrier is stage it + 1's -- same ring, same stages in flight: 97 us against 77 at three planes,
+  //  52 against 45 at two.  profiles/r06_attn_ctx_ablation.txt.)
   auto step = [&](const Frags& cur, Frags& nxt, int it) {
+    const bool more = it + 1 < n_it, fill = it + NS < n_it;
+    const int nslot = slot + 1 == NS ? 0 : slot + 1;
     __builtin_amdgcn_sched_barrier(0);
     mfma_part(cur, 0);
     __builtin_amdgcn_sched_barrier(0);
-    const bool more = it + 1 < n_it, fill = it + NS < n_it;
-    const int nslot = slot + 1 == NS ? 0 : slot + 1;
     if (more) {
       // (the tail, and the step right behind a pass epilogue -- its stores share the counter and retire out of order with the loads --
       //  drain fully)
-      if (it + NS - 1 < n_it && !(ks == 0 && nc > 0)) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
+      if (it + NS - 1 < n_it && !(ks == 0 && nc > nc0)) { if (full) wait_vm<(NS - 2) * MAXP>(); else wait_vm<(NS - 2) * (MAXP - 1)>(); }
       else wait_vm<0>();
       __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave holds every fragment of the stage whose slot is refilled behind the barrier
-      __builtin_amdgcn_s_barrier();
-      read_frags(nslot, nxt);
+      if constexpr ((SUMK_CTX_ABL & 8) == 0) __builtin_amdgcn_s_barrier();
+      if constexpr ((SUMK_CTX_ABL & 4) == 0) read_frags(nslot, nxt);
+      if constexpr ((SUMK_CTX_ABL & 4) != 0) nxt = cur;
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_part(cur, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (more && fill) dma(it + NS, slot);
     slot = nslot;
-    if (++ks == nks) {                        // end of a 256-column pass: o[u][4 g + c] = CTX[query u * 32 + li][nc * 256 + 32 wave + 8 g + 4 lh + c]
+    if ((SUMK_CTX_ABL & 16) ? it + 1 == n_it : ++ks == nks) {                        // end of a 256-column pass: o[u][4 g + c] = CTX[query u * 32 + li][nc * 256 + 32 wave + 8 g + 4 lh + c]
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < QT; ++u) {
         const int q = i0 + u * 32 + li;
         if constexpr (RM) {
           float s1 = 0.f, s2 = 0.f;
@@ -491,13 +544,13 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   }
 }
 
-template <int NP, bool HP2, bool RM = false>
+template <int NP, bool HP2, bool RM = false, int QT = 2>
 __global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  attn_context_body<NP, HP2, RM>(a, lds);
+  attn_context_body<NP, HP2, RM, QT>(a, lds);
 }
 
-std::atomic<uint64_t> g_attr[18];
+std::atomic<uint64_t> g_attr[22];
 constexpr int ATTN_VAR_A = 0;      // the product's schedule variant of the logits kernel (measured: profiles/r05_attn_pw_dma_variants.txt)
 
 template <typename K>
@@ -535,7 +588,7 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
   a.AP = (char*)alpha_planes; a.ap_rp16 = a.rp16; a.CP = nullptr; a.cp_rp16 = 0;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = scale; a.ignore_self = ignore_self; a.aperture = aperture;
   a.heads = heads; a.dh = D / heads; a.ap_head_bytes = heads == 1 ? 0 : (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256);
-  a.R = nullptr; a.ldr = 0; a.moments = nullptr;
+  a.R = nullptr; a.ldr = 0; a.moments = nullptr; a.csplit = 1;
   const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips * heads);
   a.stamps = nullptr;
 #ifdef SUMK_DIAG
@@ -590,10 +643,23 @@ int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, 
   a.QKV = (const char*)qkv_planes; a.rp16 = (uint32_t)(pw_rows_pitch(rows) * 16); a.D = D; a.E = nullptr;
   a.AP = (char*)const_cast<void*>(alpha_planes); a.ap_rp16 = a.rp16; a.CP = (char*)ctx_planes; a.cp_rp16 = a.rp16;
   a.seq = seq; a.n_seq = n_seq; a.strips = (t_max + 63) / 64; a.scale = 0.f; a.ignore_self = 0; a.aperture = -1;
-  const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
   a.heads = heads; a.dh = D / heads; a.ap_head_bytes = heads == 1 ? 0 : (int64_t)align_up(pw_alpha_bytes(rows, t_max, np), 256);
-  a.R = R; a.ldr = ldr; a.moments = moments;
+  a.R = R; a.ldr = ldr; a.moments = moments; a.csplit = 1;
   constexpr int LDS3 = 4 * (6 + 24) * 1024, LDS2 = 3 * (8 + 32) * 1024, LDS3H = 4 * (12 + 24) * 1024, LDS2H = 3 * (16 + 32) * 1024;
+  // single head, D a whole number of 512-column halves: 128-query blocks x half the columns (SUMK_ATTN_WIDE=0: the 64-query strips, A/B)
+  static const bool wide_on = !(getenv("SUMK_ATTN_WIDE") && getenv("SUMK_ATTN_WIDE")[0] == '0');
+  if (heads == 1 && wide_on && D % 512 == 0) {
+    a.strips = (t_max + 127) / 128; a.csplit = 2;
+    const unsigned gridw = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips * a.csplit);
+    constexpr int LDS3W = 4 * (12 + 24) * 1024, LDS2W = 6 * (8 + 16) * 1024;
+#define SUMK_B_WIDE(NP_, RM_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<NP_, false, RM_, 4>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_context_kernel<NP_, false, RM_, 4>), dim3(gridw), dim3(512), LDS_, stream, a); }
+    if (R) { if (np == 3) SUMK_B_WIDE(3, true, LDS3W, 18) else SUMK_B_WIDE(2, true, LDS2W, 19) }
+    else { if (np == 3) SUMK_B_WIDE(3, false, LDS3W, 20) else SUMK_B_WIDE(2, false, LDS2W, 21) }
+#undef SUMK_B_WIDE
+    SUMK_HIP(hipGetLastError());
+    return SUMK_OK;
+  }
+  const unsigned grid = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips);
   if (heads > 1) {
     if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<3, true>, 12, LDS3H)); hipLaunchKernelGGL((attn_pw_context_kernel<3, true>), dim3(grid), dim3(512), LDS3H, stream, a); }
     else { SUMK_TRY(set_lds_once(attn_pw_context_kernel<2, true>, 13, LDS2H)); hipLaunchKernelGGL((attn_pw_context_kernel<2, true>), dim3(grid), dim3(512), LDS2H, stream, a); }

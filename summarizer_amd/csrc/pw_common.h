@@ -23,6 +23,43 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NP]) {
   }
 }
 
+// Which (video, sub-block) a workgroup owns, from the FLAT list of real blocks (videos in order, blocks_of(T) entries each): the hardware deals workgroup
+// ids round-robin over the 8 XCDs, so XCD x = id % 8 takes the contiguous range [x G, (x + 1) G) of the list, G = ceil(total / 8) -- every XCD gets the
+// same number of blocks (+- 1) whatever the videos' lengths, and a video's blocks still share an L2.  (Dealing whole VIDEOS round-robin, id % 8 = video % 8,
+// gave one XCD 34 blocks for its 32 CUs on the S-TVSum batch at 128-query blocks: a second round on that XCD, the launch twice as long.)
+// Every wave computes the same answer: 64 videos per step, one per lane, an inclusive scan by shuffles.
+template <typename F>
+__device__ __forceinline__ bool locate_block(const SeqInfo* seq, int n_seq, F blocks_of, int& sv, int& sub) {
+  const int lane = threadIdx.x & 63;
+  auto scan = [&](int v0, int& cnt) {
+    const int v = v0 + lane;
+    cnt = v < n_seq ? blocks_of(seq[v].T) : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    return inc;
+  };
+  int total = 0, cnt;
+  // (every shuffled value below is wave-uniform by construction; readfirstlane says so to the compiler, which otherwise treats the loop exits -- and with
+  //  them every address the caller derives from sv / sub -- as divergent: waterfall loops around each LDS-DMA instruction)
+  for (int v0 = 0; v0 < n_seq; v0 += 64) total += __builtin_amdgcn_readfirstlane(__shfl(scan(v0, cnt), 63));
+  const int G = (total + 7) >> 3, slot = blockIdx.x >> 3;
+  const int L = (blockIdx.x & 7) * G + slot;
+  if (slot >= G || L >= total) return false;
+  int base = 0;
+  for (int v0 = 0; v0 < n_seq; v0 += 64) {
+    const int inc = scan(v0, cnt), tot = __builtin_amdgcn_readfirstlane(__shfl(inc, 63));
+    if (L < base + tot) {
+      const int first = __ffsll((unsigned long long)__ballot(base + inc > L)) - 1;
+      sv = __builtin_amdgcn_readfirstlane(v0 + first);
+      sub = __builtin_amdgcn_readfirstlane(L - base - __shfl(inc - cnt, first));
+      return true;
+    }
+    base += tot;
+  }
+  return false;
+}
+
 // kernel arguments of the plane GEMMs (gemm_pw.hip: 32x32x16 MFMA; gemm_pw16.hip: 16x16x32 MFMA, two planes)
 struct PwArgs {
   const char* A; const char* B;
