@@ -1,7 +1,7 @@
 // Per-video attention of the split-bf16 scoring path on operand planes (SUMK_PRECISION_BF16X6 / BF16X3 inference, T <= 320 keys):
 // reference summarizer/models/vasnet.py:118-131 (logits = Q K^T * scale, masks, softmax over keys, context = alpha V).
 //
-// Two launches, both one workgroup per (video, 64 query rows), both reading the K / Q / V PLANES the projection GEMM's epilogue wrote
+// Two launches -- A one workgroup per (video, 64 query rows), B one per (video, 128 query rows, half of the columns) since round 6 -- both reading the K / Q / V PLANES the projection GEMM's epilogue wrote
 // (gemm_pw.hip, PW_PLANES: "KB planes" of the (R x 3D) matrix [Q | K | V]) -- nothing is split on the vector ALU inside a k-loop:
 //   A  attn_pw_logits_kernel : S^T[key][query] = K . Q^T over D (NT, both operands K-contiguous planes), masked softmax in registers (the
 //      transposed product leaves 4 consecutive keys of ONE query per lane register quad), alpha split into planes in registers and
@@ -300,14 +300,11 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
 template <int NP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_pw_logits_mh_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int xcd = blockIdx.x & 7;
-  int slot = blockIdx.x >> 3;
-  const int head = slot % a.heads;           // (the heads of one strip are neighbours in the grid: they share the strip's query rows and the video's keys in L2)
-  slot /= a.heads;
-  const int s = (slot / a.strips) * 8 + xcd, strip = slot - (slot / a.strips) * a.strips;
-  if (s >= a.n_seq) return;
+  int s, sub;
+  const int nh = a.heads;
+  if (!locate_block(a.seq, a.n_seq, [nh](int t) { return ((t + AP_ROWS - 1) / AP_ROWS) * nh; }, s, sub)) return;
+  const int strip = sub / nh, head = sub - strip * nh;      // (the heads of one strip are neighbours in the list: they share the strip's query rows and the video's keys in L2)
   const SeqInfo si = a.seq[s];
-  if (strip * AP_ROWS >= si.T) return;
   switch ((si.T + 63) >> 6) {
     case 1: attn_logits_body<NP, 1, 0, true>(a, si, strip, head, lds); break;
     case 2: attn_logits_body<NP, 2, 0, true>(a, si, strip, head, lds); break;
@@ -334,7 +331,7 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {    
 }
 
 // ------------------------------------------------------------------------------------------------ B: context = alpha . V
-// EIGHT waves; per pass of 256 output columns wave w owns columns 32 w + [0, 32) for both 32-query tiles.  A stage holds KH k16 blocks of keys
+// EIGHT waves; per pass of 256 output columns wave w owns columns 32 w + [0, 32) for every 32-query tile of the block (QT = 2 or 4 tiles).  A stage holds KH k16 blocks of keys
 // (three planes: one block, a ring of four 30-KB stages; two planes: two blocks, a ring of three 40-KB stages -- with 60-KB stages only two
 // fit and every step waited for its own refill: 107 us instead of ~70 at bf16x6):
 //   alpha: KH k16 blocks x NSUB sub-arrays x 64 query rows x 16 B (plain 1-KiB pieces);
@@ -352,26 +349,18 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {    
 // bounds these launches (~35-45 GB/s per CU, MI355X_MICROARCH.md "Indexed rows": the Infinity-Cache rate).  One k16 block per stage in both plane counts.
 template <int NP, bool HP2, bool RM = false, int QT = 2>
 __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* const lds) {
-  constexpr int KH = (NP == 3 || QT == 4) ? 1 : 2, NS = QT == 4 ? (NP == 3 ? 4 : 6) : (NP == 3 ? 4 : 3);           // (rings of 5 / 4 stages: measured, no change)
+  constexpr int KH = (NP == 3 || QT == 4) ? 1 : 2, NS = QT == 4 ? (NP == 3 ? (HP2 ? 3 : 4) : (HP2 ? 4 : 6)) : (NP == 3 ? 4 : 3);           // (rings of 5 / 4 stages: measured, no change)
   constexpr int NSETS = HP2 ? 2 : 1;
   constexpr int QR = 32 * QT, QH = QT / 2;                             // query rows per block; 64-row alpha pieces per sub-array
   constexpr int NSUB = 2 * NP, A_SET = KH * NSUB * QR * 16, A_BYTES = NSETS * A_SET, V_BYTES = KH * 8 * NP * 1024, STAGE = A_BYTES + V_BYTES;
   constexpr int NLW = SUMK_ATTN_NLW;
   constexpr int NA = NSETS * KH * NSUB * QH, NV = KH * 8 * NP, NPIECE = NA + NV, MAXP = (NPIECE + NLW - 1) / NLW;
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
-  static_assert(!(HP2 && QT != 2), "the multi-head form keeps 64-query strips");
   int sv, bsub;
-  if constexpr (QT == 4) {
-    const int cs = a.csplit;
-    if (!locate_block(a.seq, a.n_seq, [cs](int t) { return ((t + QR - 1) / QR) * cs; }, sv, bsub)) return;
-  } else {
-    const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3;
-    sv = (bslot / a.strips) * 8 + xcd; bsub = bslot - (bslot / a.strips) * a.strips;
-    if (sv >= a.n_seq) return;
-  }
-  const int strip = bsub / a.csplit, chalf = bsub - strip * a.csplit;
+  const int cs = a.csplit;
+  if (!locate_block(a.seq, a.n_seq, [cs](int t) { return ((t + QR - 1) / QR) * cs; }, sv, bsub)) return;       // pw_common.h: every XCD the same number of blocks
+  const int strip = bsub / cs, chalf = bsub - strip * cs;
   const SeqInfo si = a.seq[sv];
-  if (strip * QR >= si.T) return;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = si.T, i0 = strip * QR, D = a.D;
@@ -550,7 +539,7 @@ __global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
   attn_context_body<NP, HP2, RM, QT>(a, lds);
 }
 
-std::atomic<uint64_t> g_attr[22];
+std::atomic<uint64_t> g_attr[24];
 constexpr int ATTN_VAR_A = 0;      // the product's schedule variant of the logits kernel (measured: profiles/r05_attn_pw_dma_variants.txt)
 
 template <typename K>
@@ -648,13 +637,14 @@ int launch_attn_pw_context(int np, const void* qkv_planes, int64_t rows, int D, 
   constexpr int LDS3 = 4 * (6 + 24) * 1024, LDS2 = 3 * (8 + 32) * 1024, LDS3H = 4 * (12 + 24) * 1024, LDS2H = 3 * (16 + 32) * 1024;
   // single head, D a whole number of 512-column halves: 128-query blocks x half the columns (SUMK_ATTN_WIDE=0: the 64-query strips, A/B)
   static const bool wide_on = !(getenv("SUMK_ATTN_WIDE") && getenv("SUMK_ATTN_WIDE")[0] == '0');
-  if (heads == 1 && wide_on && D % 512 == 0) {
+  if (wide_on && D % 512 == 0) {
     a.strips = (t_max + 127) / 128; a.csplit = 2;
     const unsigned gridw = (unsigned)(8 * ((n_seq + 7) / 8) * a.strips * a.csplit);
-    constexpr int LDS3W = 4 * (12 + 24) * 1024, LDS2W = 6 * (8 + 16) * 1024;
-#define SUMK_B_WIDE(NP_, RM_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<NP_, false, RM_, 4>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_context_kernel<NP_, false, RM_, 4>), dim3(gridw), dim3(512), LDS_, stream, a); }
-    if (R) { if (np == 3) SUMK_B_WIDE(3, true, LDS3W, 18) else SUMK_B_WIDE(2, true, LDS2W, 19) }
-    else { if (np == 3) SUMK_B_WIDE(3, false, LDS3W, 20) else SUMK_B_WIDE(2, false, LDS2W, 21) }
+    constexpr int LDS3W = 4 * (12 + 24) * 1024, LDS2W = 6 * (8 + 16) * 1024, LDS3WH = 3 * (24 + 24) * 1024, LDS2WH = 4 * (16 + 16) * 1024;
+#define SUMK_B_WIDE(NP_, HP_, RM_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_context_kernel<NP_, HP_, RM_, 4>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_context_kernel<NP_, HP_, RM_, 4>), dim3(gridw), dim3(512), LDS_, stream, a); }
+    if (heads > 1) { if (np == 3) SUMK_B_WIDE(3, true, false, LDS3WH, 22) else SUMK_B_WIDE(2, true, false, LDS2WH, 23) }
+    else if (R) { if (np == 3) SUMK_B_WIDE(3, false, true, LDS3W, 18) else SUMK_B_WIDE(2, false, true, LDS2W, 19) }
+    else { if (np == 3) SUMK_B_WIDE(3, false, false, LDS3W, 20) else SUMK_B_WIDE(2, false, false, LDS2W, 21) }
 #undef SUMK_B_WIDE
     SUMK_HIP(hipGetLastError());
     return SUMK_OK;
