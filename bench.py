@@ -163,6 +163,9 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16
                                note=f"algorithmic fp32 FLOP of the product; the kernel issues {int(mf)} dense bf16 MFMA FLOP per algorithmic FLOP, so the "
                                     f"ceiling is the 2.5 PFLOP/s bf16 peak / {int(mf)}.  The chip holds ~1.7 GHz (not 2.4) under this load (in-kernel "
                                     "s_memtime / s_memrealtime stamps, profiles/r05_pw_stamps.txt): PMC passes under profiles/r06_pmc_pw_*")
+        sus = mfma_sustained()
+        if sus:
+            rec["roofline"]["frac_of_sustained"] = round(fl / us / 1e6 / (sus["bf16_16x16x32" if precision == "bf16x3" else "bf16_32x32x16"] / mf), 4)
         # `traffic` as the headline's: from separate rocprofv3 --pmc passes of THIS launch (scripts/pmc_pass.sh + pmc_to_json.py), kept under profiles/
         tp = os.path.join(ROOT, "profiles", f"r06_pmc_pw_{'x3' if precision == 'bf16x3' else 'x6'}_qkv.json")
         if os.path.exists(tp) and frames == 12003 and D == 1024:
@@ -170,6 +173,29 @@ def alt_precision_leg(model, x, lens, ref_scores, steps, frames, precision="bf16
             rec["roofline"]["traffic"] = pmc.get("gemm_qkv_hbm_bytes_per_launch")
             rec["roofline"]["traffic_source"] = f"static: profiles/{os.path.basename(tp)} ({pmc.get('kernel', '')[:70]}; algorithmic {pmc.get('algorithmic_bytes_per_launch')} B)"
     return rec
+
+
+_SUSTAINED = None
+
+
+def mfma_sustained():
+    """The matrix-pipe rate THIS box sustains with nothing but MFMAs in flight (csrc/mfma_probe.hip; ~3 ms per kind, outside every timed region): the
+    practical ceiling of an MFMA-bound launch here.  `peak` in the roofline objects stays the guide's figure; `frac_of_sustained` is against this one."""
+    global _SUSTAINED
+    if _SUSTAINED is None:
+        from summarizer_amd import kernels as _k
+        try:
+            kinds = (("bf16_32x32x16", "bf16"), ("bf16_16x16x32", "bf16_16"), ("f32_32x32x2", "f32"))
+            r = {name: round(_k.mfma_sustained_rate(kind, 8000, True)[0], 1) for name, kind in kinds}
+            r["constant_operands"] = {name: round(_k.mfma_sustained_rate(kind, 8000, False)[0], 1) for name, kind in kinds}
+            r.update(unit="TFLOP/s", note="measured live: one 512-thread workgroup per CU issuing only MFMAs (4 independent accumulators per wave, no memory traffic), "
+                                          "8 000 x 16 MFMAs per wave, every MFMA of an iteration on its own pseudo-random operand registers (`constant_operands`: one constant "
+                                          "pair feeding all of them -- the chip clocks higher when the operand buses do not toggle); the guide's dense peaks are 2500 (bf16) "
+                                          "and 157.3 (f32) TFLOP/s at 2.4 GHz")
+            _SUSTAINED = r
+        except Exception as e:          # noqa: BLE001
+            _SUSTAINED = dict(error=f"{type(e).__name__}: {e}"[:200])
+    return _SUSTAINED if "error" not in _SUSTAINED else None
 
 
 def folded_leg(model, x, lens, ref_scores, steps, frames, precision="fp32"):
@@ -1054,6 +1080,13 @@ def main():
                    roofline=roof)
         if graph is not None:
             out["config"]["hip_graph"] = "step captured once, timed region = graph replays"
+        sus = mfma_sustained()
+        if sus:
+            out["mfma_sustained"] = sus
+            if roof and roof.get("bound") == "mfma":
+                key = "f32_32x32x2" if args.precision == "fp32" else "bf16_32x32x16"
+                div = {"fp32": 1.0, "bf16": 1.0, "bf16x3": 3.0, "bf16x6": 6.0}[args.precision]
+                roof["frac_of_sustained"] = round(roof["achieved"] / (sus[key] / div), 4)
         if step_ms is not None:
             out["step_ms_device_events"] = step_ms
         if kern:

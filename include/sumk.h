@@ -537,6 +537,14 @@ int sumk_prof_read(int32_t tag, double* total_ms, int64_t* launches, int32_t res
  * {whole block, k-loops, epilogues, tiles}; synchronises the device.  Returns SUMK_ERR_ARG when stamping is off. */
 int sumk_prof_gemm_stamps(uint64_t* out, int32_t n_blocks);
 
+/* Measurement utility (no reference counterpart; bench.py's `mfma_sustained`): the rate the matrix pipes of the current device SUSTAIN with nothing but
+ * MFMAs in flight -- one workgroup of eight waves per CU, four independent accumulators per wave, operands in registers, no memory traffic.  One warm-up
+ * launch, one timed launch of `iters` x 16 MFMAs per wave (HIP events on `stream`; synchronises).  kind 0: v_mfma_f32_32x32x16_bf16, 1:
+ * v_mfma_f32_32x32x2_f32, 2: v_mfma_f32_16x16x32_bf16; + 4: every MFMA of an iteration reads its own pseudo-random operand registers (the operand buses
+ * toggle as under real data: the rate a real kernel can hope for) instead of one constant pair.  *tflops = dense TFLOP/s over the whole chip, *seconds
+ * (may be null) = the timed launch. */
+int sumk_probe_mfma_rate(int32_t kind, int32_t iters, double* tflops, double* seconds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,7 @@ _SIGS = {
     "sumk_eval_videos": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32]),
     "sumk_prof_enable": (C.c_int, [C.c_int32]),
     "sumk_prof_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+    "sumk_probe_mfma_rate": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "sumk_prof_gemm_stamps": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
 }
 

@@ -382,6 +382,15 @@ def health_check():
     _lib.check(_lib.load().sumk_health_check(_stream()), "sumk_health_check")
 
 
+def mfma_sustained_rate(kind="bf16", iters=4000, random_operands=False):
+    """Measurement utility: dense TFLOP/s the current device sustains with nothing but MFMAs in flight (csrc/mfma_probe.hip) -- the practical ceiling of
+    an MFMA-bound launch on THIS box, beside the guide's peak.  kind: "bf16" (32x32x16), "f32" (32x32x2), "bf16_16" (16x16x32).  Returns (tflops, seconds)."""
+    code = {"bf16": 0, "f32": 1, "bf16_16": 2}[kind] + (4 if random_operands else 0)
+    t, sec = C.c_double(0.0), C.c_double(0.0)
+    _lib.check(_lib.load().sumk_probe_mfma_rate(code, int(iters), C.byref(t), C.byref(sec), _stream()), "sumk_probe_mfma_rate")
+    return t.value, sec.value
+
+
 def frame_head_forward(h, w, b):
     """scores = sigmoid(h @ w.T + b) for h (n_rows, F), w (1, F) or (F,), b (1,)."""
     lib = _lib.load()

@@ -271,3 +271,19 @@ def test_training_step_is_hip_graph_capturable_and_replays_advance_adam(monkeypa
     assert int(ob._state[0]) == 4                                             # the device-side step counter followed the replays
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert torch.equal(pa, pb), k
+
+
+def test_mfma_rate_probe_is_plausible_and_refuses_bad_arguments():
+    """csrc/mfma_probe.hip (bench.py's `mfma_sustained`): the three MFMA kinds land between a tenth of and slightly above the guide's dense peaks (2 500
+    TFLOP/s bf16, 157.3 f32), and a longer run gives the same rate (the figure is a rate, not a launch-overhead artefact)."""
+    from summarizer_amd import _lib, kernels
+    lib = _lib.load()
+    for rnd in (False, True):
+        for kind, peak in (("bf16", 2500.0), ("bf16_16", 2500.0), ("f32", 157.3)):
+            t1, s1 = kernels.mfma_sustained_rate(kind, 2000, rnd)
+            t2, s2 = kernels.mfma_sustained_rate(kind, 8000, rnd)
+            assert 0.1 * peak < t1 < 1.05 * peak and 0.1 * peak < t2 < 1.05 * peak, (kind, rnd, t1, t2)
+            assert abs(t1 - t2) < 0.25 * t2 and s2 > 2.5 * s1, (kind, rnd, t1, t2, s1, s2)
+    t = C.c_double(0)
+    assert lib.sumk_probe_mfma_rate(7, 10, C.byref(t), None, None) == -1
+    assert lib.sumk_probe_mfma_rate(0, 0, C.byref(t), None, None) == -1
