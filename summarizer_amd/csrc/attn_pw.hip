@@ -54,7 +54,10 @@ struct AttnPwArgs {
 // rows; NS stages in a ring, ONE barrier per step behind all but the last key tile's MFMAs (gemm_pw.hip's loop).
 // VAR (when a wave issues the DMA pieces that refill the slot a barrier freed): 0 = after the step's last MFMAs, 1 = right behind the
 // barrier, 2 = spread: a share behind every key tile's MFMAs, from the step's last tile through the next step's tiles in front of the barrier.
-template <int NP, int NJ, int VAR, bool MH = false>
+// NT: the K / Q loads carry the non-temporal policy.  Chosen by the host when the [Q | K | V] planes are larger than ~3/4 of the Infinity Cache: the logits
+// launch then streams its 2/3 of them without displacing V, which launch B reads next (three planes, S-TVSum: B 73 -> 63 us, A unchanged; two planes, where
+// all the planes fit the cache anyway: A 43.5 -> 52 us, B unchanged -- hence not unconditional; nt on B's own loads: slower in both.  profiles/r06_attn_ctx_ablation.txt)
+template <int NP, int NJ, int VAR, bool MH = false, bool NT = false>
 __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqInfo& si, const int strip, const int head, char* const lds) {
   constexpr int NSUB = 2 * NP, T64 = NJ * 64, ROWS = T64 + 64, STAGE = NSUB * ROWS * 16;
   // (deeper rings, 4 / 6 stages, were measured: no change -- the stream is not latency-bound).  MH (multi-head form: dh / 16 = 8 steps per block, the
@@ -95,7 +98,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
     for (int i = 0; i < MAXP; ++i) {
       if (i % n_shares != share) continue;
       if (i == MAXP - 1 && !full) break;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + pl[i]), 16, vlane, kb * k_step + pg[i], 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vptr)(st + pl[i]), 16, vlane, kb * k_step + pg[i], 0, NT ? 2 : 0);
     }
   };
   auto dma = [&](int kb, int slot) { dma_share(kb, slot, 0, 1); };
@@ -297,7 +300,7 @@ __device__ __forceinline__ void attn_logits_body(const AttnPwArgs& a, const SeqI
 #endif
 }
 
-template <int NP>
+template <int NP, bool NT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_pw_logits_mh_kernel(AttnPwArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int s, sub;
@@ -306,15 +309,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int strip = sub / nh, head = sub - strip * nh;      // (the heads of one strip are neighbours in the list: they share the strip's query rows and the video's keys in L2)
   const SeqInfo si = a.seq[s];
   switch ((si.T + 63) >> 6) {
-    case 1: attn_logits_body<NP, 1, 0, true>(a, si, strip, head, lds); break;
-    case 2: attn_logits_body<NP, 2, 0, true>(a, si, strip, head, lds); break;
-    case 3: attn_logits_body<NP, 3, 0, true>(a, si, strip, head, lds); break;
-    case 4: attn_logits_body<NP, 4, 0, true>(a, si, strip, head, lds); break;
-    default: attn_logits_body<NP, 5, 0, true>(a, si, strip, head, lds); break;
+    case 1: attn_logits_body<NP, 1, 0, true, NT>(a, si, strip, head, lds); break;
+    case 2: attn_logits_body<NP, 2, 0, true, NT>(a, si, strip, head, lds); break;
+    case 3: attn_logits_body<NP, 3, 0, true, NT>(a, si, strip, head, lds); break;
+    case 4: attn_logits_body<NP, 4, 0, true, NT>(a, si, strip, head, lds); break;
+    default: attn_logits_body<NP, 5, 0, true, NT>(a, si, strip, head, lds); break;
   }
 }
 
-template <int NP, int VAR>
+template <int NP, int VAR, bool NT = false>
 __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {       // single head (the multi-head form: attn_pw_logits_mh_kernel)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int head = 0;
@@ -322,11 +325,11 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {    
   if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AP_ROWS - 1) / AP_ROWS; }, s, strip)) return;      // every XCD the same number of strips
   const SeqInfo si = a.seq[s];
   switch ((si.T + 63) >> 6) {
-    case 1: attn_logits_body<NP, 1, VAR>(a, si, strip, head, lds); break;
-    case 2: attn_logits_body<NP, 2, VAR>(a, si, strip, head, lds); break;
-    case 3: attn_logits_body<NP, 3, VAR>(a, si, strip, head, lds); break;
-    case 4: attn_logits_body<NP, 4, VAR>(a, si, strip, head, lds); break;
-    default: attn_logits_body<NP, 5, VAR>(a, si, strip, head, lds); break;
+    case 1: attn_logits_body<NP, 1, VAR, false, NT>(a, si, strip, head, lds); break;
+    case 2: attn_logits_body<NP, 2, VAR, false, NT>(a, si, strip, head, lds); break;
+    case 3: attn_logits_body<NP, 3, VAR, false, NT>(a, si, strip, head, lds); break;
+    case 4: attn_logits_body<NP, 4, VAR, false, NT>(a, si, strip, head, lds); break;
+    default: attn_logits_body<NP, 5, VAR, false, NT>(a, si, strip, head, lds); break;
   }
 }
 
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(512) void attn_pw_context_kernel(AttnPwArgs a) {
   attn_context_body<NP, HP2, RM, QT>(a, lds);
 }
 
-std::atomic<uint64_t> g_attr[24];
+std::atomic<uint64_t> g_attr[28];
 constexpr int ATTN_VAR_A = 0;      // the product's schedule variant of the logits kernel (measured: profiles/r05_attn_pw_dma_variants.txt)
 
 template <typename K>
@@ -591,6 +594,10 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
 #endif
   [[maybe_unused]] static const int var = SUMK_TUNE_ENV("SUMK_ATTN_VAR_A") ? atoi(SUMK_TUNE_ENV("SUMK_ATTN_VAR_A")) : ATTN_VAR_A;      // (diagnostic build only)
   constexpr int LDS3 = 3 * (6 * 384 * 16) + 4096, LDS2 = 4 * (4 * 384 * 16) + 4096;
+  // non-temporal K / Q loads when the planes do not fit the Infinity Cache beside what the next launch reads (SUMK_ATTN_NT=0 / 1 forces it: A/B)
+  static const int nt_env = getenv("SUMK_ATTN_NT") ? atoi(getenv("SUMK_ATTN_NT")) : -1;
+  // (single head only: on the Transformer's multi-head launches the rule measured 1 % slower at three planes)
+  const bool nt = nt_env >= 0 ? nt_env != 0 : (heads == 1 && pw_planes_bytes(rows, 3 * D, np) > ((size_t)192 << 20));
 #define SUMK_A_CASE(NP_, V_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_logits_kernel<NP_, V_>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_logits_kernel<NP_, V_>), dim3(grid), dim3(512), LDS_, stream, a); }
 #ifdef SUMK_DIAG
   if (np == 3 && var == 3) { SUMK_A_CASE(3, 3, LDS3, 10) } else if (np == 3 && var == 4) { SUMK_A_CASE(3, 4, LDS3, 11) } else if (np == 3 && var == 5) { SUMK_A_CASE(3, 5, LDS3, 9) } else
@@ -599,8 +606,14 @@ int launch_attn_pw_logits(int np, const void* qkv_planes, int64_t rows, int D, f
 #endif
   if (heads > 1) {
     constexpr int LDSH3 = 2 * (6 * 384 * 16) + 4096, LDSH2 = 3 * (4 * 384 * 16) + 4096;      // 76 KB each: two blocks per CU
-    if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_logits_mh_kernel<3>, 8, LDSH3)); hipLaunchKernelGGL(attn_pw_logits_mh_kernel<3>, dim3(grid), dim3(512), LDSH3, stream, a); }
-    else { SUMK_TRY(set_lds_once(attn_pw_logits_mh_kernel<2>, 9 + 5, LDSH2)); hipLaunchKernelGGL(attn_pw_logits_mh_kernel<2>, dim3(grid), dim3(512), LDSH2, stream, a); }
+#define SUMK_MH_CASE(NP_, NT_, LDS_, I_) { SUMK_TRY(set_lds_once(attn_pw_logits_mh_kernel<NP_, NT_>, I_, LDS_)); hipLaunchKernelGGL((attn_pw_logits_mh_kernel<NP_, NT_>), dim3(grid), dim3(512), LDS_, stream, a); }
+    if (np == 3) { if (nt) SUMK_MH_CASE(3, true, LDSH3, 24) else SUMK_MH_CASE(3, false, LDSH3, 8) }
+    else { if (nt) SUMK_MH_CASE(2, true, LDSH2, 25) else SUMK_MH_CASE(2, false, LDSH2, 14) }
+#undef SUMK_MH_CASE
+  } else
+  if (nt) {
+    if (np == 3) { SUMK_TRY(set_lds_once(attn_pw_logits_kernel<3, 0, true>, 26, LDS3)); hipLaunchKernelGGL((attn_pw_logits_kernel<3, 0, true>), dim3(grid), dim3(512), LDS3, stream, a); }
+    else { SUMK_TRY(set_lds_once(attn_pw_logits_kernel<2, 0, true>, 27, LDS2)); hipLaunchKernelGGL((attn_pw_logits_kernel<2, 0, true>), dim3(grid), dim3(512), LDS2, stream, a); }
   } else
   if (np == 3) SUMK_A_CASE(3, 0, LDS3, 2) else SUMK_A_CASE(2, 0, LDS2, 5)
 #undef SUMK_A_CASE
