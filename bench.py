@@ -38,9 +38,12 @@ def _compact(o, top=True):
     """The JSON line without free text: every leg's numbers stay, notes / provenance go (--notes keeps them).  The contract's own text
     fields (metric, unit, config.workload, cpu_baseline.sample, roofline.kernel) stay."""
     if isinstance(o, dict):
-        return {k: _compact(v, False) for k, v in o.items() if k not in _VERBOSE_KEYS}
+        # (the legs' own cpu_baseline objects keep value / cores / kind; their `sample` text stays for the headline's only)
+        return {k: _compact(v, k == "cpu_baseline" and top) for k, v in o.items() if k not in _VERBOSE_KEYS and not (k == "sample" and not top and o.get("kind") and "value" in o)}
     if isinstance(o, list):
         return [_compact(v, False) for v in o]
+    if isinstance(o, float) and o != 0.0 and abs(o) < 1e-3:
+        return float(f"{o:.3g}")          # (score differences: three significant digits)
     return o
 
 
@@ -985,6 +988,9 @@ def main():
             return dict(error=err) if err else res
         train_leg = collective_leg(run_train_leg, "fp32")
         train_leg_bf16 = collective_leg(run_train_leg, "bf16")
+        train_leg_x6 = collective_leg(run_train_leg, "bf16x6")      # the same step in the fp32-grade split arithmetic: one figure, inside the fp32 leg
+        if isinstance(train_leg, dict) and isinstance(train_leg_x6, dict) and "ms_per_step" in train_leg and "ms_per_step" in train_leg_x6:
+            train_leg["bf16x6_ms_per_step"] = train_leg_x6["ms_per_step"]
 
         def run_one_video_leg():
             """The trainers' DEFAULT schedule under data parallelism: batch_videos = 1 -- every rank steps on ONE video (vasnet.py:193-212
@@ -1032,9 +1038,12 @@ def main():
             sec_local = sec
             if dist is not None:          # the same step with the exchange left out (every rank then steps on its own gradient)
                 sec_local = timed_steps(lambda: step(False), n_train)
+            dsn.precision = "bf16x6"                                      # the same step with the projections' products in the fp32-grade split arithmetic
+            sec_x6 = timed_steps(step, n_train)
+            dsn.precision = "fp32"
             from summarizer_amd import kernels as _kk
             _kk.health_check()                                            # persistent recurrences: no hand-off timed out
-            rec = dict(frames_per_s=round(frames * world / sec, 1), ms_per_step=round(sec * 1e3, 4), steps=n_train,
+            rec = dict(frames_per_s=round(frames * world / sec, 1), ms_per_step=round(sec * 1e3, 4), bf16x6_ms_per_step=round(sec_x6 * 1e3, 4), steps=n_train,
                        allreduce_bytes_per_step=int(opt.flat_grad.numel() * 4) if world > 1 else 0,
                        collectives_per_step=2 if world > 1 else 0,
                        note="DSN (BiLSTM 1024 -> 2 x 256) REINFORCE step: scores, 5 Bernoulli episodes, reward kernel, policy loss, "
