@@ -15,7 +15,7 @@ typedef float pf32x16 __attribute__((ext_vector_type(16)));
 // kind 0: v_mfma_f32_32x32x16_bf16 (32 768 FLOP), 1: v_mfma_f32_32x32x2_f32 (4 096 FLOP), 2: v_mfma_f32_16x16x32_bf16 (16 384 FLOP)
 // RANDOM: every MFMA of an iteration reads its own operand registers, filled with pseudo-random values (the operand buses toggle as under real data);
 // else one constant operand pair feeds all of them
-template <int KIND, bool RANDOM>
+template <int KIND, bool RANDOM, bool BOTH = false>
 __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float seed, float* sink) {
   pf32x16 acc[4];
 #pragma unroll
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float seed, f
     for (int u = 0; u < 4; ++u)          // 16 MFMAs per iteration, consecutive ones on different accumulators
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int qa = RANDOM ? u : 0, qb = RANDOM ? t : 0;
+        const int qa = RANDOM ? (BOTH ? ((t + u) & 3) : u) : 0, qb = RANDOM ? t : 0;      // BOTH: the A operand changes with every MFMA too (else every fourth)
         if constexpr (KIND == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16v[qa], b16v[qb], acc[t], 0, 0, 0);
         else if constexpr (KIND == 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[qa], bf[qb], acc[t], 0, 0, 0);
         else c4[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16v[qa], b16v[qb], c4[t], 0, 0, 0);
@@ -66,10 +66,10 @@ __global__ __launch_bounds__(512) void mfma_rate_kernel(int iters, float seed, f
 }  // namespace sumk
 
 extern "C" int sumk_probe_mfma_rate(int32_t kind_in, int32_t iters, double* tflops, double* seconds, void* stream_) {
-  const int kind = kind_in & 3, random = (kind_in >> 2) & 1;      // bit 2: pseudo-random operands, a different register pair per MFMA
+  const int kind = kind_in & 3, random = (kind_in >> 2) & 1, both = (kind_in >> 3) & 1;      // bit 2: pseudo-random operands, a different register pair per MFMA
   using namespace sumk;
   hipStream_t stream = (hipStream_t)stream_;
-  SUMK_ARG(kind_in >= 0 && kind_in <= 6 && kind <= 2 && iters >= 1 && tflops, "probe_mfma_rate: kind 0..2 (+ 4: random operands), iters >= 1");
+  SUMK_ARG(kind_in >= 0 && kind_in <= 14 && kind <= 2 && (!both || random) && iters >= 1 && tflops, "probe_mfma_rate: kind 0..2 (+ 4: random operands), iters >= 1");
   int dev = 0, cus = 0;
   SUMK_HIP(hipGetDevice(&dev));
   SUMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -79,7 +79,9 @@ extern "C" int sumk_probe_mfma_rate(int32_t kind_in, int32_t iters, double* tflo
   SUMK_HIP(hipEventCreate(&e0)); SUMK_HIP(hipEventCreate(&e1));
   auto launch = [&]() {
 #define SUMK_PROBE(K_, R_) hipLaunchKernelGGL((mfma_rate_kernel<K_, R_>), dim3(cus), dim3(512), 0, stream, iters, 0.5f, sink)
-    if (kind == 0) { if (random) SUMK_PROBE(0, true); else SUMK_PROBE(0, false); }
+    if (kind == 0 && both) hipLaunchKernelGGL((mfma_rate_kernel<0, true, true>), dim3(cus), dim3(512), 0, stream, iters, 0.5f, sink);
+    else if (kind == 2 && both) hipLaunchKernelGGL((mfma_rate_kernel<2, true, true>), dim3(cus), dim3(512), 0, stream, iters, 0.5f, sink);
+    else if (kind == 0) { if (random) SUMK_PROBE(0, true); else SUMK_PROBE(0, false); }
     else if (kind == 1) { if (random) SUMK_PROBE(1, true); else SUMK_PROBE(1, false); }
     else { if (random) SUMK_PROBE(2, true); else SUMK_PROBE(2, false); }
 #undef SUMK_PROBE
