@@ -634,6 +634,7 @@ def main():
                          "the whole line fits the 8 KB of stdout tail the round driver keeps; profiles/ holds a --notes copy of the line")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the side legs (split-bf16 / folded modes, per-kernel pass, training leg): what profiling runs use")
+    ap.add_argument("--no-probe", action="store_true", help="skip the MFMA rate probe (mfma_sustained): profiling runs, whose kernel table it would lead")
     ap.add_argument("--model", choices=["vasnet", "dsn", "slstm", "transformer", "sumgan"], default="vasnet",
                     help="headline = vasnet; dsn = BiLSTM 1024->2x256; slstm = SumGAN's 2-layer BiLSTM 1024->2x1024; "
                          "sumgan (--mode train only) = one SumGANTrainer video step: selector+encoder, decoder and "
@@ -1089,7 +1090,7 @@ def main():
                    roofline=roof)
         if graph is not None:
             out["config"]["hip_graph"] = "step captured once, timed region = graph replays"
-        sus = mfma_sustained()
+        sus = None if args.no_probe else mfma_sustained()
         if sus:
             out["mfma_sustained"] = sus
             if roof and roof.get("bound") == "mfma":

@@ -8,7 +8,7 @@ timeout 900 python3 bench.py --notes 2>/dev/null | tail -1 > $OUT/bench_default_
 timeout 600 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_driver_flags_line.json
 prof() {   # name, bench args...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o p -- python3 bench.py --no-cpu-baseline --headline-only --steps 30 --warmup 5 "$@" > $OUT/prof_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o p -- python3 bench.py --no-cpu-baseline --headline-only --no-probe --steps 30 --warmup 5 "$@" > $OUT/prof_$name.log 2>&1
   cp $OUT/prof_$name/*/p_kernel_stats.csv $OUT/${name}_kernel_stats.csv 2>/dev/null || cp $OUT/prof_$name/p_kernel_stats.csv $OUT/${name}_kernel_stats.csv
   tail -1 $OUT/prof_$name.log | grep '^{' >> $OUT/bench_lines_profiled.jsonl
   rm -rf $OUT/prof_$name

@@ -362,8 +362,8 @@ template <bool BWD>
 __global__ __launch_bounds__(512) void attn_strip_kernel(AttnStripArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int s, strip;
-  if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AT_ROWS - 1) / AT_ROWS; }, s, strip)) return;      // pw_common.h: every XCD the same number of strips
-  const SeqInfo si = a.seq[s];
+  SeqInfo si;
+  if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AT_ROWS - 1) / AT_ROWS; }, si, s, strip)) return;      // pw_common.h: every XCD the same number of strips
   switch ((si.T + 63) >> 6) {
     case 1: attn_strip_body<BWD, 1>(a, si, strip, lds); break;
     case 2: attn_strip_body<BWD, 2>(a, si, strip, lds); break;

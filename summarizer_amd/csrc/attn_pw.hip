@@ -305,9 +305,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int s, sub;
   const int nh = a.heads;
-  if (!locate_block(a.seq, a.n_seq, [nh](int t) { return ((t + AP_ROWS - 1) / AP_ROWS) * nh; }, s, sub)) return;
+  SeqInfo si;
+  if (!locate_block(a.seq, a.n_seq, [nh](int t) { return ((t + AP_ROWS - 1) / AP_ROWS) * nh; }, si, s, sub)) return;
   const int strip = sub / nh, head = sub - strip * nh;      // (the heads of one strip are neighbours in the list: they share the strip's query rows and the video's keys in L2)
-  const SeqInfo si = a.seq[s];
   switch ((si.T + 63) >> 6) {
     case 1: attn_logits_body<NP, 1, 0, true, NT>(a, si, strip, head, lds); break;
     case 2: attn_logits_body<NP, 2, 0, true, NT>(a, si, strip, head, lds); break;
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(512) void attn_pw_logits_kernel(AttnPwArgs a) {    
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int head = 0;
   int s, strip;
-  if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AP_ROWS - 1) / AP_ROWS; }, s, strip)) return;      // every XCD the same number of strips
-  const SeqInfo si = a.seq[s];
+  SeqInfo si;
+  if (!locate_block(a.seq, a.n_seq, [](int t) { return (t + AP_ROWS - 1) / AP_ROWS; }, si, s, strip)) return;      // every XCD the same number of strips
   switch ((si.T + 63) >> 6) {
     case 1: attn_logits_body<NP, 1, VAR, false, NT>(a, si, strip, head, lds); break;
     case 2: attn_logits_body<NP, 2, VAR, false, NT>(a, si, strip, head, lds); break;
@@ -361,9 +361,9 @@ __device__ __forceinline__ void attn_context_body(const AttnPwArgs& a, char* con
   static_assert(NS * STAGE <= 160 * 1024, "LDS map");
   int sv, bsub;
   const int cs = a.csplit;
-  if (!locate_block(a.seq, a.n_seq, [cs](int t) { return ((t + QR - 1) / QR) * cs; }, sv, bsub)) return;       // pw_common.h: every XCD the same number of blocks
+  SeqInfo si;
+  if (!locate_block(a.seq, a.n_seq, [cs](int t) { return ((t + QR - 1) / QR) * cs; }, si, sv, bsub)) return;       // pw_common.h: every XCD the same number of blocks
   const int strip = bsub / cs, chalf = bsub - strip * cs;
-  const SeqInfo si = a.seq[sv];
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = si.T, i0 = strip * QR, D = a.D;

@@ -27,32 +27,50 @@ __device__ __forceinline__ void split4(f32x4 r, u32x2 (&pl)[NP]) {
 // ids round-robin over the 8 XCDs, so XCD x = id % 8 takes the contiguous range [x G, (x + 1) G) of the list, G = ceil(total / 8) -- every XCD gets the
 // same number of blocks (+- 1) whatever the videos' lengths, and a video's blocks still share an L2.  (Dealing whole VIDEOS round-robin, id % 8 = video % 8,
 // gave one XCD 34 blocks for its 32 CUs on the S-TVSum batch at 128-query blocks: a second round on that XCD, the launch twice as long.)
-// Every wave computes the same answer: 64 videos per step, one per lane, an inclusive scan by shuffles.
+// Every wave computes the same answer: 64 videos per step, one per lane -- ONE 32-byte load per lane (the whole SeqInfo, so that the chosen video's entry is
+// read out of a lane's registers instead of by a second, dependent load), an inclusive scan of the block counts over DPP (six VALU adds; by ds_bpermute
+// shuffles the scan alone cost a block ~0.5 us), a ballot.  Every result is wave-uniform by construction and comes out of readlane / readfirstlane: left as
+// VGPR values the compiler treats every address derived from them as divergent and wraps each LDS-DMA instruction in a waterfall loop.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1 (lanes without a source keep 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8   -> scanned inside each row of 16
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 template <typename F>
-__device__ __forceinline__ bool locate_block(const SeqInfo* seq, int n_seq, F blocks_of, int& sv, int& sub) {
+__device__ __forceinline__ bool locate_block(const SeqInfo* seq, int n_seq, F blocks_of, SeqInfo& si, int& sv, int& sub) {
+  static_assert(sizeof(SeqInfo) == 32, "SeqInfo is read as two 16-byte halves");
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
-  auto scan = [&](int v0, int& cnt) {
-    const int v = v0 + lane;
-    cnt = v < n_seq ? blocks_of(seq[v].T) : 0;
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
-    return inc;
+  i32x4 lo, hi;          // this lane's video: {eoff (2 dwords), row0, T}, {ldE, pad_, e16off (2 dwords)}
+  int cnt;
+  auto chunk = [&](int v0) {                                // loads the lane's video of this 64-video step; returns the inclusive scan of the block counts
+    const i32x4* p = reinterpret_cast<const i32x4*>(seq + min(v0 + lane, n_seq - 1));
+    lo = p[0]; hi = p[1];
+    cnt = v0 + lane < n_seq ? blocks_of(lo[3]) : 0;
+    return wave_inclusive_scan(cnt);
   };
-  int total = 0, cnt;
-  // (every shuffled value below is wave-uniform by construction; readfirstlane says so to the compiler, which otherwise treats the loop exits -- and with
-  //  them every address the caller derives from sv / sub -- as divergent: waterfall loops around each LDS-DMA instruction)
-  for (int v0 = 0; v0 < n_seq; v0 += 64) total += __builtin_amdgcn_readfirstlane(__shfl(scan(v0, cnt), 63));
+  int inc = chunk(0);
+  int total = __builtin_amdgcn_readlane(inc, 63);
+  for (int v0 = 64; v0 < n_seq; v0 += 64) total += __builtin_amdgcn_readlane(chunk(v0), 63);
   const int G = (total + 7) >> 3, slot = blockIdx.x >> 3;
   const int L = (blockIdx.x & 7) * G + slot;
   if (slot >= G || L >= total) return false;
   int base = 0;
   for (int v0 = 0; v0 < n_seq; v0 += 64) {
-    const int inc = scan(v0, cnt), tot = __builtin_amdgcn_readfirstlane(__shfl(inc, 63));
+    if (n_seq > 64) inc = chunk(v0);                         // (one step: the scan of the first pass is still in registers)
+    const int tot = __builtin_amdgcn_readlane(inc, 63);
     if (L < base + tot) {
       const int first = __ffsll((unsigned long long)__ballot(base + inc > L)) - 1;
-      sv = __builtin_amdgcn_readfirstlane(v0 + first);
-      sub = __builtin_amdgcn_readfirstlane(L - base - __shfl(inc - cnt, first));
+      sv = v0 + first;
+      sub = L - base - __builtin_amdgcn_readlane(inc - cnt, first);
+      auto rl = [&](int x) { return (uint32_t)__builtin_amdgcn_readlane(x, first); };
+      si.eoff = (int64_t)(((uint64_t)rl(lo[1]) << 32) | rl(lo[0])); si.row0 = (int32_t)rl(lo[2]); si.T = (int32_t)rl(lo[3]);
+      si.ldE = (int32_t)rl(hi[0]); si.pad_ = (int32_t)rl(hi[1]); si.e16off = (int64_t)(((uint64_t)rl(hi[3]) << 32) | rl(hi[2]));
       return true;
     }
     base += tot;
