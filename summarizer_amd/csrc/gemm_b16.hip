@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256, 3) void gemm_b16_kernel(GemmKArgs ka) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(s.a), (short)0, s.na, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(s.b), (short)0, s.nb, 0x00020000);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) ra[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rA, voa[p], kt * s.sa, 0);
+    for (int p = 0; p < 4; ++p) ra[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rA, voa[p], kt * __builtin_amdgcn_readfirstlane(s.sa), 0);     // (uniform strides: see the wide kernel's gload_slice)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) rb[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rB, vob[p], kt * s.sb, 0);
+    for (int p = 0; p < 4; ++p) rb[p] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rB, vob[p], kt * __builtin_amdgcn_readfirstlane(s.sb), 0);
   };
   auto swrite = [&]() {
 #pragma unroll
@@ -249,9 +249,11 @@ __global__ __launch_bounds__(512) void gemm_b16_wide_kernel(GemmKArgs ka) {
   // (BM = 192: A has chunks 0..2).  Slice q of k-tile kt + 1 is written to the other LDS stage, then the same registers are re-loaded
   // with k-tile kt + 2, behind the MFMAs of step q of k-tile kt -- the LDS store burst and the load issue are spread over the k-tile
   // instead of standing between the barrier and the first MFMA.
+  // (the k-tile strides are wave-uniform but travel through the tile loop's Src copies, where the compiler re-classes them as divergent -- each MC-operand
+  //  load then sat in a waterfall loop, sixteen per k-tile in the TN kernels: readfirstlane at the use)
   auto gload_slice = [&](const Src& s, int kt, int q) {
-    if (q < NLA) ra[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(s.ra, voa[q], kt * s.sa, 0);
-    if (q < NLB) rb[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(s.rb, vob[q], kt * s.sb, 0);
+    if (q < NLA) ra[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(s.ra, voa[q], kt * uni(s.sa), 0);
+    if (q < NLB) rb[q] = (u32x4)__builtin_amdgcn_raw_buffer_load_b128(s.rb, vob[q], kt * uni(s.sb), 0);
   };
   auto gload = [&](const Src& s, int kt) {
 #pragma unroll

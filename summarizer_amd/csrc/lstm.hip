@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_wide2_kernel(Wide2Args a) {
   const int d = (blockIdx.x & 7) >> 2;                    // team = direction
   const int slot = (blockIdx.x >> 3) * 4 + (blockIdx.x & 3);
   if (slot >= a.n_active) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform, and said so: as a VGPR value it put each of a step's 32 exchange loads -- their scalar offset is wave * ... -- into a waterfall loop)
   const int li = lane & 31, lh = lane >> 5;
   const int u0 = slot * a.upm, nu = min(a.upm, H - u0);
   bool dead = false;   // (wave 0) a wait timed out: results are invalid, state[0] says so
