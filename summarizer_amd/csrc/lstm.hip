@@ -2025,8 +2025,19 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
           const float* xp = a.coal ? xb + ((int64_t)slot * 32 * a.gsize + ei) * 8 + eu : xb + (int64_t)ei * H + j;
           const int64_t xs = a.coal ? (int64_t)a.gsize * 8 : (int64_t)32 * H;        // producer to producer
           float pv[32];
+          if (a.n_active == 32) {
+            // All 32 members (H = 256 at 8 units each, the DSN shape): no per-member predicate, and the member stride walks a 32-bit VGPR offset of a buffer
+            // load.  The generic form below kept 32 predicate masks and 32 64-bit offsets alive across the step loop -- 145 spilled SGPRs, four v_readlane
+            // and a branch in front of every one of these loads, ~1 000 of a step's 7 400 cycles, all behind the poll.
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0x7FFFFFFF, 0x00020000);
+            unsigned vo = (unsigned)(xp - xb) * 4u;
+            const unsigned st = (unsigned)xs * 4u;
 #pragma unroll
-          for (int m = 0; m < 32; ++m) pv[m] = m < a.n_active ? ld_sc1(xp + (int64_t)m * xs) : 0.f;
+            for (int m = 0; m < 32; ++m) { pv[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, vo, 0, 16 /* sc1 */)); vo += st; }
+          } else {
+#pragma unroll
+            for (int m = 0; m < 32; ++m) pv[m] = m < a.n_active ? ld_sc1(xp + (int64_t)m * xs) : 0.f;
+          }
           float rec = 0.f;
 #pragma unroll
           for (int m = 0; m < 32; ++m) rec += pv[m];
