@@ -1994,17 +1994,34 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
           const unsigned long long* xp = a.ll + ((((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * a.gsize + (need ? ei : 0)) * H + (need ? j : 0);
           unsigned spins = 0;
           unsigned long long ll_t0 = 0;
+          const unsigned long long* xb64 = a.ll + (((int64_t)((t + 1) & 1) * a.n_items + item) * 32) * a.gsize * H;
           while (true) {
             unsigned long long pv[32];
+            bool ok = true;
+            float rec = 0.f;
+            if (a.n_active == 32) {     // all members present: 32-bit buffer offsets walked in a VGPR, no per-member predicate (see the counter form below)
+              typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+              const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(xb64), (short)0, 0x7FFFFFFF, 0x00020000);
+              unsigned vo = (unsigned)(xp - xb64) * 8u;
+              const unsigned st = (unsigned)(a.gsize * H) * 8u;
+#pragma unroll
+              for (int m = 0; m < 32; ++m) { pv[m] = __builtin_bit_cast(unsigned long long, (u32x2_)__builtin_amdgcn_raw_buffer_load_b64(xr, vo, 0, 16 /* sc1 */)); vo += st; }
+#pragma unroll
+              for (int m = 0; m < 32; ++m) {
+                ok = ok && (unsigned)(pv[m] >> 32) == want;
+                rec += __builtin_bit_cast(float, (unsigned)pv[m]);
+              }
+              ok = ok || !need;
+              if (!need) rec = 0.f;
+            } else {
 #pragma unroll
             for (int m = 0; m < 32; ++m)
               pv[m] = (need && m < a.n_active) ? __hip_atomic_load(xp + (int64_t)m * a.gsize * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            bool ok = true;
-            float rec = 0.f;
 #pragma unroll
             for (int m = 0; m < 32; ++m) {
               if (need && m < a.n_active) ok = ok && (unsigned)(pv[m] >> 32) == want;
               rec += __builtin_bit_cast(float, (unsigned)pv[m]);       // fixed order m = 0 .. 31 (absent members add +0)
+            }
             }
             rec_ll = rec;
             if (__all(ok) || dead) break;
