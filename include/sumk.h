@@ -160,9 +160,10 @@ int sumk_bilstm_wplanes_build(int32_t In, int32_t H, const sumk_lstm_layer_weigh
 
 size_t sumk_bilstm_workspace_bytes(int32_t In, int32_t H, int32_t n_seq, const int32_t* seq_off_host, int32_t training);
 /* precision: SUMK_PRECISION_FP32, or SUMK_PRECISION_BF16X3 / SUMK_PRECISION_BF16X6 for the input projection (and, for 256 < H <= 1024, the
- * recurrent product: inference only for BF16X6) in the split-bf16 arithmetics described at sumk_vasnet_opts.  Round 6: with w->w_planes given
- * (inference, H <= 256, In = 1024, <= 64 videos) the projection is computed INSIDE the persistent recurrence from x itself -- no G, no GEMM
- * launch (csrc/lstm.hip, lstm_persist_proj_kernel); x_planes then only serves the fallback.  The workspace of 256 < H <= 1024 holds the
+ * recurrent product: inference only for BF16X6) in the split-bf16 arithmetics described at sumk_vasnet_opts.  With w->x_planes / w->w_planes given
+ * (inference) the projection runs on operand planes in front of the recurrence; SUMK_LSTM_PROJ=1 in the environment computes it INSIDE the persistent
+ * recurrence instead (H <= 256, In = 1024, <= 64 videos; csrc/lstm.hip, lstm_persist_proj_kernel -- slower since the recurrence's last speed-up, kept as
+ * an A/B path).  The workspace of 256 < H <= 1024 holds the
  * forward recurrence's exchange buffer (1 MB per 64 videos): ask sumk_bilstm_workspace_bytes again after upgrading the library. */
 int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, int32_t n_seq,
                               const int32_t* seq_off_host, const int32_t* seq_off_dev,

@@ -1,5 +1,5 @@
 """Probe of DSN scoring on the S-TVSum batch per precision: whole call and the recurrence launch alone (sumk_prof_*).
-SUMK_LSTM_PROJ=0 keeps the plane GEMM in front of the recurrence (the round-5 path)."""
+SUMK_LSTM_PROJ=1 runs the projection inside the recurrence (lstm_persist_proj_kernel); default: the plane GEMM in front."""
 import ctypes as C
 import os
 import sys
@@ -42,6 +42,6 @@ for prec in ["fp32", "bf16x6", "bf16x3"]:
         lib.sumk_prof_enable(0)
     kernels.health_check()
     out[prec] = s.cpu().numpy()
-    print(f"{prec:7s} PROJ={os.environ.get('SUMK_LSTM_PROJ', '1')}: whole call {dt * 1e3:7.3f} ms; recurrence launch {ms.value / max(cnt.value, 1) * 1e3:8.1f} us "
+    print(f"{prec:7s} PROJ={os.environ.get('SUMK_LSTM_PROJ', '0')}: whole call {dt * 1e3:7.3f} ms; recurrence launch {ms.value / max(cnt.value, 1) * 1e3:8.1f} us "
           f"= {ms.value / max(cnt.value, 1) * 1e3 / max(lens):6.2f} us per step", flush=True)
 print("max |bf16x6 - fp32| =", float(np.abs(out["bf16x6"] - out["fp32"]).max()), " max |bf16x3 - fp32| =", float(np.abs(out["bf16x3"] - out["fp32"]).max()))

@@ -728,10 +728,12 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
               const unsigned o = (need_row && k0 + 2 * p < H) ? rowb + 8u * (unsigned)(k0 + 2 * p) : 0x7ffffff0u;     // beyond num_records: zeros
               va[p] = __builtin_amdgcn_raw_buffer_load_b128(lrsrc, o, 0, 16 /* sc1 */);
             }
+            // Branch-free tag checks.  With `if (needed) ok = ok && tag == want && ...` the compiler built a ladder of exec-mask branches, one per tag, around
+            // counted vmcnt waits: 0.45 us of a 2.55-us step (816 -> 665 us per DSN recurrence launch, same results).
             bool ok = true;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-              if (need_row && k0 + 2 * p < H) ok = ok && va[p][1] == want && va[p][3] == want;
+              ok = ok & (((va[p][1] == want) & (va[p][3] == want)) | !(need_row && k0 + 2 * p < H));
             if (__all(ok) || dead) break;
             if (pk_ll_timed_out(spins, ll_t0)) {     // never hang the GPU: flag the failure and stop waiting
               if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
@@ -790,8 +792,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_kernel(PersistArgs a)
 #pragma unroll
             for (int c = 0; c < CPW; ++c) {
               const int k = (wave * CPW + c) * 8 + 4 * lh;
-              if (need_row && k < H)
-                ok = ok && va[2 * c][1] == want && va[2 * c][3] == want && va[2 * c + 1][1] == want && va[2 * c + 1][3] == want;
+              ok = ok & (((va[2 * c][1] == want) & (va[2 * c][3] == want) & (va[2 * c + 1][1] == want) & (va[2 * c + 1][3] == want)) | !(need_row && k < H));      // (branch-free: see the 16-row form above)
             }
             if (__all(ok) || dead) break;
             if (pk_ll_timed_out(spins, ll_t0)) {     // never hang the GPU: flag the failure and stop waiting
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_proj_kernel(PersistPr
           bool ok = true;
 #pragma unroll
           for (int p = 0; p < 4; ++p)
-            if (need_row && k0 + 2 * p < H) ok = ok && va[p][1] == want && va[p][3] == want;
+            ok = ok & (((va[p][1] == want) & (va[p][3] == want)) | !(need_row && k0 + 2 * p < H));      // (branch-free tag checks: lstm_persist_kernel)
           if (__all(ok) || dead) break;
           if (pk_ll_timed_out(spins, ll_t0)) {     // never hang the GPU: flag the failure and stop waiting
             if (lane == 0) { atomicOr(a.state, 1u); atomicOr(&g_sumk_health, 1u); }
@@ -2008,10 +2009,10 @@ __global__ __launch_bounds__(PK_THREADS) void lstm_persist_bwd_kernel(PersistBwd
               for (int m = 0; m < 32; ++m) { pv[m] = __builtin_bit_cast(unsigned long long, (u32x2_)__builtin_amdgcn_raw_buffer_load_b64(xr, vo, 0, 16 /* sc1 */)); vo += st; }
 #pragma unroll
               for (int m = 0; m < 32; ++m) {
-                ok = ok && (unsigned)(pv[m] >> 32) == want;
+                ok = ok & ((unsigned)(pv[m] >> 32) == want);
                 rec += __builtin_bit_cast(float, (unsigned)pv[m]);
               }
-              ok = ok || !need;
+              ok = ok | !need;
               if (!need) rec = 0.f;
             } else {
 #pragma unroll
@@ -2518,10 +2519,13 @@ extern "C" int sumk_bilstm_layer_forward(const float* x, int32_t In, int32_t H, 
   const int np_in = precision == SUMK_PRECISION_BF16X6 ? 3 : precision == SUMK_PRECISION_BF16X3 ? 2 : 0;
   static const bool persist_ok = persistent_kernels_usable();
   const bool planes_in = !training && np_in && w->x_planes && w->w_planes && bilstm_wplanes_ok(In, H, np_in) && R >= 1024 && pw_ok(R, 8 * (int64_t)H, In, R, 8 * (int64_t)H, np_in);
-  // round 6: with operand planes at hand and the H <= 256 persistent recurrence on 16-row MFMAs, the projection runs INSIDE the recurrence
-  // (lstm_persist_proj_kernel): no G, no GEMM launch.  SUMK_LSTM_PROJ=0 keeps the plane GEMM in front (A/B: tests/test_gpu_lstm.py)
+  // round 6: with operand planes at hand and the H <= 256 persistent recurrence on 16-row MFMAs, the projection CAN run inside the recurrence
+  // (lstm_persist_proj_kernel): no G, no GEMM launch.  It was the default while the plain recurrence cost 2.55 us per step (1.065 against 1.09 ms at three
+  // planes); with the branch-free tag checks the plain step is 2.05 us and the plane GEMM in front of it wins (DSN scoring bf16x6 0.94-0.96 against 1.04-1.05
+  // ms, bf16x3 0.84-0.88 against 0.88-0.89: the projection costs 1.07 us per step inside, 0.23 ms as a launch) -- SUMK_LSTM_PROJ=1 selects the fused form
+  // (A/B: tests/test_gpu_lstm.py)
   {
-    static const bool proj_on = !(getenv("SUMK_LSTM_PROJ") && getenv("SUMK_LSTM_PROJ")[0] == '0');
+    static const bool proj_on = getenv("SUMK_LSTM_PROJ") && getenv("SUMK_LSTM_PROJ")[0] == '1';
     static const bool ll_on = !(getenv("SUMK_LSTM_LL") && getenv("SUMK_LSTM_LL")[0] == '0');
     static const bool m16_on = !(getenv("SUMK_LSTM_M16") && getenv("SUMK_LSTM_M16")[0] == '0');
     const int gsize = std::min(32, std::max(1, (2 * n_seq + PK_TEAMS - 1) / PK_TEAMS));

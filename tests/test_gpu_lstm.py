@@ -335,7 +335,7 @@ def test_dsn_projection_inside_the_recurrence(tmp_path, H, lens):
     import os, subprocess, sys
     from oracle import lstm_np
     out = {}
-    for tag, env in (("gemm", {"SUMK_LSTM_PROJ": "0"}), ("fused", {})):
+    for tag, env in (("gemm", {"SUMK_LSTM_PROJ": "0"}), ("fused", {"SUMK_LSTM_PROJ": "1"})):      # (opt-in since the round's last pass: the plane GEMM in front measured faster)
         f = tmp_path / f"{tag}.npz"
         r = subprocess.run([sys.executable, "-c", _PROJ_CHILD, str(f), str(H), ",".join(map(str, lens))], env=dict(os.environ, **env),
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
