@@ -2,7 +2,7 @@
 # kernel stats of the modes this round touched + the headline, every mode's own bench line, the recurrence probes.  Outputs under
 # gpurun_out/r06_final (copied into profiles/ by hand).  PMC passes: scripts/pmc_pass.sh (separate call).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r06_final; mkdir -p $OUT
+OUT=${OUT:-gpurun_out/r06_final}; mkdir -p $OUT
 timeout 900 python3 bench.py 2>$OUT/default.err | tail -1 > $OUT/bench_default_line.json
 timeout 900 python3 bench.py --notes 2>/dev/null | tail -1 > $OUT/bench_default_line_notes.json
 timeout 600 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_driver_flags_line.json
@@ -27,7 +27,10 @@ prof slstm_score_bf16x6 --model slstm --precision bf16x6
 prof slstm_score_bf16x3 --model slstm --precision bf16x3
 prof slstm_train --model slstm --mode train --steps 5 --warmup 2
 prof stress_bf16x6 --workload stress --precision bf16x6 --steps 3 --warmup 1
-for args in "" "--precision bf16x6" "--precision bf16x3" "--mode train" "--mode train --precision bf16" "--model dsn" "--model dsn --precision bf16x6" "--model dsn --precision bf16x3" "--model dsn --mode train" "--model dsn --mode reinforce" "--model slstm" "--model slstm --precision bf16x6" "--model slstm --precision bf16x3" "--model slstm --mode train --steps 5 --warmup 2" "--model transformer" "--model transformer --precision bf16x6" "--model transformer --precision bf16x3" "--precision bf16x6 --fold-vo" "--precision bf16x3 --fold-vo" "--workload stress --steps 3 --warmup 1" "--workload stress --precision bf16x6 --steps 3 --warmup 1" "--workload stress --precision bf16x3 --steps 3 --warmup 1" "--mode stream"; do
+prof transformer_score_bf16x6 --model transformer --precision bf16x6
+prof transformer_score_bf16x3 --model transformer --precision bf16x3
+prof vasnet_score_folded_bf16x6 --precision bf16x6 --fold-vo
+for args in "" "--precision bf16x6" "--precision bf16x3" "--mode train" "--mode train --precision bf16" "--model dsn" "--model dsn --precision bf16x6" "--model dsn --precision bf16x3" "--model dsn --mode train" "--model dsn --mode reinforce" "--model dsn --mode reinforce --precision bf16x6" "--model dsn --mode train --precision bf16x6" "--mode train --precision bf16x6" "--model slstm" "--model slstm --precision bf16x6" "--model slstm --precision bf16x3" "--model slstm --mode train --steps 5 --warmup 2" "--model transformer" "--model transformer --precision bf16x6" "--model transformer --precision bf16x3" "--precision bf16x6 --fold-vo" "--precision bf16x3 --fold-vo" "--workload stress --steps 3 --warmup 1" "--workload stress --precision bf16x6 --steps 3 --warmup 1" "--workload stress --precision bf16x3 --steps 3 --warmup 1" "--mode stream"; do
   timeout 300 python3 bench.py --no-cpu-baseline --headline-only --steps 30 --warmup 5 $args 2>/dev/null | tail -1 | grep '^{' >> $OUT/bench_lines.jsonl
 done
 python3 scripts/probes/wide2_probe.py > $OUT/wide2_probe.txt 2>&1
