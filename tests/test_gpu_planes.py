@@ -462,3 +462,52 @@ def test_long_videos_on_the_plane_gemm(tmp_path):
                 assert np.array_equal(rev[offr[jr]:offr[jr + 1]], a[off[i]:off[i + 1]]), (name, prec, i)
             ran_other_kernels |= not np.array_equal(a, b)
     assert ran_other_kernels
+
+
+_RECUT_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from summarizer_amd.models.vasnet import VASNet
+from summarizer_amd.models.transformer import Transformer
+D = 1024
+lens = [int(v) for v in sys.argv[2].split(",")]
+g = torch.Generator().manual_seed(9)
+x = (torch.randn(sum(lens), D, generator=g) * 0.3).to("cuda:0")
+out = {}
+for name, kw in (("plain", {}), ("folded", dict(fold_vo=True)), ("aperture", dict(attention_aperture=30))):
+    torch.manual_seed(3)
+    m = VASNet(input_size=D, **kw).to("cuda:0").eval()
+    for prec in ("bf16x6", "bf16x3"):
+        m.precision = prec
+        with torch.no_grad():
+            out[f"vasnet_{name}_{prec}"] = m.score_packed(x, lens).cpu().numpy()
+torch.manual_seed(4)
+t = Transformer(input_size=D).to("cuda:0").eval()
+for prec in ("bf16x6", "bf16x3"):
+    t.precision = prec
+    with torch.no_grad():
+        out[f"transformer_{prec}"] = t.score_packed(x, lens).cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_attention_recut_switches_do_not_change_a_bit(tmp_path):
+    """Round 6's re-cut of the attention launches on planes is a change of WHO computes WHAT, not of the arithmetic: per accumulator the plane products and the
+    key order are the same.  `SUMK_ATTN_WIDE=0` (context launch on 64-query strips x all columns instead of 128-query blocks x half the columns) and
+    `SUMK_ATTN_NT=0 / 1` (cache policy of the logits launch's K / Q loads) must reproduce the default's scores BIT FOR BIT -- VASNet plain / folded (the context
+    launch adds the residual and emits the LayerNorm moments) / banded mask and the Transformer scorer (multi-head forms), both plane counts, on a ragged batch
+    (1 ... 320 frames; enough rows for the plane path)."""
+    import os, subprocess, sys
+    lens = [320, 1, 129, 64, 255, 300, 2, 200] + [int(t) for t in np.random.default_rng(8).integers(100, 321, size=42)]
+    out = {}
+    for tag, env in (("default", {}), ("strips64", {"SUMK_ATTN_WIDE": "0"}), ("nt0", {"SUMK_ATTN_NT": "0"}), ("nt1", {"SUMK_ATTN_NT": "1"})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _RECUT_CHILD, str(f), ",".join(map(str, lens))], env=dict(os.environ, **env),
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = dict(np.load(f))
+    assert len(out["default"]) == 8
+    for k, ref in out["default"].items():
+        assert np.isfinite(ref).all(), k
+        for tag in ("strips64", "nt0", "nt1"):
+            assert np.array_equal(out[tag][k], ref), (tag, k, float(np.abs(out[tag][k] - ref).max()))
