@@ -97,3 +97,23 @@ def test_plane_size_queries_need_no_gpu(lib):
     assert lib.sumk_attn_planes_alpha_bytes(12003, 320, 3) == 12032 * 320 * 3 * 2 + 8192
     assert lib.sumk_attn_planes_alpha_bytes(12003, 300, 2) == 12032 * 320 * 2 * 2 + 8192        # key count rounded up to 32
     assert lib.sumk_attn_planes_alpha_bytes(0, 320, 3) == 0 and lib.sumk_attn_planes_alpha_bytes(10, 320, 1) == 0
+
+
+def test_hot_kernels_compile_without_waterfall_loops(tmp_path):
+    """The compiler wraps a buffer instruction in a WATERFALL loop (v_readfirstlane / v_cmp_eq / s_and_saveexec ... s_cbranch_execnz) when it cannot prove
+    the instruction's descriptor or scalar offset wave-uniform.  Round 6 found such loops around every LDS-DMA instruction of a re-cut attention launch
+    (block coordinates out of shuffles), around the MC-operand loads of the wide bf16 GEMM (k-tile strides carried through the tile loop) and around the 32
+    exchange loads per step of the sLSTM recurrence (wave id left in a VGPR) -- DESIGN.md section 3, "reading the compiler's output".  The four sources
+    they lived in must compile to gfx950 assembly without one (CPU only: hipcc cross-compiles; scripts/check_waterfalls.sh does every source)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "summarizer_amd", "csrc")
+    names = ["attn_pw", "attn_b16", "gemm_b16", "lstm"]
+    procs = [(n, subprocess.Popen([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-S", "--cuda-device-only", n + ".hip", "-o", str(tmp_path / (n + ".s"))],
+                                  cwd=csrc, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)) for n in names]
+    for n, p in procs:
+        assert p.wait(timeout=900) == 0, n
+        asm = open(tmp_path / (n + ".s")).read()
+        assert "v_mfma" in asm, n
+        assert asm.count("s_and_saveexec_b64 vcc, vcc") == 0, (n, asm.count("s_and_saveexec_b64 vcc, vcc"))
