@@ -73,10 +73,13 @@ extern "C" int sumk_probe_mfma_rate(int32_t kind_in, int32_t iters, double* tflo
   int dev = 0, cus = 0;
   SUMK_HIP(hipGetDevice(&dev));
   SUMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  // (resources released on every path: the HIP calls below report through rc instead of returning early)
   float* sink = nullptr;
-  SUMK_HIP(hipMalloc(&sink, 64));
-  hipEvent_t e0, e1;
-  SUMK_HIP(hipEventCreate(&e0)); SUMK_HIP(hipEventCreate(&e1));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0.f;
+  hipError_t err = hipMalloc(&sink, 64);
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
   auto launch = [&]() {
 #define SUMK_PROBE(K_, R_) hipLaunchKernelGGL((mfma_rate_kernel<K_, R_>), dim3(cus), dim3(512), 0, stream, iters, 0.5f, sink)
     if (kind == 0 && both) hipLaunchKernelGGL((mfma_rate_kernel<0, true, true>), dim3(cus), dim3(512), 0, stream, iters, 0.5f, sink);
@@ -86,15 +89,18 @@ extern "C" int sumk_probe_mfma_rate(int32_t kind_in, int32_t iters, double* tflo
     else { if (random) SUMK_PROBE(2, true); else SUMK_PROBE(2, false); }
 #undef SUMK_PROBE
   };
-  launch();                                  // warm-up: code object, clocks
-  SUMK_HIP(hipEventRecord(e0, stream));
-  launch();
-  SUMK_HIP(hipEventRecord(e1, stream));
-  SUMK_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  SUMK_HIP(hipEventElapsedTime(&ms, e0, e1));
-  SUMK_HIP(hipGetLastError());
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+  if (err == hipSuccess) {
+    launch();                                  // warm-up: code object, clocks
+    err = hipEventRecord(e0, stream);
+    if (err == hipSuccess) { launch(); err = hipEventRecord(e1, stream); }
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (err == hipSuccess) err = hipGetLastError();
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (sink) (void)hipFree(sink);
+  if (err != hipSuccess) return hip_fail(err, "probe_mfma_rate");
   const double flop_per = kind == 0 ? 32768.0 : kind == 1 ? 4096.0 : 16384.0;
   const double flops = (double)cus * 8.0 * (double)iters * 16.0 * flop_per;
   *tflops = flops / ((double)ms * 1e-3) / 1e12;
